@@ -1,0 +1,593 @@
+// a7: bundle-adjustment arithmetic on the device (float64).
+//
+//   * ba_eval_kernel     one thread per observation: pinhole residual + analytic 2x6 / 2x3 Jacobian blocks.
+//                        The <= 8 camera rotations R(rvec) and the Rodrigues derivative factor M are built
+//                        once per workgroup in LDS (oracle/trf_lsmr.py:rotation_and_dfactor).
+//   * matvec / rmatvec   J v and J^T u on the block form.  J^T u needs a reduction over all observations of a
+//                        camera: observations are pre-grouped by camera (cam_perm / cam_start), every
+//                        (camera, chunk) workgroup reduces its slice in a fixed order, a second kernel sums the
+//                        DF3D chunks in order -> bit-reproducible (no floating-point atomics).
+//   * df3d_ba_lsmr       Fong & Saunders LSMR on A = J diag(d) with damping, the inner solver of scipy's
+//                        trust-region-reflective step (oracle/trf_lsmr.py:lsmr).  Vectors stay on the device;
+//                        three scalars (beta, alpha, |x|) come back to the host per iteration.
+// All kernels are latency/launch-bound at the reference's sizes (1e5 observations): ~15 MB per Jacobian pass.
+#include <cmath>
+
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_CAM = 8;
+constexpr int NCHUNK = 32;      // chunks per camera in the J^T u / column-norm reductions
+constexpr int RED_BLOCKS = 256;  // partial blocks of the generic sum-of-squares / dot reductions
+
+struct CamLds {
+    double R[MAX_CAM][9];
+    double M[MAX_CAM][9];
+    double t[MAX_CAM][3];
+    double k[MAX_CAM][4];
+};
+
+__device__ void cam_prep(const double* __restrict__ x, const double* __restrict__ intr4, int ncam, CamLds& L) {
+    const int c = threadIdx.x;
+    if (c < ncam) {
+        const double r0 = x[c * 6 + 0], r1 = x[c * 6 + 1], r2 = x[c * 6 + 2];
+        const double th2 = r0 * r0 + r1 * r1 + r2 * r2;
+        double R[9], M[9];
+        if (th2 < 1e-24) {
+            // first-order: R = I + [r]x, M = I
+            R[0] = 1; R[1] = -r2; R[2] = r1;
+            R[3] = r2; R[4] = 1; R[5] = -r0;
+            R[6] = -r1; R[7] = r0; R[8] = 1;
+            M[0] = 1; M[1] = 0; M[2] = 0; M[3] = 0; M[4] = 1; M[5] = 0; M[6] = 0; M[7] = 0; M[8] = 1;
+        } else {
+            const double th = sqrt(th2);
+            const double k0 = r0 / th, k1 = r1 / th, k2 = r2 / th;
+            const double s = sin(th), cm = 1.0 - cos(th);
+            // R = I + s K + (1-c) K^2
+            const double K[9] = {0, -k2, k1, k2, 0, -k0, -k1, k0, 0};
+            double K2[9];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double acc = 0;
+                    for (int l = 0; l < 3; ++l) acc += K[i * 3 + l] * K[l * 3 + j];
+                    K2[i * 3 + j] = acc;
+                }
+            for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + s * K[i] + cm * K2[i];
+            // M = (r r^T + (R^T - I) [r]x) / |r|^2
+            const double S[9] = {0, -r2, r1, r2, 0, -r0, -r1, r0, 0};
+            const double rv[3] = {r0, r1, r2};
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double acc = rv[i] * rv[j];
+                    for (int l = 0; l < 3; ++l) acc += (R[l * 3 + i] - (l == i ? 1.0 : 0.0)) * S[l * 3 + j];
+                    M[i * 3 + j] = acc / th2;
+                }
+        }
+        for (int i = 0; i < 9; ++i) {
+            L.R[c][i] = R[i];
+            L.M[c][i] = M[i];
+        }
+        for (int i = 0; i < 3; ++i) L.t[c][i] = x[c * 6 + 3 + i];
+        for (int i = 0; i < 4; ++i) L.k[c][i] = intr4[c * 4 + i];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void ba_eval_kernel(df3d_ba_problem p, const double* __restrict__ x,
+                                                      double* __restrict__ r, double* __restrict__ Jc,
+                                                      double* __restrict__ Jp) {
+    __shared__ CamLds L;
+    cam_prep(x, p.intr4, p.ncam, L);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.nobs) return;
+    const int c = p.cam_idx[i];
+    const int q = p.pt_idx[i];
+    const double* Xp = x + 6 * p.ncam + 3 * (size_t)q;
+    const double X0 = Xp[0], X1 = Xp[1], X2 = Xp[2];
+    const double* R = L.R[c];
+    const double xc = R[0] * X0 + R[1] * X1 + R[2] * X2 + L.t[c][0];
+    const double yc = R[3] * X0 + R[4] * X1 + R[5] * X2 + L.t[c][1];
+    const double zc = R[6] * X0 + R[7] * X1 + R[8] * X2 + L.t[c][2];
+    const double fx = L.k[c][0], fy = L.k[c][1], cx = L.k[c][2], cy = L.k[c][3];
+    const double iz = 1.0 / zc;
+    if (r) {
+        const double2 o = *reinterpret_cast<const double2*>(p.obs_xy + 2 * (size_t)i);
+        double2 res;
+        res.x = fx * xc * iz + cx - o.x;
+        res.y = fy * yc * iz + cy - o.y;
+        *reinterpret_cast<double2*>(r + 2 * (size_t)i) = res;
+    }
+    if (Jc && Jp) {
+        // d pi / d Xc
+        const double a00 = fx * iz, a02 = -fx * xc * iz * iz;
+        const double a11 = fy * iz, a12 = -fy * yc * iz * iz;
+        // point block: dpi * R
+        const size_t n = (size_t)p.nobs;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            Jp[(0 * 3 + k) * n + i] = a00 * R[0 + k] + a02 * R[6 + k];
+            Jp[(1 * 3 + k) * n + i] = a11 * R[3 + k] + a12 * R[6 + k];
+        }
+        // rotation block: dpi * (-R [X]x M)
+        // G = [X]x M
+        const double* M = L.M[c];
+        double G[9];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            G[0 + k] = -X2 * M[3 + k] + X1 * M[6 + k];
+            G[3 + k] = X2 * M[0 + k] - X0 * M[6 + k];
+            G[6 + k] = -X1 * M[0 + k] + X0 * M[3 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double d0 = -(R[0] * G[0 + k] + R[1] * G[3 + k] + R[2] * G[6 + k]);
+            const double d1 = -(R[3] * G[0 + k] + R[4] * G[3 + k] + R[5] * G[6 + k]);
+            const double d2 = -(R[6] * G[0 + k] + R[7] * G[3 + k] + R[8] * G[6 + k]);
+            Jc[(0 * 6 + k) * n + i] = a00 * d0 + a02 * d2;
+            Jc[(1 * 6 + k) * n + i] = a11 * d1 + a12 * d2;
+        }
+        // translation block: dpi
+        Jc[(0 * 6 + 3) * n + i] = a00;
+        Jc[(0 * 6 + 4) * n + i] = 0.0;
+        Jc[(0 * 6 + 5) * n + i] = a02;
+        Jc[(1 * 6 + 3) * n + i] = 0.0;
+        Jc[(1 * 6 + 4) * n + i] = a11;
+        Jc[(1 * 6 + 5) * n + i] = a12;
+    }
+}
+
+__global__ __launch_bounds__(256) void ba_matvec_kernel(df3d_ba_problem p, const double* __restrict__ Jc,
+                                                        const double* __restrict__ Jp,
+                                                        const double* __restrict__ d,
+                                                        const double* __restrict__ v, double* __restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.nobs) return;
+    const size_t n = (size_t)p.nobs;
+    const int c = p.cam_idx[i];
+    const int q = p.pt_idx[i];
+    double y0 = 0.0, y1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int col = c * 6 + k;
+        const double vk = d ? d[col] * v[col] : v[col];
+        y0 += Jc[(0 * 6 + k) * n + i] * vk;
+        y1 += Jc[(1 * 6 + k) * n + i] * vk;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const size_t col = 6 * (size_t)p.ncam + 3 * (size_t)q + k;
+        const double vk = d ? d[col] * v[col] : v[col];
+        y0 += Jp[(0 * 3 + k) * n + i] * vk;
+        y1 += Jp[(1 * 3 + k) * n + i] * vk;
+    }
+    double2 out;
+    out.x = y0;
+    out.y = y1;
+    *reinterpret_cast<double2*>(y + 2 * (size_t)i) = out;
+}
+
+// fixed-order block reduction of one double per thread (256 threads): wave butterflies then 4 -> 1 in LDS
+__device__ __forceinline__ double block_reduce_256(double v, double* lds4) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds4[wave] = v;
+    __syncthreads();
+    return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+// stage 1 of J^T u (SQUARE = false) or of the column norms (SQUARE = true), camera columns only:
+// partial[(c * NCHUNK + chunk) * 6 + k]
+template <bool SQUARE>
+__global__ __launch_bounds__(256) void ba_cam_partial_kernel(df3d_ba_problem p, const double* __restrict__ Jc,
+                                                             const double* __restrict__ u,
+                                                             double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    const int chunk = blockIdx.x, c = blockIdx.y;
+    const int lo = p.cam_start[c], hi = p.cam_start[c + 1];
+    const int cnt = hi - lo;
+    const int per = (cnt + NCHUNK - 1) / NCHUNK;
+    const int a = lo + chunk * per;
+    const int b = min(a + per, hi);
+    const size_t n = (size_t)p.nobs;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int s = a + (int)threadIdx.x; s < b; s += 256) {
+        const int i = p.cam_perm[s];
+        double u0 = 1.0, u1 = 1.0;
+        if (!SQUARE) {
+            const double2 uu = *reinterpret_cast<const double2*>(u + 2 * (size_t)i);
+            u0 = uu.x;
+            u1 = uu.y;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double j0 = Jc[(0 * 6 + k) * n + i], j1 = Jc[(1 * 6 + k) * n + i];
+            acc[k] += SQUARE ? (j0 * j0 + j1 * j1) : (j0 * u0 + j1 * u1);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double tot = block_reduce_256(acc[k], lds4);
+        if (threadIdx.x == 0) partial[((size_t)c * NCHUNK + chunk) * 6 + k] = tot;
+    }
+}
+
+// stage 2: one thread per unknown
+template <bool SQUARE>
+__global__ __launch_bounds__(256) void ba_rmatvec_final_kernel(df3d_ba_problem p, const double* __restrict__ Jp,
+                                                               const double* __restrict__ d,
+                                                               const double* __restrict__ u,
+                                                               const double* __restrict__ partial,
+                                                               double* __restrict__ w) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long ncols = 6ll * p.ncam + 3ll * p.npts;
+    if (k >= ncols) return;
+    double acc = 0.0;
+    if (k < 6 * p.ncam) {
+        const int c = (int)(k / 6), col = (int)(k % 6);
+        for (int ch = 0; ch < NCHUNK; ++ch) acc += partial[((size_t)c * NCHUNK + ch) * 6 + col];
+    } else {
+        const long long kk = k - 6 * p.ncam;
+        const int q = (int)(kk / 3), col = (int)(kk % 3);
+        const size_t n = (size_t)p.nobs;
+        for (int i = p.pt_start[q]; i < p.pt_start[q + 1]; ++i) {
+            const double j0 = Jp[(0 * 3 + col) * n + i], j1 = Jp[(1 * 3 + col) * n + i];
+            if (SQUARE) {
+                acc += j0 * j0 + j1 * j1;
+            } else {
+                acc += j0 * u[2 * (size_t)i] + j1 * u[2 * (size_t)i + 1];
+            }
+        }
+    }
+    w[k] = (d && !SQUARE) ? d[k] * acc : acc;
+}
+
+// ---- generic float64 vector helpers -------------------------------------------------------------
+// out = a*x + b*y (y may be null); optionally accumulates sum(out^2) partials (fixed RED_BLOCKS blocks)
+template <bool SUMSQ>
+// (x, y and out may alias element-wise: no __restrict__ on them)
+__global__ __launch_bounds__(256) void axpby_kernel(double a, const double* x, double b, const double* y,
+                                                    double* out, size_t n, double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double v = a * x[i];
+        if (y) v += b * y[i];
+        out[i] = v;
+        if (SUMSQ) acc += v * v;
+    }
+    if (SUMSQ) {
+        const double tot = block_reduce_256(acc, lds4);
+        if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ a, const double* __restrict__ b,
+                                                  size_t n, double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += a[i] * b[i];
+    const double tot = block_reduce_256(acc, lds4);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// sums `count` partials in index order into result[0]
+__global__ __launch_bounds__(256) void final_sum_kernel(const double* __restrict__ partial, int count,
+                                                        double* __restrict__ result) {
+    __shared__ double lds4[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += 256) acc += partial[i];
+    const double tot = block_reduce_256(acc, lds4);
+    if (threadIdx.x == 0) result[0] = tot;
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const double* x, const double* y, double* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = x[i] * y[i];
+}
+
+// LSMR vector update:  hbar = h - c1*hbar ; x += c2*hbar ; h = v - c3*h ; partial sum(x^2)
+__global__ __launch_bounds__(256) void lsmr_update_kernel(double c1, double c2, double c3, double* __restrict__ hbar,
+                                                          double* __restrict__ h, double* __restrict__ x,
+                                                          const double* __restrict__ v, size_t n,
+                                                          double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double hi = h[i];
+        const double hb = hi - c1 * hbar[i];
+        const double xi = x[i] + c2 * hb;
+        hbar[i] = hb;
+        x[i] = xi;
+        h[i] = v[i] - c3 * hi;
+        acc += xi * xi;
+    }
+    const double tot = block_reduce_256(acc, lds4);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+inline int grid_for(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > RED_BLOCKS ? RED_BLOCKS : b));
+}
+
+int check_problem(const df3d_ba_problem* p) {
+    DF3D_CHECK_ARG(p != nullptr, "null problem");
+    DF3D_CHECK_ARG(p->ncam >= 1 && p->ncam <= MAX_CAM, "ncam must be in [1, 8]");
+    DF3D_CHECK_ARG(p->nobs > 0 && p->npts > 0, "empty problem");
+    DF3D_CHECK_ARG(p->intr4 && p->obs_xy && p->cam_idx && p->pt_idx && p->pt_start && p->cam_perm && p->cam_start,
+                   "null array in problem");
+    return DF3D_OK;
+}
+
+// host-visible reduction result: sum of squares / dot -> host double (synchronous)
+int read_back(const double* dev_scalar, double* host, hipStream_t s) {
+    DF3D_HIP(hipMemcpyAsync(host, dev_scalar, sizeof(double), hipMemcpyDeviceToHost, s));
+    DF3D_HIP(hipStreamSynchronize(s));
+    return DF3D_OK;
+}
+
+int launch_rmatvec(const df3d_ba_problem* p, const double* Jc, const double* Jp, const double* d, const double* u,
+                   double* w, double* scratch, hipStream_t s) {
+    hipLaunchKernelGGL(ba_cam_partial_kernel<false>, dim3(NCHUNK, p->ncam), dim3(256), 0, s, *p, Jc, u, scratch);
+    const long long ncols = 6ll * p->ncam + 3ll * p->npts;
+    hipLaunchKernelGGL(ba_rmatvec_final_kernel<false>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, *p, Jp,
+                       d, u, scratch, w);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+int launch_matvec(const df3d_ba_problem* p, const double* Jc, const double* Jp, const double* d, const double* v,
+                  double* y, hipStream_t s) {
+    hipLaunchKernelGGL(ba_matvec_kernel, dim3((p->nobs + 255) / 256), dim3(256), 0, s, *p, Jc, Jp, d, v, y);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+void sym_ortho(double a, double b, double& c, double& s, double& r) {
+    auto sgn = [](double v) { return (v > 0) - (v < 0); };
+    if (b == 0) {
+        c = sgn(a);
+        s = 0;
+        r = std::fabs(a);
+    } else if (a == 0) {
+        c = 0;
+        s = sgn(b);
+        r = std::fabs(b);
+    } else if (std::fabs(b) > std::fabs(a)) {
+        const double tau = a / b;
+        s = sgn(b) / std::sqrt(1 + tau * tau);
+        c = s * tau;
+        r = b / s;
+    } else {
+        const double tau = b / a;
+        c = sgn(a) / std::sqrt(1 + tau * tau);
+        s = c * tau;
+        r = a / c;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int df3d_ba_eval(const df3d_ba_problem* p, const double* x_dev, double* r_dev, double* Jc_dev, double* Jp_dev,
+                 void* stream) {
+    if (int rc = check_problem(p)) return rc;
+    DF3D_CHECK_ARG(x_dev != nullptr, "null x");
+    DF3D_CHECK_ARG((Jc_dev == nullptr) == (Jp_dev == nullptr), "Jc and Jp must be given together");
+    hipLaunchKernelGGL(ba_eval_kernel, dim3((p->nobs + 255) / 256), dim3(256), 0, df3d::as_stream(stream), *p, x_dev,
+                       r_dev, Jc_dev, Jp_dev);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+int df3d_ba_colsq(const df3d_ba_problem* p, const double* Jc_dev, const double* Jp_dev, double* colsq_dev,
+                  double* scratch_dev, void* stream) {
+    if (int rc = check_problem(p)) return rc;
+    DF3D_CHECK_ARG(Jc_dev && Jp_dev && colsq_dev && scratch_dev, "null pointer");
+    hipStream_t s = df3d::as_stream(stream);
+    hipLaunchKernelGGL(ba_cam_partial_kernel<true>, dim3(NCHUNK, p->ncam), dim3(256), 0, s, *p, Jc_dev, nullptr,
+                       scratch_dev);
+    const long long ncols = 6ll * p->ncam + 3ll * p->npts;
+    hipLaunchKernelGGL(ba_rmatvec_final_kernel<true>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, *p,
+                       Jp_dev, nullptr, nullptr, scratch_dev, colsq_dev);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+int df3d_ba_matvec(const df3d_ba_problem* p, const double* Jc_dev, const double* Jp_dev, const double* d_dev,
+                   const double* v_dev, double* y_dev, void* stream) {
+    if (int rc = check_problem(p)) return rc;
+    DF3D_CHECK_ARG(Jc_dev && Jp_dev && v_dev && y_dev, "null pointer");
+    return launch_matvec(p, Jc_dev, Jp_dev, d_dev, v_dev, y_dev, df3d::as_stream(stream));
+}
+
+int df3d_ba_rmatvec(const df3d_ba_problem* p, const double* Jc_dev, const double* Jp_dev, const double* d_dev,
+                    const double* u_dev, double* w_dev, double* scratch_dev, void* stream) {
+    if (int rc = check_problem(p)) return rc;
+    DF3D_CHECK_ARG(Jc_dev && Jp_dev && u_dev && w_dev && scratch_dev, "null pointer");
+    return launch_rmatvec(p, Jc_dev, Jp_dev, d_dev, u_dev, w_dev, scratch_dev, df3d::as_stream(stream));
+}
+
+int df3d_vec_dot(const double* a_dev, const double* b_dev, size_t n, double* result_host, double* scratch_dev,
+                 void* stream) {
+    DF3D_CHECK_ARG(a_dev && b_dev && result_host && scratch_dev, "null pointer");
+    hipStream_t s = df3d::as_stream(stream);
+    const int g = grid_for(n);
+    hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(256), 0, s, a_dev, b_dev, n, scratch_dev);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, scratch_dev, g, scratch_dev + RED_BLOCKS);
+    DF3D_LAUNCH_CHECK();
+    return read_back(scratch_dev + RED_BLOCKS, result_host, s);
+}
+
+int df3d_vec_axpby(double a, const double* x_dev, double b, const double* y_dev, double* out_dev, size_t n,
+                   void* stream) {
+    DF3D_CHECK_ARG(x_dev && out_dev, "null pointer");
+    hipLaunchKernelGGL(axpby_kernel<false>, dim3(grid_for(n)), dim3(256), 0, df3d::as_stream(stream), a, x_dev, b,
+                       y_dev, out_dev, n, nullptr);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+int df3d_vec_mul(const double* x_dev, const double* y_dev, double* out_dev, size_t n, void* stream) {
+    DF3D_CHECK_ARG(x_dev && y_dev && out_dev, "null pointer");
+    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, df3d::as_stream(stream), x_dev, y_dev, out_dev, n);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+size_t df3d_ba_lsmr_work_doubles(const df3d_ba_problem* p) {
+    if (!p) return 0;
+    const size_t m = 2 * (size_t)p->nobs, n = 6 * (size_t)p->ncam + 3 * (size_t)p->npts;
+    // u, tmp_m (m each); v, h, hbar, tmp_n (n each); scratch
+    return 2 * m + 4 * n + DF3D_BA_SCRATCH_DOUBLES + 64;
+}
+
+int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, const double* d_dev,
+                 const double* b_dev, double damp, double atol, double btol, double conlim, int maxiter,
+                 double* x_dev, double* work_dev, double* info_host, void* stream) {
+    if (int rc = check_problem(p)) return rc;
+    DF3D_CHECK_ARG(Jc && Jp && b_dev && x_dev && work_dev && info_host, "null pointer");
+    hipStream_t s = df3d::as_stream(stream);
+    const size_t m = 2 * (size_t)p->nobs, n = 6 * (size_t)p->ncam + 3 * (size_t)p->npts;
+    if (maxiter <= 0) maxiter = (int)(m < n ? m : n);
+    double* u = work_dev;
+    double* tmp_m = u + m;
+    double* v = tmp_m + m;
+    double* h = v + n;
+    double* hbar = h + n;
+    double* tmp_n = hbar + n;
+    double* scratch = tmp_n + n;                  // DF3D_BA_SCRATCH_DOUBLES: camera partials
+    double* red = scratch + 2048;                 // RED_BLOCKS partials + result slot
+    double* result = red + RED_BLOCKS;
+    const int gm = grid_for(m), gn = grid_for(n);
+
+    auto sumsq_axpby = [&](double a, const double* x, double bb, const double* y, double* out, size_t len, int g,
+                           double* host) -> int {
+        hipLaunchKernelGGL(axpby_kernel<true>, dim3(g), dim3(256), 0, s, a, x, bb, y, out, len, red);
+        hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, red, g, result);
+        DF3D_LAUNCH_CHECK();
+        return read_back(result, host, s);
+    };
+
+    double ss = 0.0;
+    // u = b ; normb
+    if (int rc = sumsq_axpby(1.0, b_dev, 0.0, nullptr, u, m, gm, &ss)) return rc;
+    const double normb = std::sqrt(ss);
+    double beta = normb, alpha = 0.0;
+    DF3D_HIP(hipMemsetAsync(x_dev, 0, n * sizeof(double), s));
+    DF3D_HIP(hipMemsetAsync(hbar, 0, n * sizeof(double), s));
+    if (beta > 0) {
+        if (int rc = df3d_vec_axpby(1.0 / beta, u, 0.0, nullptr, u, m, stream)) return rc;
+        if (int rc = launch_rmatvec(p, Jc, Jp, d_dev, u, tmp_n, scratch, s)) return rc;
+        if (int rc = sumsq_axpby(1.0, tmp_n, 0.0, nullptr, v, n, gn, &ss)) return rc;
+        alpha = std::sqrt(ss);
+    } else {
+        DF3D_HIP(hipMemsetAsync(v, 0, n * sizeof(double), s));
+    }
+    if (alpha > 0)
+        if (int rc = df3d_vec_axpby(1.0 / alpha, v, 0.0, nullptr, v, n, stream)) return rc;
+
+    int itn = 0, istop = 0;
+    double zetabar = alpha * beta, alphabar = alpha;
+    double rho = 1, rhobar = 1, cbar = 1, sbar = 0;
+    DF3D_HIP(hipMemcpyAsync(h, v, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    double betadd = beta, betad = 0, rhodold = 1, tautildeold = 0, thetatilde = 0, zeta = 0, dd = 0;
+    double normA2 = alpha * alpha, maxrbar = 0, minrbar = 1e100;
+    double normA = std::sqrt(normA2), condA = 1, normx = 0;
+    const double ctol = conlim > 0 ? 1.0 / conlim : 0.0;
+    double normr = beta, normar = alpha * beta;
+
+    auto finish = [&]() {
+        info_host[0] = istop;
+        info_host[1] = itn;
+        info_host[2] = normr;
+        info_host[3] = normar;
+        info_host[4] = normA;
+        info_host[5] = condA;
+        info_host[6] = normx;
+        info_host[7] = 0;
+        return DF3D_OK;
+    };
+    if (normar == 0 || normb == 0) {
+        DF3D_HIP(hipStreamSynchronize(s));
+        return finish();
+    }
+
+    while (itn < maxiter) {
+        ++itn;
+        // u = A v - alpha u ; beta = |u|
+        if (int rc = launch_matvec(p, Jc, Jp, d_dev, v, tmp_m, s)) return rc;
+        if (int rc = sumsq_axpby(1.0, tmp_m, -alpha, u, u, m, gm, &ss)) return rc;
+        beta = std::sqrt(ss);
+        if (beta > 0) {
+            if (int rc = df3d_vec_axpby(1.0 / beta, u, 0.0, nullptr, u, m, stream)) return rc;
+            // v = A^T u - beta v ; alpha = |v|
+            if (int rc = launch_rmatvec(p, Jc, Jp, d_dev, u, tmp_n, scratch, s)) return rc;
+            if (int rc = sumsq_axpby(1.0, tmp_n, -beta, v, v, n, gn, &ss)) return rc;
+            alpha = std::sqrt(ss);
+            if (alpha > 0)
+                if (int rc = df3d_vec_axpby(1.0 / alpha, v, 0.0, nullptr, v, n, stream)) return rc;
+        }
+        double chat, shat, alphahat;
+        sym_ortho(alphabar, damp, chat, shat, alphahat);
+        const double rhoold = rho;
+        double c, sn;
+        sym_ortho(alphahat, beta, c, sn, rho);
+        const double thetanew = sn * alpha;
+        alphabar = c * alpha;
+        const double rhobarold = rhobar, zetaold = zeta;
+        const double thetabar = sbar * rho;
+        const double rhotemp = cbar * rho;
+        sym_ortho(cbar * rho, thetanew, cbar, sbar, rhobar);
+        zeta = cbar * zetabar;
+        zetabar = -sbar * zetabar;
+        // hbar = h - c1 hbar ; x += c2 hbar ; h = v - c3 h ; normx
+        hipLaunchKernelGGL(lsmr_update_kernel, dim3(gn), dim3(256), 0, s, thetabar * rho / (rhoold * rhobarold),
+                           zeta / (rho * rhobar), thetanew / rho, hbar, h, x_dev, v, n, red);
+        hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, red, gn, result);
+        DF3D_LAUNCH_CHECK();
+        if (int rc = read_back(result, &ss, s)) return rc;
+        normx = std::sqrt(ss);
+
+        const double betaacute = chat * betadd;
+        const double betacheck = -shat * betadd;
+        const double betahat = c * betaacute;
+        betadd = -sn * betaacute;
+        const double thetatildeold = thetatilde;
+        double ctildeold, stildeold, rhotildeold;
+        sym_ortho(rhodold, thetabar, ctildeold, stildeold, rhotildeold);
+        thetatilde = stildeold * rhobar;
+        rhodold = ctildeold * rhobar;
+        betad = -stildeold * betad + ctildeold * betahat;
+        tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold;
+        const double taud = (zeta - thetatilde * tautildeold) / rhodold;
+        dd += betacheck * betacheck;
+        normr = std::sqrt(dd + (betad - taud) * (betad - taud) + betadd * betadd);
+        normA2 += beta * beta;
+        normA = std::sqrt(normA2);
+        normA2 += alpha * alpha;
+        maxrbar = std::fmax(maxrbar, rhobarold);
+        if (itn > 1) minrbar = std::fmin(minrbar, rhobarold);
+        condA = std::fmax(maxrbar, rhotemp) / std::fmin(minrbar, rhotemp);
+        normar = std::fabs(zetabar);
+        const double test1 = normr / normb;
+        const double test2 = (normA * normr) != 0 ? normar / (normA * normr) : INFINITY;
+        const double test3 = 1.0 / condA;
+        const double t1 = test1 / (1 + normA * normx / normb);
+        const double rtol = btol + atol * normA * normx / normb;
+        if (itn >= maxiter) istop = 7;
+        if (1 + test3 <= 1) istop = 6;
+        if (1 + test2 <= 1) istop = 5;
+        if (1 + t1 <= 1) istop = 4;
+        if (test3 <= ctol) istop = 3;
+        if (test2 <= atol) istop = 2;
+        if (test1 <= rtol) istop = 1;
+        if (istop > 0) break;
+    }
+    return finish();
+}
+
+}  // extern "C"

@@ -1,0 +1,473 @@
+// Device kernels of the stacked-hourglass engine (a2).  NHWC activations, gfx950 MFMA.
+//
+//   conv_mfma_kernel<T, TAPS, BN, RB>
+//       1x1 (TAPS=1) and 3x3/pad 1 (TAPS=9) convolutions as an implicit GEMM
+//           out[m, n] = sum_{tap, c} act(in[pixel(m) + tap, c]) * W[tap][n][c]  (+ bias, + residual, ReLU)
+//       with m = (view, y, x) flattened.  Workgroup tile 128 pixels x BN channels, 4 wavefronts, each owning
+//       32x32 MFMA tiles (v_mfma_f32_32x32x2_f32 for T=float: exact f32 FMA chains at the 157 TF rate;
+//       v_mfma_f32_32x32x16_bf16 for T=bf16).  Per K-step both operands are staged global -> registers -> LDS
+//       as RB-byte row segments (16-byte chunks), double-buffered with one barrier per step; the global loads
+//       for step s+1 are issued before the MFMAs of step s.  Rows are padded by 16 bytes in LDS, which makes
+//       the 16-byte ds_read of a 32-row fragment conflict-free (row pitch 80 B / 144 B: see DESIGN.md).
+//       A 16-byte fragment holds 4 (f32) or 8 (bf16) consecutive K values of one row; lanes 0-31 take the
+//       even 16-byte chunk and lanes 32-63 the odd one, which permutes K inside the step identically for
+//       both operands (the sum over K is unchanged).
+//       Fusions: eval-mode BN + ReLU of the *input* (pre-activation bottlenecks) while staging; bias, residual
+//       add and ReLU in the epilogue; optional NCHW plane output for the final heat-maps.
+//   stem_kernel       7x7 stride-2 convolution 3 -> 64 (+ folded BN, ReLU) from an LDS-resident input patch.
+//   pool2_kernel      2x2 max-pool;  upadd_kernel  out = a + nearest-upsample2(b).   HBM-bound, 16-byte lanes.
+#pragma once
+#include <hip/hip_bf16.h>
+#include <hip/hip_runtime.h>
+
+namespace hgk {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+struct ConvArgs {
+    const void* in;
+    void* out;          // NHWC [M, out_pitch] (may be null when only the NCHW output is wanted)
+    const void* res;    // NHWC residual [M, res_pitch] or null
+    float* out_nchw;    // float32 planes [views, cout_real, H*W] or null
+    const void* w;      // [TAPS][cout][cin]  (T)
+    const float* bias;  // [cout] f32
+    const float* scale; // [cin] f32 or null: input BN as x*scale+shift then ReLU
+    const float* shift;
+    long long M;        // views * H * W
+    int H, W;
+    int cin, cout;      // padded: cin multiple of RB/sizeof(T), cout multiple of BN
+    int in_pitch, out_pitch, res_pitch;
+    int relu;
+    int cout_real;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    // round to nearest even (NaN not expected in activations)
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static constexpr int BYTES = 4;
+    static constexpr int PER16 = 4;  // elements per 16-byte chunk
+};
+template <>
+struct Elem<__hip_bfloat16> {
+    static constexpr int BYTES = 2;
+    static constexpr int PER16 = 8;
+};
+
+// apply y = max(x*s + t, 0) to one 16-byte chunk of channels starting at channel c
+template <typename T>
+__device__ __forceinline__ u32x4 preact_chunk(u32x4 raw, const float* __restrict__ scale,
+                                              const float* __restrict__ shift, int c) {
+    if constexpr (sizeof(T) == 4) {
+        const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(shift + c);
+        f32x4 v = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(v[i], s[i], t[i]), 0.0f);
+        return __builtin_bit_cast(u32x4, v);
+    } else {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + c);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(scale + c + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + c);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(shift + c + 4);
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float lo = bf16_bits_to_f32((unsigned short)(raw[i] & 0xffffu));
+            const float hi = bf16_bits_to_f32((unsigned short)(raw[i] >> 16));
+            const float sl = i < 2 ? s0[2 * i] : s1[2 * i - 4], sh = i < 2 ? s0[2 * i + 1] : s1[2 * i - 3];
+            const float tl = i < 2 ? t0[2 * i] : t1[2 * i - 4], th = i < 2 ? t0[2 * i + 1] : t1[2 * i - 3];
+            const float a = fmaxf(fmaf(lo, sl, tl), 0.0f), b = fmaxf(fmaf(hi, sh, th), 0.0f);
+            o[i] = (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16);
+        }
+        return o;
+    }
+}
+
+// one 16-byte A fragment x one 16-byte B fragment -> accumulate into a 32x32 tile
+template <typename T>
+__device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x16& acc) {
+    if constexpr (sizeof(T) == 4) {
+        const f32x4 af = __builtin_bit_cast(f32x4, a);
+        const f32x4 bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                      acc, 0, 0, 0);
+    }
+}
+
+// Tile geometry for a given BN
+template <int BN>
+struct Geo;
+template <>
+struct Geo<128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; };
+template <>
+struct Geo<64> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 1; };
+template <>
+struct Geo<32> { static constexpr int WM = 4, WN = 1, TM = 1, TN = 1; };
+
+constexpr int BM = 128;
+
+template <typename T, int TAPS, int BN, int RB>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
+    using G = Geo<BN>;
+    constexpr int PITCH = RB + 16;                 // LDS row pitch in bytes
+    constexpr int CPR = RB / 16;                   // 16-byte chunks per row per step
+    constexpr int ROWS_PER_PASS = 256 / CPR;       // rows covered by one pass of the 256 threads
+    constexpr int A_PASSES = BM / ROWS_PER_PASS;
+    constexpr int B_PASSES = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+    constexpr int KE = RB / Elem<T>::BYTES;        // K elements per step
+    constexpr int A_BYTES = BM * PITCH, B_BYTES = BN * PITCH;
+    static_assert(BN % 32 == 0 && A_PASSES >= 1, "tile");
+
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // one pipeline stage: A tile then B tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / G::WN, wn = wave % G::WN;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- staging assignment: thread -> (row, 16-byte chunk) ------------------------------------------
+    const int chunk = tid % CPR;
+    const int srow = tid / CPR;
+    const unsigned char* a_ptr[A_PASSES];  // pointer to in[pixel][0] (bytes) for each staged row
+    int a_yx[A_PASSES];                    // (y << 16) | x, or -1 when the row is beyond M
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        const long long m = m0 + srow + i * ROWS_PER_PASS;
+        if (m < p.M) {
+            const int hw = p.H * p.W;
+            const int pix = (int)(m % hw);
+            a_yx[i] = ((pix / p.W) << 16) | (pix % p.W);
+            a_ptr[i] = reinterpret_cast<const unsigned char*>(p.in) + (size_t)m * p.in_pitch * Elem<T>::BYTES;
+        } else {
+            a_yx[i] = -1;
+            a_ptr[i] = reinterpret_cast<const unsigned char*>(p.in);
+        }
+    }
+    const int ksteps_per_tap = p.cin / KE;
+    const int nsteps = TAPS * ksteps_per_tap;
+
+    u32x4 ra[A_PASSES], rb[B_PASSES];
+
+    auto load_step = [&](int s) {
+        const int tap = TAPS == 1 ? 0 : s / ksteps_per_tap;
+        const int kc = TAPS == 1 ? s : s - tap * ksteps_per_tap;
+        const int c0 = kc * KE + chunk * Elem<T>::PER16;  // first channel of this thread's chunk
+        int dy = 0, dx = 0;
+        if (TAPS == 9) {
+            dy = tap / 3 - 1;
+            dx = tap % 3 - 1;
+        }
+        const long long tap_off = ((long long)dy * p.W + dx) * p.in_pitch * Elem<T>::BYTES;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            bool ok = a_yx[i] >= 0;
+            if (TAPS == 9 && ok) {
+                const int y = (a_yx[i] >> 16) + dy, x = (a_yx[i] & 0xffff) + dx;
+                ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            }
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                v = *reinterpret_cast<const u32x4*>(a_ptr[i] + tap_off + (size_t)c0 * Elem<T>::BYTES);
+                if (TAPS == 1 && p.scale) v = preact_chunk<T>(v, p.scale, p.shift, c0);
+            }
+            ra[i] = v;
+        }
+        const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) +
+                                     ((size_t)tap * p.cout * p.cin + (size_t)c0) * Elem<T>::BYTES;
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) {
+            const int n = srow + i * ROWS_PER_PASS;
+            if (BN % ROWS_PER_PASS == 0 || n < BN)
+                rb[i] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(n0 + n) * p.cin * Elem<T>::BYTES);
+        }
+    };
+    auto store_step = [&](int buf) {
+        unsigned char* const sa = smem + buf * STAGE_BYTES;
+        unsigned char* const sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i)
+            *reinterpret_cast<u32x4*>(sa + (srow + i * ROWS_PER_PASS) * PITCH + chunk * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) {
+            const int n = srow + i * ROWS_PER_PASS;
+            if (BN % ROWS_PER_PASS == 0 || n < BN) *reinterpret_cast<u32x4*>(sb + n * PITCH + chunk * 16) = rb[i];
+        }
+    };
+
+    f32x16 acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fragment read offsets (bytes) inside a tile
+    const int frag_row = lane & 31;
+    const int frag_half = (lane >> 5) * 16;
+    const int a_off = (wm * (G::TM * 32) + frag_row) * PITCH + frag_half;
+    const int b_off = (wn * (G::TN * 32) + frag_row) * PITCH + frag_half;
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        const unsigned char* const sa = smem + buf * STAGE_BYTES;
+        const unsigned char* const sb = sa + A_BYTES;
+        if (s + 1 < nsteps) load_step(s + 1);
+#pragma unroll
+        for (int j = 0; j < RB / 32; ++j) {
+            u32x4 af[G::TM], bf[G::TN];
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i)
+                af[i] = *reinterpret_cast<const u32x4*>(sa + a_off + i * 32 * PITCH + j * 32);
+#pragma unroll
+            for (int i = 0; i < G::TN; ++i)
+                bf[i] = *reinterpret_cast<const u32x4*>(sb + b_off + i * 32 * PITCH + j * 32);
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+                for (int k = 0; k < G::TN; ++k) mfma_chunk<T>(af[i], bf[k], acc[i][k]);
+        }
+        if (s + 1 < nsteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------
+    // C layout of the 32x32 MFMA: column (channel) = lane & 31, row (pixel) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int hw = p.H * p.W;
+#pragma unroll
+    for (int j = 0; j < G::TN; ++j) {
+        const int n = n0 + wn * (G::TN * 32) + j * 32 + (lane & 31);
+        const float bias = p.bias[n];
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i) {
+            const long long mbase = m0 + wm * (G::TM * 32) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = mbase + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + bias;
+                if (m < p.M) {
+                    if (p.res) {
+                        if constexpr (sizeof(T) == 4)
+                            v += reinterpret_cast<const float*>(p.res)[(size_t)m * p.res_pitch + n];
+                        else
+                            v += bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.res)[(size_t)m * p.res_pitch + n]);
+                    }
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (p.out) {
+                        if constexpr (sizeof(T) == 4)
+                            reinterpret_cast<float*>(p.out)[(size_t)m * p.out_pitch + n] = v;
+                        else
+                            reinterpret_cast<unsigned short*>(p.out)[(size_t)m * p.out_pitch + n] = f32_to_bf16_bits(v);
+                    }
+                }
+                acc[i][j][r] = v;
+            }
+            if (p.out_nchw && n < p.cout_real) {
+                // 4 consecutive registers = 4 consecutive pixels of one plane
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long long m = mbase + 8 * q;
+                    if (m + 3 < p.M) {
+                        const long long view = m / hw;
+                        const int pix = (int)(m - view * hw);
+                        f32x4 o = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(p.out_nchw + ((size_t)view * p.cout_real + n) * hw + pix) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// stem: 7x7 / stride 2 / pad 3 convolution 3 -> 64 with folded BN + ReLU.  images f32 NHWC [V, H, W, 3].
+// Workgroup = 8 x 16 output pixels x 64 channels; input patch 21 x 37 x 3 and the whole 147 x 64 weight
+// matrix live in LDS.  K index k = ky*21 + kx*3 + c, so a patch row is contiguous in k.
+// -----------------------------------------------------------------------------------------------------
+struct StemArgs {
+    const float* img;
+    void* out;           // NHWC [V, H/2, W/2, 64] (T)
+    const float* w;      // [148][64] f32, k-major (row 147 = 0)
+    const float* bias;   // [64]
+    int V, H, W;         // input size
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
+    constexpr int PR = 21, PC = 37, PROW = 112;  // patch rows, cols, floats per patch row (111 padded)
+    constexpr int KTOT = 148;
+    __shared__ float patch[PR * PROW];
+    __shared__ float wl[KTOT * 64];
+    const int OH = p.H / 2, OW = p.W / 2;
+    const int tiles_x = OW / 16, tiles_y = OH / 8;
+    int b = blockIdx.x;
+    const int tx0 = (b % tiles_x) * 16;
+    b /= tiles_x;
+    const int ty0 = (b % tiles_y) * 8;
+    const int view = b / tiles_y;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < KTOT * 64 / 4; i += 256)
+        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
+    const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
+    const float* img = p.img + (size_t)view * p.H * p.W * 3;
+    for (int i = tid; i < PR * PROW; i += 256) {
+        const int r = i / PROW, cc = i % PROW;
+        const int y = iy0 + r, x = ix0 + cc / 3;
+        float v = 0.0f;
+        if (cc < PC * 3 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+            v = img[((size_t)y * p.W + x) * 3 + cc % 3];
+        patch[i] = v;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31;                 // pixel inside the wave's 2 x 16 sub-tile
+    const int py = wave * 2 + (m >> 4), px = m & 15;
+    const int a_base = (2 * py) * PROW + 6 * px;
+    const int khalf = lane >> 5;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+#pragma unroll 2
+    for (int s = 0; s < KTOT / 2; ++s) {
+        const int k = 2 * s + khalf;
+        const int ky = k / 21, kk = k - ky * 21;
+        const float a = (k < 147) ? patch[a_base + ky * PROW + kk] : 0.0f;
+        const float b0 = wl[k * 64 + (lane & 31)];
+        const float b1 = wl[k * 64 + 32 + (lane & 31)];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+    const int n = lane & 31;
+    const float bias0 = p.bias[n], bias1 = p.bias[32 + n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int oy = ty0 + wave * 2 + (mm >> 4), ox = tx0 + (mm & 15);
+        const size_t o = (((size_t)view * OH + oy) * OW + ox) * 64;
+        const float v0 = fmaxf(acc0[r] + bias0, 0.0f), v1 = fmaxf(acc1[r] + bias1, 0.0f);
+        if constexpr (sizeof(T) == 4) {
+            reinterpret_cast<float*>(p.out)[o + n] = v0;
+            reinterpret_cast<float*>(p.out)[o + 32 + n] = v1;
+        } else {
+            reinterpret_cast<unsigned short*>(p.out)[o + n] = f32_to_bf16_bits(v0);
+            reinterpret_cast<unsigned short*>(p.out)[o + 32 + n] = f32_to_bf16_bits(v1);
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// 2x2 max-pool and nearest-upsample + add: one thread per 16-byte channel chunk
+// -----------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ u32x4 max_chunk(u32x4 a, u32x4 b) {
+    if constexpr (sizeof(T) == 4) {
+        f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], y[i]);
+        return __builtin_bit_cast(u32x4, x);
+    } else {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float al = bf16_bits_to_f32((unsigned short)(a[i] & 0xffffu)), ah = bf16_bits_to_f32((unsigned short)(a[i] >> 16));
+            const float bl = bf16_bits_to_f32((unsigned short)(b[i] & 0xffffu)), bh = bf16_bits_to_f32((unsigned short)(b[i] >> 16));
+            o[i] = (unsigned)f32_to_bf16_bits(fmaxf(al, bl)) | ((unsigned)f32_to_bf16_bits(fmaxf(ah, bh)) << 16);
+        }
+        return o;
+    }
+}
+template <typename T>
+__device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b) {
+    if constexpr (sizeof(T) == 4) {
+        f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
+        x += y;
+        return __builtin_bit_cast(u32x4, x);
+    } else {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float al = bf16_bits_to_f32((unsigned short)(a[i] & 0xffffu)), ah = bf16_bits_to_f32((unsigned short)(a[i] >> 16));
+            const float bl = bf16_bits_to_f32((unsigned short)(b[i] & 0xffffu)), bh = bf16_bits_to_f32((unsigned short)(b[i] >> 16));
+            o[i] = (unsigned)f32_to_bf16_bits(al + bl) | ((unsigned)f32_to_bf16_bits(ah + bh) << 16);
+        }
+        return o;
+    }
+}
+
+// in [V, H, W, C] -> out [V, H/2, W/2, C];  chunks = C * sizeof(T) / 16 per pixel
+template <typename T>
+__global__ __launch_bounds__(256) void pool2_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, long long total,
+                                                    int OH, int OW, int chunks) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = (int)(idx % chunks);
+    long long pidx = idx / chunks;
+    const int ox = (int)(pidx % OW);
+    pidx /= OW;
+    const int oy = (int)(pidx % OH);
+    const long long v = pidx / OH;
+    const int W = OW * 2;
+    const size_t base = (((size_t)v * OH * 2 + 2 * oy) * W + 2 * ox) * chunks + ch;
+    const u32x4 a = in[base], b = in[base + chunks], c = in[base + (size_t)W * chunks], d = in[base + (size_t)W * chunks + chunks];
+    out[idx] = max_chunk<T>(max_chunk<T>(a, b), max_chunk<T>(c, d));
+}
+
+// out[v, y, x, :] = a[v, y, x, :] + b[v, y/2, x/2, :]   (out may alias a)
+template <typename T>
+__global__ __launch_bounds__(256) void upadd_kernel(const u32x4* a, const u32x4* __restrict__ b, u32x4* out, long long total,
+                                                    int H, int W, int chunks) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = (int)(idx % chunks);
+    long long pidx = idx / chunks;
+    const int x = (int)(pidx % W);
+    pidx /= W;
+    const int y = (int)(pidx % H);
+    const long long v = pidx / H;
+    const size_t bidx = (((size_t)v * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * chunks + ch;
+    out[idx] = add_chunk<T>(a[idx], b[bidx]);
+}
+
+// debug / parity export: NHWC with channel pitch -> dense float32 NHWC with c channels
+template <typename T>
+__global__ __launch_bounds__(256) void export_kernel(const void* __restrict__ in, float* __restrict__ out, long long pixels,
+                                                     int c, int pitch) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= pixels * c) return;
+    const long long pix = idx / c;
+    const int ch = (int)(idx % c);
+    if constexpr (sizeof(T) == 4)
+        out[idx] = reinterpret_cast<const float*>(in)[(size_t)pix * pitch + ch];
+    else
+        out[idx] = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(in)[(size_t)pix * pitch + ch]);
+}
+
+// weights f32 -> bf16 bits (round to nearest even)
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = f32_to_bf16_bits(in[i]);
+}
+
+}  // namespace hgk

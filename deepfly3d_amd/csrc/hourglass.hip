@@ -1,0 +1,533 @@
+// a2: stacked-hourglass engine -- layer plan, parameter manifest, workspace planning and launches.
+//
+// The engine owns WHICH kernel runs on WHICH tensor (the plan below is the 2-stack, depth-4,
+// pre-activation-bottleneck hourglass df2d uses: SURVEY.md App. B; constants reference df3d/config.py:18,33,36)
+// and nothing else: weights, activations and the stream belong to the caller.
+//
+// BatchNorm handling (eval mode): a BN that directly follows a convolution (bn2, bn3 inside a bottleneck, the
+// stem's bn1, the BN of fc) is folded into that convolution's weights and bias by the HOST packer; the BN on a
+// bottleneck's *input* (bn1) cannot be folded because the raw tensor also feeds the skip connection, so it is
+// applied as x*scale+shift -> ReLU while the conv1 kernel stages its input tile.
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "hg_kernels.h"
+
+using namespace hgk;
+
+namespace {
+
+enum StepKind { ST_STEM, ST_CONV, ST_POOL, ST_UPADD };
+
+struct TensorDesc {
+    size_t off;  // elements per view, from the start of the activation area
+    int h, w, c, pitch;
+};
+
+struct ConvPlan {
+    int taps, cin, cout, cin_pad, cout_pad;
+    bool preact, relu, nchw_out;
+    size_t w_off, b_off, s_off, t_off;  // float offsets into the blob (s/t only when preact)
+};
+
+struct Step {
+    StepKind kind;
+    std::string name;
+    int in, out, res;  // tensor ids (res = -1: none; UPADD: in = hi-res, res = low-res)
+    ConvPlan conv;
+};
+
+struct Allocator {
+    // first-fit allocator over "elements per view"; offsets multiple of 64 elements
+    struct Blk { size_t off, size; };
+    std::vector<Blk> free_list;
+    size_t top = 0, peak = 0;
+    size_t alloc(size_t n) {
+        n = (n + 63) & ~size_t(63);
+        for (size_t i = 0; i < free_list.size(); ++i)
+            if (free_list[i].size >= n) {
+                size_t off = free_list[i].off;
+                free_list[i].off += n;
+                free_list[i].size -= n;
+                if (!free_list[i].size) free_list.erase(free_list.begin() + i);
+                return off;
+            }
+        size_t off = top;
+        top += n;
+        peak = std::max(peak, top);
+        return off;
+    }
+    void release(size_t off, size_t n) {
+        n = (n + 63) & ~size_t(63);
+        free_list.push_back({off, n});
+        std::sort(free_list.begin(), free_list.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+        for (size_t i = 0; i + 1 < free_list.size();) {
+            if (free_list[i].off + free_list[i].size == free_list[i + 1].off) {
+                free_list[i].size += free_list[i + 1].size;
+                free_list.erase(free_list.begin() + i + 1);
+            } else
+                ++i;
+        }
+        if (!free_list.empty() && free_list.back().off + free_list.back().size == top) {
+            top = free_list.back().off;
+            free_list.pop_back();
+        }
+    }
+};
+
+}  // namespace
+
+struct df3d_hg {
+    int dtype = DF3D_DTYPE_F32;
+    int num_stacks = 2;
+    int H = 256, W = 512;
+    int classes = 19;
+    int rb_override = 0;  // 0 = auto, 64 or 128: staged row bytes per K-step (tuning knob)
+    std::vector<TensorDesc> tensors;
+    std::vector<Step> steps;
+    std::vector<df3d_hg_param> params;
+    size_t blob_floats = 0;
+    size_t act_elems_per_view = 0;
+    const float* blob = nullptr;
+    const void* lowp = nullptr;  // bf16 copy of the blob (same offsets, in elements) when dtype = bf16
+    int final_tensor = -1;
+    double flops_per_view = 0, elems_per_view = 0;
+
+    Allocator alloc;
+
+    int elem_bytes() const { return dtype == DF3D_DTYPE_BF16 ? 2 : 4; }
+
+    int new_tensor(int h, int w, int c, int pitch = 0) {
+        if (!pitch) pitch = c;
+        TensorDesc t{alloc.alloc((size_t)h * w * pitch), h, w, c, pitch};
+        tensors.push_back(t);
+        return (int)tensors.size() - 1;
+    }
+    void free_tensor(int id) {
+        const TensorDesc& t = tensors[id];
+        alloc.release(t.off, (size_t)t.h * t.w * t.pitch);
+    }
+    size_t add_param(const std::string& name, int kind, int taps, int cin, int cout, int cin_pad, int cout_pad, size_t count) {
+        df3d_hg_param p;
+        memset(&p, 0, sizeof(p));
+        snprintf(p.name, sizeof(p.name), "%s", name.c_str());
+        p.kind = kind;
+        p.taps = taps;
+        p.cin = cin;
+        p.cout = cout;
+        p.cin_pad = cin_pad;
+        p.cout_pad = cout_pad;
+        p.offset = blob_floats;
+        p.count = count;
+        blob_floats += (count + 63) & ~size_t(63);
+        params.push_back(p);
+        return p.offset;
+    }
+
+    // one convolution step; returns the output tensor id
+    int conv(const std::string& name, int in, int taps, int cout, bool preact, bool relu, int res, bool nchw_out = false) {
+        const TensorDesc ti = tensors[in];
+        const int cin = ti.c;
+        const int cin_pad = ti.pitch;                  // inputs are stored padded
+        const int cout_pad = (cout + 31) / 32 * 32;
+        Step st;
+        st.kind = ST_CONV;
+        st.name = name;
+        st.in = in;
+        st.res = res;
+        st.conv = ConvPlan{taps, cin, cout, cin_pad, cout_pad, preact, relu, nchw_out, 0, 0, 0, 0};
+        st.conv.w_off = add_param(name, 0, taps, cin, cout, cin_pad, cout_pad, (size_t)taps * cout_pad * cin_pad);
+        st.conv.b_off = add_param(name, 1, taps, cin, cout, cin_pad, cout_pad, cout_pad);
+        if (preact) {
+            st.conv.s_off = add_param(name, 2, taps, cin, cout, cin_pad, cout_pad, cin_pad);
+            st.conv.t_off = add_param(name, 3, taps, cin, cout, cin_pad, cout_pad, cin_pad);
+        }
+        st.out = nchw_out ? -1 : new_tensor(ti.h, ti.w, cout, cout_pad);
+        steps.push_back(st);
+        const double px = (double)ti.h * ti.w;
+        flops_per_view += 2.0 * px * taps * cin * cout;
+        elems_per_view += px * (cin + cout + (res >= 0 ? cout : 0));
+        return st.out;
+    }
+    int bottleneck(const std::string& name, int x, int planes) {
+        const int cin = tensors[x].c, cout = 2 * planes;
+        int a = conv(name + ".conv1", x, 1, planes, true, true, -1);
+        int b = conv(name + ".conv2", a, 9, planes, false, true, -1);
+        free_tensor(a);
+        int skip = x;
+        if (cin != cout) skip = conv(name + ".downsample.0", x, 1, cout, false, false, -1);
+        int o = conv(name + ".conv3", b, 1, cout, false, false, skip);
+        free_tensor(b);
+        if (skip != x) free_tensor(skip);
+        return o;
+    }
+    int pool(const std::string& name, int x) {
+        const TensorDesc t = tensors[x];
+        Step st;
+        st.kind = ST_POOL;
+        st.name = name;
+        st.in = x;
+        st.res = -1;
+        st.out = new_tensor(t.h / 2, t.w / 2, t.c, t.pitch);
+        steps.push_back(st);
+        elems_per_view += (double)t.h * t.w * t.c * 1.25;
+        return st.out;
+    }
+    // hi += upsample(lo), in place on hi
+    int upadd(const std::string& name, int hi, int lo) {
+        const TensorDesc t = tensors[hi];
+        Step st;
+        st.kind = ST_UPADD;
+        st.name = name;
+        st.in = hi;
+        st.res = lo;
+        st.out = hi;
+        steps.push_back(st);
+        elems_per_view += (double)t.h * t.w * t.c * 2.25;
+        return hi;
+    }
+    int hourglass(const std::string& name, int n, int x, int planes) {
+        const std::string lv = name + "." + std::to_string(n - 1);
+        int up1 = bottleneck(lv + ".0.0", x, planes);
+        int low = pool(lv + ".pool", x);
+        int low1 = bottleneck(lv + ".1.0", low, planes);
+        free_tensor(low);
+        int low2;
+        if (n > 1)
+            low2 = hourglass(name, n - 1, low1, planes);
+        else
+            low2 = bottleneck(lv + ".3.0", low1, planes);
+        free_tensor(low1);
+        int low3 = bottleneck(lv + ".2.0", low2, planes);
+        free_tensor(low2);
+        upadd(lv + ".upadd", up1, low3);
+        free_tensor(low3);
+        return up1;
+    }
+
+    void build() {
+        tensors.clear();
+        steps.clear();
+        params.clear();
+        blob_floats = 0;
+        alloc = Allocator();
+        flops_per_view = elems_per_view = 0;
+        // stem
+        Step st;
+        st.kind = ST_STEM;
+        st.name = "conv1";
+        st.in = -1;
+        st.res = -1;
+        st.conv = ConvPlan{49, 3, 64, 3, 64, false, true, false, 0, 0, 0, 0};
+        st.conv.w_off = add_param("conv1", 0, 49, 3, 64, 3, 64, 148 * 64);
+        st.conv.b_off = add_param("conv1", 1, 49, 3, 64, 3, 64, 64);
+        st.out = new_tensor(H / 2, W / 2, 64);
+        steps.push_back(st);
+        flops_per_view += 2.0 * (H / 2) * (W / 2) * 147 * 64;
+        elems_per_view += (double)H * W * 3 + (double)(H / 2) * (W / 2) * 64;
+        int x = st.out;
+        int l1 = bottleneck("layer1.0", x, 64);
+        free_tensor(x);
+        int p1 = pool("maxpool", l1);
+        free_tensor(l1);
+        int l2 = bottleneck("layer2.0", p1, 128);
+        free_tensor(p1);
+        x = bottleneck("layer3.0", l2, 128);
+        free_tensor(l2);
+        for (int s = 0; s < num_stacks; ++s) {
+            const std::string S = std::to_string(s);
+            int y = hourglass("hg." + S + ".hg", 4, x, 128);
+            int r = bottleneck("res." + S + ".0", y, 128);
+            free_tensor(y);
+            int f = conv("fc." + S + ".0", r, 1, 256, false, true, -1);
+            free_tensor(r);
+            const bool last = s == num_stacks - 1;
+            int sc = conv("score." + S, f, 1, classes, false, false, -1, last);
+            if (!last) {
+                int t = conv("fc_." + S, f, 1, 256, false, false, x);
+                free_tensor(f);
+                free_tensor(x);
+                int xn = conv("score_." + S, sc, 1, 256, false, false, t);
+                free_tensor(sc);
+                free_tensor(t);
+                x = xn;
+            } else {
+                free_tensor(f);
+                free_tensor(x);
+            }
+        }
+        act_elems_per_view = alloc.peak;
+    }
+};
+
+namespace {
+
+template <typename T, int TAPS, int BN, int RB>
+int launch_conv_t(const ConvArgs& a, hipStream_t s) {
+    constexpr int LDS = 2 * (BM + BN) * (RB + 16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, TAPS, BN, RB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    const long long mt = (a.M + BM - 1) / BM;
+    dim3 grid((unsigned)mt, (unsigned)(a.cout / BN));
+    hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, BN, RB>), grid, dim3(256), LDS, s, a);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+template <typename T, int TAPS, int BN>
+int launch_conv_rb(const ConvArgs& a, int rb, hipStream_t s) {
+    if (rb == 128) return launch_conv_t<T, TAPS, BN, 128>(a, s);
+    return launch_conv_t<T, TAPS, BN, 64>(a, s);
+}
+
+template <typename T>
+int launch_conv(const ConvArgs& a, int taps, int rb, hipStream_t s) {
+    const int bn = (a.cout % 128 == 0) ? 128 : (a.cout % 64 == 0 ? 64 : 32);
+    if (taps == 1) {
+        if (bn == 128) return launch_conv_rb<T, 1, 128>(a, rb, s);
+        if (bn == 64) return launch_conv_rb<T, 1, 64>(a, rb, s);
+        return launch_conv_rb<T, 1, 32>(a, rb, s);
+    }
+    if (bn == 128) return launch_conv_rb<T, 9, 128>(a, rb, s);
+    if (bn == 64) return launch_conv_rb<T, 9, 64>(a, rb, s);
+    df3d::set_error("3x3 convolution with cout %d unsupported", a.cout);
+    return DF3D_EINVAL;
+}
+
+template <typename T>
+int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps, unsigned char* act, hipStream_t s) {
+    const int eb = sizeof(T);
+    auto tptr = [&](int id) -> unsigned char* { return act + h->tensors[id].off * (size_t)n * eb; };
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(eb == 4 ? (const void*)h->blob : h->lowp);
+    for (int i = 0; i < upto; ++i) {
+        const Step& st = h->steps[i];
+        switch (st.kind) {
+            case ST_STEM: {
+                StemArgs a;
+                a.img = images;
+                a.out = tptr(st.out);
+                a.w = h->blob + st.conv.w_off;
+                a.bias = h->blob + st.conv.b_off;
+                a.V = n;
+                a.H = h->H;
+                a.W = h->W;
+                const int blocks = n * (h->H / 2 / 8) * (h->W / 2 / 16);
+                hipLaunchKernelGGL((stem_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
+                DF3D_LAUNCH_CHECK();
+                break;
+            }
+            case ST_CONV: {
+                const TensorDesc& ti = h->tensors[st.in];
+                ConvArgs a;
+                a.in = tptr(st.in);
+                a.out = st.out >= 0 ? tptr(st.out) : nullptr;
+                a.res = st.res >= 0 ? tptr(st.res) : nullptr;
+                a.out_nchw = st.conv.nchw_out ? heatmaps : nullptr;
+                a.w = wb + st.conv.w_off * eb;
+                a.bias = h->blob + st.conv.b_off;
+                a.scale = st.conv.preact ? h->blob + st.conv.s_off : nullptr;
+                a.shift = st.conv.preact ? h->blob + st.conv.t_off : nullptr;
+                a.M = (long long)n * ti.h * ti.w;
+                a.H = ti.h;
+                a.W = ti.w;
+                a.cin = st.conv.cin_pad;
+                a.cout = st.conv.cout_pad;
+                a.in_pitch = ti.pitch;
+                a.out_pitch = st.out >= 0 ? h->tensors[st.out].pitch : 0;
+                a.res_pitch = st.res >= 0 ? h->tensors[st.res].pitch : 0;
+                a.relu = st.conv.relu;
+                a.cout_real = st.conv.cout;
+                const int ke128 = 128 / eb;
+                int rb = (st.conv.cin_pad % ke128 == 0) ? 128 : 64;
+                if (h->rb_override == 64) rb = 64;
+                if (int rc = launch_conv<T>(a, st.conv.taps, rb, s)) return rc;
+                break;
+            }
+            case ST_POOL: {
+                const TensorDesc& to = h->tensors[st.out];
+                const int chunks = to.pitch * eb / 16;
+                const long long total = (long long)n * to.h * to.w * chunks;
+                hipLaunchKernelGGL((pool2_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                                   reinterpret_cast<const u32x4*>(tptr(st.in)), reinterpret_cast<u32x4*>(tptr(st.out)),
+                                   total, to.h, to.w, chunks);
+                DF3D_LAUNCH_CHECK();
+                break;
+            }
+            case ST_UPADD: {
+                const TensorDesc& to = h->tensors[st.out];
+                const int chunks = to.pitch * eb / 16;
+                const long long total = (long long)n * to.h * to.w * chunks;
+                hipLaunchKernelGGL((upadd_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                                   reinterpret_cast<const u32x4*>(tptr(st.in)), reinterpret_cast<const u32x4*>(tptr(st.res)),
+                                   reinterpret_cast<u32x4*>(tptr(st.out)), total, to.h, to.w, chunks);
+                DF3D_LAUNCH_CHECK();
+                break;
+            }
+        }
+    }
+    return DF3D_OK;
+}
+
+int check_forward_args(df3d_hg* h, const float* images, int n, void* ws, size_t ws_bytes) {
+    DF3D_CHECK_ARG(h != nullptr, "null handle");
+    if (!h->blob) {
+        df3d::set_error("df3d_hg_forward: weights not set (call df3d_hg_set_weights first)");
+        return DF3D_ESTATE;
+    }
+    DF3D_CHECK_ARG(n > 0, "n must be positive");
+    DF3D_CHECK_ARG(images && ws, "null pointer");
+    DF3D_CHECK_ARG(ws_bytes >= df3d_hg_workspace_bytes(h, n), "workspace too small");
+    DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "workspace must be 256-byte aligned");
+    return DF3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int df3d_hg_create(int dtype, int num_stacks, df3d_hg** out) {
+    DF3D_CHECK_ARG(out != nullptr, "null out");
+    DF3D_CHECK_ARG(dtype == DF3D_DTYPE_F32 || dtype == DF3D_DTYPE_BF16, "dtype must be DF3D_DTYPE_F32 or DF3D_DTYPE_BF16");
+    DF3D_CHECK_ARG(num_stacks >= 1 && num_stacks <= 8, "num_stacks must be in [1, 8]");
+    df3d_hg* h = new df3d_hg();
+    h->dtype = dtype;
+    h->num_stacks = num_stacks;
+    h->build();
+    *out = h;
+    return DF3D_OK;
+}
+
+void df3d_hg_destroy(df3d_hg* h) { delete h; }
+
+int df3d_hg_set_input(df3d_hg* h, int height, int width) {
+    DF3D_CHECK_ARG(h != nullptr, "null handle");
+    DF3D_CHECK_ARG(height > 0 && width > 0 && height % 64 == 0 && width % 64 == 0, "input height and width must be multiples of 64");
+    h->H = height;
+    h->W = width;
+    const float* blob = h->blob;
+    const void* lowp = h->lowp;
+    h->build();  // parameter manifest does not depend on the spatial size
+    h->blob = blob;
+    h->lowp = lowp;
+    return DF3D_OK;
+}
+
+int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
+    DF3D_CHECK_ARG(h && key, "null argument");
+    if (!strcmp(key, "row_bytes")) {
+        DF3D_CHECK_ARG(value == 0 || value == 64 || value == 128, "row_bytes must be 0, 64 or 128");
+        h->rb_override = value;
+        return DF3D_OK;
+    }
+    df3d::set_error("df3d_hg_set_option: unknown key %s", key);
+    return DF3D_EINVAL;
+}
+
+int df3d_hg_num_params(const df3d_hg* h) { return h ? (int)h->params.size() : 0; }
+
+int df3d_hg_param_desc(const df3d_hg* h, int i, df3d_hg_param* out) {
+    DF3D_CHECK_ARG(h && out, "null argument");
+    DF3D_CHECK_ARG(i >= 0 && i < (int)h->params.size(), "index out of range");
+    *out = h->params[i];
+    return DF3D_OK;
+}
+
+size_t df3d_hg_blob_floats(const df3d_hg* h) { return h ? h->blob_floats : 0; }
+
+size_t df3d_hg_lowp_bytes(const df3d_hg* h) {
+    if (!h || h->dtype != DF3D_DTYPE_BF16) return 0;
+    return h->blob_floats * 2;
+}
+
+int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void* stream) {
+    DF3D_CHECK_ARG(h && blob_dev, "null argument");
+    DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(blob_dev) & 255) == 0, "blob must be 256-byte aligned");
+    if (h->dtype == DF3D_DTYPE_BF16) {
+        DF3D_CHECK_ARG(lowp_dev != nullptr, "bf16 engine needs a df3d_hg_lowp_bytes() device buffer");
+        DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(lowp_dev) & 255) == 0, "lowp buffer must be 256-byte aligned");
+        hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(1024), dim3(256), 0, df3d::as_stream(stream), blob_dev,
+                           reinterpret_cast<unsigned short*>(lowp_dev), h->blob_floats);
+        DF3D_LAUNCH_CHECK();
+        h->lowp = lowp_dev;
+    }
+    h->blob = blob_dev;
+    return DF3D_OK;
+}
+
+size_t df3d_hg_workspace_bytes(const df3d_hg* h, int n) {
+    if (!h || n <= 0) return 0;
+    return h->act_elems_per_view * (size_t)n * h->elem_bytes() + 256;
+}
+
+int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_dev, void* workspace_dev,
+                    size_t workspace_bytes, void* stream) {
+    if (int rc = check_forward_args(h, images_dev, n, workspace_dev, workspace_bytes)) return rc;
+    DF3D_CHECK_ARG(heatmaps_dev != nullptr, "null heatmaps");
+    unsigned char* act = reinterpret_cast<unsigned char*>(workspace_dev);
+    if (h->dtype == DF3D_DTYPE_F32)
+        return run_steps<float>(h, images_dev, n, (int)h->steps.size(), heatmaps_dev, act, df3d::as_stream(stream));
+    return run_steps<__hip_bfloat16>(h, images_dev, n, (int)h->steps.size(), heatmaps_dev, act, df3d::as_stream(stream));
+}
+
+int df3d_hg_work(const df3d_hg* h, int n, double* flops, double* bytes) {
+    DF3D_CHECK_ARG(h && flops && bytes, "null argument");
+    *flops = h->flops_per_view * n;
+    *bytes = h->elems_per_view * n * h->elem_bytes();
+    return DF3D_OK;
+}
+
+int df3d_hg_num_steps(const df3d_hg* h) { return h ? (int)h->steps.size() : 0; }
+
+int df3d_hg_step_desc(const df3d_hg* h, int step, char* name_buf, int buflen, int* hwc) {
+    DF3D_CHECK_ARG(h && name_buf && hwc && buflen > 0, "null argument");
+    DF3D_CHECK_ARG(step >= 0 && step < (int)h->steps.size(), "step out of range");
+    const Step& st = h->steps[step];
+    snprintf(name_buf, buflen, "%s", st.name.c_str());
+    if (st.out >= 0) {
+        const TensorDesc& t = h->tensors[st.out];
+        hwc[0] = t.h;
+        hwc[1] = t.w;
+        hwc[2] = t.c;
+    } else {
+        hwc[0] = h->H / 4;
+        hwc[1] = h->W / 4;
+        hwc[2] = h->classes;
+    }
+    return DF3D_OK;
+}
+
+int df3d_hg_forward_upto(df3d_hg* h, const float* images_dev, int n, int upto, float* out_dev, void* workspace_dev,
+                         size_t workspace_bytes, void* stream) {
+    if (int rc = check_forward_args(h, images_dev, n, workspace_dev, workspace_bytes)) return rc;
+    DF3D_CHECK_ARG(upto >= 1 && upto <= (int)h->steps.size(), "upto out of range");
+    DF3D_CHECK_ARG(out_dev != nullptr, "null output");
+    const Step& st = h->steps[upto - 1];
+    unsigned char* act = reinterpret_cast<unsigned char*>(workspace_dev);
+    hipStream_t s = df3d::as_stream(stream);
+    // a final NCHW step writes straight into out_dev (as heat-maps)
+    int rc;
+    if (h->dtype == DF3D_DTYPE_F32)
+        rc = run_steps<float>(h, images_dev, n, upto, out_dev, act, s);
+    else
+        rc = run_steps<__hip_bfloat16>(h, images_dev, n, upto, out_dev, act, s);
+    if (rc) return rc;
+    if (st.out < 0) return DF3D_OK;
+    const TensorDesc& t = h->tensors[st.out];
+    const long long pixels = (long long)n * t.h * t.w;
+    const long long total = pixels * t.c;
+    const void* src = act + t.off * (size_t)n * h->elem_bytes();
+    if (h->dtype == DF3D_DTYPE_F32)
+        hipLaunchKernelGGL((export_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, out_dev, pixels, t.c, t.pitch);
+    else
+        hipLaunchKernelGGL((export_kernel<__hip_bfloat16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, out_dev, pixels, t.c, t.pitch);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+}  // extern "C"

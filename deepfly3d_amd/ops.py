@@ -1,0 +1,66 @@
+"""Thin host wrappers over the C ABI for the non-network kernels (a3 arg-max, a4 re-layout, a6 triangulation).
+
+Inputs/outputs are torch CUDA tensors (device memory + stream plumbing only); every computation is a
+libdf3d_hip.so kernel.  No CPU fallback: a missing library or GPU raises `_native.NativeLibraryError`.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need(t, dtype, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous {dtype} CUDA tensor")
+
+
+def heatmap_argmax(heatmaps):
+    """heatmaps [n, J, H, W] float32 (cuda) -> (points [n, J, 2] float32 (row/H, col/W), conf [n, J] float32)."""
+    lib = _native.load()
+    _need(heatmaps, torch.float32, "heatmaps")
+    n, j, h, w = heatmaps.shape
+    pts = torch.empty((n, j, 2), dtype=torch.float32, device=heatmaps.device)
+    conf = torch.empty((n, j), dtype=torch.float32, device=heatmaps.device)
+    _native.check(
+        lib.df3d_heatmap_argmax(heatmaps.data_ptr(), n, j, h, w, pts.data_ptr(), conf.data_ptr(), _stream(heatmaps)),
+        "df3d_heatmap_argmax",
+    )
+    return pts, conf
+
+
+def relayout_19_to_38(points19, camera_ordering):
+    """points19 [7, T, 19, 2] float32 (cuda) -> [7, T, 38, 2] float64 (reference df3d/core.py:187-203)."""
+    lib = _native.load()
+    _need(points19, torch.float32, "points19")
+    if points19.shape[0] != 7 or points19.shape[2] != 19 or points19.shape[3] != 2:
+        raise ValueError("points19 must be [7, T, 19, 2]")
+    T = points19.shape[1]
+    order = (ctypes.c_int * 7)(*[int(c) for c in camera_ordering])
+    out = torch.empty((7, T, 38, 2), dtype=torch.float64, device=points19.device)
+    _native.check(lib.df3d_relayout_19_to_38(points19.data_ptr(), order, T, out.data_ptr(), _stream(points19)), "df3d_relayout_19_to_38")
+    return out
+
+
+def triangulate(P, points2d_px):
+    """P [ncam, 3, 4] float64 (numpy or tensor), points2d_px [ncam, T, J, 2] float64 cuda (row_px, col_px)
+    -> X [T, J, 3] float64 cuda; zeros where fewer than two cameras see the joint."""
+    lib = _native.load()
+    _need(points2d_px, torch.float64, "points2d_px")
+    ncam, T, J, two = points2d_px.shape
+    if two != 2:
+        raise ValueError("points2d_px must be [ncam, T, J, 2]")
+    Ph = np.ascontiguousarray(P.detach().cpu().numpy() if isinstance(P, torch.Tensor) else P, dtype=np.float64)
+    if Ph.shape != (ncam, 3, 4):
+        raise ValueError("P must be [ncam, 3, 4]")
+    X = torch.empty((T, J, 3), dtype=torch.float64, device=points2d_px.device)
+    _native.check(
+        lib.df3d_triangulate(Ph.ctypes.data_as(ctypes.c_void_p), points2d_px.data_ptr(), ncam, T, J, X.data_ptr(), _stream(points2d_px)),
+        "df3d_triangulate",
+    )
+    return X

@@ -1,0 +1,188 @@
+/*
+ * df3d_hip.h -- C ABI of libdf3d_hip.so, the MI355X (gfx950) back-end of the DeepFly3D per-frame hot
+ * path.  Plain C: pointers, sizes, no torch / C++ types.  This is the drop-in boundary: every entry
+ * point replaces one piece of work the reference reaches through its two Python imports
+ *     from df2d.inference import inference_folder        (reference df3d/core.py:11)
+ *     from pyba.CameraNetwork import CameraNetwork       (reference df3d/core.py:12)
+ * The reference has no FFI of its own; INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer named *_dev is DEVICE memory owned by the caller (a torch tensor's data_ptr()).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous
+ *     on that stream unless the comment says "synchronous".
+ *   - return value: 0 = DF3D_OK, negative = error; df3d_last_error() returns a thread-local message.
+ *   - no exceptions cross the ABI; handles are not thread-safe, distinct handles are independent.
+ */
+#ifndef DF3D_HIP_H
+#define DF3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DF3D_OK 0
+#define DF3D_EINVAL (-1)  /* bad argument                       */
+#define DF3D_EHIP (-2)    /* a HIP runtime call failed          */
+#define DF3D_ESTATE (-3)  /* handle not ready (weights missing) */
+#define DF3D_ENOGPU (-4)  /* no gfx950 device visible           */
+
+#define DF3D_DTYPE_F32 0
+#define DF3D_DTYPE_BF16 1
+
+const char* df3d_last_error(void);
+int df3d_version(void);
+/* number of visible HIP devices (<0 on error); name of device `dev` copied to buf */
+int df3d_device_count(void);
+int df3d_device_name(int dev, char* buf, int buflen);
+
+/* ------------------------------------------------------------------------------------------------
+ * a3  heat-map -> point + confidence.   Replaces df2d's heatmap2points / confidence extraction behind
+ *     inference_folder(..., return_confidence=True)          (reference df3d/core.py:177-185,
+ *     semantics reference README.md:404: arg-max over (h, w), confidence = the max value).
+ * hm_dev   [n, joints, h, w] float32 planes (NCHW, the reference's heat-map layout)
+ * pts_dev  [n, joints, 2]    float32   (row / h, col / w)   -- the reference's normalised (row, col)
+ * conf_dev [n, joints]       float32   the peak value
+ * Ties resolve to the first index in row-major order.  h*w must be a multiple of 4.
+ * ---------------------------------------------------------------------------------------------- */
+int df3d_heatmap_argmax(const float* hm_dev, int n, int joints, int h, int w, float* pts_dev, float* conf_dev,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a4  19 -> 38 joint re-layout and un-flip.   Replaces reference df3d/core.py:187-203.
+ * pts19_dev [7, T, 19, 2] float32 (network order), ordering[7] HOST ints (camera_ordering),
+ * out_dev   [7, T, 38, 2] float64 normalised (row, col).
+ * ---------------------------------------------------------------------------------------------- */
+int df3d_relayout_19_to_38(const float* pts19_dev, const int* ordering_host, int T, double* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a6  multi-view DLT triangulation.   Replaces pyba CameraNetwork.triangulate()
+ *     (call site reference df3d/core.py:355).
+ * P          [ncam, 3, 4] float64   K[R|t], pixel units (device OR host pointer; 84 doubles travel as
+ *            a kernel argument)
+ * pts_px_dev [ncam, T, J, 2] float64 (row_px, col_px); a camera sees (t, j) iff both are != 0
+ * X_dev      [T, J, 3] float64; 0 where fewer than 2 cameras see the joint.      ncam <= 8.
+ * ---------------------------------------------------------------------------------------------- */
+int df3d_triangulate(const double* P, const double* pts_px_dev, int ncam, int T, int J, double* X_dev,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a7  bundle adjustment building blocks.   Replaces the arithmetic under pyba
+ *     CameraNetwork.bundle_adjust(update_intrinsic=False, update_distort=False)
+ *     (call site reference df3d/core.py:249).  Unknowns x = [ncam x (rvec, tvec)] ++ [npts x XYZ];
+ *     observation i links camera cam_idx[i] to point pt_idx[i]; observations of one point are
+ *     contiguous: point p owns observations [pt_start[p], pt_start[p+1]).
+ * All arrays are device float64 / int32.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct df3d_ba_problem {
+    int ncam;              /* <= 8                                                        */
+    int nobs;              /* number of 2-D observations (residual vector has 2*nobs)     */
+    int npts;              /* number of 3-D points                                        */
+    const double* intr4;   /* [ncam, 4]  fx, fy, cx, cy                                   */
+    const double* obs_xy;  /* [nobs, 2]  x = col_px, y = row_px                           */
+    const int* cam_idx;    /* [nobs]                                                      */
+    const int* pt_idx;     /* [nobs]                                                      */
+    const int* pt_start;   /* [npts + 1]  observations of point p: [pt_start[p], pt_start[p+1]) */
+    const int* cam_perm;   /* [nobs]      observation ids grouped by camera (stable order)      */
+    const int* cam_start;  /* [ncam + 1]  camera c owns cam_perm[cam_start[c] : cam_start[c+1]] */
+} df3d_ba_problem;
+
+/* Jacobian storage is component-major so per-observation threads read/write coalesced:
+ *   Jc_dev [12, nobs]  entry (row*6 + col, i) = d r[2i+row] / d cam(cam_idx[i])[col]   (rvec 0..2, tvec 3..5)
+ *   Jp_dev [ 6, nobs]  entry (row*3 + col, i) = d r[2i+row] / d point(pt_idx[i])[col]
+ * scratch_dev arguments need DF3D_BA_SCRATCH_DOUBLES doubles; reductions run in a fixed order, so
+ * results are bit-reproducible run to run. */
+#define DF3D_BA_SCRATCH_DOUBLES 4096
+
+/* residuals r[2*nobs] (interleaved x0,y0,x1,y1,...) and analytic Jacobian blocks at x; any of
+ * r_dev / Jc_dev / Jp_dev may be NULL to skip it (Jc and Jp go together). */
+int df3d_ba_eval(const df3d_ba_problem* p, const double* x_dev, double* r_dev, double* Jc_dev, double* Jp_dev,
+                 void* stream);
+/* colsq[n] = sum over rows of J[:, k]^2  (for scipy's x_scale='jac').  n = 6*ncam + 3*npts */
+int df3d_ba_colsq(const df3d_ba_problem* p, const double* Jc_dev, const double* Jp_dev, double* colsq_dev,
+                  double* scratch_dev, void* stream);
+/* y[2*nobs] = J * (d .* v)      (d_dev may be NULL = ones) */
+int df3d_ba_matvec(const df3d_ba_problem* p, const double* Jc_dev, const double* Jp_dev, const double* d_dev,
+                   const double* v_dev, double* y_dev, void* stream);
+/* w[n] = d .* (J^T u)           (d_dev may be NULL = ones) */
+int df3d_ba_rmatvec(const df3d_ba_problem* p, const double* Jc_dev, const double* Jp_dev, const double* d_dev,
+                    const double* u_dev, double* w_dev, double* scratch_dev, void* stream);
+
+/* LSMR on A = J*diag(d) with Tikhonov `damp`, the inner solve of scipy's TRF (tr_solver='lsmr').
+ * Synchronous (reads scalars back every iteration).  x_dev[n] receives the solution.
+ * work_dev: at least df3d_ba_lsmr_work_doubles(p) doubles (includes the scratch).  info_host[8] =
+ * {istop, itn, normr, normar, normA, condA, normx, 0}. */
+size_t df3d_ba_lsmr_work_doubles(const df3d_ba_problem* p);
+int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc_dev, const double* Jp_dev, const double* d_dev,
+                 const double* b_dev, double damp, double atol, double btol, double conlim, int maxiter,
+                 double* x_dev, double* work_dev, double* info_host, void* stream);
+
+/* small device-vector helpers used by the host TRF driver (all float64, asynchronous except dot) */
+int df3d_vec_dot(const double* a_dev, const double* b_dev, size_t n, double* result_host, double* scratch_dev,
+                 void* stream); /* synchronous; scratch_dev >= 1024 doubles */
+int df3d_vec_axpby(double a, const double* x_dev, double b, const double* y_dev, double* out_dev, size_t n,
+                   void* stream); /* out = a*x + b*y (y may be NULL)        */
+int df3d_vec_mul(const double* x_dev, const double* y_dev, double* out_dev, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a2  stacked-hourglass forward.   Replaces the network forward inside df2d's inference_folder
+ *     (call site reference df3d/core.py:177-185; 2 stacks / 19 maps / 64x128 heat-maps:
+ *     reference df3d/config.py:18,33,36).
+ *
+ * The engine owns the layer plan (which convolution follows which); the caller owns all memory:
+ *   1. df3d_hg_create(dtype, num_stacks, &h)
+ *   2. for i in [0, df3d_hg_num_params(h)): df3d_hg_param_desc(h, i, &d) names one packed tensor
+ *      (e.g. "layer1.0.conv1") with its shape; the caller fills a float32 host blob of
+ *      df3d_hg_blob_floats(h) floats at d.offset and uploads it:  df3d_hg_set_weights(h, blob_dev, ...).
+ *      Packed layout per convolution: weight [taps][cout_pad][cin_pad] (k contiguous), bias[cout_pad],
+ *      and for pre-activated convs in_scale[cin_pad], in_shift[cin_pad] (eval-mode BN as y = x*s + t).
+ *      The stem ("conv1", taps = 49) is packed [148][64]: row k = ky*21 + kx*3 + c, 64 outputs contiguous.
+ *      BatchNorms that FOLLOW a convolution are folded into its weight/bias by the caller (the Python packer
+ *      deepfly3d_amd/hourglass.py does this in float64).
+ *   3. df3d_hg_forward(h, images_dev, n, heatmaps_dev, workspace_dev, workspace_bytes, stream)
+ *      images_dev   [n, 256, 512, 3] float32 NHWC      (any H, W multiple of 64 via df3d_hg_set_input)
+ *      heatmaps_dev [n, 19, H/4, W/4] float32 NCHW
+ *      workspace    >= df3d_hg_workspace_bytes(h, n)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct df3d_hg df3d_hg;
+
+typedef struct df3d_hg_param {
+    char name[64];   /* e.g. "hg.0.hg.3.0.0.conv2"                                    */
+    int kind;        /* 0 weight, 1 bias, 2 in_scale, 3 in_shift                       */
+    int taps;        /* 1, 9 or 49                                                     */
+    int cin, cout;   /* logical sizes                                                  */
+    int cin_pad, cout_pad;
+    size_t offset;   /* in floats, into the blob                                       */
+    size_t count;    /* in floats                                                      */
+} df3d_hg_param;
+
+int df3d_hg_create(int dtype, int num_stacks, df3d_hg** out);
+void df3d_hg_destroy(df3d_hg* h);
+int df3d_hg_set_input(df3d_hg* h, int height, int width);
+int df3d_hg_num_params(const df3d_hg* h);
+int df3d_hg_param_desc(const df3d_hg* h, int i, df3d_hg_param* out);
+size_t df3d_hg_blob_floats(const df3d_hg* h);
+/* bf16 engines keep a bf16 copy of the blob: lowp_dev must hold df3d_hg_lowp_bytes(h) bytes (NULL for f32). */
+size_t df3d_hg_lowp_bytes(const df3d_hg* h);
+int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void* stream);
+/* tuning knobs: "row_bytes" = 0 (auto) | 64 | 128 bytes staged per operand row per K-step */
+int df3d_hg_set_option(df3d_hg* h, const char* key, int value);
+size_t df3d_hg_workspace_bytes(const df3d_hg* h, int n);
+int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_dev, void* workspace_dev,
+                    size_t workspace_bytes, void* stream);
+/* algorithmic work of one forward over n views: FLOPs and activation bytes (fusion model M1 of
+ * SURVEY.md 8d evaluated on this engine's own plan) */
+int df3d_hg_work(const df3d_hg* h, int n, double* flops, double* bytes);
+/* debugging / layer-wise parity: number of plan steps, and run only steps [0, upto) then copy the
+ * tensor produced by step upto-1 (NHWC, engine dtype widened to float32) into out_dev */
+int df3d_hg_num_steps(const df3d_hg* h);
+int df3d_hg_step_desc(const df3d_hg* h, int step, char* name_buf, int buflen, int* n_h_w_c /*[3]: h, w, c*/);
+int df3d_hg_forward_upto(df3d_hg* h, const float* images_dev, int n, int upto, float* out_dev, void* workspace_dev,
+                         size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DF3D_HIP_H */
