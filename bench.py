@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Benchmark of the DeepFly3D per-frame hot path on MI355X (BASELINE.json metric: frames/sec, 7-view 2D -> 3D).
+
+    python bench.py --gpus 1 --steps 125 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): per GPU `steps x frames_per_step` synthetic frames (default 125 x 8 = 1 000),
+each 7 views of 256 x 512 x 3 float32, seeded and resident in HBM before the timed region; 2-stack hourglass in
+fp32 with seeded synthetic weights (no checkpoints offline); fixed calib.pkl cameras.  One "step" = one batch of
+`frames_per_step` frames through the whole path: hourglass -> arg-max/confidence -> 19->38 layout -> DLT.
+N > 1: every rank owns its own frame range (weak scaling) and the per-frame results are gathered to rank 0 once
+(RCCL), inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+PEAK_HBM_GBS = 8000.0
+KERNEL_CLASSES = ["conv1x1_mfma", "conv3x3_mfma", "stem7x7_mfma", "maxpool2", "upsample_add"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=125)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--pool-frames", type=int, default=0, help="distinct frames resident in HBM (0 = steps*frames_per_step, capped at 1000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def host_cores():
+    """Usable host cores: CPU affinity, clipped by the cgroup CPU quota when the box is containerised."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(np.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(state_dict, frames_cpu, calib, target_seconds):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores, bounded sample."""
+    from oracle import geometry as og
+    from oracle import hourglass_torch as oh
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    net = oh.HourglassNet()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state_dict.items()}, strict=False)
+    net.eval()
+    P = og.projection_matrices(calib["R"], calib["tvec"], calib["intr"])
+
+    def run(frames):
+        F = frames.shape[0]
+        hm = oh.forward_nhwc(net, frames.reshape(F * 7, *frames.shape[2:])).numpy()
+        pts, conf = og.heatmap_argmax(hm)
+        pts = pts.reshape(F, 7, 19, 2).transpose(1, 0, 2, 3)
+        p38 = og.relayout_19_to_38(pts, list(range(7)))
+        return og.triangulate_dlt_batched(og.pixels_from_normalised(p38, [960, 480]), P)
+
+    t0 = time.time()
+    run(frames_cpu[:1])
+    t1 = time.time() - t0
+    n = int(max(1, min(frames_cpu.shape[0], round(target_seconds / max(t1, 1e-3)))))
+    t0 = time.time()
+    run(frames_cpu[:n])
+    dt = time.time() - t0
+    return {
+        "value": n / dt,
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n} frames x 7 views (256x512 f32): torch-CPU fp32 hourglass + numpy arg-max/layout/DLT, {dt:.1f} s",
+    }
+
+
+def main():
+    a = parse()
+    from deepfly3d_amd import _native
+    from deepfly3d_amd import distributed as dd
+    from deepfly3d_amd.config import load_calibration
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.pipeline import FramePipeline
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    rank, world, local_rank = dd.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    _native.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    fps_step = a.frames_per_step
+    sd = synthetic_state_dict(0)
+    engine = HourglassEngine(sd, dtype=a.dtype, device=dev)
+    cal = load_calibration()
+    calib = {k: np.stack([cal[c][k] for c in range(7)]) for k in ("R", "tvec", "intr", "distort")}
+    pipe = FramePipeline(engine, calib["R"], calib["tvec"], calib["intr"])
+
+    total_frames = a.steps * fps_step
+    pool = a.pool_frames or min(total_frames, 1000)
+    pool = max(fps_step, (pool // fps_step) * fps_step)
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    frames = torch.empty((pool, 7, 256, 512, 3), dtype=torch.float32, device=dev)
+    for i in range(0, pool, 64):  # bounded temporary memory
+        frames[i : i + 64].uniform_(0.0, 1.0, generator=gen)
+    outs = pipe.allocate_outputs(total_frames)
+
+    def step(i, t0):
+        lo = (i * fps_step) % pool
+        pipe.run_batch(frames[lo : lo + fps_step], *outs, t0)
+
+    for w in range(a.warmup):
+        step(w, 0)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t_start = time.perf_counter()
+    for i in range(a.steps):
+        step(i, i * fps_step)
+    gathered = dd.gather_results(*outs, num_frames=total_frames * world, rank=rank, world_size=world)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roof = None
+    if not a.no_roofline and rank == 0:
+        # same stream, HIP events around every launch of each kernel class, over a few steps
+        lib = _native.load()
+        import ctypes
+
+        _native.check(lib.df3d_hg_profile(engine.h, 1))
+        nprof = min(a.steps, 4)
+        for i in range(nprof):
+            step(i, i * fps_step)
+        torch.cuda.synchronize()
+        per = []
+        for k, name in enumerate(KERNEL_CLASSES):
+            ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+            _native.check(lib.df3d_hg_profile_read(engine.h, k, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n)))
+            if n.value:
+                per.append({"kernel": name, "launches": n.value, "avg_us": 1e3 * ms.value / n.value, "total_ms": ms.value,
+                            "tflops": fl.value / ms.value / 1e9, "gbs_algorithmic": by.value / ms.value / 1e6})
+        _native.check(lib.df3d_hg_profile(engine.h, 0))
+        dom = max(per, key=lambda d: d["total_ms"])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(f"{a.dtype}:{dom['kernel']}")
+        compute_bound = dom["kernel"].startswith(("conv", "stem"))
+        roof = {
+            "bound": "mfma" if compute_bound else "hbm",
+            "kernel": dom["kernel"],
+            "achieved": dom["tflops"] if compute_bound else dom["gbs_algorithmic"],
+            "peak": PEAK_TFLOPS[a.dtype] if compute_bound else PEAK_HBM_GBS,
+            "unit": "TFLOP/s" if compute_bound else "GB/s",
+            "traffic": traffic,
+            "avg_launch_us": dom["avg_us"],
+            "kernels": per,
+        }
+        roof["frac"] = roof["achieved"] / roof["peak"]
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / a.steps
+        fl, by = engine.work(fps_step * 7)
+        line = {
+            "metric": "frames/sec (7-view 2D->3D)",
+            "value": world * total_frames / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": a.dtype,
+            "data": "synthetic (seeded uniform frames resident in HBM, seeded synthetic hourglass weights, data/calib.pkl cameras)",
+            "config": {
+                "workload": f"BASELINE configs[{1 if a.dtype == 'f32' else 2}]: {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {a.dtype}, "
+                            "arg-max + 38-joint layout + fp64 DLT with fixed calib.pkl",
+                "frames_per_step": fps_step,
+                "frames_per_gpu": total_frames,
+                "parallelism": f"frame-sharded x{world}, one gather",
+                "hourglass_tflops_end_to_end": fl / (ms_step * 1e-3) / 1e12,
+                "hourglass_gbs_algorithmic_end_to_end": by / (ms_step * 1e-3) / 1e9,
+            },
+        }
+        if roof is not None:
+            line["roofline"] = roof
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(sd, frames[:16].cpu(), calib, a.cpu_seconds)
+            except Exception as e:  # the baseline is reporting only; never hide the GPU number
+                line["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

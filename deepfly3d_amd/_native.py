@@ -52,9 +52,11 @@ PROTOTYPES = {
     "df3d_version": (c_int, []),
     "df3d_device_count": (c_int, []),
     "df3d_device_name": (c_int, [c_int, c_char_p, c_int]),
+    "df3d_preprocess_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
     "df3d_heatmap_argmax": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_relayout_19_to_38": (c_int, [c_void_p, POINTER(c_int), c_int, c_void_p, c_void_p]),
     "df3d_triangulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_triangulate_scaled": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_ba_eval": (c_int, [POINTER(BAProblem), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_ba_colsq": (c_int, [POINTER(BAProblem), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_ba_matvec": (c_int, [POINTER(BAProblem), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -68,6 +70,8 @@ PROTOTYPES = {
     "df3d_vec_dot": (c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_double), c_void_p, c_void_p]),
     "df3d_vec_axpby": (c_int, [c_double, c_void_p, c_double, c_void_p, c_void_p, c_size_t, c_void_p]),
     "df3d_vec_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "df3d_vec_absmax": (c_int, [c_void_p, c_size_t, POINTER(c_double), c_void_p, c_void_p]),
+    "df3d_ba_update_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "df3d_hg_create": (c_int, [c_int, c_int, POINTER(c_void_p)]),
     "df3d_hg_destroy": (None, [c_void_p]),
     "df3d_hg_set_input": (c_int, [c_void_p, c_int, c_int]),
@@ -80,6 +84,8 @@ PROTOTYPES = {
     "df3d_hg_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "df3d_hg_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "df3d_hg_work": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_double)]),
+    "df3d_hg_profile": (c_int, [c_void_p, c_int]),
+    "df3d_hg_profile_read": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int)]),
     "df3d_hg_num_steps": (c_int, [c_void_p]),
     "df3d_hg_step_desc": (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int)]),
     "df3d_hg_forward_upto": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -1,0 +1,338 @@
+"""a7: bundle adjustment driver (extrinsics + 3-D points; intrinsics and distortion frozen).
+
+Replaces the solver under pyba's `CameraNetwork.bundle_adjust(update_intrinsic=False, update_distort=False)`
+(call site reference df3d/core.py:249), which is scipy's
+    least_squares(method='trf', jac_sparsity=..., x_scale='jac', ftol=1e-4)         (SURVEY.md App. A.3).
+Parity with the reference requires reproducing that solver's ITERATE SEQUENCE (the problem has a free 7-DoF
+gauge and stops early), so this file mirrors the trust-region-reflective loop of scipy's `trf_no_bounds`
+with its LSMR 2-D-subspace step -- the scalar control flow (a handful of iterations on 2x2 systems) runs
+here on the host, every vector operation runs in libdf3d_hip.so:
+
+    residuals + analytic Jacobian blocks ....... df3d_ba_eval
+    column norms for x_scale='jac' ............. df3d_ba_colsq
+    J v, J^T u ................................. df3d_ba_matvec / df3d_ba_rmatvec
+    damped LSMR on J diag(d) ................... df3d_ba_lsmr  (device vectors, host scalars)
+    dot / axpby / elementwise products ......... df3d_vec_*
+
+There is no CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native
+from . import ops
+
+
+def _rotvec_from_matrix(R):
+    """Rodrigues vector of a rotation matrix (float64, host; 7 cameras -> parameter packing only)."""
+    R = np.asarray(R, np.float64)
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s = 0.5 * np.linalg.norm(w)
+    c = 0.5 * (np.trace(R) - 1.0)
+    theta = np.arctan2(s, c)
+    if s > 1e-8:
+        return w / (2.0 * s) * theta
+    if c > 0:  # near identity
+        return 0.5 * w
+    # near pi: axis from the symmetric part
+    A = 0.5 * (R + np.eye(3))
+    k = int(np.argmax(np.diag(A)))
+    axis = A[k] / np.sqrt(A[k, k])
+    if w @ axis < 0:
+        axis = -axis
+    return axis * theta
+
+
+def _matrix_from_rotvec(r):
+    r = np.asarray(r, np.float64)
+    th = np.linalg.norm(r)
+    K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    K = K / th
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
+class BAProblemDevice:
+    """Observation tables on the device (built once per calibration window) + work buffers."""
+
+    def __init__(self, points2d_px, intr, device):
+        p = np.asarray(points2d_px, np.float64)
+        ncam, T, J, _ = p.shape
+        vis = (p[..., 0] != 0) & (p[..., 1] != 0)
+        ok = vis.sum(axis=0) >= 2  # (T, J)
+        slot = np.full((T, J), -1, dtype=np.int64)
+        slot[ok] = np.arange(int(ok.sum()))
+        # observations in (frame, joint, camera) order: move the camera axis last and flatten
+        vis_tjc = np.moveaxis(vis, 0, 2) & ok[..., None]
+        t_i, j_i, c_i = np.nonzero(vis_tjc)
+        self.slot = slot
+        self.ncam, self.npts, self.nobs = ncam, int(ok.sum()), int(t_i.size)
+        if self.nobs == 0:
+            raise ValueError("bundle adjustment needs at least one joint seen by two cameras")
+        cam_idx = c_i.astype(np.int32)
+        pt_idx = slot[t_i, j_i].astype(np.int32)
+        obs_xy = np.stack([p[c_i, t_i, j_i, 1], p[c_i, t_i, j_i, 0]], axis=1)  # x = col_px, y = row_px
+        counts = np.bincount(pt_idx, minlength=self.npts)
+        pt_start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        cam_perm = np.argsort(cam_idx, kind="stable").astype(np.int32)
+        cam_start = np.concatenate([[0], np.cumsum(np.bincount(cam_idx, minlength=ncam))]).astype(np.int32)
+        intr = np.asarray(intr, np.float64)
+        intr4 = np.stack([intr[:, 0, 0], intr[:, 1, 1], intr[:, 0, 2], intr[:, 1, 2]], axis=1)
+
+        dev = torch.device(device)
+        self.device = dev
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        self.t = dict(intr4=up(intr4), obs_xy=up(obs_xy), cam_idx=up(cam_idx), pt_idx=up(pt_idx), pt_start=up(pt_start),
+                      cam_perm=up(cam_perm), cam_start=up(cam_start))
+        self.c = _native.BAProblem(
+            ncam, self.nobs, self.npts, self.t["intr4"].data_ptr(), self.t["obs_xy"].data_ptr(), self.t["cam_idx"].data_ptr(),
+            self.t["pt_idx"].data_ptr(), self.t["pt_start"].data_ptr(), self.t["cam_perm"].data_ptr(), self.t["cam_start"].data_ptr(),
+        )
+        self.m = 2 * self.nobs
+        self.n = 6 * ncam + 3 * self.npts
+
+
+class _Dev:
+    """Device-vector arithmetic through the C ABI (float64)."""
+
+    def __init__(self, prob):
+        self.lib = _native.load()
+        self.p = prob
+        self.dev = prob.device
+        self.scratch = torch.empty(4096, dtype=torch.float64, device=self.dev)
+        self._res = ctypes.c_double()
+
+    def stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def new(self, n):
+        return torch.empty(n, dtype=torch.float64, device=self.dev)
+
+    def dot(self, a, b):
+        _native.check(self.lib.df3d_vec_dot(a.data_ptr(), b.data_ptr(), a.numel(), ctypes.byref(self._res), self.scratch.data_ptr(), self.stream()), "df3d_vec_dot")
+        return self._res.value
+
+    def absmax(self, a):
+        _native.check(self.lib.df3d_vec_absmax(a.data_ptr(), a.numel(), ctypes.byref(self._res), self.scratch.data_ptr(), self.stream()), "df3d_vec_absmax")
+        return self._res.value
+
+    def norm(self, a):
+        return float(np.sqrt(self.dot(a, a)))
+
+    def axpby(self, a, x, b, y, out):
+        _native.check(self.lib.df3d_vec_axpby(a, x.data_ptr(), b, y.data_ptr() if y is not None else None, out.data_ptr(), x.numel(), self.stream()), "df3d_vec_axpby")
+        return out
+
+    def mul(self, x, y, out):
+        _native.check(self.lib.df3d_vec_mul(x.data_ptr(), y.data_ptr(), out.data_ptr(), x.numel(), self.stream()), "df3d_vec_mul")
+        return out
+
+    def eval(self, x, r=None, Jc=None, Jp=None):
+        _native.check(
+            self.lib.df3d_ba_eval(ctypes.byref(self.p.c), x.data_ptr(), r.data_ptr() if r is not None else None,
+                                  Jc.data_ptr() if Jc is not None else None, Jp.data_ptr() if Jp is not None else None, self.stream()),
+            "df3d_ba_eval",
+        )
+
+    def colsq(self, Jc, Jp, out):
+        _native.check(self.lib.df3d_ba_colsq(ctypes.byref(self.p.c), Jc.data_ptr(), Jp.data_ptr(), out.data_ptr(), self.scratch.data_ptr(), self.stream()), "df3d_ba_colsq")
+        return out
+
+    def matvec(self, Jc, Jp, d, v, out):
+        _native.check(self.lib.df3d_ba_matvec(ctypes.byref(self.p.c), Jc.data_ptr(), Jp.data_ptr(), d.data_ptr() if d is not None else None, v.data_ptr(), out.data_ptr(), self.stream()), "df3d_ba_matvec")
+        return out
+
+    def rmatvec(self, Jc, Jp, d, u, out):
+        _native.check(self.lib.df3d_ba_rmatvec(ctypes.byref(self.p.c), Jc.data_ptr(), Jp.data_ptr(), d.data_ptr() if d is not None else None, u.data_ptr(), out.data_ptr(), self.scratch.data_ptr(), self.stream()), "df3d_ba_rmatvec")
+        return out
+
+    def lsmr(self, Jc, Jp, d, b, damp, x_out, work, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=0):
+        info = (ctypes.c_double * 8)()
+        _native.check(
+            self.lib.df3d_ba_lsmr(ctypes.byref(self.p.c), Jc.data_ptr(), Jp.data_ptr(), d.data_ptr(), b.data_ptr(), damp, atol, btol, conlim, maxiter,
+                                  x_out.data_ptr(), work.data_ptr(), info, self.stream()),
+            "df3d_ba_lsmr",
+        )
+        return list(info)
+
+
+def _solve_trust_region_2d(B, g, Delta):
+    """2-D trust-region subproblem (host, 2x2): Newton step if inside, else the boundary minimiser."""
+    try:
+        L = np.linalg.cholesky(B)
+        p = -np.linalg.solve(L.T, np.linalg.solve(L, g))
+        if p @ p <= Delta**2:
+            return p
+    except np.linalg.LinAlgError:
+        pass
+    a, b, c = B[0, 0] * Delta**2, B[0, 1] * Delta**2, B[1, 1] * Delta**2
+    d, f = g[0] * Delta, g[1] * Delta
+    t = np.roots(np.array([-b + d, 2 * (a - c + f), 6 * b, 2 * (-a + c + f), -b - d]))
+    t = np.real(t[np.isreal(t)])
+    p = Delta * np.vstack((2 * t / (1 + t**2), (1 - t**2) / (1 + t**2)))
+    value = 0.5 * np.sum(p * (B @ p), axis=0) + g @ p
+    return p[:, np.argmin(value)]
+
+
+def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None):
+    """Trust-region-reflective least squares without bounds, LSMR subspace step, x_scale='jac'.
+    x0: device float64 [n].  Returns dict(x=device tensor, cost, nfev, njev, status, lsmr_iters, optimality)."""
+    dv = _Dev(prob)
+    m, n, nobs = prob.m, prob.n, prob.nobs
+    x = x0.clone()
+    f = dv.new(m)
+    f_new = dv.new(m)
+    Jc = dv.new(12 * nobs)
+    Jp = dv.new(6 * nobs)
+    g = dv.new(n)
+    g_h = dv.new(n)
+    gn_h = dv.new(n)
+    scale = dv.new(n)
+    scale_inv = dv.new(n)
+    tmp_n = dv.new(n)
+    tmp_n2 = dv.new(n)
+    s0 = dv.new(n)
+    s1 = dv.new(n)
+    step_h = dv.new(n)
+    x_new = dv.new(n)
+    Js0 = dv.new(m)
+    Js1 = dv.new(m)
+    tmp_m = dv.new(m)
+    work = dv.new(dv.lib.df3d_ba_lsmr_work_doubles(ctypes.byref(prob.c)))
+
+    def refresh_scale(first):
+        dv.colsq(Jc, Jp, tmp_n)
+        _native.check(dv.lib.df3d_ba_update_scale(tmp_n.data_ptr(), scale_inv.data_ptr(), scale.data_ptr(), n, 1 if first else 0, dv.stream()), "df3d_ba_update_scale")
+
+    dv.eval(x, f, Jc, Jp)
+    nfev = njev = 1
+    cost = 0.5 * dv.dot(f, f)
+    dv.rmatvec(Jc, Jp, None, f, g)
+    refresh_scale(True)
+    dv.mul(x, scale_inv, tmp_n)
+    Delta = dv.norm(tmp_n)
+    if Delta == 0:
+        Delta = 1.0
+    if max_nfev is None:
+        max_nfev = n * 100
+    status = None
+    lsmr_iters = []
+    g_norm = None
+    while True:
+        g_norm = dv.absmax(g)
+        if g_norm < gtol:
+            status = 1
+        if status is not None or nfev == max_nfev:
+            break
+        d = scale
+        dv.mul(d, g, g_h)
+        # Tikhonov term from the 1-D Cauchy model along -g_h
+        dv.matvec(Jc, Jp, d, g_h, tmp_m)
+        a = 0.5 * dv.dot(tmp_m, tmp_m)
+        gh2 = dv.dot(g_h, g_h)
+        b = -gh2
+        to_tr = Delta / np.sqrt(gh2)
+        cand = [0.0, to_tr]
+        if a != 0:
+            ext = -0.5 * b / a
+            if 0 < ext < to_tr:
+                cand.append(ext)
+        cand = np.asarray(cand)
+        ag_value = np.min(cand * (a * cand + b))
+        reg_term = -ag_value / Delta**2
+        damp = float(np.sqrt(reg_term))
+        info = dv.lsmr(Jc, Jp, d, f, damp, gn_h, work)
+        lsmr_iters.append(int(info[1]))
+        # orthonormal basis S = qr([g_h, gn_h]) (Householder sign convention of LAPACK: R diagonal < 0)
+        n0 = np.sqrt(gh2)
+        dv.axpby(-1.0 / n0, g_h, 0.0, None, s0)
+        r01 = dv.dot(s0, gn_h)
+        dv.axpby(1.0, gn_h, -r01, s0, s1)
+        n1 = dv.norm(s1)
+        dv.axpby(-1.0 / n1, s1, 0.0, None, s1)
+        dv.matvec(Jc, Jp, d, s0, Js0)
+        dv.matvec(Jc, Jp, d, s1, Js1)
+        b00, b01, b11 = dv.dot(Js0, Js0), dv.dot(Js0, Js1), dv.dot(Js1, Js1)
+        B_S = np.array([[b00, b01], [b01, b11]])
+        g_S = np.array([dv.dot(s0, g_h), dv.dot(s1, g_h)])
+        actual_reduction = -1.0
+        cost_new = cost
+        while actual_reduction <= 0 and nfev < max_nfev:
+            p_S = _solve_trust_region_2d(B_S, g_S, Delta)
+            dv.axpby(float(p_S[0]), s0, float(p_S[1]), s1, step_h)
+            # predicted reduction = -(0.5 |J_h step|^2 + step . g_h), with J_h step = p0 Js0 + p1 Js1
+            dv.axpby(float(p_S[0]), Js0, float(p_S[1]), Js1, tmp_m)
+            predicted_reduction = -(0.5 * dv.dot(tmp_m, tmp_m) + dv.dot(step_h, g_h))
+            dv.mul(d, step_h, tmp_n2)  # step
+            dv.axpby(1.0, x, 1.0, tmp_n2, x_new)
+            dv.eval(x_new, f_new, None, None)
+            nfev += 1
+            step_h_norm = dv.norm(step_h)
+            cost_new = 0.5 * dv.dot(f_new, f_new)
+            if not np.isfinite(cost_new):
+                Delta = 0.25 * step_h_norm
+                continue
+            actual_reduction = cost - cost_new
+            if predicted_reduction > 0:
+                ratio = actual_reduction / predicted_reduction
+            elif predicted_reduction == actual_reduction == 0:
+                ratio = 1
+            else:
+                ratio = 0
+            Delta_new = Delta
+            if ratio < 0.25:
+                Delta_new = 0.25 * step_h_norm
+            elif ratio > 0.75 and step_h_norm > 0.95 * Delta:
+                Delta_new = 2.0 * Delta
+            step_norm = dv.norm(tmp_n2)
+            ftol_ok = actual_reduction < ftol * cost and ratio > 0.25
+            xtol_ok = step_norm < xtol * (xtol + dv.norm(x))
+            if ftol_ok and xtol_ok:
+                status = 4
+            elif ftol_ok:
+                status = 2
+            elif xtol_ok:
+                status = 3
+            if status is not None:
+                break
+            Delta = Delta_new
+        if actual_reduction > 0:
+            x, x_new = x_new, x
+            f, f_new = f_new, f
+            cost = cost_new
+            dv.eval(x, None, Jc, Jp)
+            njev += 1
+            dv.rmatvec(Jc, Jp, None, f, g)
+            refresh_scale(False)
+    if status is None:
+        status = 0
+    return dict(x=x, cost=cost, nfev=nfev, njev=njev, status=status, lsmr_iters=lsmr_iters, optimality=g_norm)
+
+
+def bundle_adjust(points2d_px, R, tvec, intr, device="cuda:0", return_info=False):
+    """points2d_px (ncam, T, J, 2) float64 (row_px, col_px); R (ncam,3,3), tvec (ncam,3), intr (ncam,3,3).
+    Returns adjusted (R, tvec) as float64 numpy arrays (+ solver info)."""
+    _native.require_gpu()
+    R = np.asarray(R, np.float64)
+    tvec = np.asarray(tvec, np.float64)
+    intr = np.asarray(intr, np.float64)
+    ncam = R.shape[0]
+    dev = torch.device(device)
+    prob = BAProblemDevice(points2d_px, intr, dev)
+    # initial points: DLT with the initial calibration (HIP kernel)
+    P = np.einsum("cij,cjk->cik", intr, np.concatenate([R, tvec[..., None]], axis=-1))
+    px_dev = torch.from_numpy(np.ascontiguousarray(points2d_px, dtype=np.float64)).to(dev)
+    X0 = ops.triangulate(P, px_dev)
+    cams = np.concatenate([np.stack([_rotvec_from_matrix(R[c]) for c in range(ncam)]), tvec], axis=1).ravel()
+    sel = torch.from_numpy((prob.slot.ravel() >= 0)).to(dev)
+    x0 = torch.cat([torch.from_numpy(cams).to(dev), X0.reshape(-1, 3)[sel].reshape(-1)])
+    res = solve_trf(prob, x0)
+    cams_new = res["x"][: 6 * ncam].cpu().numpy().reshape(ncam, 6)
+    R_new = np.stack([_matrix_from_rotvec(cams_new[c, :3]) for c in range(ncam)])
+    t_new = cams_new[:, 3:].copy()
+    if return_info:
+        return R_new, t_new, res
+    return R_new, t_new

@@ -1,0 +1,134 @@
+"""a5 / a6 / a7 / a8: the `pyba.CameraNetwork`-shaped object `df3d.core.Core` drives
+(call sites reference df3d/core.py:120-126, 165, 246-250, 339, 355-360, 396).
+
+Holds per-camera R, tvec, intr, distort and the 2-D detections in PIXELS, (row, col) order
+(= normalised * [H, W], reference df3d/core.py:247).  `triangulate()` and `bundle_adjust()` run on the
+MI355X through libdf3d_hip.so; nothing here computes on the CPU beyond packing a few 3x4 matrices.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _native, ops
+from . import bundle_adjust as _ba
+
+
+class Camera:
+    def __init__(self, cam_id, points2d, R=None, tvec=None, intr=None, distort=None, image_path=None):
+        self.cam_id = cam_id
+        self.points2d = points2d  # (T, J, 2) pixels, (row, col)
+        self.R = None if R is None else np.array(R, dtype=np.float64)
+        self.tvec = None if tvec is None else np.array(tvec, dtype=np.float64).reshape(3)
+        self.intr = None if intr is None else np.array(intr, dtype=np.float64)
+        self.distort = np.zeros(5) if distort is None else np.array(distort, dtype=np.float64).reshape(-1)
+        self.image_path = image_path
+
+    def __getitem__(self, img_id):
+        return self.points2d[img_id]
+
+    def has_calibration(self):
+        return self.R is not None and self.tvec is not None and self.intr is not None
+
+    @property
+    def P(self):
+        return self.intr @ np.concatenate([self.R, self.tvec[:, None]], axis=1)
+
+    def is_empty(self):
+        return self.points2d is None or not np.any(self.points2d)
+
+    def get_image(self, img_id):
+        """The camera's image as an ndarray (IO plumbing; reference core.py:323)."""
+        from PIL import Image
+
+        path = self.image_path.format(cam_id=self.cam_id, img_id=img_id)
+        if not os.path.exists(path):
+            path = self.image_path.format(cam_id=self.cam_id, img_id=f"{img_id:06d}")
+        return np.asarray(Image.open(path))
+
+    def summarize(self):
+        # key order as in the reference's golden pickles
+        return {"R": self.R, "tvec": self.tvec, "distort": self.distort, "intr": self.intr}
+
+
+class CameraNetwork:
+    def __init__(self, points2d, calib=None, image_path=None, colors=None, bones=None, device=None):
+        """points2d: (ncam, T, J, 2) float64 pixels (row, col).  calib: {cam_id: {R, tvec, intr, distort}};
+        extra non-camera keys (e.g. a whole df3d_result dict, reference core.py:120-126) are ignored."""
+        self._points2d = np.ascontiguousarray(points2d, dtype=np.float64)
+        self.image_path = image_path
+        self.colors, self.bones = colors, bones
+        self.device = device
+        ncam = self._points2d.shape[0]
+        self.cam_list = []
+        lookup = {}
+        if calib is not None:
+            for k, v in calib.items():
+                if isinstance(k, (int, np.integer)) and isinstance(v, dict) and "R" in v:
+                    lookup[int(k)] = v
+        for c in range(ncam):
+            cal = lookup.get(c, {})
+            self.cam_list.append(Camera(c, self._points2d[c], cal.get("R"), cal.get("tvec"), cal.get("intr"), cal.get("distort"), image_path))
+        self.points3d = None
+
+    def __getitem__(self, cam_id):
+        return self.cam_list[cam_id]
+
+    @property
+    def points2d(self):
+        return self._points2d
+
+    def has_calibration(self):
+        return all(c.has_calibration() for c in self.cam_list)
+
+    def _device(self):
+        _native.require_gpu()
+        return torch.device(self.device if self.device is not None else f"cuda:{torch.cuda.current_device()}")
+
+    def _stack(self):
+        R = np.stack([c.R for c in self.cam_list])
+        t = np.stack([c.tvec for c in self.cam_list])
+        K = np.stack([c.intr for c in self.cam_list])
+        return R, t, K
+
+    def triangulate(self):
+        """Multi-view DLT of every (frame, joint) seen by >= 2 cameras (HIP kernel, float64)."""
+        dev = self._device()
+        P = np.stack([c.P for c in self.cam_list])
+        px = torch.from_numpy(self._points2d).to(dev)
+        self.points3d = ops.triangulate(P, px).cpu().numpy()
+        return self.points3d
+
+    def bundle_adjust(self, update_intrinsic=False, update_distort=False):
+        """Adjust camera extrinsics (+ internal 3-D points); intrinsics / distortion stay frozen -- the only
+        configuration the reference uses (core.py:249)."""
+        if update_intrinsic or update_distort:
+            raise NotImplementedError("only update_intrinsic=False, update_distort=False is supported (the reference's call)")
+        R, t, K = self._stack()
+        R_new, t_new, info = _ba.bundle_adjust(self._points2d, R, t, K, device=self._device(), return_info=True)
+        for c, cam in enumerate(self.cam_list):
+            cam.R, cam.tvec = R_new[c], t_new[c]
+        self.ba_info = {k: v for k, v in info.items() if k != "x"}
+        self.triangulate()
+        return self.ba_info
+
+    def reprojection_error(self):
+        """Mean pixel distance between observations and re-projected triangulated joints."""
+        if self.points3d is None:
+            self.triangulate()
+        R, t, K = self._stack()
+        p = self._points2d
+        vis = (p[..., 0] != 0) & (p[..., 1] != 0)
+        ok = vis.sum(axis=0) >= 2
+        vis = vis & ok[None]
+        Xc = np.einsum("cij,tkj->ctki", R, self.points3d) + t[:, None, None, :]
+        u = K[:, 0, 0][:, None, None] * Xc[..., 0] / Xc[..., 2] + K[:, 0, 2][:, None, None]
+        v = K[:, 1, 1][:, None, None] * Xc[..., 1] / Xc[..., 2] + K[:, 1, 2][:, None, None]
+        err = np.sqrt((u - p[..., 1]) ** 2 + (v - p[..., 0]) ** 2)
+        return float(err[vis].mean())
+
+    def summarize(self):
+        out = {c.cam_id: c.summarize() for c in self.cam_list}
+        out["points3d"] = self.points3d
+        out["points2d"] = self._points2d
+        return out

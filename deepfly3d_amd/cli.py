@@ -1,0 +1,151 @@
+"""`df3d-cli` on the MI355X back-end: same flags, defaults and exit codes as reference df3d/cli.py:15-358.
+Video rendering flags are accepted and reported as unsupported (visualisation is out of scope)."""
+import argparse
+import logging
+import sys
+from collections import deque
+from pathlib import Path
+
+from . import logger
+from .core import Core
+
+
+def parse_cli_args(argv=None):
+    p = argparse.ArgumentParser(description="DeepFly3D pose estimation (MI355X back-end)")
+    p.add_argument("-v", "--verbose", help="Enable info output (such as progress bars)", action="store_true")
+    p.add_argument("-vv", "--verbose2", help="Enable debug output", action="store_true")
+    p.add_argument("-d", "--debug", help="Displays the argument list for debugging purposes", action="store_true")
+    p.add_argument("input_folder", help="Without additional arguments, a folder containing unlabeled images.", metavar="INPUT")
+    p.add_argument("--output-folder", default=None,
+                   help="Folder where results are written; default: INPUT suffixed with '_df3d'.")
+    p.add_argument("-r", "--recursive", help="INPUT is a folder. Successively use its subfolders named 'images/'", action="store_true")
+    p.add_argument("-f", "--from-file", help="INPUT is a text-file, where each line names a folder.", action="store_true")
+    p.add_argument("-x", "--delete-images", help="Delete expanded image files after running (only if the .mp4 exists).", action="store_true")
+    p.add_argument("-n", "--num-images-max", help="Maximal number of images to process (0 = all).", default=0, type=int)
+    p.add_argument("--order", "--camera-ids", help="Ordering of the cameras, e.g. --order 0 1 4 3 2 5 6.",
+                   default=[0, 1, 2, 3, 4, 5, 6], type=int, nargs="*")
+    p.add_argument("--video-2d", help="Generate pose2d videos", action="store_true")
+    p.add_argument("--video-3d", help="Generate pose3d videos", action="store_true")
+    p.add_argument("--skip-pose-estimation", help="Skip 2D and 3D pose estimation", dest="skip_estimation", action="store_true")
+    p.add_argument("--batch-size", help="Batch size for inference", type=int, default=8)
+    p.add_argument("--pin-memory-disabled", help="Disable pinned host staging buffers", action="store_true")
+    p.add_argument("--output-fps", help="FPS for output videos.", type=float, default=None)
+    p.add_argument("--dtype", help="hourglass arithmetic on the GPU: f32 (default) or bf16", choices=["f32", "bf16"], default="f32")
+    args = p.parse_args(argv)
+    inp = Path(args.input_folder).expanduser().resolve()
+    args.output_folder = str(inp.with_name(inp.stem + "_df3d")) if args.output_folder is None else str(Path(args.output_folder).expanduser().resolve())
+    args.input_folder = str(inp)
+    return args
+
+
+def setup_logger(args):
+    handler = logging.StreamHandler()
+    handler.setLevel(logging.DEBUG)
+    lg = logger.getLogger()
+    lg.addHandler(handler)
+    lg.setLevel(logging.DEBUG if args.verbose2 else logging.INFO if args.verbose else logging.WARNING)
+
+
+def print_debug(args):
+    print(f"Enabled logging level: {logging.getLevelName(logger.getLogger().getEffectiveLevel())}")
+    print("Arguments are:")
+    for k, v in vars(args).items():
+        print(f"\t{k}: {v}")
+    print()
+    return 0
+
+
+def run(args):
+    if args.skip_estimation and not args.video_2d and not args.video_3d:
+        logger.info("Nothing to do. Check your command-line arguments.")
+        return 0
+    logger.info(f"\nWorking in {args.input_folder}")
+    core = Core(args.input_folder, args.output_folder, args.num_images_max, args.order, dtype=args.dtype)
+    if not args.skip_estimation:
+        core.pose2d_estimation(args.batch_size, args.pin_memory_disabled)
+        core.save()
+    core.calibrate_calc(0, core.max_img_id)
+    core.save()
+    if args.video_2d or args.video_3d:
+        logger.warning("--video-2d/--video-3d: video rendering is not part of the MI355X hot-path build; skipped.")
+    if args.delete_images:
+        core.delete_images()
+    return 0
+
+
+def run_in_folders(args, folders):
+    errors = []
+    for folder in folders:
+        try:
+            args.input_folder = str(folder)  # like the reference, every folder writes into the one output folder
+            run(args)
+        except KeyboardInterrupt:
+            logger.warning("Keyboard Interrupt received. Terminating...")
+            break
+        except Exception as e:  # per-folder isolation, as the reference does
+            errors.append((folder, e))
+            logger.error(f"An error occured while processing {folder}. Continuing...")
+    if errors:
+        logger.error(f"\n{len(errors)} out of {len(folders)} folders terminated with errors.")
+        for folder, exc in errors:
+            logger.error(f"\nIn {folder}", exc_info=exc)
+
+
+def find_subfolders(path, name):
+    """Breadth-first search for sub-folders called `name`, not descending into matches."""
+    found, queue, seen = [], deque([Path(path)]), set()
+    while queue:
+        cur = queue.popleft()
+        if cur.is_dir() and cur not in seen:
+            seen.add(cur)
+            if cur.name == name:
+                found.append(str(cur))
+            else:
+                queue.extend(cur.iterdir())
+    return found
+
+
+def run_recursive(args):
+    sub = find_subfolders(args.input_folder, "images")
+    logger.info(f"Found {len(sub)} subfolder(s):\n-" + "\n-".join(sub))
+    args.recursive = False
+    run_in_folders(args, sub)
+
+
+def run_from_file(args):
+    try:
+        with open(args.input_folder, "r") as f:
+            folders = [line.strip() for line in f]
+    except FileNotFoundError:
+        logger.error(f"Unable to find the file {args.input_folder}")
+        return 1
+    except IsADirectoryError:
+        logger.error(f"{args.input_folder} is a directory, please provide a file instead.")
+        return 1
+    folders = [Path(f) for f in dict.fromkeys(folders) if f.strip()]
+    bad = [f for f in folders if not f.is_dir()]
+    for f in bad:
+        logger.error(f"[Error] Not a directory or does not exist: {f}")
+    if bad:
+        return 1
+    args.from_file = False
+    run_in_folders(args, folders)
+
+
+def main(argv=None):
+    args = parse_cli_args(argv)
+    setup_logger(args)
+    if args.debug:
+        return print_debug(args)
+    if args.from_file and args.recursive:
+        logger.error('Error: choose an input method between "from file" and "recursive" but not both.')
+        return 1
+    if args.recursive:
+        return run_recursive(args)
+    if args.from_file:
+        return run_from_file(args)
+    return run(args)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,233 @@
+"""`Core`: the reference's orchestration surface (df3d.core.Core, reference df3d/core.py:62-544) on the
+MI355X back-end.  Same constructor, methods, attributes, exceptions and result-pickle schema for the hot path:
+
+    core = Core(input_folder, output_folder=None, num_images_max=None, camera_ordering=[0..6])
+    core.pose2d_estimation(batch_size=8, disable_pin_memory=False)     # reference :170-203
+    core.save()                                                        # reference :349-369
+    core.calibrate_calc(min_img_id, max_img_id)                        # reference :229-250
+    core.save()
+
+GUI-only methods (manual corrections, error navigation) are out of scope.
+"""
+import glob
+import os
+import pickle
+import re
+import subprocess
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _native, logger, ops
+from .camera_network import CameraNetwork
+from .config import config, load_calibration
+from .db import PoseDB
+from .inference import inference_folder
+from .os_util import get_max_img_id, parse_vid_name
+from .procrustes import procrustes_separate
+
+_KNOWN_ORDERINGS = [
+    (r"/CLC/", [0, 6, 5, 4, 3, 2, 1]),
+    (r"/FA/", [6, 5, 4, 3, 2, 1, 0]),
+    (r"/SG/", [6, 5, 4, 3, 2, 1, 0]),
+    (r"Laura", [0, 6, 5, 4, 3, 2, 1]),
+    (r"AYMANNS_Florian", [6, 5, 4, 3, 2, 1, 0]),
+    (r"sample/test", [0, 1, 2, 3, 4, 5, 6]),
+    (r"/JB/", [6, 5, 4, 3, 2, 1, 0]),
+]
+
+
+def find_default_camera_ordering(input_folder):
+    """Lab-specific defaults keyed on the folder path (reference df3d/core.py:24-59)."""
+    folder = str(input_folder)
+    for pattern, order in _KNOWN_ORDERINGS:
+        if re.search(pattern, folder):
+            logger.debug(f"Default camera ordering found: {order}")
+            return np.array(order)
+    raise NotImplementedError(
+        f"Cannot find camera ordering for folder {folder}. Please set your camera ordering using the --order flag. "
+        "Example usage is df3d-cli /your/path/images/ --order 0 1 2 3 4 5 6"
+    )
+
+
+def relayout_points2d(points19, camera_ordering, device=None):
+    """(7, T, 19, 2) network output -> (7, T, 38, 2) float64 skeleton layout, on the device
+    (df3d_relayout_19_to_38; reference df3d/core.py:187-203)."""
+    _native.require_gpu()
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    t = torch.as_tensor(np.ascontiguousarray(points19, dtype=np.float32)).to(dev)
+    return ops.relayout_19_to_38(t, camera_ordering).cpu().numpy()
+
+
+class Core:
+    """Main interface to the 2-D and 3-D pose estimation (reference df3d/core.py:62)."""
+
+    def __init__(self, input_folder: str, output_folder: Optional[str] = None, num_images_max: Optional[int] = None,
+                 camera_ordering: List[int] = [0, 1, 2, 3, 4, 5, 6], dtype: str = "f32", device=None):
+        self.dtype, self.device = dtype, device
+        self.input_folder = input_folder
+        self.output_folder = self.input_folder + "_df3d" if output_folder is None else output_folder
+        self.expand_videos()
+        self.fps = self.get_fps()
+        self.num_images_max = num_images_max if num_images_max is not None else 0
+        self.max_img_id = get_max_img_id(self.input_folder)
+        if self.num_images_max > 0:
+            self.num_images = min(self.num_images_max, self.max_img_id + 1)
+            self.max_img_id = self.num_images - 1
+        else:
+            self.num_images = self.max_img_id + 1
+        self._image_path = os.path.join(self.input_folder, "camera_{cam_id}_img_{img_id}.jpg")
+        image0 = self._image_path.format(cam_id=0, img_id=0)
+        if "image_shape" in config:
+            self.image_shape = config["image_shape"]
+        if os.path.exists(image0):
+            from PIL import Image
+
+            with Image.open(image0) as im:
+                shape0 = [im.size[0], im.size[1]]  # [W, H]
+            if "image_shape" in config and shape0 != self.image_shape:
+                raise ValueError(f"Actual image shape {shape0} does not match config.py image shape {self.image_shape}")
+            self.image_shape = config["image_shape"] = shape0
+        if not hasattr(self, "image_shape"):
+            raise ValueError(f"Image shape not specified in config and could not be read from {image0}")
+
+        self.db = PoseDB(self.output_folder)
+        self.camera_ordering = self.setup_camera_ordering(camera_ordering)
+        self.camNet = None
+        self.points2d = None
+        self.points3d = None
+        self.conf = None
+        if os.path.exists(self.save_path):  # resume from an earlier result (reference :109-126)
+            with open(self.save_path, "rb") as f:
+                prev = pickle.load(f)
+            self.points2d = prev["points2d"]
+            self.conf = prev["heatmap_confidence"]
+            if "points3d" in prev:
+                self.points3d = prev["points3d"]
+            self.camNet = CameraNetwork(prev["points2d"] * self.image_shape[::-1], calib=prev, image_path=self._image_path, device=self.device)
+
+    # -- properties -----------------------------------------------------------------------------------
+    @property
+    def input_folder(self):
+        return self._input_folder
+
+    @input_folder.setter
+    def input_folder(self, value):
+        value = os.path.abspath(value).rstrip("/")
+        assert os.path.isdir(value), f"Not a directory {value}"
+        self._input_folder = value
+
+    @property
+    def output_folder(self):
+        return self._output_folder
+
+    @output_folder.setter
+    def output_folder(self, value):
+        os.makedirs(value, exist_ok=True)
+        value = os.path.abspath(value).rstrip("/")
+        assert os.path.isdir(value), f"Not a directory {value}"
+        self._output_folder = value
+
+    @property
+    def number_of_joints(self):
+        return config["num_joints"]
+
+    @property
+    def has_pose(self):
+        return True
+
+    @property
+    def has_calibration(self):
+        return self.camNet.has_calibration()
+
+    @property
+    def save_path(self):
+        return os.path.join(self.output_folder, "df3d_result_{}.pkl".format(self.input_folder.replace("/", "_")))
+
+    # -- hot path -------------------------------------------------------------------------------------
+    def pose2d_estimation(self, batch_size: int = 8, disable_pin_memory: bool = False):
+        """2-D pose on every frame of every camera, then the 19 -> 38 joint layout (reference :170-203)."""
+        flip = [cam for idx, cam in enumerate(self.camera_ordering) if idx > 3]
+        points19, self.conf = inference_folder(
+            folder=self.input_folder, camera_ids_to_flip=flip, return_heatmap=False, return_confidence=True,
+            max_img_id=self.max_img_id, batch_size=batch_size, disable_pin_memory=disable_pin_memory, dtype=self.dtype, device=self.device,
+        )
+        self.points2d = relayout_points2d(points19, self.camera_ordering, self.device)
+
+    def calibrate_calc(self, min_img_id, max_img_id):
+        """Bundle adjustment from the shipped initial calibration (reference :229-250; like the reference the
+        image-id range is accepted and unused)."""
+        calib = load_calibration()
+        reordered = {int(cidx): calib[idx] for idx, cidx in enumerate(self.camera_ordering)}
+        self.camNet = CameraNetwork(self.points2d * self.image_shape[::-1], calib=reordered, image_path=self._image_path, device=self.device)
+        self.camNet.bundle_adjust(update_intrinsic=False, update_distort=False)
+        print(f"Reprojection error is {self.camNet.reprojection_error()}")
+
+    def get_points3d(self):
+        raise NotImplementedError("the smoothed/rotated video pose (reference core.py:332-343) is out of scope; use the pkl's points3d")
+
+    def save(self):
+        """Write df3d_result_*.pkl with the reference's schema and key order (reference :349-369)."""
+        result = {"points2d": np.copy(self.points2d)}
+        if self.camNet is not None and self.camNet.has_calibration():
+            self.camNet.triangulate()
+            pts3d = self.camNet.points3d
+            result["points3d_wo_procrustes"] = pts3d
+            result["points3d"] = procrustes_separate(pts3d)
+            result = {**self.camNet.summarize(), **result}
+        else:
+            logger.debug("Triangulation skipped.")
+        result["camera_ordering"] = self.camera_ordering
+        result["heatmap_confidence"] = self.conf
+        with open(self.save_path, "wb") as f:
+            pickle.dump(result, f)
+        print(f"Saved results at: {self.save_path}")
+
+    # -- helpers --------------------------------------------------------------------------------------
+    def setup_camera_ordering(self, camera_ordering) -> np.ndarray:
+        if camera_ordering is None:
+            camera_ordering = find_default_camera_ordering(self.input_folder)
+        return np.array(camera_ordering)
+
+    def get_image(self, cam_id, img_id):
+        return self.camNet.cam_list[cam_id].get_image(img_id)
+
+    def get_fps(self):
+        rates = []
+        for vid in glob.glob(os.path.join(self.input_folder, "camera_?.mp4")):
+            cmd = ["ffprobe", "-v", "error", "-select_streams", "v:0", "-show_entries", "stream=avg_frame_rate", "-of",
+                   "default=noprint_wrappers=1:nokey=1", vid]
+            try:
+                rates.append(subprocess.check_output(cmd, text=True))
+            except Exception:
+                logger.warning(f"Command failed: {' '.join(cmd)}")
+                break
+        if not rates:
+            return None
+        rate = rates[0]
+        try:
+            return float(rate)
+        except ValueError:
+            pass
+        try:
+            num, den = map(int, rate.split("/"))
+            return num / den if den else None
+        except ValueError:
+            logger.warning(f'Could not parse framerate "{rate}" returned by ffprobe, so setting fps to None.')
+            return None
+
+    def expand_videos(self):
+        """camera_x.mp4 -> camera_x_img_y.jpg through ffmpeg when the frames are not there yet (reference :446-459)."""
+        for vid in glob.glob(os.path.join(self.input_folder, "camera_?.mp4")):
+            cam_id = parse_vid_name(os.path.basename(vid))
+            have = any(os.path.exists(os.path.join(self.input_folder, f"camera_{cam_id}_img_{n}.jpg")) for n in ("0", "000000"))
+            if not have:
+                subprocess.call(f"ffmpeg -nostats -loglevel error -i {vid} -qscale:v 2 -start_number 0 {self.input_folder}/camera_{cam_id}_img_%d.jpg  < /dev/null", shell=True)
+
+    def delete_images(self):
+        """Remove expanded frames of cameras whose .mp4 is present (reference :461-475)."""
+        for vid in glob.glob(os.path.join(self.input_folder, "camera_[0-9].mp4")):
+            cam_id = parse_vid_name(os.path.basename(vid))
+            for img in glob.glob(os.path.join(self.input_folder, f"camera_{cam_id}_img_*.jpg")):
+                os.remove(img)

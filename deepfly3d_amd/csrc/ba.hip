@@ -307,6 +307,34 @@ __global__ __launch_bounds__(256) void lsmr_update_kernel(double c1, double c2, 
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// x_scale='jac' bookkeeping: scale_inv = sqrt(colsq) (zeros -> 1 on the first call, running max later)
+__global__ __launch_bounds__(256) void update_scale_kernel(const double* __restrict__ colsq, double* __restrict__ scale_inv,
+                                                           double* __restrict__ scale, size_t n, int first) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double si = sqrt(colsq[i]);
+        if (first) {
+            if (si == 0.0) si = 1.0;
+        } else {
+            si = fmax(si, scale_inv[i]);
+        }
+        scale_inv[i] = si;
+        scale[i] = 1.0 / si;
+    }
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const double* __restrict__ a, size_t n, double* __restrict__ partial) {
+    __shared__ double lds[256];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc = fmax(acc, fabs(a[i]));
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) lds[threadIdx.x] = fmax(lds[threadIdx.x], lds[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = lds[0];
+}
+
 inline int grid_for(size_t n) {
     size_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > RED_BLOCKS ? RED_BLOCKS : b));
@@ -434,6 +462,25 @@ int df3d_vec_axpby(double a, const double* x_dev, double b, const double* y_dev,
 int df3d_vec_mul(const double* x_dev, const double* y_dev, double* out_dev, size_t n, void* stream) {
     DF3D_CHECK_ARG(x_dev && y_dev && out_dev, "null pointer");
     hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, df3d::as_stream(stream), x_dev, y_dev, out_dev, n);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+int df3d_vec_absmax(const double* a_dev, size_t n, double* result_host, double* scratch_dev, void* stream) {
+    DF3D_CHECK_ARG(a_dev && result_host && scratch_dev, "null pointer");
+    hipStream_t s = df3d::as_stream(stream);
+    const int g = grid_for(n);
+    hipLaunchKernelGGL(absmax_kernel, dim3(g), dim3(256), 0, s, a_dev, n, scratch_dev);
+    hipLaunchKernelGGL(absmax_kernel, dim3(1), dim3(256), 0, s, scratch_dev, (size_t)g, scratch_dev + RED_BLOCKS);
+    DF3D_LAUNCH_CHECK();
+    return read_back(scratch_dev + RED_BLOCKS, result_host, s);
+}
+
+int df3d_ba_update_scale(const double* colsq_dev, double* scale_inv_dev, double* scale_dev, size_t n, int first,
+                         void* stream) {
+    DF3D_CHECK_ARG(colsq_dev && scale_inv_dev && scale_dev, "null pointer");
+    hipLaunchKernelGGL(update_scale_kernel, dim3(grid_for(n)), dim3(256), 0, df3d::as_stream(stream), colsq_dev,
+                       scale_inv_dev, scale_dev, n, first);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }

@@ -50,7 +50,8 @@ __device__ __forceinline__ void jacobi_rotate(double (&a)[4][4], double (&v)[4][
 }
 
 __global__ __launch_bounds__(256) void triangulate_kernel(CamP cams, const double* __restrict__ pts, int ncam,
-                                                          long long TJ, double* __restrict__ X) {
+                                                          long long TJ, double row_scale, double col_scale,
+                                                          double* __restrict__ X) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= TJ) return;
 
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(CamP cams, const doubl
     int nviews = 0;
     for (int c = 0; c < ncam; ++c) {
         const double2 rc = *reinterpret_cast<const double2*>(pts + ((size_t)c * TJ + idx) * 2);
-        const double row = rc.x, col = rc.y;
+        const double row = rc.x * row_scale, col = rc.y * col_scale;
         if (row != 0.0 && col != 0.0) {
             ++nviews;
             double r0[4], r1[4];
@@ -160,8 +161,8 @@ __global__ __launch_bounds__(256) void relayout_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int df3d_triangulate(const double* P_dev_or_host, const double* pts_px_dev, int ncam, int T, int J,
-                                double* X_dev, void* stream) {
+static int triangulate_impl(const double* P_dev_or_host, const double* pts_px_dev, double row_scale, double col_scale,
+                            int ncam, int T, int J, double* X_dev, void* stream) {
     DF3D_CHECK_ARG(ncam >= 1 && ncam <= MAX_CAM, "ncam must be in [1, 8]");
     DF3D_CHECK_ARG(T >= 0 && J > 0, "bad shape");
     if (T == 0) return DF3D_OK;
@@ -185,9 +186,20 @@ extern "C" int df3d_triangulate(const double* P_dev_or_host, const double* pts_p
     const long long TJ = (long long)T * J;
     const int blocks = (int)((TJ + 255) / 256);
     hipLaunchKernelGGL(triangulate_kernel, dim3(blocks), dim3(256), 0, df3d::as_stream(stream), cams, pts_px_dev,
-                       ncam, TJ, X_dev);
+                       ncam, TJ, row_scale, col_scale, X_dev);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
+}
+
+extern "C" int df3d_triangulate(const double* P, const double* pts_px_dev, int ncam, int T, int J, double* X_dev,
+                                void* stream) {
+    return triangulate_impl(P, pts_px_dev, 1.0, 1.0, ncam, T, J, X_dev, stream);
+}
+
+extern "C" int df3d_triangulate_scaled(const double* P, const double* pts_norm_dev, double row_scale, double col_scale,
+                                       int ncam, int T, int J, double* X_dev, void* stream) {
+    DF3D_CHECK_ARG(row_scale > 0 && col_scale > 0, "scales must be positive");
+    return triangulate_impl(P, pts_norm_dev, row_scale, col_scale, ncam, T, J, X_dev, stream);
 }
 
 extern "C" int df3d_relayout_19_to_38(const float* pts19_dev, const int* ordering_host, int T, double* out_dev,

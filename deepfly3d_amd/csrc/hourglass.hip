@@ -97,6 +97,12 @@ struct df3d_hg {
 
     Allocator alloc;
 
+    // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
+    bool profiling = false;
+    struct Timed { hipEvent_t a, b; int cls; double flops, bytes; };
+    std::vector<Timed> timed;
+    std::vector<hipEvent_t> event_pool;
+
     int elem_bytes() const { return dtype == DF3D_DTYPE_BF16 ? 2 : 4; }
 
     int new_tensor(int h, int w, int c, int pitch = 0) {
@@ -300,6 +306,40 @@ int launch_conv(const ConvArgs& a, int taps, int rb, hipStream_t s) {
     return DF3D_EINVAL;
 }
 
+enum KernelClass { KC_CONV1 = 0, KC_CONV3 = 1, KC_STEM = 2, KC_POOL = 3, KC_UPADD = 4, KC_COUNT = 5 };
+
+hipEvent_t get_event(df3d_hg* h) {
+    if (!h->event_pool.empty()) {
+        hipEvent_t e = h->event_pool.back();
+        h->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ScopedTimer {
+    df3d_hg* h;
+    hipStream_t s;
+    df3d_hg::Timed t;
+    bool on;
+    ScopedTimer(df3d_hg* h_, hipStream_t s_, int cls, double flops, double bytes) : h(h_), s(s_), on(h_->profiling) {
+        if (!on) return;
+        t.a = get_event(h);
+        t.b = get_event(h);
+        t.cls = cls;
+        t.flops = flops;
+        t.bytes = bytes;
+        (void)hipEventRecord(t.a, s);
+    }
+    ~ScopedTimer() {
+        if (!on) return;
+        (void)hipEventRecord(t.b, s);
+        h->timed.push_back(t);
+    }
+};
+
 template <typename T>
 int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps, unsigned char* act, hipStream_t s) {
     const int eb = sizeof(T);
@@ -318,6 +358,8 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.H = h->H;
                 a.W = h->W;
                 const int blocks = n * (h->H / 2 / 8) * (h->W / 2 / 16);
+                const double opx = (double)n * (h->H / 2) * (h->W / 2);
+                ScopedTimer tm(h, s, KC_STEM, 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb));
                 hipLaunchKernelGGL((stem_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
                 DF3D_LAUNCH_CHECK();
                 break;
@@ -346,6 +388,9 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 const int ke128 = 128 / eb;
                 int rb = (st.conv.cin_pad % ke128 == 0) ? 128 : 64;
                 if (h->rb_override == 64) rb = 64;
+                const double mm = (double)a.M;
+                ScopedTimer tm(h, s, st.conv.taps == 1 ? KC_CONV1 : KC_CONV3, 2.0 * mm * st.conv.taps * st.conv.cin * st.conv.cout,
+                               mm * eb * (st.conv.cin + st.conv.cout + (st.res >= 0 ? st.conv.cout : 0)));
                 if (int rc = launch_conv<T>(a, st.conv.taps, rb, s)) return rc;
                 break;
             }
@@ -353,6 +398,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 const TensorDesc& to = h->tensors[st.out];
                 const int chunks = to.pitch * eb / 16;
                 const long long total = (long long)n * to.h * to.w * chunks;
+                ScopedTimer tm(h, s, KC_POOL, 0.0, (double)total * 16 * 5);
                 hipLaunchKernelGGL((pool2_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                                    reinterpret_cast<const u32x4*>(tptr(st.in)), reinterpret_cast<u32x4*>(tptr(st.out)),
                                    total, to.h, to.w, chunks);
@@ -363,6 +409,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 const TensorDesc& to = h->tensors[st.out];
                 const int chunks = to.pitch * eb / 16;
                 const long long total = (long long)n * to.h * to.w * chunks;
+                ScopedTimer tm(h, s, KC_UPADD, 0.0, (double)total * 16 * 2.25);
                 hipLaunchKernelGGL((upadd_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                                    reinterpret_cast<const u32x4*>(tptr(st.in)), reinterpret_cast<const u32x4*>(tptr(st.res)),
                                    reinterpret_cast<u32x4*>(tptr(st.out)), total, to.h, to.w, chunks);
@@ -403,7 +450,15 @@ int df3d_hg_create(int dtype, int num_stacks, df3d_hg** out) {
     return DF3D_OK;
 }
 
-void df3d_hg_destroy(df3d_hg* h) { delete h; }
+void df3d_hg_destroy(df3d_hg* h) {
+    if (!h) return;
+    for (auto& t : h->timed) {
+        (void)hipEventDestroy(t.a);
+        (void)hipEventDestroy(t.b);
+    }
+    for (auto e : h->event_pool) (void)hipEventDestroy(e);
+    delete h;
+}
 
 int df3d_hg_set_input(df3d_hg* h, int height, int width) {
     DF3D_CHECK_ARG(h != nullptr, "null handle");
@@ -479,6 +534,35 @@ int df3d_hg_work(const df3d_hg* h, int n, double* flops, double* bytes) {
     DF3D_CHECK_ARG(h && flops && bytes, "null argument");
     *flops = h->flops_per_view * n;
     *bytes = h->elems_per_view * n * h->elem_bytes();
+    return DF3D_OK;
+}
+
+int df3d_hg_profile(df3d_hg* h, int enable) {
+    DF3D_CHECK_ARG(h != nullptr, "null handle");
+    h->profiling = enable != 0;
+    for (auto& t : h->timed) {
+        h->event_pool.push_back(t.a);
+        h->event_pool.push_back(t.b);
+    }
+    h->timed.clear();
+    return DF3D_OK;
+}
+
+int df3d_hg_profile_read(df3d_hg* h, int kernel_class, double* ms, double* flops, double* bytes, int* launches) {
+    DF3D_CHECK_ARG(h && ms && flops && bytes && launches, "null argument");
+    DF3D_CHECK_ARG(kernel_class >= 0 && kernel_class < KC_COUNT, "kernel_class out of range");
+    *ms = *flops = *bytes = 0.0;
+    *launches = 0;
+    for (auto& t : h->timed) {
+        if (t.cls != kernel_class) continue;
+        DF3D_HIP(hipEventSynchronize(t.b));
+        float e = 0.f;
+        DF3D_HIP(hipEventElapsedTime(&e, t.a, t.b));
+        *ms += e;
+        *flops += t.flops;
+        *bytes += t.bytes;
+        *launches += 1;
+    }
     return DF3D_OK;
 }
 

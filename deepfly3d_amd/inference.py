@@ -1,0 +1,138 @@
+"""a1: the `df2d.inference`-shaped entry point `df3d.core.Core.pose2d_estimation` calls
+(reference df3d/core.py:177-185):
+
+    points2d, conf = inference_folder(folder=..., camera_ids_to_flip=[...], return_heatmap=False,
+                                      return_confidence=True, max_img_id=..., batch_size=8,
+                                      disable_pin_memory=False)
+    points2d: (7, T, 19, 2) float32 normalised (row/64, col/128);  conf: (7, T, 19, 1) float32
+
+Pipeline on the device: uint8 frames -> df3d_preprocess_u8 (flip / resize / normalise) -> df3d_hg_forward
+(stacked hourglass) -> df3d_heatmap_argmax.  JPEG decoding is host IO (Pillow).  No CPU compute fallback.
+
+Weights: a bearpaw/df2d `state_dict` checkpoint (`sh8_deepfly.tar`, reference df3d/config.py:30-32) is looked
+up in $DF3D_WEIGHTS or deepfly3d_amd/weights/.  It is not redistributable offline; for plumbing tests set
+DF3D_SYNTHETIC_WEIGHTS=<seed> to use seeded synthetic parameters (the results are then meaningless poses).
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _native, ops
+from .config import config
+from .hourglass import HourglassEngine
+from .os_util import image_path_for
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+# df2d's normalisation constants are not in the reference checkout ("parity unpinned"): kept as data
+PREPROCESS = {"mean": (0.22, 0.22, 0.22), "std": (1.0, 1.0, 1.0)}
+
+_engine_cache = {}
+
+
+def load_state_dict(path=None):
+    """Locate and load the hourglass parameters ({name: array})."""
+    if os.environ.get("DF3D_SYNTHETIC_WEIGHTS") is not None:
+        from .synthetic import synthetic_state_dict
+
+        return synthetic_state_dict(int(os.environ["DF3D_SYNTHETIC_WEIGHTS"]))
+    cands = [path, os.environ.get("DF3D_WEIGHTS"), os.path.join(_HERE, "weights", "sh8_deepfly.tar")]
+    for cand in cands:
+        if cand and os.path.exists(cand):
+            ckpt = torch.load(cand, map_location="cpu", weights_only=False)
+            sd = ckpt.get("state_dict", ckpt) if isinstance(ckpt, dict) else ckpt
+            return {k[len("module.") :] if k.startswith("module.") else k: v for k, v in sd.items()}
+    raise FileNotFoundError(
+        "hourglass weights not found: put sh8_deepfly.tar under deepfly3d_amd/weights/ or set DF3D_WEIGHTS "
+        "(or DF3D_SYNTHETIC_WEIGHTS=<seed> for plumbing tests)"
+    )
+
+
+def get_engine(dtype="f32", device=None, state_dict=None):
+    _native.require_gpu()
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    key = (dtype, str(dev), id(state_dict) if state_dict is not None else None)
+    if key not in _engine_cache:
+        sd = state_dict if state_dict is not None else load_state_dict()
+        _engine_cache[key] = HourglassEngine(sd, dtype=dtype, device=dev, num_stacks=config["num_stacks"])
+    return _engine_cache[key]
+
+
+def preprocess_u8(frames_u8, flip, out_hw=(256, 512)):
+    """frames_u8 [n, H, W] or [n, H, W, C] uint8 cuda; flip [n] uint8/bool cuda or None -> float32 NHWC [n, OH, OW, 3]."""
+    lib = _native.load()
+    if frames_u8.dim() == 3:
+        frames_u8 = frames_u8.unsqueeze(-1)
+    if not (frames_u8.is_cuda and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()):
+        raise ValueError("frames must be a contiguous uint8 CUDA tensor")
+    n, H, W, C = frames_u8.shape
+    out = torch.empty((n, out_hw[0], out_hw[1], 3), dtype=torch.float32, device=frames_u8.device)
+    mean = (ctypes.c_float * 3)(*PREPROCESS["mean"])
+    std = (ctypes.c_float * 3)(*PREPROCESS["std"])
+    fl = None
+    if flip is not None:
+        fl = flip.to(device=frames_u8.device, dtype=torch.uint8).contiguous()
+    _native.check(
+        lib.df3d_preprocess_u8(frames_u8.data_ptr(), fl.data_ptr() if fl is not None else None, n, H, W, C, out.data_ptr(), out_hw[0], out_hw[1],
+                               mean, std, torch.cuda.current_stream(frames_u8.device).cuda_stream),
+        "df3d_preprocess_u8",
+    )
+    return out
+
+
+def inference_views(images, engine, return_heatmap=False):
+    """images: float32 NHWC [n, 256, 512, 3] cuda -> (points [n, 19, 2], conf [n, 19]) (+ heat-maps)."""
+    hm = engine.forward(images)
+    pts, conf = ops.heatmap_argmax(hm)
+    return (pts, conf, hm) if return_heatmap else (pts, conf)
+
+
+def _read_gray(path):
+    from PIL import Image
+
+    with Image.open(path) as im:
+        return np.asarray(im.convert("L"))
+
+
+def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return_confidence=True, max_img_id=None,
+                     batch_size=8, disable_pin_memory=False, dtype="f32", device=None, state_dict=None):
+    """Drop-in for df2d.inference.inference_folder (see module docstring)."""
+    _native.require_gpu()
+    if max_img_id is None:
+        from .os_util import get_max_img_id
+
+        max_img_id = get_max_img_id(folder)
+    T = max_img_id + 1
+    ncam = config["num_cameras"]
+    engine = get_engine(dtype=dtype, device=device, state_dict=state_dict)
+    dev = engine.device
+    flip_set = set(int(c) for c in camera_ids_to_flip)
+    items = [(c, t) for c in range(ncam) for t in range(T)]
+    points = torch.empty((ncam, T, config["num_predict"], 2), dtype=torch.float32, device=dev)
+    conf = torch.empty((ncam, T, config["num_predict"], 1), dtype=torch.float32, device=dev)
+    heat = [] if return_heatmap else None
+    bs = max(1, int(batch_size))
+    for lo in range(0, len(items), bs):
+        chunk = items[lo : lo + bs]
+        frames = np.stack([_read_gray(image_path_for(folder, c, t)) for c, t in chunk])
+        host = torch.from_numpy(frames)
+        if not disable_pin_memory:
+            host = host.pin_memory()
+        fr = host.to(dev, non_blocking=not disable_pin_memory)
+        flip = torch.tensor([1 if c in flip_set else 0 for c, _ in chunk], dtype=torch.uint8)
+        x = preprocess_u8(fr.contiguous(), flip.to(dev), tuple(config["input_shape"]))
+        res = inference_views(x, engine, return_heatmap=return_heatmap)
+        cam = torch.tensor([c for c, _ in chunk], device=dev)
+        tt = torch.tensor([t for _, t in chunk], device=dev)
+        points[cam, tt] = res[0]
+        conf[cam, tt, :, 0] = res[1]
+        if return_heatmap:
+            heat.append(res[2].cpu())
+    out = [points.cpu().numpy()]
+    if return_heatmap:
+        hm = torch.cat(heat).numpy()
+        out.append(hm.reshape(ncam, T, *hm.shape[1:]))
+    if return_confidence:
+        out.append(conf.cpu().numpy())
+    return tuple(out) if len(out) > 1 else out[0]

@@ -39,6 +39,15 @@ int df3d_device_count(void);
 int df3d_device_name(int dev, char* buf, int buflen);
 
 /* ------------------------------------------------------------------------------------------------
+ * a1  input front-end of df2d's inference_folder (call site reference df3d/core.py:177-185): uint8 frames
+ *     [n, H, W, C] (C = 1 or 3) -> float32 NHWC [n, OH, OW, 3]: optional left-right flip per view
+ *     (flip_dev[n] uint8, may be NULL; the reference flips cameras ordering[4:]), bilinear resize with
+ *     half-pixel centres, (v/255 - mean[c]) / std[c].  mean3/std3 are HOST float[3].
+ * ---------------------------------------------------------------------------------------------- */
+int df3d_preprocess_u8(const unsigned char* img_dev, const unsigned char* flip_dev, int n, int H, int W, int C,
+                       float* out_dev, int OH, int OW, const float* mean3_host, const float* std3_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a3  heat-map -> point + confidence.   Replaces df2d's heatmap2points / confidence extraction behind
  *     inference_folder(..., return_confidence=True)          (reference df3d/core.py:177-185,
  *     semantics reference README.md:404: arg-max over (h, w), confidence = the max value).
@@ -67,6 +76,10 @@ int df3d_relayout_19_to_38(const float* pts19_dev, const int* ordering_host, int
  * ---------------------------------------------------------------------------------------------- */
 int df3d_triangulate(const double* P, const double* pts_px_dev, int ncam, int T, int J, double* X_dev,
                      void* stream);
+/* same, taking NORMALISED (row, col) detections and multiplying by (row_scale, col_scale) = (H, W) in the kernel,
+ * i.e. the reference's `points2d * image_shape[::-1]` (df3d/core.py:247) fused into the triangulation */
+int df3d_triangulate_scaled(const double* P, const double* pts_norm_dev, double row_scale, double col_scale, int ncam,
+                            int T, int J, double* X_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a7  bundle adjustment building blocks.   Replaces the arithmetic under pyba
@@ -125,6 +138,11 @@ int df3d_vec_dot(const double* a_dev, const double* b_dev, size_t n, double* res
 int df3d_vec_axpby(double a, const double* x_dev, double b, const double* y_dev, double* out_dev, size_t n,
                    void* stream); /* out = a*x + b*y (y may be NULL)        */
 int df3d_vec_mul(const double* x_dev, const double* y_dev, double* out_dev, size_t n, void* stream);
+int df3d_vec_absmax(const double* a_dev, size_t n, double* result_host, double* scratch_dev, void* stream); /* sync */
+/* scipy's x_scale='jac': scale_inv = sqrt(colsq) (0 -> 1 when first != 0, else max with the previous value),
+ * scale = 1 / scale_inv */
+int df3d_ba_update_scale(const double* colsq_dev, double* scale_inv_dev, double* scale_dev, size_t n, int first,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a2  stacked-hourglass forward.   Replaces the network forward inside df2d's inference_folder
@@ -175,6 +193,12 @@ int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_
 /* algorithmic work of one forward over n views: FLOPs and activation bytes (fusion model M1 of
  * SURVEY.md 8d evaluated on this engine's own plan) */
 int df3d_hg_work(const df3d_hg* h, int n, double* flops, double* bytes);
+/* per-kernel-class timing with HIP events recorded on the launch stream around every launch (small overhead:
+ * enable it for a measurement pass only).  kernel_class: 0 = 1x1 convolutions, 1 = 3x3 convolutions, 2 = stem,
+ * 3 = max-pool, 4 = upsample+add.  df3d_hg_profile(h, 1) clears previous samples; df3d_hg_profile_read() waits
+ * for the events and returns the summed duration (ms), algorithmic FLOPs and bytes, and the launch count. */
+int df3d_hg_profile(df3d_hg* h, int enable);
+int df3d_hg_profile_read(df3d_hg* h, int kernel_class, double* ms, double* flops, double* bytes, int* launches);
 /* debugging / layer-wise parity: number of plan steps, and run only steps [0, upto) then copy the
  * tensor produced by step upto-1 (NHWC, engine dtype widened to float32) into out_dev */
 int df3d_hg_num_steps(const df3d_hg* h);

@@ -1,0 +1,89 @@
+"""CPU tests: the C-ABI library builds for gfx950, loads, and exports every symbol include/df3d_hip.h declares
+(no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "df3d_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(df3d_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_documented_surface():
+    syms = _declared_symbols()
+    for needed in ("df3d_hg_forward", "df3d_heatmap_argmax", "df3d_triangulate", "df3d_ba_eval", "df3d_ba_lsmr", "df3d_relayout_19_to_38", "df3d_preprocess_u8"):
+        assert needed in syms
+
+
+def test_library_exports_every_declared_symbol(native_lib):
+    missing = [s for s in _declared_symbols() if not hasattr(native_lib, s)]
+    assert not missing, f"libdf3d_hip.so lacks {missing}"
+
+
+def test_python_prototypes_cover_the_header(native_lib):
+    from deepfly3d_amd import _native
+
+    assert sorted(_native.PROTOTYPES) == _declared_symbols()
+
+
+def test_library_is_gfx950_code_object():
+    from deepfly3d_amd import _native
+
+    blob = open(_native.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"sm_" not in blob
+
+
+def test_argument_validation_without_gpu(native_lib):
+    """Entry points validate arguments before touching the device, so this runs on CPU."""
+    from deepfly3d_amd import _native
+
+    assert native_lib.df3d_version() >= 100
+    rc = native_lib.df3d_heatmap_argmax(None, 1, 19, 3, 5, None, None, None)  # 15 pixels: not a multiple of 4
+    assert rc == -1 and b"multiple of 4" in native_lib.df3d_last_error()
+    order = (ctypes.c_int * 7)(0, 1, 2, 3, 4, 5, 5)
+    rc = native_lib.df3d_relayout_19_to_38(ctypes.c_void_p(16), order, 2, ctypes.c_void_p(16), None)
+    assert rc == -1 and b"permutation" in native_lib.df3d_last_error()
+    h = ctypes.c_void_p()
+    assert native_lib.df3d_hg_create(7, 2, ctypes.byref(h)) == -1
+    assert native_lib.df3d_hg_create(_native.DF3D_DTYPE_F32, 2, ctypes.byref(h)) == 0
+    # forward before weights are set is a state error, never a silent success
+    rc = native_lib.df3d_hg_forward(h, ctypes.c_void_p(256), 1, ctypes.c_void_p(256), ctypes.c_void_p(256), 1 << 40, None)
+    assert rc == -3 and b"weights" in native_lib.df3d_last_error()
+    native_lib.df3d_hg_destroy(h)
+
+
+def test_engine_plan_accounting(native_lib):
+    """FLOPs / bytes of the engine's own plan equal the SURVEY.md 8d figures (35.993 GFLOP, 647.3 MB per view fp32)."""
+    from deepfly3d_amd import _native
+
+    for dtype, mb in ((_native.DF3D_DTYPE_F32, 647.33), (_native.DF3D_DTYPE_BF16, 323.67)):
+        h = ctypes.c_void_p()
+        assert native_lib.df3d_hg_create(dtype, 2, ctypes.byref(h)) == 0
+        fl, by = ctypes.c_double(), ctypes.c_double()
+        assert native_lib.df3d_hg_work(h, 1, ctypes.byref(fl), ctypes.byref(by)) == 0
+        assert abs(fl.value / 1e9 - 35.9934) < 1e-3
+        assert abs(by.value / 1e6 - mb) < 0.05
+        assert native_lib.df3d_hg_num_steps(h) == 119
+        native_lib.df3d_hg_destroy(h)
+
+
+def test_no_gpu_fails_loudly(native_lib):
+    import torch
+
+    from deepfly3d_amd import _native
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_native.NativeLibraryError):
+        _native.require_gpu()
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    with pytest.raises(_native.NativeLibraryError):
+        HourglassEngine(synthetic_state_dict(0))

@@ -1,0 +1,136 @@
+"""-m gpu end-to-end tests through the reference-shaped surface (Core / CameraNetwork / pipeline / inference)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry as og
+from oracle import hourglass_torch as oh
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample_folder(tmp_path, golden_dir):
+    src = os.path.join(golden_dir, "images")
+    folder = tmp_path / "working"
+    folder.mkdir()
+    for f in os.listdir(src):
+        os.symlink(os.path.join(src, f), folder / f)
+    return str(folder)
+
+
+def test_calibration_like_the_reference_test(native_lib, cuda, tmp_path, golden_dir):
+    """Mirror of reference tests/test_df3d.py:198-244 (test_calibration): golden 2-D injected -> calibrate_calc ->
+    save -> pickle equals the golden 3-D result (points atol 1e-5, cameras atol 1e-4, ordering bit-exact, schema)."""
+    from deepfly3d_amd.config import config
+    from deepfly3d_amd.core import Core
+
+    config.pop("image_shape", None)
+    g2, g3 = np.load(f"{golden_dir}/golden_2d.npz"), np.load(f"{golden_dir}/golden_3d.npz")
+    core = Core(_sample_folder(tmp_path, golden_dir), str(tmp_path / "working_df3d"), num_images_max=0, camera_ordering=[0, 1, 2, 3, 4, 5, 6])
+    core.num_images = 15
+    core.points2d = g2["points2d"]
+    core.conf = g2["heatmap_confidence"]
+    core.calibrate_calc(0, 100)
+    core.save()
+    with open(core.save_path, "rb") as f:
+        saved = pickle.load(f)
+    assert [str(k) for k in saved.keys()] == list(g3["key_order"])
+    np.testing.assert_allclose(saved["points3d_wo_procrustes"], g3["points3d_wo_procrustes"], atol=1e-5)
+    np.testing.assert_allclose(saved["points3d"], g3["points3d"], atol=1e-5)
+    for cam in range(7):
+        assert list(saved[cam].keys()) == list(g3["cam_key_order"])
+        for key in ("R", "tvec", "intr", "distort"):
+            np.testing.assert_allclose(saved[cam][key], g3[key][cam], atol=1e-4)
+    assert saved["camera_ordering"].dtype == np.int64 and np.array_equal(saved["camera_ordering"], g3["camera_ordering"])
+    assert np.array_equal(saved["points2d"], g3["points2d"]) and np.array_equal(saved["heatmap_confidence"], g3["heatmap_confidence"])
+    assert abs(core.camNet.reprojection_error() - 2.94) < 0.05
+    config.pop("image_shape", None)
+
+
+def test_pipeline_matches_oracle_stage_by_stage(native_lib, cuda, golden_dir):
+    """Device pipeline (hourglass -> arg-max -> layout -> DLT) on 3 frames against the oracle fed the DEVICE
+    heat-maps' arg-max input: index work bit-exact, DLT to 1e-9 relative; heat-maps within the fp32 tolerance."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.pipeline import FramePipeline
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    sd = synthetic_state_dict(0)
+    eng = HourglassEngine(sd, dtype="f32", device=cuda)
+    c = np.load(f"{golden_dir}/calib.npz")
+    pipe = FramePipeline(eng, c["R"], c["tvec"], c["intr"], camera_ordering=[6, 5, 4, 3, 2, 1, 0])
+    frames = torch.rand((3, 7, 256, 512, 3), generator=torch.Generator().manual_seed(1))
+    p2, conf, p3 = pipe.run(frames.to(cuda), frames_per_batch=2)
+    hm = eng.forward(frames.reshape(21, 256, 512, 3).to(cuda)).cpu().numpy()
+    pts, cf = og.heatmap_argmax(hm)
+    pts = pts.reshape(3, 7, 19, 2).transpose(1, 0, 2, 3)
+    p38 = og.relayout_19_to_38(pts, [6, 5, 4, 3, 2, 1, 0])
+    assert np.array_equal(p2.cpu().numpy(), p38)
+    assert np.array_equal(conf.cpu().numpy(), cf.reshape(3, 7, 19).transpose(1, 0, 2))
+    ref = og.triangulate_dlt(og.pixels_from_normalised(p38, [960, 480]), og.projection_matrices(c["R"], c["tvec"], c["intr"]))
+    got = p3.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    net = oh.HourglassNet()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    net.eval()
+    hm_ref = oh.forward_nhwc(net, frames[0]).numpy()
+    assert np.abs(hm[:7] - hm_ref).max() < 2e-4 * np.abs(hm_ref).max()
+
+
+def test_inference_folder_plumbing(native_lib, cuda, tmp_path, golden_dir, monkeypatch):
+    """df2d-shaped entry point on the reference's sample jpgs with synthetic weights: shapes, dtypes, value grid,
+    flip handling and batch-size independence (numerical parity with df2d is unpinned: weights absent)."""
+    from deepfly3d_amd import inference
+
+    monkeypatch.setenv("DF3D_SYNTHETIC_WEIGHTS", "0")
+    folder = _sample_folder(tmp_path, golden_dir)
+    pts, conf = inference.inference_folder(folder=folder, camera_ids_to_flip=[4, 5, 6], return_heatmap=False, return_confidence=True,
+                                           max_img_id=1, batch_size=8, disable_pin_memory=False)
+    assert pts.shape == (7, 2, 19, 2) and conf.shape == (7, 2, 19, 1) and pts.dtype == np.float32 and conf.dtype == np.float32
+    grid = pts.astype(np.float64) * np.array([64.0, 128.0])
+    assert np.array_equal(grid, np.round(grid)) and grid[..., 0].max() < 64 and grid[..., 1].max() < 128
+    pts2, conf2, hm = None, None, None
+    out = inference.inference_folder(folder=folder, camera_ids_to_flip=[4, 5, 6], return_heatmap=True, return_confidence=True,
+                                     max_img_id=1, batch_size=3, disable_pin_memory=True)
+    pts2, hm, conf2 = out
+    assert np.array_equal(pts, pts2) and np.array_equal(conf, conf2) and hm.shape == (7, 2, 19, 64, 128)
+    # flipping a camera changes its detections, not the others'
+    pts3, _ = inference.inference_folder(folder=folder, camera_ids_to_flip=[5, 6], max_img_id=1, batch_size=8)
+    assert np.array_equal(pts3[[0, 1, 2, 3, 5, 6]], pts[[0, 1, 2, 3, 5, 6]]) and not np.array_equal(pts3[4], pts[4])
+
+
+def test_preprocess_kernel_against_torch(native_lib, cuda):
+    """Front-end kernel vs a torch restatement: bilinear (half-pixel centres, no antialias) + flip + normalise."""
+    from deepfly3d_amd import inference
+
+    img = torch.randint(0, 256, (3, 480, 960), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))
+    flip = torch.tensor([0, 1, 0], dtype=torch.uint8)
+    out = inference.preprocess_u8(img.to(cuda), flip.to(cuda)).cpu()
+    x = img.float() / 255.0
+    x[1] = x[1].flip(-1)
+    ref = torch.nn.functional.interpolate(x[:, None], size=(256, 512), mode="bilinear", align_corners=False, antialias=False)[:, 0]
+    ref = (ref - 0.22)[..., None].expand(-1, -1, -1, 3)
+    assert out.shape == (3, 256, 512, 3)
+    assert (out - ref).abs().max() < 1e-5
+
+
+def test_full_cli_run_on_sample_images(native_lib, cuda, tmp_path, golden_dir, monkeypatch):
+    """df3d-cli end to end on the sample jpgs (synthetic weights): one result file with the reference's schema."""
+    from deepfly3d_amd import cli
+    from deepfly3d_amd.config import config
+
+    config.pop("image_shape", None)
+    monkeypatch.setenv("DF3D_SYNTHETIC_WEIGHTS", "0")
+    folder = _sample_folder(tmp_path, golden_dir)
+    # random-weight detections are not geometrically consistent; the run must still complete and save
+    assert cli.main([folder, "--batch-size", "7", "-n", "2"]) == 0
+    out_dir = folder + "_df3d"
+    files = [f for f in os.listdir(out_dir) if f.startswith("df3d_result")]
+    assert len(files) == 1
+    with open(os.path.join(out_dir, files[0]), "rb") as f:
+        d = pickle.load(f)
+    assert [str(k) for k in d.keys()] == ["0", "1", "2", "3", "4", "5", "6", "points3d", "points2d", "points3d_wo_procrustes", "camera_ordering", "heatmap_confidence"]
+    assert d["points2d"].shape == (7, 2, 38, 2) and d["points3d"].shape == (2, 38, 3) and d["heatmap_confidence"].shape == (7, 2, 19, 1)
+    config.pop("image_shape", None)

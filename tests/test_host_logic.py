@@ -1,0 +1,202 @@
+"""CPU tests of the host-side logic: parameter packing / BN folding, frame sharding, folder discovery, CLI flags,
+Procrustes (product copy) against the reference-executed vectors, result schema."""
+import ctypes
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_procrustes_product_matches_reference_vectors(golden_dir):
+    from deepfly3d_amd.procrustes import procrustes_separate
+
+    for name in ("procrustes_golden", "procrustes_jitter"):
+        d = np.load(f"{golden_dir}/{name}.npz")
+        inp = d["inp"].copy()
+        out = procrustes_separate(inp)
+        assert np.abs(out - d["out"]).max() < 1e-12
+        assert np.array_equal(inp, d["inp"])  # unlike the reference's in-place centring, the input is left intact
+
+
+def test_package_data_matches_reference_fixtures(golden_dir):
+    from deepfly3d_amd.config import load_calibration, load_procrustes_template
+
+    c = np.load(f"{golden_dir}/calib.npz")
+    cal = load_calibration()
+    for cam in range(7):
+        for k in ("R", "tvec", "intr", "distort"):
+            assert np.array_equal(cal[cam][k], c[k][cam])
+    assert np.array_equal(load_procrustes_template(), np.load(f"{golden_dir}/template.npz")["points3d"])
+
+
+def test_bn_folding_and_packing_reproduce_the_oracle_layer(native_lib):
+    """pack_state_dict folds bn2 into conv1 etc.; check one bottleneck numerically against torch (CPU, float64)."""
+    from deepfly3d_amd import _native
+    from deepfly3d_amd.hourglass import pack_state_dict
+    from oracle import hourglass_torch as oh
+
+    net = oh.build(seed=1)
+    h = ctypes.c_void_p()
+    assert native_lib.df3d_hg_create(_native.DF3D_DTYPE_F32, 2, ctypes.byref(h)) == 0
+    blob = pack_state_dict(h, net.state_dict())
+    d = _native.HGParam()
+    params = {}
+    for i in range(native_lib.df3d_hg_num_params(h)):
+        native_lib.df3d_hg_param_desc(h, i, ctypes.byref(d))
+        params[(d.name.decode(), d.kind)] = (blob[d.offset : d.offset + d.count].copy(), d.taps, d.cin, d.cout, d.cin_pad, d.cout_pad)
+    native_lib.df3d_hg_destroy(h)
+    blk = net.layer3[0].double()
+    x = torch.randn(1, 256, 5, 6, dtype=torch.float64)
+    with torch.no_grad():
+        ref = torch.relu(blk.bn2(blk.conv1(torch.relu(blk.bn1(x)))))
+    w, taps, cin, cout, cin_pad, cout_pad = params[("layer3.0.conv1", 0)]
+    b = params[("layer3.0.conv1", 1)][0][:cout]
+    s = params[("layer3.0.conv1", 2)][0][:cin]
+    t = params[("layer3.0.conv1", 3)][0][:cin]
+    W = w.reshape(taps, cout_pad, cin_pad)[0, :cout, :cin].astype(np.float64)
+    a = np.maximum(x.numpy() * s[None, :, None, None] + t[None, :, None, None], 0)
+    got = np.maximum(np.einsum("oc,nchw->nohw", W, a) + b[None, :, None, None], 0)
+    assert np.abs(got - ref.numpy()).max() < 1e-5 * np.abs(ref.numpy()).max()
+    # stem packing: [148][64], k = ky*21 + kx*3 + c, BN folded
+    ws = params[("conv1", 0)][0].reshape(148, 64)
+    sd = net.state_dict()
+    scale = (sd["bn1.weight"] / torch.sqrt(sd["bn1.running_var"] + 1e-5)).numpy()
+    assert np.allclose(ws[2 * 21 + 3 * 3 + 1, 5], sd["conv1.weight"][5, 1, 2, 3].item() * scale[5], rtol=1e-6)
+    assert np.all(ws[147] == 0)
+    # padded score_ input channels are zero
+    wsc = params[("score_.0", 0)]
+    assert wsc[4] == 32 and np.all(wsc[0].reshape(1, 256, 32)[0, :, 19:] == 0)
+
+
+def test_synthetic_state_dict_matches_oracle_module_shapes():
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+    from oracle import hourglass_torch as oh
+
+    sd = synthetic_state_dict(0)
+    ref = {k: tuple(v.shape) for k, v in oh.HourglassNet().state_dict().items() if not k.endswith("num_batches_tracked")}
+    assert {k: v.shape for k, v in sd.items()} == ref
+    again = synthetic_state_dict(0)
+    assert all(np.array_equal(sd[k], again[k]) for k in sd)
+
+
+@pytest.mark.parametrize("T,world,align", [(100000, 8, 1000), (1000, 8, 1), (15, 4, 1), (7, 8, 1), (100000, 3, 1000), (0, 2, 1)])
+def test_shard_ranges_cover_exactly(T, world, align):
+    from deepfly3d_amd.distributed import all_ranges
+
+    r = all_ranges(T, world, align)
+    assert r[0][0] == 0 and r[-1][1] == T
+    for (a0, a1), (b0, b1) in zip(r, r[1:]):
+        assert a1 == b0 and a0 <= a1
+    assert all(a % align == 0 for a, _ in r if a < T)
+    sizes = [b - a for a, b in r]
+    assert max(sizes) - min(sizes) <= align
+
+
+def test_os_util_and_core_folder_discovery(tmp_path, golden_dir):
+    from deepfly3d_amd import os_util
+
+    src = os.path.join(golden_dir, "images")
+    folder = tmp_path / "images"
+    folder.mkdir()
+    for f in os.listdir(src):
+        os.symlink(os.path.join(src, f), folder / f)
+    assert os_util.get_max_img_id(str(folder)) == 1
+    assert os_util.parse_img_name("camera_3_img_000012.jpg") == (3, 12)
+    assert os_util.parse_vid_name("camera_5.mp4") == 5
+    with pytest.raises(FileNotFoundError):
+        os_util.get_max_img_id(str(tmp_path))
+    # Core without a GPU: construction (discovery, image shape, PoseDB side effect, ordering) works on CPU
+    from deepfly3d_amd.config import config
+    from deepfly3d_amd.core import Core, find_default_camera_ordering
+
+    config.pop("image_shape", None)
+    core = Core(str(folder), str(tmp_path / "out"), num_images_max=0, camera_ordering=[0, 1, 2, 3, 4, 5, 6])
+    assert core.num_images == 2 and core.image_shape == [960, 480]
+    assert np.array_equal(core.camera_ordering, np.arange(7))
+    assert core.save_path.endswith("df3d_result_" + str(folder).replace("/", "_") + ".pkl")
+    assert any(f.startswith("pose_corr") for f in os.listdir(tmp_path / "out"))
+    assert Core(str(folder), str(tmp_path / "out"), num_images_max=1).num_images == 1
+    assert list(find_default_camera_ordering("/data/CLC/x")) == [0, 6, 5, 4, 3, 2, 1]
+    with pytest.raises(NotImplementedError):
+        find_default_camera_ordering("/nowhere")
+    config["image_shape"] = [1, 1]
+    with pytest.raises(ValueError):
+        Core(str(folder), str(tmp_path / "out"))
+    config.pop("image_shape", None)
+
+
+def test_core_save_schema_2d_only_and_resume(tmp_path, golden_dir):
+    """2-D-only save (reference core.py:351-365) and the resume path (core.py:109-126) without a GPU."""
+    from deepfly3d_amd.config import config
+    from deepfly3d_amd.core import Core
+
+    src = os.path.join(golden_dir, "images")
+    folder = tmp_path / "images"
+    folder.mkdir()
+    for f in os.listdir(src):
+        os.symlink(os.path.join(src, f), folder / f)
+    config.pop("image_shape", None)
+    g2 = np.load(f"{golden_dir}/golden_2d.npz")
+    core = Core(str(folder), str(tmp_path / "out"))
+    core.points2d, core.conf = g2["points2d"][:, :2], g2["heatmap_confidence"][:, :2]
+    core.save()
+    with open(core.save_path, "rb") as f:
+        d = pickle.load(f)
+    assert list(d.keys()) == ["points2d", "camera_ordering", "heatmap_confidence"]
+    assert d["camera_ordering"].dtype == np.int64
+    core2 = Core(str(folder), str(tmp_path / "out"))  # resumes from the pickle
+    assert np.array_equal(core2.points2d, d["points2d"]) and core2.camNet is not None
+    assert not core2.camNet.has_calibration()
+    assert np.array_equal(core2.camNet.points2d, d["points2d"] * np.array([480.0, 960.0]))
+    config.pop("image_shape", None)
+
+
+def test_cli_flags_and_exit_codes(tmp_path, capsys):
+    from deepfly3d_amd import cli
+
+    a = cli.parse_cli_args([str(tmp_path / "imgs")])
+    assert a.output_folder == str(tmp_path / "imgs_df3d") and a.batch_size == 8 and a.order == list(range(7))
+    assert not a.skip_estimation and a.num_images_max == 0 and a.output_fps is None
+    a = cli.parse_cli_args([str(tmp_path), "--camera-ids", "6", "5", "4", "3", "2", "1", "0", "-n", "5", "--batch-size", "4", "--pin-memory-disabled", "-x"])
+    assert a.order == [6, 5, 4, 3, 2, 1, 0] and a.num_images_max == 5 and a.batch_size == 4 and a.pin_memory_disabled and a.delete_images
+    assert cli.main([str(tmp_path), "-d"]) == 0
+    assert cli.main([str(tmp_path), "-r", "-f"]) == 1
+    assert cli.main([str(tmp_path / "missing.txt"), "-f"]) == 1
+    assert cli.main([str(tmp_path), "-f"]) == 1  # a directory is not a list file
+    assert cli.main([str(tmp_path), "--skip-pose-estimation"]) == 0  # nothing to do
+    (tmp_path / "a" / "images").mkdir(parents=True)
+    (tmp_path / "b" / "c" / "images").mkdir(parents=True)
+    assert sorted(cli.find_subfolders(str(tmp_path), "images")) == sorted([str(tmp_path / "a" / "images"), str(tmp_path / "b" / "c" / "images")])
+
+
+def test_camera_network_bookkeeping(golden_dir):
+    """CameraNetwork tolerates a whole result dict as `calib`, keeps pixel (row, col) points, summarises in the
+    golden key order; reprojection error of the golden result is the value the reference prints (~2.94 px)."""
+    from deepfly3d_amd.camera_network import CameraNetwork
+
+    g3 = np.load(f"{golden_dir}/golden_3d.npz")
+    calib = {c: {"R": g3["R"][c], "tvec": g3["tvec"][c], "intr": g3["intr"][c], "distort": g3["distort"][c]} for c in range(7)}
+    calib.update({"points2d": g3["points2d"], "meta": None, np.int64(3): calib[3]})
+    net = CameraNetwork(g3["points2d"] * np.array([480.0, 960.0]), calib=calib)
+    assert net.has_calibration() and net[2].cam_id == 2 and net.cam_list[5][3].shape == (38, 2)
+    net.points3d = g3["points3d_wo_procrustes"]
+    assert abs(net.reprojection_error() - 2.9424) < 1e-3
+    s = net.summarize()
+    assert list(s.keys()) == [0, 1, 2, 3, 4, 5, 6, "points3d", "points2d"]
+    assert list(s[0].keys()) == ["R", "tvec", "distort", "intr"]
+    with pytest.raises(NotImplementedError):
+        net.bundle_adjust(update_intrinsic=True)
+    assert not CameraNetwork(g3["points2d"], calib=None).has_calibration()
+
+
+def test_assemble_result_schema(golden_dir):
+    from deepfly3d_amd.distributed import assemble_result
+
+    g3 = np.load(f"{golden_dir}/golden_3d.npz")
+    cams = {k: g3[k] for k in ("R", "tvec", "intr", "distort")}
+    out = assemble_result(g3["points2d"], g3["heatmap_confidence"][..., 0], g3["points3d_wo_procrustes"], cams, g3["camera_ordering"])
+    assert [str(k) for k in out.keys()] == list(g3["key_order"])
+    assert np.abs(out["points3d"] - g3["points3d"]).max() < 1e-12
+    assert out["heatmap_confidence"].shape == (7, 15, 19, 1) and out["points2d"].dtype == np.float64
