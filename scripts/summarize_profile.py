@@ -1,0 +1,65 @@
+"""Summarise rocprofv3 outputs into profiles/: python scripts/summarize_profile.py <tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir>]
+
+* copies <stats_dir>/*_kernel_stats.csv (top rows, kernel names shortened) to profiles/<tag>_kernel_stats.csv
+* if PMC dirs are given: per-kernel HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes
+  (FETCH_SIZE on gfx950 reports half of a wide coalesced read stream: MI355X_MICROARCH.md "HBM"; separate --pmc passes)
+  -> profiles/<tag>_traffic.csv and profiles/traffic.json (read by bench.py for roofline.traffic)
+"""
+import collections, csv, glob, json, os, re, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLASS = [("conv_mfma_kernel<float, 1,", "f32:conv1x1_mfma"), ("conv_mfma_kernel<float, 9,", "f32:conv3x3_mfma"),
+         ("conv_mfma_kernel<__hip_bfloat16, 1,", "bf16:conv1x1_mfma"), ("conv_mfma_kernel<__hip_bfloat16, 9,", "bf16:conv3x3_mfma"),
+         ("bottleneck_kernel<float", "f32:bottleneck_fused"), ("bottleneck_kernel<__hip_bfloat16", "bf16:bottleneck_fused")]
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name[:110]
+
+
+def main():
+    tag, stats_dir = sys.argv[1], sys.argv[2]
+    out_dir = os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    stats = glob.glob(os.path.join(stats_dir, "*kernel_stats.csv"))[0]
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows[:25]:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+    if len(sys.argv) >= 5:
+        agg = collections.defaultdict(lambda: {"n": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+        for d in sys.argv[3:5]:
+            for r in csv.DictReader(open(glob.glob(os.path.join(d, "*counter_collection.csv"))[0])):
+                a = agg[short(r["Kernel_Name"])]
+                a[r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Counter_Name"] == "FETCH_SIZE":
+                    a["n"] += 1
+        traffic = {}
+        tj = os.path.join(out_dir, "traffic.json")
+        if os.path.exists(tj):
+            traffic = json.load(open(tj))
+        cls = collections.defaultdict(lambda: [0, 0.0])
+        with open(os.path.join(out_dir, f"{tag}_traffic.csv"), "w") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "launches", "FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch", "hbm_bytes_per_launch=(2*FETCH+WRITE)*1024"])
+            for k, a in sorted(agg.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"] + kv[1]["WRITE_SIZE"])):
+                if not a["n"] or "at::native" in k:
+                    continue
+                b = (2 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024
+                w.writerow([k, a["n"], a["FETCH_SIZE"] / a["n"], a["WRITE_SIZE"] / a["n"], b / a["n"]])
+                for pat, name in CLASS:
+                    if pat in k:
+                        cls[name][0] += a["n"]
+                        cls[name][1] += b
+        for name, (n, b) in cls.items():
+            traffic[name] = b / n
+        json.dump(traffic, open(tj, "w"), indent=1, sort_keys=True)
+        print(json.dumps(traffic, indent=1))
+
+
+if __name__ == "__main__":
+    main()
