@@ -43,6 +43,8 @@ class HGParam(Structure):
         ("cout_pad", c_int),
         ("offset", c_size_t),
         ("count", c_size_t),
+        ("kperm", c_int),
+        ("reserved", c_int),
     ]
 
 

@@ -65,30 +65,37 @@ struct Elem<__hip_bfloat16> {
     static constexpr int PER16 = 8;
 };
 
-// apply y = max(x*s + t, 0) to one 16-byte chunk of channels starting at channel c
+// Input BatchNorm + ReLU, y = max(x*s + t, 0), on one 16-byte chunk of channels starting at channel c.
+// Split in two so the scale/shift loads can be issued with the prefetch (PreactCoef::load) and the arithmetic
+// happens after the MFMAs of the current step (preact_apply).
 template <typename T>
-__device__ __forceinline__ u32x4 preact_chunk(u32x4 raw, const float* __restrict__ scale,
-                                              const float* __restrict__ shift, int c) {
+struct PreactCoef {
+    static constexpr int N = Elem<T>::PER16 / 4;  // float4 groups: 1 (f32) or 2 (bf16)
+    f32x4 s[N], t[N];
+    __device__ __forceinline__ void load(const float* __restrict__ scale, const float* __restrict__ shift, int c) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            s[i] = *reinterpret_cast<const f32x4*>(scale + c + 4 * i);
+            t[i] = *reinterpret_cast<const f32x4*>(shift + c + 4 * i);
+        }
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ u32x4 preact_apply(u32x4 raw, const PreactCoef<T>& k) {
     if constexpr (sizeof(T) == 4) {
-        const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(shift + c);
         f32x4 v = __builtin_bit_cast(f32x4, raw);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(v[i], s[i], t[i]), 0.0f);
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(v[i], k.s[0][i], k.t[0][i]), 0.0f);
         return __builtin_bit_cast(u32x4, v);
     } else {
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + c);
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(scale + c + 4);
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + c);
-        const f32x4 t1 = *reinterpret_cast<const f32x4*>(shift + c + 4);
         u32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float lo = bf16_bits_to_f32((unsigned short)(raw[i] & 0xffffu));
             const float hi = bf16_bits_to_f32((unsigned short)(raw[i] >> 16));
-            const float sl = i < 2 ? s0[2 * i] : s1[2 * i - 4], sh = i < 2 ? s0[2 * i + 1] : s1[2 * i - 3];
-            const float tl = i < 2 ? t0[2 * i] : t1[2 * i - 4], th = i < 2 ? t0[2 * i + 1] : t1[2 * i - 3];
-            const float a = fmaxf(fmaf(lo, sl, tl), 0.0f), b = fmaxf(fmaf(hi, sh, th), 0.0f);
+            const float a = fmaxf(fmaf(lo, k.s[i >> 1][(2 * i) & 3], k.t[i >> 1][(2 * i) & 3]), 0.0f);
+            const float b = fmaxf(fmaf(hi, k.s[i >> 1][(2 * i + 1) & 3], k.t[i >> 1][(2 * i + 1) & 3]), 0.0f);
             o[i] = (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16);
         }
         return o;
@@ -165,6 +172,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     const int nsteps = TAPS * ksteps_per_tap;
 
     u32x4 ra[A_PASSES], rb[B_PASSES];
+    bool ra_ok[A_PASSES];
+    PreactCoef<T> coef;
 
     auto load_step = [&](int s) {
         const int tap = TAPS == 1 ? 0 : s / ksteps_per_tap;
@@ -184,12 +193,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                 ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             }
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) {
-                v = *reinterpret_cast<const u32x4*>(a_ptr[i] + tap_off + (size_t)c0 * Elem<T>::BYTES);
-                if (TAPS == 1 && p.scale) v = preact_chunk<T>(v, p.scale, p.shift, c0);
-            }
+            if (ok) v = *reinterpret_cast<const u32x4*>(a_ptr[i] + tap_off + (size_t)c0 * Elem<T>::BYTES);
             ra[i] = v;
+            ra_ok[i] = ok;
         }
+        if (TAPS == 1 && p.scale) coef.load(p.scale, p.shift, c0);
         const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) +
                                      ((size_t)tap * p.cout * p.cin + (size_t)c0) * Elem<T>::BYTES;
 #pragma unroll
@@ -202,6 +210,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     auto store_step = [&](int buf) {
         unsigned char* const sa = smem + buf * STAGE_BYTES;
         unsigned char* const sb = sa + A_BYTES;
+        // the input BN + ReLU is applied here, AFTER the MFMAs of the current step, so the global loads issued by
+        // load_step() stay in flight across the whole compute phase
+        if (TAPS == 1 && p.scale) {
+#pragma unroll
+            for (int i = 0; i < A_PASSES; ++i)
+                if (ra_ok[i]) ra[i] = preact_apply<T>(ra[i], coef);
+        }
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i)
             *reinterpret_cast<u32x4*>(sa + (srow + i * ROWS_PER_PASS) * PITCH + chunk * 16) = ra[i];
@@ -234,6 +249,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         const unsigned char* const sa = smem + buf * STAGE_BYTES;
         const unsigned char* const sb = sa + A_BYTES;
         if (s + 1 < nsteps) load_step(s + 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads ABOVE the MFMA block (hipcc sinks them otherwise)
 #pragma unroll
         for (int j = 0; j < RB / 32; ++j) {
             u32x4 af[G::TM], bf[G::TN];
@@ -262,17 +278,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < G::TM; ++i) {
             const long long mbase = m0 + wm * (G::TM * 32) + i * 32 + 4 * (lane >> 5);
+            // all 16 residual loads of the tile are issued before the first store (loads may not pass stores
+            // to possibly aliasing memory, so interleaving them would serialise 16 round trips)
+            float resv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = mbase + (r & 3) + 8 * (r >> 2);
+                resv[r] = 0.0f;
+                if (p.res && m < p.M) {
+                    if constexpr (sizeof(T) == 4)
+                        resv[r] = reinterpret_cast<const float*>(p.res)[(size_t)m * p.res_pitch + n];
+                    else
+                        resv[r] = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.res)[(size_t)m * p.res_pitch + n]);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long m = mbase + (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r] + bias;
                 if (m < p.M) {
-                    if (p.res) {
-                        if constexpr (sizeof(T) == 4)
-                            v += reinterpret_cast<const float*>(p.res)[(size_t)m * p.res_pitch + n];
-                        else
-                            v += bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.res)[(size_t)m * p.res_pitch + n]);
-                    }
+                    v += resv[r];
                     if (p.relu) v = fmaxf(v, 0.0f);
                     if (p.out) {
                         if constexpr (sizeof(T) == 4)
@@ -468,6 +493,328 @@ __global__ __launch_bounds__(256) void export_kernel(const void* __restrict__ in
 // weights f32 -> bf16 bits (round to nearest even)
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = f32_to_bf16_bits(in[i]);
+}
+
+
+// =====================================================================================================
+// Fused pre-activation bottleneck  (256 -> 128 -> 128 -> 256, the block that makes up 29 of the network's
+// 32 bottlenecks):    out = W3 relu(bn3(W2 (*) relu(bn2(W1 relu(bn1 x))))) + x
+// One workgroup = one 8 x 16 output tile.  x is read once (10 x 18 halo tile), the output written once; the two
+// 128-channel intermediates never leave the CU:
+//   phase 1  t1 = relu(W1' relu(bn1 x) + b1')  on the 180 halo pixels (GEMM 192 x 128 x 256) -> LDS [180][128],
+//            out-of-image halo pixels forced to 0 (= the zero padding of the 3x3 convolution).
+//            Wave w owns output channels 32w..32w+31 for all 6 pixel tiles (x fragments are shared through LDS).
+//   phase 2  t2^T = W2' (*) t1: rows = output channels (A = W2 taps, staged), columns = the wave's 32 pixels
+//            (B = t1 read straight from the LDS tile at the tap-shifted pixel) -> 4 accumulator tiles per wave.
+//   phase 3  out = W3 relu(t2 + b2') + b3 + x.  The transposed phase-2 accumulators ARE valid MFMA A operands:
+//            accumulator register r of channel tile m holds, for pixel lane&31, channel 32m + (r&3) + 8(r>>2) +
+//            4(lane>>5) -- a permutation of K that is matched on the W3 side by which 16-byte chunk a lane reads
+//            (f32) / by the host's K order of the packed W3 (bf16).  So t2 never goes through LDS.
+// LDS (fp32): t1 180 x 528 B = 95 KB + staging 51 KB (phase 1) / 37 KB (phases 2, 3) -> one workgroup per CU.
+// =====================================================================================================
+struct BottleneckArgs {
+    const void* in;     // NHWC [V, H, W, 256]
+    void* out;          // NHWC [V, H, W, 256]
+    const void* w1;     // [128][256]
+    const void* w2;     // [9][128][128]
+    const void* w3;     // [256][128]
+    const float* b1;    // [128] (bn2 folded)
+    const float* b2;    // [128] (bn3 folded)
+    const float* b3;    // [256]
+    const float* s1;    // [256] bn1 scale
+    const float* t1;    // [256] bn1 shift
+    int V, H, W;
+};
+
+constexpr int BT_TH = 8, BT_TW = 16;              // output tile
+constexpr int BT_HW = BT_TW + 2;                  // halo tile width (18)
+constexpr int BT_HALO = (BT_TH + 2) * BT_HW;      // 180 halo pixels
+constexpr int BT_HROWS = 192;                     // padded to 6 MFMA row tiles
+
+template <typename T>
+struct BtCfg {
+    static constexpr int EB = Elem<T>::BYTES;
+    static constexpr int T1_PITCH = 128 * EB + 16;                 // bytes per halo pixel in the t1 tile
+    static constexpr int T1_BYTES = BT_HALO * T1_PITCH;
+    static constexpr int RB1 = 64;                                 // staged row bytes, phase 1
+    static constexpr int RB2 = 128;                                // phases 2 and 3
+    static constexpr int STAGE1 = (BT_HROWS + 128) * (RB1 + 16);   // x rows + W1 rows
+    static constexpr int STAGE2 = 128 * (RB2 + 16);                // W2 / W3 rows
+    static constexpr int STAGE_BYTES = 2 * (STAGE1 > STAGE2 ? STAGE1 : STAGE2);
+    static constexpr int MISC = 128 * 4 + 64;                      // b2' + validity masks
+    static constexpr int LDS_BYTES = T1_BYTES + STAGE_BYTES + MISC;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
+    using C = BtCfg<T>;
+    constexpr int EB = C::EB;
+    constexpr int PER16 = Elem<T>::PER16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const t1_lds = smem;
+    unsigned char* const stage = smem + C::T1_BYTES;
+    float* const b2_lds = reinterpret_cast<float*>(smem + C::T1_BYTES + C::STAGE_BYTES);
+    unsigned long long* const valid_lds = reinterpret_cast<unsigned long long*>(b2_lds + 128);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5;          // which 16-byte chunk of a 32-byte K group this lane reads
+    const int l31 = lane & 31;
+    const int tiles_x = p.W / BT_TW, tiles_y = p.H / BT_TH;
+    int b = blockIdx.x;
+    const int tx0 = (b % tiles_x) * BT_TW;
+    b /= tiles_x;
+    const int ty0 = (b % tiles_y) * BT_TH;
+    const int view = b / tiles_y;
+    const unsigned char* const xin = reinterpret_cast<const unsigned char*>(p.in) + (size_t)view * p.H * p.W * 256 * EB;
+
+    // validity of the 192 halo rows (inside the image?) as three 64-bit masks
+    if (tid < BT_HROWS) {
+        const int hy = tid / BT_HW, hx = tid % BT_HW;
+        const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+        const bool ok = tid < BT_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) valid_lds[wave] = m;
+    }
+    if (tid < 128) b2_lds[tid] = p.b2[tid];
+
+    // =========================== phase 1: t1 = relu(W1' relu(bn1 x) + b1') on the halo ===================
+    {
+        constexpr int RB = C::RB1, PITCH = RB + 16, CPR = RB / 16, RPP = 256 / CPR;   // 4 chunks/row, 64 rows/pass
+        constexpr int KE = RB / EB;
+        constexpr int XP = BT_HROWS / RPP, WP = 128 / RPP;                             // 3 and 2 passes
+        constexpr int X_BYTES = BT_HROWS * PITCH;
+        constexpr int NSTEPS = 256 / KE;
+        const int chunk = tid % CPR, srow = tid / CPR;
+        const unsigned char* xp[XP];
+        bool xok[XP];
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int hp = srow + i * RPP;
+            const int hy = hp / BT_HW, hx = hp % BT_HW;
+            const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+            xok[i] = hp < BT_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            xp[i] = xin + ((size_t)(xok[i] ? y : 0) * p.W + (xok[i] ? x : 0)) * 256 * EB;
+        }
+        u32x4 rx[XP], rw[WP];
+        PreactCoef<T> coef;
+        auto load1 = [&](int s) {
+            const int c0 = s * KE + chunk * PER16;
+            coef.load(p.s1, p.t1, c0);
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (xok[i]) v = *reinterpret_cast<const u32x4*>(xp[i] + (size_t)c0 * EB);
+                rx[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < WP; ++i)
+                rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.w1) + ((size_t)(srow + i * RPP) * 256 + c0) * EB);
+        };
+        auto store1 = [&](int buf) {
+            unsigned char* const sx = stage + buf * C::STAGE1;
+            unsigned char* const sw = sx + X_BYTES;
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                if (xok[i]) rx[i] = preact_apply<T>(rx[i], coef);  // bn1 + ReLU, deferred past the MFMAs
+                *reinterpret_cast<u32x4*>(sx + (srow + i * RPP) * PITCH + chunk * 16) = rx[i];
+            }
+#pragma unroll
+            for (int i = 0; i < WP; ++i) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
+        };
+        f32x16 acc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        load1(0);
+        store1(0);
+        __syncthreads();
+        for (int s = 0; s < NSTEPS; ++s) {
+            const unsigned char* const sx = stage + (s & 1) * C::STAGE1;
+            const unsigned char* const sw = sx + X_BYTES;
+            if (s + 1 < NSTEPS) load1(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < RB / 32; ++j) {
+                const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (wave * 32 + l31) * PITCH + j * 32 + half * 16);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + (i * 32 + l31) * PITCH + j * 32 + half * 16);
+                    mfma_chunk<T>(xf, wf, acc[i]);
+                }
+            }
+            if (s + 1 < NSTEPS) store1((s & 1) ^ 1);
+            __syncthreads();
+        }
+        // epilogue: bias + ReLU, zero outside the image, into the t1 tile (rows = halo pixels, 128 channels)
+        const int n = wave * 32 + l31;
+        const float bias = p.b1[n];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const unsigned long long vm = valid_lds[i >> 1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int hp = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (hp < BT_HALO) {
+                    const bool ok = (vm >> (hp & 63)) & 1ull;
+                    const float v = ok ? fmaxf(acc[i][r] + bias, 0.0f) : 0.0f;
+                    if constexpr (EB == 4)
+                        *reinterpret_cast<float*>(t1_lds + hp * C::T1_PITCH + n * 4) = v;
+                    else
+                        *reinterpret_cast<unsigned short*>(t1_lds + hp * C::T1_PITCH + n * 2) = f32_to_bf16_bits(v);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // =========================== phase 2: t2^T = W2' (*) t1 ==============================================
+    constexpr int RB = C::RB2, PITCH = RB + 16, CPR = RB / 16, RPP = 256 / CPR;   // 8 chunks/row, 32 rows/pass
+    constexpr int KE = RB / EB;
+    constexpr int WPASS = 128 / RPP;                                               // 4
+    const int chunk = tid % CPR, srow = tid / CPR;
+    u32x4 rw[WPASS];
+    auto load_w = [&](const void* wbase, size_t row_stride_elems, size_t elem_off) {
+#pragma unroll
+        for (int i = 0; i < WPASS; ++i)
+            rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wbase) +
+                                                    ((size_t)(srow + i * RPP) * row_stride_elems + elem_off + chunk * PER16) * EB);
+    };
+    auto store_w = [&](int buf) {
+        unsigned char* const sw = stage + buf * C::STAGE2;
+#pragma unroll
+        for (int i = 0; i < WPASS; ++i) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
+    };
+
+    // this wave's 32 pixels: tile rows 2*wave, 2*wave + 1
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
+    f32x16 t2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t2[m][r] = 0.0f;
+    {
+        constexpr int KSTEPS = 128 / KE;          // K-steps per tap
+        constexpr int NSTEPS = 9 * KSTEPS;
+        load_w(p.w2, 128, 0);
+        store_w(0);
+        __syncthreads();
+        for (int s = 0; s < NSTEPS; ++s) {
+            const int tap = s / KSTEPS, kc = s - tap * KSTEPS;
+            const unsigned char* const sw = stage + (s & 1) * C::STAGE2;
+            if (s + 1 < NSTEPS) {
+                const int tap1 = (s + 1) / KSTEPS, kc1 = (s + 1) - tap1 * KSTEPS;
+                load_w(p.w2, 128, (size_t)tap1 * 128 * 128 + (size_t)kc1 * KE);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const unsigned char* const tb = t1_lds + ((py + ky) * BT_HW + (px + kx)) * C::T1_PITCH + kc * RB + half * 16;
+#pragma unroll
+            for (int j = 0; j < RB / 32; ++j) {
+                const u32x4 tf = *reinterpret_cast<const u32x4*>(tb + j * 32);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (m * 32 + l31) * PITCH + j * 32 + half * 16);
+                    mfma_chunk<T>(wf, tf, t2[m]);
+                }
+            }
+            if (s + 1 < NSTEPS) store_w((s & 1) ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // bias + ReLU on t2 (channel of register r in tile m: 32m + (r&3) + 8(r>>2) + 4*half)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2_lds + 32 * m + 8 * q + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = fmaxf(t2[m][4 * q + e] + bb[e], 0.0f);
+        }
+
+    // =========================== phase 3: out = W3 t2 + b3 + x ==========================================
+    // two halves of 128 output channels; K-step = KE channels of t2 = accumulator registers of one/two tiles
+#pragma unroll 1
+    for (int nh = 0; nh < 2; ++nh) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        constexpr int NSTEPS = 128 / KE;
+        const void* w3h = reinterpret_cast<const unsigned char*>(p.w3) + (size_t)nh * 128 * 128 * EB;
+        load_w(w3h, 128, 0);
+        store_w(0);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NSTEPS; ++s) {
+            const unsigned char* const sw = stage + (s & 1) * C::STAGE2;
+            if (s + 1 < NSTEPS) load_w(w3h, 128, (size_t)(s + 1) * KE);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (EB == 4) {
+                // KE = 32 channels = channel tile m = s; 16-channel group q2: registers 8*q2 .. 8*q2+7
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        // registers 8*q2 + 4*jj + e hold channels 16*q2 + 8*jj + 4*half + e  -> 16-byte chunk (4*q2 + 2*jj + half)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 wf = *reinterpret_cast<const f32x4*>(sw + (i * 32 + l31) * PITCH + (4 * q2 + 2 * jj + half) * 16);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(t2[s][8 * q2 + 4 * jj + e], wf[e], acc[i], 0, 0, 0);
+                        }
+                    }
+            } else {
+                // KE = 64 channels = channel tiles 2s, 2s+1; per tile two MFMAs (registers 0-7 and 8-15).
+                // Packed W3 K order (host): position 8*(2*q + half) + e  <->  channel 16*q + 8*(e>>2) + 4*half + (e&3) within the tile
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2) {
+                        bf16x8 af;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) af[e] = (__bf16)t2[2 * s + mm][8 * q2 + e];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sw + (i * 32 + l31) * PITCH + (mm * 32 + (2 * q2 + half) * 8) * 2);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf, acc[i], 0, 0, 0);
+                        }
+                    }
+            }
+            if (s + 1 < NSTEPS) store_w((s & 1) ^ 1);
+            __syncthreads();
+        }
+        // epilogue: rows = this wave's pixels... (A = t2: rows are pixels lane&31 -> accumulator ROWS are pixels)
+        // D[row = pixel (r&3) + 8(r>>2) + 4*half][col = channel nh*128 + 32 i + l31]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = nh * 128 + i * 32 + l31;
+            const float bias = p.b3[n];
+            float xr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {  // all residual loads first (see conv_mfma_kernel)
+                const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;   // pixel index inside the wave's 32
+                const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * 256 + n;
+                if constexpr (EB == 4)
+                    xr[r] = reinterpret_cast<const float*>(xin)[po];
+                else
+                    xr[r] = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(xin)[po]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * 256 + n;
+                const float v = acc[i][r] + bias + xr[r];
+                if constexpr (EB == 4)
+                    reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * 256 * 4)[po] = v;
+                else
+                    reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * 256 * 2)[po] = f32_to_bf16_bits(v);
+            }
+        }
+    }
 }
 
 }  // namespace hgk

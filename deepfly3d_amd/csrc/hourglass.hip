@@ -19,7 +19,7 @@ using namespace hgk;
 
 namespace {
 
-enum StepKind { ST_STEM, ST_CONV, ST_POOL, ST_UPADD };
+enum StepKind { ST_STEM, ST_CONV, ST_POOL, ST_UPADD, ST_BOTTLENECK };
 
 struct TensorDesc {
     size_t off;  // elements per view, from the start of the activation area
@@ -36,7 +36,8 @@ struct Step {
     StepKind kind;
     std::string name;
     int in, out, res;  // tensor ids (res = -1: none; UPADD: in = hi-res, res = low-res)
-    ConvPlan conv;
+    ConvPlan conv;     // ST_CONV / ST_STEM; for ST_BOTTLENECK: conv = conv1, conv2b = conv2, conv3b = conv3
+    ConvPlan conv2b, conv3b;
 };
 
 struct Allocator {
@@ -85,6 +86,7 @@ struct df3d_hg {
     int H = 256, W = 512;
     int classes = 19;
     int rb_override = 0;  // 0 = auto, 64 or 128: staged row bytes per K-step (tuning knob)
+    int fuse = 1;         // 1 = 256->128->128->256 bottlenecks at >= 16x32 run as ONE fused kernel
     std::vector<TensorDesc> tensors;
     std::vector<Step> steps;
     std::vector<df3d_hg_param> params;
@@ -115,9 +117,11 @@ struct df3d_hg {
         const TensorDesc& t = tensors[id];
         alloc.release(t.off, (size_t)t.h * t.w * t.pitch);
     }
-    size_t add_param(const std::string& name, int kind, int taps, int cin, int cout, int cin_pad, int cout_pad, size_t count) {
+    size_t add_param(const std::string& name, int kind, int taps, int cin, int cout, int cin_pad, int cout_pad, size_t count,
+                     int kperm = 0) {
         df3d_hg_param p;
         memset(&p, 0, sizeof(p));
+        p.kperm = kperm;
         snprintf(p.name, sizeof(p.name), "%s", name.c_str());
         p.kind = kind;
         p.taps = taps;
@@ -132,33 +136,58 @@ struct df3d_hg {
         return p.offset;
     }
 
+    ConvPlan plan_conv(const std::string& name, int taps, int cin, int cin_pad, int cout, bool preact, bool relu, bool nchw_out,
+                       int kperm = 0) {
+        const int cout_pad = (cout + 31) / 32 * 32;
+        ConvPlan c{taps, cin, cout, cin_pad, cout_pad, preact, relu, nchw_out, 0, 0, 0, 0};
+        c.w_off = add_param(name, 0, taps, cin, cout, cin_pad, cout_pad, (size_t)taps * cout_pad * cin_pad, kperm);
+        c.b_off = add_param(name, 1, taps, cin, cout, cin_pad, cout_pad, cout_pad);
+        if (preact) {
+            c.s_off = add_param(name, 2, taps, cin, cout, cin_pad, cout_pad, cin_pad);
+            c.t_off = add_param(name, 3, taps, cin, cout, cin_pad, cout_pad, cin_pad);
+        }
+        return c;
+    }
+    void account_conv(double px, int taps, int cin, int cout, bool res) {
+        flops_per_view += 2.0 * px * taps * cin * cout;
+        elems_per_view += px * (cin + cout + (res ? cout : 0));
+    }
     // one convolution step; returns the output tensor id
     int conv(const std::string& name, int in, int taps, int cout, bool preact, bool relu, int res, bool nchw_out = false) {
         const TensorDesc ti = tensors[in];
-        const int cin = ti.c;
-        const int cin_pad = ti.pitch;                  // inputs are stored padded
-        const int cout_pad = (cout + 31) / 32 * 32;
         Step st;
         st.kind = ST_CONV;
         st.name = name;
         st.in = in;
         st.res = res;
-        st.conv = ConvPlan{taps, cin, cout, cin_pad, cout_pad, preact, relu, nchw_out, 0, 0, 0, 0};
-        st.conv.w_off = add_param(name, 0, taps, cin, cout, cin_pad, cout_pad, (size_t)taps * cout_pad * cin_pad);
-        st.conv.b_off = add_param(name, 1, taps, cin, cout, cin_pad, cout_pad, cout_pad);
-        if (preact) {
-            st.conv.s_off = add_param(name, 2, taps, cin, cout, cin_pad, cout_pad, cin_pad);
-            st.conv.t_off = add_param(name, 3, taps, cin, cout, cin_pad, cout_pad, cin_pad);
-        }
-        st.out = nchw_out ? -1 : new_tensor(ti.h, ti.w, cout, cout_pad);
+        st.conv = plan_conv(name, taps, ti.c, ti.pitch, cout, preact, relu, nchw_out);
+        st.out = nchw_out ? -1 : new_tensor(ti.h, ti.w, cout, st.conv.cout_pad);
         steps.push_back(st);
-        const double px = (double)ti.h * ti.w;
-        flops_per_view += 2.0 * px * taps * cin * cout;
-        elems_per_view += px * (cin + cout + (res >= 0 ? cout : 0));
+        account_conv((double)ti.h * ti.w, taps, ti.c, cout, res >= 0);
         return st.out;
     }
     int bottleneck(const std::string& name, int x, int planes) {
         const int cin = tensors[x].c, cout = 2 * planes;
+        const TensorDesc tx = tensors[x];
+        if (fuse && cin == 256 && planes == 128 && tx.h % 8 == 0 && tx.w % 16 == 0 && tx.h >= 16 && tx.w >= 32) {
+            // the whole block in one kernel (hg_kernels.h: bottleneck_kernel); algorithmic work is accounted
+            // exactly as for the three separate convolutions (model M1), although far fewer bytes really move
+            Step st;
+            st.kind = ST_BOTTLENECK;
+            st.name = name + ".conv3";
+            st.in = x;
+            st.res = x;
+            st.conv = plan_conv(name + ".conv1", 1, 256, 256, 128, true, true, false);
+            st.conv2b = plan_conv(name + ".conv2", 9, 128, 128, 128, false, true, false);
+            st.conv3b = plan_conv(name + ".conv3", 1, 128, 128, 256, false, false, false, dtype == DF3D_DTYPE_BF16 ? 1 : 0);
+            st.out = new_tensor(tx.h, tx.w, 256);
+            steps.push_back(st);
+            const double px = (double)tx.h * tx.w;
+            account_conv(px, 1, 256, 128, false);
+            account_conv(px, 9, 128, 128, false);
+            account_conv(px, 1, 128, 256, true);
+            return st.out;
+        }
         int a = conv(name + ".conv1", x, 1, planes, true, true, -1);
         int b = conv(name + ".conv2", a, 9, planes, false, true, -1);
         free_tensor(a);
@@ -306,7 +335,7 @@ int launch_conv(const ConvArgs& a, int taps, int rb, hipStream_t s) {
     return DF3D_EINVAL;
 }
 
-enum KernelClass { KC_CONV1 = 0, KC_CONV3 = 1, KC_STEM = 2, KC_POOL = 3, KC_UPADD = 4, KC_COUNT = 5 };
+enum KernelClass { KC_CONV1 = 0, KC_CONV3 = 1, KC_STEM = 2, KC_POOL = 3, KC_UPADD = 4, KC_BOTTLENECK = 5, KC_COUNT = 6 };
 
 hipEvent_t get_event(df3d_hg* h) {
     if (!h->event_pool.empty()) {
@@ -394,6 +423,35 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 if (int rc = launch_conv<T>(a, st.conv.taps, rb, s)) return rc;
                 break;
             }
+            case ST_BOTTLENECK: {
+                const TensorDesc& ti = h->tensors[st.in];
+                BottleneckArgs a;
+                a.in = tptr(st.in);
+                a.out = tptr(st.out);
+                a.w1 = wb + st.conv.w_off * eb;
+                a.w2 = wb + st.conv2b.w_off * eb;
+                a.w3 = wb + st.conv3b.w_off * eb;
+                a.b1 = h->blob + st.conv.b_off;
+                a.b2 = h->blob + st.conv2b.b_off;
+                a.b3 = h->blob + st.conv3b.b_off;
+                a.s1 = h->blob + st.conv.s_off;
+                a.t1 = h->blob + st.conv.t_off;
+                a.V = n;
+                a.H = ti.h;
+                a.W = ti.w;
+                static bool attr_done = false;
+                if (!attr_done) {
+                    DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<T>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, BtCfg<T>::LDS_BYTES));
+                    attr_done = true;
+                }
+                const double px = (double)n * ti.h * ti.w;
+                ScopedTimer tm(h, s, KC_BOTTLENECK, 2.0 * px * (256.0 * 128 + 9.0 * 128 * 128 + 128.0 * 256), px * eb * 512.0);
+                const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
+                hipLaunchKernelGGL((bottleneck_kernel<T>), dim3(blocks), dim3(256), BtCfg<T>::LDS_BYTES, s, a);
+                DF3D_LAUNCH_CHECK();
+                break;
+            }
             case ST_POOL: {
                 const TensorDesc& to = h->tensors[st.out];
                 const int chunks = to.pitch * eb / 16;
@@ -475,6 +533,13 @@ int df3d_hg_set_input(df3d_hg* h, int height, int width) {
 
 int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
     DF3D_CHECK_ARG(h && key, "null argument");
+    if (!strcmp(key, "fuse")) {
+        DF3D_CHECK_ARG(value == 0 || value == 1, "fuse must be 0 or 1");
+        DF3D_CHECK_ARG(h->blob == nullptr, "set 'fuse' before df3d_hg_set_weights (it changes the parameter manifest)");
+        h->fuse = value;
+        h->build();
+        return DF3D_OK;
+    }
     if (!strcmp(key, "row_bytes")) {
         DF3D_CHECK_ARG(value == 0 || value == 64 || value == 128, "row_bytes must be 0, 64 or 128");
         h->rb_override = value;

@@ -77,6 +77,12 @@ def pack_state_dict(engine_handle, state_dict):
             else:  # [tap][cout_pad][cin_pad]
                 packed = np.zeros((d.taps, d.cout_pad, d.cin_pad))
                 packed[:, :cout, :cin] = w.transpose(2, 3, 0, 1).reshape(d.taps, cout, cin)
+                if d.kperm:  # K order the bf16 fused bottleneck expects (see include/df3d_hip.h: df3d_hg_param.kperm)
+                    pos = np.arange(32)
+                    q, hh, e = pos // 16, (pos // 8) % 2, pos % 8
+                    src = 16 * q + 8 * (e // 4) + 4 * hh + (e % 4)
+                    idx = (32 * np.arange(d.cin_pad // 32)[:, None] + src[None, :]).ravel()
+                    packed = packed[:, :, idx]
             view[:] = packed.ravel().astype(np.float32)
         elif d.kind == 1:
             view[: d.cout] = b.astype(np.float32)
@@ -89,7 +95,7 @@ def pack_state_dict(engine_handle, state_dict):
 class HourglassEngine:
     """The device engine: `forward(images_nhwc) -> heat-maps (n, 19, H/4, W/4)` on the current torch stream."""
 
-    def __init__(self, state_dict, dtype="f32", num_stacks=2, device=None, height=256, width=512, row_bytes=0):
+    def __init__(self, state_dict, dtype="f32", num_stacks=2, device=None, height=256, width=512, row_bytes=0, fuse=True):
         _native.require_gpu()
         self.lib = _native.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -100,6 +106,8 @@ class HourglassEngine:
         self.h = h
         self.height, self.width = height, width
         _native.check(self.lib.df3d_hg_set_input(self.h, height, width), "df3d_hg_set_input")
+        if not fuse:
+            _native.check(self.lib.df3d_hg_set_option(self.h, b"fuse", 0), "df3d_hg_set_option")
         if row_bytes:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"row_bytes", row_bytes), "df3d_hg_set_option")
         blob = pack_state_dict(self.h, state_dict)

@@ -174,6 +174,10 @@ typedef struct df3d_hg_param {
     int cin_pad, cout_pad;
     size_t offset;   /* in floats, into the blob                                       */
     size_t count;    /* in floats                                                      */
+    int kperm;       /* 1: weight K (cin) order is permuted inside every 32-channel group: packed position
+                        8*(2q + h) + e holds channel 16q + 8*(e>>2) + 4h + (e&3)  (q, h in {0,1}, e in 0..7);
+                        used by the bf16 fused bottleneck, whose conv3 consumes MFMA accumulators directly */
+    int reserved;
 } df3d_hg_param;
 
 int df3d_hg_create(int dtype, int num_stacks, df3d_hg** out);
@@ -185,7 +189,8 @@ size_t df3d_hg_blob_floats(const df3d_hg* h);
 /* bf16 engines keep a bf16 copy of the blob: lowp_dev must hold df3d_hg_lowp_bytes(h) bytes (NULL for f32). */
 size_t df3d_hg_lowp_bytes(const df3d_hg* h);
 int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void* stream);
-/* tuning knobs: "row_bytes" = 0 (auto) | 64 | 128 bytes staged per operand row per K-step */
+/* knobs: "fuse" = 1 (default) | 0: run 256->128->128->256 bottlenecks as one fused kernel -- must be set before
+ * the weights (it changes the manifest);  "row_bytes" = 0 (auto) | 64 | 128 bytes staged per operand row per K-step */
 int df3d_hg_set_option(df3d_hg* h, const char* key, int value);
 size_t df3d_hg_workspace_bytes(const df3d_hg* h, int n);
 int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_dev, void* workspace_dev,
@@ -195,7 +200,7 @@ int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_
 int df3d_hg_work(const df3d_hg* h, int n, double* flops, double* bytes);
 /* per-kernel-class timing with HIP events recorded on the launch stream around every launch (small overhead:
  * enable it for a measurement pass only).  kernel_class: 0 = 1x1 convolutions, 1 = 3x3 convolutions, 2 = stem,
- * 3 = max-pool, 4 = upsample+add.  df3d_hg_profile(h, 1) clears previous samples; df3d_hg_profile_read() waits
+ * 3 = max-pool, 4 = upsample+add, 5 = fused bottleneck.  df3d_hg_profile(h, 1) clears previous samples; df3d_hg_profile_read() waits
  * for the events and returns the summed duration (ms), algorithmic FLOPs and bytes, and the launch count. */
 int df3d_hg_profile(df3d_hg* h, int enable);
 int df3d_hg_profile_read(df3d_hg* h, int kernel_class, double* ms, double* flops, double* bytes, int* launches);

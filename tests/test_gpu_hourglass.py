@@ -39,13 +39,14 @@ def _rel_err(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("row_bytes", [0, 64])
-def test_fp32_every_step_matches_oracle(native_lib, cuda, oracle_net, images, traced, row_bytes):
+@pytest.mark.parametrize("fuse,row_bytes", [(True, 0), (False, 0), (False, 64)])
+def test_fp32_every_step_matches_oracle(native_lib, cuda, oracle_net, images, traced, fuse, row_bytes):
+    """Every plan step (fused bottlenecks: the block output; unfused: every convolution) against the oracle."""
     from deepfly3d_amd.hourglass import HourglassEngine
 
-    eng = HourglassEngine(oracle_net.state_dict(), dtype="f32", device=cuda, row_bytes=row_bytes)
+    eng = HourglassEngine(oracle_net.state_dict(), dtype="f32", device=cuda, row_bytes=row_bytes, fuse=fuse)
     steps = eng.steps()
-    assert len(steps) == len(traced), (len(steps), len(traced))
+    assert len(steps) == (len(traced) if not fuse else len(traced) - 2 * 17), (len(steps), len(traced))
     img = images.to(cuda)
     worst = (0.0, None)
     for k, (name, hwc) in enumerate(steps, start=1):
@@ -86,10 +87,11 @@ def test_fp32_work_accounting(native_lib, cuda, oracle_net):
     assert 0.55e9 < nbytes < 0.75e9  # fusion model M1: ~647 MB per view in fp32
 
 
-def test_bf16_forward_close_to_oracle(native_lib, cuda, oracle_net, images, traced):
+@pytest.mark.parametrize("fuse", [True, False])
+def test_bf16_forward_close_to_oracle(native_lib, cuda, oracle_net, images, traced, fuse):
     from deepfly3d_amd.hourglass import HourglassEngine
 
-    eng = HourglassEngine(oracle_net.state_dict(), dtype="bf16", device=cuda)
+    eng = HourglassEngine(oracle_net.state_dict(), dtype="bf16", device=cuda, fuse=fuse)
     hm = eng.forward(images.to(cuda)).cpu()
     ref = traced["score.1"]
     err = _rel_err(hm, ref)
