@@ -27,7 +27,7 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 PEAK_HBM_GBS = 8000.0
-KERNEL_CLASSES = ["conv1x1_mfma", "conv3x3_mfma", "stem7x7_mfma", "maxpool2", "upsample_add", "bottleneck_fused"]
+KERNEL_CLASSES = ["conv1x1_mfma", "conv3x3_mfma", "stem7x7_mfma", "maxpool2", "upsample_add", "bottleneck_fused", "head_fused"]
 
 
 def parse():
@@ -171,7 +171,7 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get(f"{a.dtype}:{dom['kernel']}")
-        compute_bound = dom["kernel"].startswith(("conv", "stem", "bottleneck"))
+        compute_bound = dom["kernel"].startswith(("conv", "stem", "bottleneck", "head"))
         roof = {
             "bound": "mfma" if compute_bound else "hbm",
             "kernel": dom["kernel"],

@@ -19,7 +19,7 @@ using namespace hgk;
 
 namespace {
 
-enum StepKind { ST_STEM, ST_CONV, ST_POOL, ST_UPADD, ST_BOTTLENECK };
+enum StepKind { ST_STEM, ST_CONV, ST_POOL, ST_UPADD, ST_BOTTLENECK, ST_HEAD };
 
 struct TensorDesc {
     size_t off;  // elements per view, from the start of the activation area
@@ -37,7 +37,8 @@ struct Step {
     std::string name;
     int in, out, res;  // tensor ids (res = -1: none; UPADD: in = hi-res, res = low-res)
     ConvPlan conv;     // ST_CONV / ST_STEM; for ST_BOTTLENECK: conv = conv1, conv2b = conv2, conv3b = conv3
-    ConvPlan conv2b, conv3b;
+    ConvPlan conv2b, conv3b, conv4b;  // ST_HEAD: conv = fc, conv2b = score, conv3b = fc_, conv4b = score_
+    bool last = false;
 };
 
 struct Allocator {
@@ -276,6 +277,37 @@ struct df3d_hg {
             int y = hourglass("hg." + S + ".hg", 4, x, 128);
             int r = bottleneck("res." + S + ".0", y, 128);
             free_tensor(y);
+            if (fuse) {
+                // fc -> score -> (fc_, score_) + x in one kernel (hg_kernels.h: head_kernel)
+                const bool last = s == num_stacks - 1;
+                const int kp = dtype == DF3D_DTYPE_BF16 ? 1 : 0;
+                const TensorDesc tr = tensors[r];
+                Step st;
+                st.kind = ST_HEAD;
+                st.last = last;
+                st.name = last ? "score." + S : "score_." + S;
+                st.in = r;
+                st.res = last ? -1 : x;
+                st.conv = plan_conv("fc." + S + ".0", 1, 256, 256, 256, false, true, false);
+                st.conv2b = plan_conv("score." + S, 1, 256, 256, classes, false, false, last, kp);
+                const double px = (double)tr.h * tr.w;
+                account_conv(px, 1, 256, 256, false);
+                account_conv(px, 1, 256, classes, false);
+                if (!last) {
+                    st.conv3b = plan_conv("fc_." + S, 1, 256, 256, 256, false, false, false, kp);
+                    st.conv4b = plan_conv("score_." + S, 1, classes, 32, 256, false, false, false, kp);
+                    account_conv(px, 1, 256, 256, true);
+                    account_conv(px, 1, classes, 256, true);
+                    st.out = new_tensor(tr.h, tr.w, 256);
+                } else {
+                    st.out = -1;
+                }
+                steps.push_back(st);
+                free_tensor(r);
+                free_tensor(x);
+                x = st.out;
+                continue;
+            }
             int f = conv("fc." + S + ".0", r, 1, 256, false, true, -1);
             free_tensor(r);
             const bool last = s == num_stacks - 1;
@@ -335,7 +367,7 @@ int launch_conv(const ConvArgs& a, int taps, int rb, hipStream_t s) {
     return DF3D_EINVAL;
 }
 
-enum KernelClass { KC_CONV1 = 0, KC_CONV3 = 1, KC_STEM = 2, KC_POOL = 3, KC_UPADD = 4, KC_BOTTLENECK = 5, KC_COUNT = 6 };
+enum KernelClass { KC_CONV1 = 0, KC_CONV3 = 1, KC_STEM = 2, KC_POOL = 3, KC_UPADD = 4, KC_BOTTLENECK = 5, KC_HEAD = 6, KC_COUNT = 7 };
 
 hipEvent_t get_event(df3d_hg* h) {
     if (!h->event_pool.empty()) {
@@ -449,6 +481,40 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 ScopedTimer tm(h, s, KC_BOTTLENECK, 2.0 * px * (256.0 * 128 + 9.0 * 128 * 128 + 128.0 * 256), px * eb * 512.0);
                 const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
                 hipLaunchKernelGGL((bottleneck_kernel<T>), dim3(blocks), dim3(256), BtCfg<T>::LDS_BYTES, s, a);
+                DF3D_LAUNCH_CHECK();
+                break;
+            }
+            case ST_HEAD: {
+                const TensorDesc& ti = h->tensors[st.in];
+                HeadArgs a;
+                a.r = tptr(st.in);
+                a.x = st.last ? nullptr : tptr(st.res);
+                a.out = st.last ? nullptr : tptr(st.out);
+                a.heat = st.last ? heatmaps : nullptr;
+                a.wfc = wb + st.conv.w_off * eb;
+                a.wsc = wb + st.conv2b.w_off * eb;
+                a.bfc = h->blob + st.conv.b_off;
+                a.bsc = h->blob + st.conv2b.b_off;
+                a.wfc_ = st.last ? nullptr : wb + st.conv3b.w_off * eb;
+                a.wsc_ = st.last ? nullptr : wb + st.conv4b.w_off * eb;
+                a.bfc_ = st.last ? nullptr : h->blob + st.conv3b.b_off;
+                a.bsc_ = st.last ? nullptr : h->blob + st.conv4b.b_off;
+                a.M = (long long)n * ti.h * ti.w;
+                a.HW = ti.h * ti.w;
+                const void* fn = st.last ? reinterpret_cast<const void*>(head_kernel<T, true>) : reinterpret_cast<const void*>(head_kernel<T, false>);
+                static bool attr_done[2] = {false, false};
+                if (!attr_done[st.last]) {
+                    DF3D_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, HeadCfg<T>::LDS_BYTES));
+                    attr_done[st.last] = true;
+                }
+                const double mm = (double)a.M;
+                const double fl = 2.0 * mm * (256.0 * 256 + 256.0 * 19 + (st.last ? 0.0 : 256.0 * 256 + 19.0 * 256));
+                ScopedTimer tm(h, s, KC_HEAD, fl, mm * eb * (st.last ? 256.0 : 768.0) + (st.last ? mm * 19 * 4 : 0.0));
+                const unsigned blocks = (unsigned)((a.M + 127) / 128);
+                if (st.last)
+                    hipLaunchKernelGGL((head_kernel<T, true>), dim3(blocks), dim3(256), HeadCfg<T>::LDS_BYTES, s, a);
+                else
+                    hipLaunchKernelGGL((head_kernel<T, false>), dim3(blocks), dim3(256), HeadCfg<T>::LDS_BYTES, s, a);
                 DF3D_LAUNCH_CHECK();
                 break;
             }

@@ -200,7 +200,7 @@ int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_
 int df3d_hg_work(const df3d_hg* h, int n, double* flops, double* bytes);
 /* per-kernel-class timing with HIP events recorded on the launch stream around every launch (small overhead:
  * enable it for a measurement pass only).  kernel_class: 0 = 1x1 convolutions, 1 = 3x3 convolutions, 2 = stem,
- * 3 = max-pool, 4 = upsample+add, 5 = fused bottleneck.  df3d_hg_profile(h, 1) clears previous samples; df3d_hg_profile_read() waits
+ * 3 = max-pool, 4 = upsample+add, 5 = fused bottleneck, 6 = fused stack head.  df3d_hg_profile(h, 1) clears previous samples; df3d_hg_profile_read() waits
  * for the events and returns the summed duration (ms), algorithmic FLOPs and bytes, and the launch count. */
 int df3d_hg_profile(df3d_hg* h, int enable);
 int df3d_hg_profile_read(df3d_hg* h, int kernel_class, double* ms, double* flops, double* bytes, int* launches);
