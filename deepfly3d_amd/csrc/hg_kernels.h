@@ -513,16 +513,18 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
 // LDS (fp32): t1 180 x 528 B = 95 KB + staging 51 KB (phase 1) / 37 KB (phases 2, 3) -> one workgroup per CU.
 // =====================================================================================================
 struct BottleneckArgs {
-    const void* in;     // NHWC [V, H, W, 256]
-    void* out;          // NHWC [V, H, W, 256]
-    const void* w1;     // [128][256]
-    const void* w2;     // [9][128][128]
-    const void* w3;     // [256][128]
-    const float* b1;    // [128] (bn2 folded)
-    const float* b2;    // [128] (bn3 folded)
-    const float* b3;    // [256]
-    const float* s1;    // [256] bn1 scale
-    const float* t1;    // [256] bn1 shift
+    const void* in;     // NHWC [V, H, W, CIN]
+    void* out;          // NHWC [V, H, W, 2*PL]
+    const void* w1;     // [PL][CIN]
+    const void* w2;     // [9][PL][PL]
+    const void* w3;     // [2*PL][PL]      (K permuted for bf16)
+    const void* wd;     // [2*PL][CIN]     downsample (skip) convolution, DS only
+    const float* b1;    // [PL]   (bn2 folded)
+    const float* b2;    // [PL]   (bn3 folded)
+    const float* b3;    // [2*PL] (DS: conv3 bias + downsample bias, summed by the engine at set_weights time)
+    const float* bd;    // [2*PL] DS only
+    const float* s1;    // [CIN] bn1 scale
+    const float* t1;    // [CIN] bn1 shift
     int V, H, W;
 };
 
@@ -531,30 +533,39 @@ constexpr int BT_HW = BT_TW + 2;                  // halo tile width (18)
 constexpr int BT_HALO = (BT_TH + 2) * BT_HW;      // 180 halo pixels
 constexpr int BT_HROWS = 192;                     // padded to 6 MFMA row tiles
 
-template <typename T>
+// CIN -> PL -> PL -> 2*PL; DS: the skip path is a 1x1 convolution of the raw input (CIN != 2*PL)
+template <typename T, int CIN, int PL, bool DS>
 struct BtCfg {
     static constexpr int EB = Elem<T>::BYTES;
-    static constexpr int T1_PITCH = 128 * EB + 16;                 // bytes per halo pixel in the t1 tile
+    static constexpr int CO = 2 * PL;
+    static constexpr int T1_PITCH = PL * EB + 16;                  // bytes per halo pixel in the t1 tile
     static constexpr int T1_BYTES = BT_HALO * T1_PITCH;
     static constexpr int RB1 = 64;                                 // staged row bytes, phase 1
-    static constexpr int RB2 = 128;                                // phases 2 and 3
-    static constexpr int STAGE1 = (BT_HROWS + 128) * (RB1 + 16);   // x rows + W1 rows
-    static constexpr int STAGE2 = 128 * (RB2 + 16);                // W2 / W3 rows
-    static constexpr int STAGE_BYTES = 2 * (STAGE1 > STAGE2 ? STAGE1 : STAGE2);
-    static constexpr int MISC = 128 * 4 + 64;                      // b2' + validity masks
+    static constexpr int RB2 = (PL * EB) % 128 == 0 ? 128 : 64;    // phases 2 and 3 (K = PL)
+    static constexpr int RBD = 64;                                 // downsample steps of phase 3 (K = CIN)
+    static constexpr int STAGE1 = (BT_HROWS + PL) * (RB1 + 16);    // x rows + W1 rows
+    static constexpr int STAGE2 = 128 * (RB2 + 16);                // W2 (PL rows) / W3 (128 rows) 
+    static constexpr int STAGED = DS ? (128 + 128) * (RBD + 16) : 0;  // x centre rows + Wd rows
+    static constexpr int SMAX = STAGE1 > STAGE2 ? (STAGE1 > STAGED ? STAGE1 : STAGED) : (STAGE2 > STAGED ? STAGE2 : STAGED);
+    static constexpr int STAGE_BYTES = 2 * SMAX;
+    static constexpr int MISC = PL * 4 + 64;                       // b2' + validity masks
     static constexpr int LDS_BYTES = T1_BYTES + STAGE_BYTES + MISC;
+    static constexpr int NT = PL / 32;                             // channel tiles of the intermediates
 };
 
-template <typename T>
+template <typename T, int CIN, int PL, bool DS>
 __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
-    using C = BtCfg<T>;
+    using C = BtCfg<T, CIN, PL, DS>;
     constexpr int EB = C::EB;
+    constexpr int CO = C::CO;
+    constexpr int NT = C::NT;
     constexpr int PER16 = Elem<T>::PER16;
+    static_assert(PL == 128 || PL == 64, "planes");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const t1_lds = smem;
     unsigned char* const stage = smem + C::T1_BYTES;
     float* const b2_lds = reinterpret_cast<float*>(smem + C::T1_BYTES + C::STAGE_BYTES);
-    unsigned long long* const valid_lds = reinterpret_cast<unsigned long long*>(b2_lds + 128);
+    unsigned long long* const valid_lds = reinterpret_cast<unsigned long long*>(b2_lds + PL);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5;          // which 16-byte chunk of a 32-byte K group this lane reads
@@ -565,7 +576,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
     b /= tiles_x;
     const int ty0 = (b % tiles_y) * BT_TH;
     const int view = b / tiles_y;
-    const unsigned char* const xin = reinterpret_cast<const unsigned char*>(p.in) + (size_t)view * p.H * p.W * 256 * EB;
+    const unsigned char* const xin = reinterpret_cast<const unsigned char*>(p.in) + (size_t)view * p.H * p.W * CIN * EB;
 
     // validity of the 192 halo rows (inside the image?) as three 64-bit masks
     if (tid < BT_HROWS) {
@@ -575,15 +586,18 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
         const unsigned long long m = __ballot(ok);
         if (lane == 0) valid_lds[wave] = m;
     }
-    if (tid < 128) b2_lds[tid] = p.b2[tid];
+    if (tid < PL) b2_lds[tid] = p.b2[tid];
 
     // =========================== phase 1: t1 = relu(W1' relu(bn1 x) + b1') on the halo ===================
     {
         constexpr int RB = C::RB1, PITCH = RB + 16, CPR = RB / 16, RPP = 256 / CPR;   // 4 chunks/row, 64 rows/pass
         constexpr int KE = RB / EB;
-        constexpr int XP = BT_HROWS / RPP, WP = 128 / RPP;                             // 3 and 2 passes
+        constexpr int XP = BT_HROWS / RPP, WP = PL / RPP;                              // 3 and 2 (1) passes
         constexpr int X_BYTES = BT_HROWS * PITCH;
-        constexpr int NSTEPS = 256 / KE;
+        constexpr int NSTEPS = CIN / KE;
+        // wave -> (channel tile ct, row tiles rt0 .. rt0 + RT - 1)
+        constexpr int RT = 6 * NT / 4;
+        const int ct = wave % NT, rt0 = (wave / NT) * RT;
         const int chunk = tid % CPR, srow = tid / CPR;
         const unsigned char* xp[XP];
         bool xok[XP];
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
             const int hy = hp / BT_HW, hx = hp % BT_HW;
             const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
             xok[i] = hp < BT_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            xp[i] = xin + ((size_t)(xok[i] ? y : 0) * p.W + (xok[i] ? x : 0)) * 256 * EB;
+            xp[i] = xin + ((size_t)(xok[i] ? y : 0) * p.W + (xok[i] ? x : 0)) * CIN * EB;
         }
         u32x4 rx[XP], rw[WP];
         PreactCoef<T> coef;
@@ -608,7 +622,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
             }
 #pragma unroll
             for (int i = 0; i < WP; ++i)
-                rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.w1) + ((size_t)(srow + i * RPP) * 256 + c0) * EB);
+                rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.w1) + ((size_t)(srow + i * RPP) * CIN + c0) * EB);
         };
         auto store1 = [&](int buf) {
             unsigned char* const sx = stage + buf * C::STAGE1;
@@ -621,9 +635,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
 #pragma unroll
             for (int i = 0; i < WP; ++i) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
         };
-        f32x16 acc[6];
+        f32x16 acc[RT];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
         load1(0);
@@ -636,25 +650,25 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < RB / 32; ++j) {
-                const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (wave * 32 + l31) * PITCH + j * 32 + half * 16);
+                const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (ct * 32 + l31) * PITCH + j * 32 + half * 16);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + (i * 32 + l31) * PITCH + j * 32 + half * 16);
+                for (int i = 0; i < RT; ++i) {
+                    const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * PITCH + j * 32 + half * 16);
                     mfma_chunk<T>(xf, wf, acc[i]);
                 }
             }
             if (s + 1 < NSTEPS) store1((s & 1) ^ 1);
             __syncthreads();
         }
-        // epilogue: bias + ReLU, zero outside the image, into the t1 tile (rows = halo pixels, 128 channels)
-        const int n = wave * 32 + l31;
+        // epilogue: bias + ReLU, zero outside the image, into the t1 tile (rows = halo pixels, PL channels)
+        const int n = ct * 32 + l31;
         const float bias = p.b1[n];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const unsigned long long vm = valid_lds[i >> 1];
+        for (int i = 0; i < RT; ++i) {
+            const unsigned long long vm = valid_lds[(rt0 + i) >> 1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int hp = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int hp = (rt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (hp < BT_HALO) {
                     const bool ok = (vm >> (hp & 63)) & 1ull;
                     const float v = ok ? fmaxf(acc[i][r] + bias, 0.0f) : 0.0f;
@@ -669,42 +683,44 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
     __syncthreads();
 
     // =========================== phase 2: t2^T = W2' (*) t1 ==============================================
-    constexpr int RB = C::RB2, PITCH = RB + 16, CPR = RB / 16, RPP = 256 / CPR;   // 8 chunks/row, 32 rows/pass
+    constexpr int RB = C::RB2, PITCH = RB + 16, CPR = RB / 16, RPP = 256 / CPR;
     constexpr int KE = RB / EB;
-    constexpr int WPASS = 128 / RPP;                                               // 4
     const int chunk = tid % CPR, srow = tid / CPR;
+    constexpr int WPASS = 128 / RPP;   // passes for 128 rows (W3 half); W2 has PL rows
     u32x4 rw[WPASS];
-    auto load_w = [&](const void* wbase, size_t row_stride_elems, size_t elem_off) {
+    auto load_w = [&](const void* wbase, int rows, size_t row_stride_elems, size_t elem_off) {
 #pragma unroll
         for (int i = 0; i < WPASS; ++i)
-            rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wbase) +
-                                                    ((size_t)(srow + i * RPP) * row_stride_elems + elem_off + chunk * PER16) * EB);
+            if (srow + i * RPP < rows)
+                rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wbase) +
+                                                        ((size_t)(srow + i * RPP) * row_stride_elems + elem_off + chunk * PER16) * EB);
     };
-    auto store_w = [&](int buf) {
-        unsigned char* const sw = stage + buf * C::STAGE2;
+    auto store_w = [&](int buf, int rows) {
+        unsigned char* const sw = stage + buf * C::SMAX;
 #pragma unroll
-        for (int i = 0; i < WPASS; ++i) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
+        for (int i = 0; i < WPASS; ++i)
+            if (srow + i * RPP < rows) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
     };
 
     // this wave's 32 pixels: tile rows 2*wave, 2*wave + 1
     const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
-    f32x16 t2[4];
+    f32x16 t2[NT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < NT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) t2[m][r] = 0.0f;
     {
-        constexpr int KSTEPS = 128 / KE;          // K-steps per tap
+        constexpr int KSTEPS = PL / KE;          // K-steps per tap
         constexpr int NSTEPS = 9 * KSTEPS;
-        load_w(p.w2, 128, 0);
-        store_w(0);
+        load_w(p.w2, PL, PL, 0);
+        store_w(0, PL);
         __syncthreads();
         for (int s = 0; s < NSTEPS; ++s) {
             const int tap = s / KSTEPS, kc = s - tap * KSTEPS;
-            const unsigned char* const sw = stage + (s & 1) * C::STAGE2;
+            const unsigned char* const sw = stage + (s & 1) * C::SMAX;
             if (s + 1 < NSTEPS) {
                 const int tap1 = (s + 1) / KSTEPS, kc1 = (s + 1) - tap1 * KSTEPS;
-                load_w(p.w2, 128, (size_t)tap1 * 128 * 128 + (size_t)kc1 * KE);
+                load_w(p.w2, PL, PL, (size_t)tap1 * PL * PL + (size_t)kc1 * KE);
             }
             __builtin_amdgcn_sched_barrier(0);
             const int ky = tap / 3, kx = tap - 3 * ky;
@@ -713,19 +729,19 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
             for (int j = 0; j < RB / 32; ++j) {
                 const u32x4 tf = *reinterpret_cast<const u32x4*>(tb + j * 32);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < NT; ++m) {
                     const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (m * 32 + l31) * PITCH + j * 32 + half * 16);
                     mfma_chunk<T>(wf, tf, t2[m]);
                 }
             }
-            if (s + 1 < NSTEPS) store_w((s & 1) ^ 1);
+            if (s + 1 < NSTEPS) store_w((s & 1) ^ 1, PL);
             __syncthreads();
         }
     }
 
     // bias + ReLU on t2 (channel of register r in tile m: 32m + (r&3) + 8(r>>2) + 4*half)
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < NT; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 bb = *reinterpret_cast<const f32x4*>(b2_lds + 32 * m + 8 * q + 4 * half);
@@ -733,50 +749,52 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
             for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = fmaxf(t2[m][4 * q + e] + bb[e], 0.0f);
         }
 
-    // =========================== phase 3: out = W3 t2 + b3 + x ==========================================
-    // two halves of 128 output channels; K-step = KE channels of t2 = accumulator registers of one/two tiles
+    // =========================== phase 3: out = W3 t2 (+ Wd x) + b + (x) ==================================
+    // halves of 128 output channels; K-step = KE channels of t2 = accumulator registers of one/two tiles
 #pragma unroll 1
-    for (int nh = 0; nh < 2; ++nh) {
+    for (int nh = 0; nh < CO / 128; ++nh) {
         f32x16 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-        constexpr int NSTEPS = 128 / KE;
-        const void* w3h = reinterpret_cast<const unsigned char*>(p.w3) + (size_t)nh * 128 * 128 * EB;
-        load_w(w3h, 128, 0);
-        store_w(0);
+        constexpr int NSTEPS = PL / KE;
+        const void* w3h = reinterpret_cast<const unsigned char*>(p.w3) + (size_t)nh * 128 * PL * EB;
+        load_w(w3h, 128, PL, 0);
+        store_w(0, 128);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < NSTEPS; ++s) {
-            const unsigned char* const sw = stage + (s & 1) * C::STAGE2;
-            if (s + 1 < NSTEPS) load_w(w3h, 128, (size_t)(s + 1) * KE);
+            const unsigned char* const sw = stage + (s & 1) * C::SMAX;
+            if (s + 1 < NSTEPS) load_w(w3h, 128, PL, (size_t)(s + 1) * KE);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (EB == 4) {
-                // KE = 32 channels = channel tile m = s; 16-channel group q2: registers 8*q2 .. 8*q2+7
+                // one 32-channel tile per 128 staged bytes: tile index = s * (KE / 32) + mm
 #pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2)
+                for (int mm = 0; mm < KE / 32; ++mm)
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        // registers 8*q2 + 4*jj + e hold channels 16*q2 + 8*jj + 4*half + e  -> 16-byte chunk (4*q2 + 2*jj + half)
+                    for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const f32x4 wf = *reinterpret_cast<const f32x4*>(sw + (i * 32 + l31) * PITCH + (4 * q2 + 2 * jj + half) * 16);
+                        for (int jj = 0; jj < 2; ++jj) {
+                            // registers 8*q2 + 4*jj + e hold channels 16*q2 + 8*jj + 4*half + e  -> 16-byte chunk (4*q2 + 2*jj + half)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(t2[s][8 * q2 + 4 * jj + e], wf[e], acc[i], 0, 0, 0);
+                            for (int i = 0; i < 4; ++i) {
+                                const f32x4 wf = *reinterpret_cast<const f32x4*>(sw + (i * 32 + l31) * PITCH + mm * 128 + (4 * q2 + 2 * jj + half) * 16);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(t2[s * (KE / 32) + mm][8 * q2 + 4 * jj + e], wf[e], acc[i], 0, 0, 0);
+                            }
                         }
-                    }
             } else {
-                // KE = 64 channels = channel tiles 2s, 2s+1; per tile two MFMAs (registers 0-7 and 8-15).
-                // Packed W3 K order (host): position 8*(2*q + half) + e  <->  channel 16*q + 8*(e>>2) + 4*half + (e&3) within the tile
+                // per 32-channel tile two MFMAs (registers 0-7 and 8-15).  Packed W3 K order (host): position
+                // 8*(2*q + half) + e  <->  channel 16*q + 8*(e>>2) + 4*half + (e&3) within the tile
 #pragma unroll
-                for (int mm = 0; mm < 2; ++mm)
+                for (int mm = 0; mm < KE / 32; ++mm)
 #pragma unroll
                     for (int q2 = 0; q2 < 2; ++q2) {
                         bf16x8 af;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) af[e] = (__bf16)t2[2 * s + mm][8 * q2 + e];
+                        for (int e = 0; e < 8; ++e) af[e] = (__bf16)t2[s * (KE / 32) + mm][8 * q2 + e];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sw + (i * 32 + l31) * PITCH + (mm * 32 + (2 * q2 + half) * 8) * 2);
@@ -784,34 +802,83 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
                         }
                     }
             }
-            if (s + 1 < NSTEPS) store_w((s & 1) ^ 1);
+            if (s + 1 < NSTEPS) store_w((s & 1) ^ 1, 128);
             __syncthreads();
         }
-        // epilogue: rows = this wave's pixels... (A = t2: rows are pixels lane&31 -> accumulator ROWS are pixels)
-        // D[row = pixel (r&3) + 8(r>>2) + 4*half][col = channel nh*128 + 32 i + l31]
+        if constexpr (DS) {
+            // skip path: acc += x_centre[32 px][CIN] * Wd[nh half][CIN]^T, both operands staged (standard orientation)
+            constexpr int RBd = C::RBD, PITCHd = RBd + 16, CPRd = RBd / 16, RPPd = 256 / CPRd;   // 4 chunks/row, 64 rows/pass
+            constexpr int KEd = RBd / EB, NSTEPSd = CIN / KEd;
+            constexpr int XBYTES = 128 * PITCHd;
+            const int chunkd = tid % CPRd, srowd = tid / CPRd;
+            u32x4 rxd[2], rwd[2];
+            auto loadd = [&](int s) {
+                const int c0 = s * KEd + chunkd * PER16;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int pr = srowd + i * RPPd;   // pixel row 0..127 of the 8 x 16 tile
+                    rxd[i] = *reinterpret_cast<const u32x4*>(xin + (((size_t)(ty0 + (pr >> 4)) * p.W + (tx0 + (pr & 15))) * CIN + c0) * EB);
+                    rwd[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.wd) + ((size_t)(nh * 128 + pr) * CIN + c0) * EB);
+                }
+            };
+            auto stored = [&](int buf) {
+                unsigned char* const sx = stage + buf * C::SMAX;
+                unsigned char* const sw = sx + XBYTES;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    *reinterpret_cast<u32x4*>(sx + (srowd + i * RPPd) * PITCHd + chunkd * 16) = rxd[i];
+                    *reinterpret_cast<u32x4*>(sw + (srowd + i * RPPd) * PITCHd + chunkd * 16) = rwd[i];
+                }
+            };
+            loadd(0);
+            stored(0);
+            __syncthreads();
+            for (int s = 0; s < NSTEPSd; ++s) {
+                const unsigned char* const sx = stage + (s & 1) * C::SMAX;
+                const unsigned char* const sw = sx + XBYTES;
+                if (s + 1 < NSTEPSd) loadd(s + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < RBd / 32; ++j) {
+                    const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + (wave * 32 + l31) * PITCHd + j * 32 + half * 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (i * 32 + l31) * PITCHd + j * 32 + half * 16);
+                        mfma_chunk<T>(xf, wf, acc[i]);
+                    }
+                }
+                if (s + 1 < NSTEPSd) stored((s & 1) ^ 1);
+                __syncthreads();
+            }
+        }
+        // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4*half of the wave][col = channel nh*128 + 32 i + l31]
+        unsigned char* const outp = reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * CO * EB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = nh * 128 + i * 32 + l31;
-            const float bias = p.b3[n];
+            const float bias = DS ? p.b3[n] + p.bd[n] : p.b3[n];
             float xr[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {  // all residual loads first (see conv_mfma_kernel)
-                const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;   // pixel index inside the wave's 32
-                const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * 256 + n;
-                if constexpr (EB == 4)
-                    xr[r] = reinterpret_cast<const float*>(xin)[po];
-                else
-                    xr[r] = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(xin)[po]);
+            for (int r = 0; r < 16; ++r) {  // identity skip: all residual loads first (see conv_mfma_kernel)
+                xr[r] = 0.0f;
+                if constexpr (!DS) {
+                    const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;   // pixel index inside the wave's 32
+                    const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n;
+                    if constexpr (EB == 4)
+                        xr[r] = reinterpret_cast<const float*>(xin)[po];
+                    else
+                        xr[r] = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(xin)[po]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * 256 + n;
+                const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n;
                 const float v = acc[i][r] + bias + xr[r];
                 if constexpr (EB == 4)
-                    reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * 256 * 4)[po] = v;
+                    reinterpret_cast<float*>(outp)[po] = v;
                 else
-                    reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * 256 * 2)[po] = f32_to_bf16_bits(v);
+                    reinterpret_cast<unsigned short*>(outp)[po] = f32_to_bf16_bits(v);
             }
         }
     }

@@ -170,23 +170,27 @@ struct df3d_hg {
     int bottleneck(const std::string& name, int x, int planes) {
         const int cin = tensors[x].c, cout = 2 * planes;
         const TensorDesc tx = tensors[x];
-        if (fuse && cin == 256 && planes == 128 && tx.h % 8 == 0 && tx.w % 16 == 0 && tx.h >= 16 && tx.w >= 32) {
+        const bool shape_ok = (cin == 256 && planes == 128) || (cin == 128 && planes == 128) || (cin == 64 && planes == 64);
+        if (fuse && shape_ok && tx.h % 8 == 0 && tx.w % 16 == 0 && tx.h >= 16 && tx.w >= 32) {
             // the whole block in one kernel (hg_kernels.h: bottleneck_kernel); algorithmic work is accounted
-            // exactly as for the three separate convolutions (model M1), although far fewer bytes really move
+            // exactly as for the separate convolutions (model M1), although far fewer bytes really move
+            const bool ds = cin != cout;
             Step st;
             st.kind = ST_BOTTLENECK;
             st.name = name + ".conv3";
             st.in = x;
-            st.res = x;
-            st.conv = plan_conv(name + ".conv1", 1, 256, 256, 128, true, true, false);
-            st.conv2b = plan_conv(name + ".conv2", 9, 128, 128, 128, false, true, false);
-            st.conv3b = plan_conv(name + ".conv3", 1, 128, 128, 256, false, false, false, dtype == DF3D_DTYPE_BF16 ? 1 : 0);
-            st.out = new_tensor(tx.h, tx.w, 256);
+            st.res = ds ? -1 : x;
+            st.conv = plan_conv(name + ".conv1", 1, cin, cin, planes, true, true, false);
+            st.conv2b = plan_conv(name + ".conv2", 9, planes, planes, planes, false, true, false);
+            if (ds) st.conv4b = plan_conv(name + ".downsample.0", 1, cin, cin, cout, false, false, false);
+            st.conv3b = plan_conv(name + ".conv3", 1, planes, planes, cout, false, false, false, dtype == DF3D_DTYPE_BF16 ? 1 : 0);
+            st.out = new_tensor(tx.h, tx.w, cout);
             steps.push_back(st);
             const double px = (double)tx.h * tx.w;
-            account_conv(px, 1, 256, 128, false);
-            account_conv(px, 9, 128, 128, false);
-            account_conv(px, 1, 128, 256, true);
+            account_conv(px, 1, cin, planes, false);
+            account_conv(px, 9, planes, planes, false);
+            if (ds) account_conv(px, 1, cin, cout, false);
+            account_conv(px, 1, planes, cout, true);
             return st.out;
         }
         int a = conv(name + ".conv1", x, 1, planes, true, true, -1);
@@ -401,6 +405,29 @@ struct ScopedTimer {
     }
 };
 
+template <typename T, int CIN, int PL, bool DS>
+int launch_bottleneck_t(const BottleneckArgs& a, int blocks, hipStream_t s) {
+    using C = BtCfg<T, CIN, PL, DS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<T, CIN, PL, DS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((bottleneck_kernel<T, CIN, PL, DS>), dim3(blocks), dim3(256), C::LDS_BYTES, s, a);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+template <typename T>
+int launch_bottleneck(const BottleneckArgs& a, int cin, int pl, int blocks, hipStream_t s) {
+    if (cin == 256 && pl == 128) return launch_bottleneck_t<T, 256, 128, false>(a, blocks, s);
+    if (cin == 128 && pl == 128) return launch_bottleneck_t<T, 128, 128, true>(a, blocks, s);
+    if (cin == 64 && pl == 64) return launch_bottleneck_t<T, 64, 64, true>(a, blocks, s);
+    df3d::set_error("fused bottleneck %d -> %d unsupported", cin, pl);
+    return DF3D_EINVAL;
+}
+
 template <typename T>
 int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps, unsigned char* act, hipStream_t s) {
     const int eb = sizeof(T);
@@ -457,31 +484,29 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
             }
             case ST_BOTTLENECK: {
                 const TensorDesc& ti = h->tensors[st.in];
+                const bool ds = st.res < 0;
                 BottleneckArgs a;
                 a.in = tptr(st.in);
                 a.out = tptr(st.out);
                 a.w1 = wb + st.conv.w_off * eb;
                 a.w2 = wb + st.conv2b.w_off * eb;
                 a.w3 = wb + st.conv3b.w_off * eb;
+                a.wd = ds ? wb + st.conv4b.w_off * eb : nullptr;
                 a.b1 = h->blob + st.conv.b_off;
                 a.b2 = h->blob + st.conv2b.b_off;
                 a.b3 = h->blob + st.conv3b.b_off;
+                a.bd = ds ? h->blob + st.conv4b.b_off : nullptr;
                 a.s1 = h->blob + st.conv.s_off;
                 a.t1 = h->blob + st.conv.t_off;
                 a.V = n;
                 a.H = ti.h;
                 a.W = ti.w;
-                static bool attr_done = false;
-                if (!attr_done) {
-                    DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<T>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, BtCfg<T>::LDS_BYTES));
-                    attr_done = true;
-                }
+                const int cin = st.conv.cin, pl = st.conv.cout;
                 const double px = (double)n * ti.h * ti.w;
-                ScopedTimer tm(h, s, KC_BOTTLENECK, 2.0 * px * (256.0 * 128 + 9.0 * 128 * 128 + 128.0 * 256), px * eb * 512.0);
+                ScopedTimer tm(h, s, KC_BOTTLENECK, 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + (ds ? 2.0 * cin * pl : 0.0)),
+                               px * eb * (cin + 2.0 * pl));
                 const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
-                hipLaunchKernelGGL((bottleneck_kernel<T>), dim3(blocks), dim3(256), BtCfg<T>::LDS_BYTES, s, a);
-                DF3D_LAUNCH_CHECK();
+                if (int rc = launch_bottleneck<T>(a, cin, pl, blocks, s)) return rc;
                 break;
             }
             case ST_HEAD: {
