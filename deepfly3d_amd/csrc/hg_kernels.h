@@ -45,11 +45,13 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
-__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
-    // round to nearest even (NaN not expected in activations)
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+// round-to-nearest-even conversions through the hardware converter (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
 template <typename T>
@@ -96,7 +98,7 @@ __device__ __forceinline__ u32x4 preact_apply(u32x4 raw, const PreactCoef<T>& k)
             const float hi = bf16_bits_to_f32((unsigned short)(raw[i] >> 16));
             const float a = fmaxf(fmaf(lo, k.s[i >> 1][(2 * i) & 3], k.t[i >> 1][(2 * i) & 3]), 0.0f);
             const float b = fmaxf(fmaf(hi, k.s[i >> 1][(2 * i + 1) & 3], k.t[i >> 1][(2 * i + 1) & 3]), 0.0f);
-            o[i] = (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16);
+            o[i] = pack_bf16x2(a, b);
         }
         return o;
     }
@@ -419,7 +421,7 @@ __device__ __forceinline__ u32x4 max_chunk(u32x4 a, u32x4 b) {
         for (int i = 0; i < 4; ++i) {
             const float al = bf16_bits_to_f32((unsigned short)(a[i] & 0xffffu)), ah = bf16_bits_to_f32((unsigned short)(a[i] >> 16));
             const float bl = bf16_bits_to_f32((unsigned short)(b[i] & 0xffffu)), bh = bf16_bits_to_f32((unsigned short)(b[i] >> 16));
-            o[i] = (unsigned)f32_to_bf16_bits(fmaxf(al, bl)) | ((unsigned)f32_to_bf16_bits(fmaxf(ah, bh)) << 16);
+            o[i] = pack_bf16x2(fmaxf(al, bl), fmaxf(ah, bh));
         }
         return o;
     }
@@ -436,7 +438,7 @@ __device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b) {
         for (int i = 0; i < 4; ++i) {
             const float al = bf16_bits_to_f32((unsigned short)(a[i] & 0xffffu)), ah = bf16_bits_to_f32((unsigned short)(a[i] >> 16));
             const float bl = bf16_bits_to_f32((unsigned short)(b[i] & 0xffffu)), bh = bf16_bits_to_f32((unsigned short)(b[i] >> 16));
-            o[i] = (unsigned)f32_to_bf16_bits(al + bl) | ((unsigned)f32_to_bf16_bits(ah + bh) << 16);
+            o[i] = pack_bf16x2(al + bl, ah + bh);
         }
         return o;
     }
@@ -539,26 +541,31 @@ struct BtCfg {
     static constexpr int EB = Elem<T>::BYTES;
     static constexpr int CO = 2 * PL;
     static constexpr int T1_PITCH = PL * EB + 16;                  // bytes per halo pixel in the t1 tile
-    static constexpr int T1_BYTES = BT_HALO * T1_PITCH;
+    static constexpr int T1_BYTES = BT_HROWS * T1_PITCH;           // 192 rows: the 12 pad rows make the phase-1 epilogue branch-free
     static constexpr int RB1 = 64;                                 // staged row bytes, phase 1
-    static constexpr int RB2 = (PL * EB) % 128 == 0 ? 128 : 64;    // phases 2 and 3 (K = PL)
+    static constexpr int RB2 = 128;                                // phases 2 and 3 (K = PL)
+    // bf16: ONE staging buffer (two barriers per K-step) so that the workgroup needs < 80 KB of LDS and two
+    // workgroups share a CU -- the second one's MFMAs cover the first one's barrier / LDS / memory stalls.
+    // fp32: the t1 tile alone is 101 KB, one workgroup per CU, so double-buffer the staging (one barrier per step).
+    static constexpr bool SINGLE = EB == 2;
     static constexpr int RBD = 64;                                 // downsample steps of phase 3 (K = CIN)
     static constexpr int STAGE1 = (BT_HROWS + PL) * (RB1 + 16);    // x rows + W1 rows
     static constexpr int STAGE2 = 128 * (RB2 + 16);                // W2 (PL rows) / W3 (128 rows) 
     static constexpr int STAGED = DS ? (128 + 128) * (RBD + 16) : 0;  // x centre rows + Wd rows
     static constexpr int SMAX = STAGE1 > STAGE2 ? (STAGE1 > STAGED ? STAGE1 : STAGED) : (STAGE2 > STAGED ? STAGE2 : STAGED);
-    static constexpr int STAGE_BYTES = 2 * SMAX;
+    static constexpr int STAGE_BYTES = (SINGLE ? 1 : 2) * SMAX;
     static constexpr int MISC = PL * 4 + 64;                       // b2' + validity masks
     static constexpr int LDS_BYTES = T1_BYTES + STAGE_BYTES + MISC;
     static constexpr int NT = PL / 32;                             // channel tiles of the intermediates
 };
 
 template <typename T, int CIN, int PL, bool DS>
-__global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kernel(BottleneckArgs p) {
     using C = BtCfg<T, CIN, PL, DS>;
     constexpr int EB = C::EB;
     constexpr int CO = C::CO;
     constexpr int NT = C::NT;
+    constexpr bool SINGLE = C::SINGLE;
     constexpr int PER16 = Elem<T>::PER16;
     static_assert(PL == 128 || PL == 64, "planes");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -614,12 +621,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
         auto load1 = [&](int s) {
             const int c0 = s * KE + chunk * PER16;
             coef.load(p.s1, p.t1, c0);
+            // out-of-image halo rows read pixel (0,0) (a valid address) and are masked to zero in store1: no branches
 #pragma unroll
-            for (int i = 0; i < XP; ++i) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (xok[i]) v = *reinterpret_cast<const u32x4*>(xp[i] + (size_t)c0 * EB);
-                rx[i] = v;
-            }
+            for (int i = 0; i < XP; ++i) rx[i] = *reinterpret_cast<const u32x4*>(xp[i] + (size_t)c0 * EB);
 #pragma unroll
             for (int i = 0; i < WP; ++i)
                 rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.w1) + ((size_t)(srow + i * RPP) * CIN + c0) * EB);
@@ -629,8 +633,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
             unsigned char* const sw = sx + X_BYTES;
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
-                if (xok[i]) rx[i] = preact_apply<T>(rx[i], coef);  // bn1 + ReLU, deferred past the MFMAs
-                *reinterpret_cast<u32x4*>(sx + (srow + i * RPP) * PITCH + chunk * 16) = rx[i];
+                u32x4 v = preact_apply<T>(rx[i], coef);  // bn1 + ReLU, deferred past the MFMAs
+                const unsigned keep = xok[i] ? 0xffffffffu : 0u;
+                v &= keep;
+                *reinterpret_cast<u32x4*>(sx + (srow + i * RPP) * PITCH + chunk * 16) = v;
             }
 #pragma unroll
             for (int i = 0; i < WP; ++i) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
         store1(0);
         __syncthreads();
         for (int s = 0; s < NSTEPS; ++s) {
-            const unsigned char* const sx = stage + (s & 1) * C::STAGE1;
+            const unsigned char* const sx = stage + (SINGLE ? 0 : (s & 1)) * C::STAGE1;
             const unsigned char* const sw = sx + X_BYTES;
             if (s + 1 < NSTEPS) load1(s + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -657,26 +663,28 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
                     mfma_chunk<T>(xf, wf, acc[i]);
                 }
             }
-            if (s + 1 < NSTEPS) store1((s & 1) ^ 1);
+            if (SINGLE && s + 1 < NSTEPS) __syncthreads();  // every wave is done reading the only buffer
+            if (s + 1 < NSTEPS) store1(SINGLE ? 0 : (s & 1) ^ 1);
             __syncthreads();
         }
-        // epilogue: bias + ReLU, zero outside the image, into the t1 tile (rows = halo pixels, PL channels)
+        // epilogue: bias + ReLU, zero outside the image, into the t1 tile (rows = halo pixels, PL channels).
+        // Branch-free: every row (also the 12 pad rows, whose validity bit is 0) is written.
         const int n = ct * 32 + l31;
         const float bias = p.b1[n];
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
-            const unsigned long long vm = valid_lds[(rt0 + i) >> 1];
+            const unsigned vmh = (unsigned)(valid_lds[(rt0 + i) >> 1] >> (((rt0 + i) & 1) * 32 + 4 * half));
+            unsigned char* const trow = t1_lds + ((rt0 + i) * 32 + 4 * half) * C::T1_PITCH + n * EB;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int hp = (rt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (hp < BT_HALO) {
-                    const bool ok = (vm >> (hp & 63)) & 1ull;
-                    const float v = ok ? fmaxf(acc[i][r] + bias, 0.0f) : 0.0f;
-                    if constexpr (EB == 4)
-                        *reinterpret_cast<float*>(t1_lds + hp * C::T1_PITCH + n * 4) = v;
-                    else
-                        *reinterpret_cast<unsigned short*>(t1_lds + hp * C::T1_PITCH + n * 2) = f32_to_bf16_bits(v);
-                }
+                const int ro = (r & 3) + 8 * (r >> 2);
+                // select by bit mask (a ?: here makes hipcc emit one branch per register)
+                const unsigned keep = 0u - ((vmh >> ro) & 1u);
+                const float v = __uint_as_float(__float_as_uint(fmaxf(acc[i][r] + bias, 0.0f)) & keep);
+                if constexpr (EB == 4)
+                    *reinterpret_cast<float*>(trow + ro * C::T1_PITCH) = v;
+                else
+                    *reinterpret_cast<unsigned short*>(trow + ro * C::T1_PITCH) = f32_to_bf16_bits(v);
             }
         }
     }
@@ -691,7 +699,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
     auto load_w = [&](const void* wbase, int rows, size_t row_stride_elems, size_t elem_off) {
 #pragma unroll
         for (int i = 0; i < WPASS; ++i)
-            if (srow + i * RPP < rows)
+            if (PL == 128 || srow + i * RPP < rows)  // compile-time true for PL = 128 (all tiles have 128 rows)
                 rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wbase) +
                                                         ((size_t)(srow + i * RPP) * row_stride_elems + elem_off + chunk * PER16) * EB);
     };
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
         unsigned char* const sw = stage + buf * C::SMAX;
 #pragma unroll
         for (int i = 0; i < WPASS; ++i)
-            if (srow + i * RPP < rows) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
+            if (PL == 128 || srow + i * RPP < rows) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
     };
 
     // this wave's 32 pixels: tile rows 2*wave, 2*wave + 1
@@ -717,7 +725,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
         __syncthreads();
         for (int s = 0; s < NSTEPS; ++s) {
             const int tap = s / KSTEPS, kc = s - tap * KSTEPS;
-            const unsigned char* const sw = stage + (s & 1) * C::SMAX;
+            const unsigned char* const sw = stage + (SINGLE ? 0 : (s & 1)) * C::SMAX;
             if (s + 1 < NSTEPS) {
                 const int tap1 = (s + 1) / KSTEPS, kc1 = (s + 1) - tap1 * KSTEPS;
                 load_w(p.w2, PL, PL, (size_t)tap1 * PL * PL + (size_t)kc1 * KE);
@@ -725,16 +733,31 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             const int ky = tap / 3, kx = tap - 3 * ky;
             const unsigned char* const tb = t1_lds + ((py + ky) * BT_HW + (px + kx)) * C::T1_PITCH + kc * RB + half * 16;
+            // fragments of K-group j+1 are requested before the MFMAs of group j (one wave per SIMD: nothing else
+            // hides the LDS latency)
+            const unsigned char* const wrow = sw + l31 * PITCH + half * 16;
+            u32x4 tf = *reinterpret_cast<const u32x4*>(tb);
+            u32x4 wf[NT];
+#pragma unroll
+            for (int m = 0; m < NT; ++m) wf[m] = *reinterpret_cast<const u32x4*>(wrow + m * 32 * PITCH);
 #pragma unroll
             for (int j = 0; j < RB / 32; ++j) {
-                const u32x4 tf = *reinterpret_cast<const u32x4*>(tb + j * 32);
+                u32x4 tfn = tf, wfn[NT];
+                if (j + 1 < RB / 32) {
+                    tfn = *reinterpret_cast<const u32x4*>(tb + (j + 1) * 32);
 #pragma unroll
-                for (int m = 0; m < NT; ++m) {
-                    const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (m * 32 + l31) * PITCH + j * 32 + half * 16);
-                    mfma_chunk<T>(wf, tf, t2[m]);
+                    for (int m = 0; m < NT; ++m) wfn[m] = *reinterpret_cast<const u32x4*>(wrow + m * 32 * PITCH + (j + 1) * 32);
+                }
+#pragma unroll
+                for (int m = 0; m < NT; ++m) mfma_chunk<T>(wf[m], tf, t2[m]);
+                if (j + 1 < RB / 32) {
+                    tf = tfn;
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) wf[m] = wfn[m];
                 }
             }
-            if (s + 1 < NSTEPS) store_w((s & 1) ^ 1, PL);
+            if (SINGLE && s + 1 < NSTEPS) __syncthreads();
+            if (s + 1 < NSTEPS) store_w(SINGLE ? 0 : (s & 1) ^ 1, PL);
             __syncthreads();
         }
     }
@@ -765,7 +788,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < NSTEPS; ++s) {
-            const unsigned char* const sw = stage + (s & 1) * C::SMAX;
+            const unsigned char* const sw = stage + (SINGLE ? 0 : (s & 1)) * C::SMAX;
             if (s + 1 < NSTEPS) load_w(w3h, 128, PL, (size_t)(s + 1) * KE);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (EB == 4) {
@@ -802,7 +825,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
                         }
                     }
             }
-            if (s + 1 < NSTEPS) store_w((s & 1) ^ 1, 128);
+            if (SINGLE && s + 1 < NSTEPS) __syncthreads();
+            if (s + 1 < NSTEPS) store_w(SINGLE ? 0 : (s & 1) ^ 1, 128);
             __syncthreads();
         }
         if constexpr (DS) {
@@ -834,7 +858,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
             stored(0);
             __syncthreads();
             for (int s = 0; s < NSTEPSd; ++s) {
-                const unsigned char* const sx = stage + (s & 1) * C::SMAX;
+                const unsigned char* const sx = stage + (SINGLE ? 0 : (s & 1)) * C::SMAX;
                 const unsigned char* const sw = sx + XBYTES;
                 if (s + 1 < NSTEPSd) loadd(s + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -847,7 +871,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_kernel(BottleneckArgs p) {
                         mfma_chunk<T>(xf, wf, acc[i]);
                     }
                 }
-                if (s + 1 < NSTEPSd) stored((s & 1) ^ 1);
+                if (SINGLE && s + 1 < NSTEPSd) __syncthreads();
+                if (s + 1 < NSTEPSd) stored(SINGLE ? 0 : (s & 1) ^ 1);
                 __syncthreads();
             }
         }
