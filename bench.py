@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the DeepFly3D per-frame hot path on MI355X (BASELINE.json metric: frames/sec, 7-view 2D -> 3D).
 
-    python bench.py --gpus 1 --steps 125 --warmup 5
+    python bench.py --gpus 1 --steps 32 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): per GPU `steps x frames_per_step` synthetic frames (default 125 x 8 = 1 000),
+Workload (BASELINE.json configs[1]): per GPU `steps x frames_per_step` synthetic frames (default 32 x 32 = 1 024),
 each 7 views of 256 x 512 x 3 float32, seeded and resident in HBM before the timed region; 2-stack hourglass in
 fp32 with seeded synthetic weights (no checkpoints offline); fixed calib.pkl cameras.  One "step" = one batch of
 `frames_per_step` frames through the whole path: hourglass -> arg-max/confidence -> 19->38 layout -> DLT.
@@ -27,15 +27,14 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 PEAK_HBM_GBS = 8000.0
-KERNEL_CLASSES = ["conv1x1_mfma", "conv3x3_mfma", "stem7x7_mfma", "maxpool2", "upsample_add", "bottleneck_fused", "head_fused"]
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=125)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-step", type=int, default=32)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--pool-frames", type=int, default=0, help="distinct frames resident in HBM (0 = steps*frames_per_step, capped at 1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -116,7 +115,7 @@ def main():
     pipe = FramePipeline(engine, calib["R"], calib["tvec"], calib["intr"])
 
     total_frames = a.steps * fps_step
-    pool = a.pool_frames or min(total_frames, 1000)
+    pool = a.pool_frames or min(total_frames, 1024)
     pool = max(fps_step, (pool // fps_step) * fps_step)
     gen = torch.Generator(device=dev).manual_seed(rank)
     frames = torch.empty((pool, 7, 256, 512, 3), dtype=torch.float32, device=dev)
@@ -158,19 +157,21 @@ def main():
             step(i, i * fps_step)
         torch.cuda.synchronize()
         per = []
-        for k, name in enumerate(KERNEL_CLASSES):
+        buf = ctypes.create_string_buffer(128)
+        for k in range(lib.df3d_hg_profile_count(engine.h)):
             ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-            _native.check(lib.df3d_hg_profile_read(engine.h, k, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n)))
+            _native.check(lib.df3d_hg_profile_read(engine.h, k, buf, 128, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n)))
             if n.value:
-                per.append({"kernel": name, "launches": n.value, "avg_us": 1e3 * ms.value / n.value, "total_ms": ms.value,
+                per.append({"kernel": buf.value.decode(), "launches": n.value, "avg_us": 1e3 * ms.value / n.value, "total_ms": ms.value,
                             "tflops": fl.value / ms.value / 1e9, "gbs_algorithmic": by.value / ms.value / 1e6})
+        per.sort(key=lambda d: -d["total_ms"])
         _native.check(lib.df3d_hg_profile(engine.h, 0))
         dom = max(per, key=lambda d: d["total_ms"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(f"{a.dtype}:{dom['kernel']}")
+                traffic = json.load(f).get(dom["kernel"])
         compute_bound = dom["kernel"].startswith(("conv", "stem", "bottleneck", "head"))
         roof = {
             "bound": "mfma" if compute_bound else "hbm",

@@ -103,6 +103,13 @@ struct df3d_hg {
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
     bool profiling = false;
     struct Timed { hipEvent_t a, b; int cls; double flops, bytes; };
+    std::vector<std::string> kernel_names;  // class id -> kernel instantiation name (as rocprofv3 prints it, shortened)
+    int kernel_class(const std::string& name) {
+        for (size_t i = 0; i < kernel_names.size(); ++i)
+            if (kernel_names[i] == name) return (int)i;
+        kernel_names.push_back(name);
+        return (int)kernel_names.size() - 1;
+    }
     std::vector<Timed> timed;
     std::vector<hipEvent_t> event_pool;
 
@@ -371,7 +378,6 @@ int launch_conv(const ConvArgs& a, int taps, int rb, hipStream_t s) {
     return DF3D_EINVAL;
 }
 
-enum KernelClass { KC_CONV1 = 0, KC_CONV3 = 1, KC_STEM = 2, KC_POOL = 3, KC_UPADD = 4, KC_BOTTLENECK = 5, KC_HEAD = 6, KC_COUNT = 7 };
 
 hipEvent_t get_event(df3d_hg* h) {
     if (!h->event_pool.empty()) {
@@ -389,11 +395,11 @@ struct ScopedTimer {
     hipStream_t s;
     df3d_hg::Timed t;
     bool on;
-    ScopedTimer(df3d_hg* h_, hipStream_t s_, int cls, double flops, double bytes) : h(h_), s(s_), on(h_->profiling) {
+    ScopedTimer(df3d_hg* h_, hipStream_t s_, const std::string& name, double flops, double bytes) : h(h_), s(s_), on(h_->profiling) {
         if (!on) return;
         t.a = get_event(h);
         t.b = get_event(h);
-        t.cls = cls;
+        t.cls = h->kernel_class(name);
         t.flops = flops;
         t.bytes = bytes;
         (void)hipEventRecord(t.a, s);
@@ -431,6 +437,7 @@ int launch_bottleneck(const BottleneckArgs& a, int cin, int pl, int blocks, hipS
 template <typename T>
 int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps, unsigned char* act, hipStream_t s) {
     const int eb = sizeof(T);
+    const char* const tname = eb == 4 ? "float" : "__hip_bfloat16";
     auto tptr = [&](int id) -> unsigned char* { return act + h->tensors[id].off * (size_t)n * eb; };
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(eb == 4 ? (const void*)h->blob : h->lowp);
     for (int i = 0; i < upto; ++i) {
@@ -447,7 +454,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.W = h->W;
                 const int blocks = n * (h->H / 2 / 8) * (h->W / 2 / 16);
                 const double opx = (double)n * (h->H / 2) * (h->W / 2);
-                ScopedTimer tm(h, s, KC_STEM, 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb));
+                ScopedTimer tm(h, s, std::string("stem_kernel<") + tname + ">", 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb));
                 hipLaunchKernelGGL((stem_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
                 DF3D_LAUNCH_CHECK();
                 break;
@@ -477,7 +484,9 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 int rb = (st.conv.cin_pad % ke128 == 0) ? 128 : 64;
                 if (h->rb_override == 64) rb = 64;
                 const double mm = (double)a.M;
-                ScopedTimer tm(h, s, st.conv.taps == 1 ? KC_CONV1 : KC_CONV3, 2.0 * mm * st.conv.taps * st.conv.cin * st.conv.cout,
+                const int bn_tile = (a.cout % 128 == 0) ? 128 : (a.cout % 64 == 0 ? 64 : 32);
+                ScopedTimer tm(h, s, std::string("conv_mfma_kernel<") + tname + ", " + std::to_string(st.conv.taps) + ", " + std::to_string(bn_tile) + ", " + std::to_string(rb) + ">",
+                               2.0 * mm * st.conv.taps * st.conv.cin * st.conv.cout,
                                mm * eb * (st.conv.cin + st.conv.cout + (st.res >= 0 ? st.conv.cout : 0)));
                 if (int rc = launch_conv<T>(a, st.conv.taps, rb, s)) return rc;
                 break;
@@ -503,8 +512,8 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.W = ti.w;
                 const int cin = st.conv.cin, pl = st.conv.cout;
                 const double px = (double)n * ti.h * ti.w;
-                ScopedTimer tm(h, s, KC_BOTTLENECK, 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + (ds ? 2.0 * cin * pl : 0.0)),
-                               px * eb * (cin + 2.0 * pl));
+                ScopedTimer tm(h, s, std::string("bottleneck_kernel<") + tname + ", " + std::to_string(cin) + ", " + std::to_string(pl) + ", " + (ds ? "true" : "false") + ">",
+                               2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + (ds ? 2.0 * cin * pl : 0.0)), px * eb * (cin + 2.0 * pl));
                 const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
                 if (int rc = launch_bottleneck<T>(a, cin, pl, blocks, s)) return rc;
                 break;
@@ -534,7 +543,8 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 }
                 const double mm = (double)a.M;
                 const double fl = 2.0 * mm * (256.0 * 256 + 256.0 * 19 + (st.last ? 0.0 : 256.0 * 256 + 19.0 * 256));
-                ScopedTimer tm(h, s, KC_HEAD, fl, mm * eb * (st.last ? 256.0 : 768.0) + (st.last ? mm * 19 * 4 : 0.0));
+                ScopedTimer tm(h, s, std::string("head_kernel<") + tname + ", " + (st.last ? "true" : "false") + ">", fl,
+                               mm * eb * (st.last ? 256.0 : 768.0) + (st.last ? mm * 19 * 4 : 0.0));
                 const unsigned blocks = (unsigned)((a.M + 127) / 128);
                 if (st.last)
                     hipLaunchKernelGGL((head_kernel<T, true>), dim3(blocks), dim3(256), HeadCfg<T>::LDS_BYTES, s, a);
@@ -547,7 +557,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 const TensorDesc& to = h->tensors[st.out];
                 const int chunks = to.pitch * eb / 16;
                 const long long total = (long long)n * to.h * to.w * chunks;
-                ScopedTimer tm(h, s, KC_POOL, 0.0, (double)total * 16 * 5);
+                ScopedTimer tm(h, s, std::string("pool2_kernel<") + tname + ">", 0.0, (double)total * 16 * 5);
                 hipLaunchKernelGGL((pool2_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                                    reinterpret_cast<const u32x4*>(tptr(st.in)), reinterpret_cast<u32x4*>(tptr(st.out)),
                                    total, to.h, to.w, chunks);
@@ -558,7 +568,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 const TensorDesc& to = h->tensors[st.out];
                 const int chunks = to.pitch * eb / 16;
                 const long long total = (long long)n * to.h * to.w * chunks;
-                ScopedTimer tm(h, s, KC_UPADD, 0.0, (double)total * 16 * 2.25);
+                ScopedTimer tm(h, s, std::string("upadd_kernel<") + tname + ">", 0.0, (double)total * 16 * 2.25);
                 hipLaunchKernelGGL((upadd_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                                    reinterpret_cast<const u32x4*>(tptr(st.in)), reinterpret_cast<const u32x4*>(tptr(st.res)),
                                    reinterpret_cast<u32x4*>(tptr(st.out)), total, to.h, to.w, chunks);
@@ -704,9 +714,13 @@ int df3d_hg_profile(df3d_hg* h, int enable) {
     return DF3D_OK;
 }
 
-int df3d_hg_profile_read(df3d_hg* h, int kernel_class, double* ms, double* flops, double* bytes, int* launches) {
-    DF3D_CHECK_ARG(h && ms && flops && bytes && launches, "null argument");
-    DF3D_CHECK_ARG(kernel_class >= 0 && kernel_class < KC_COUNT, "kernel_class out of range");
+int df3d_hg_profile_count(const df3d_hg* h) { return h ? (int)h->kernel_names.size() : 0; }
+
+int df3d_hg_profile_read(df3d_hg* h, int kernel_class, char* name_buf, int buflen, double* ms, double* flops, double* bytes,
+                         int* launches) {
+    DF3D_CHECK_ARG(h && name_buf && buflen > 0 && ms && flops && bytes && launches, "null argument");
+    DF3D_CHECK_ARG(kernel_class >= 0 && kernel_class < (int)h->kernel_names.size(), "kernel_class out of range");
+    snprintf(name_buf, buflen, "%s", h->kernel_names[kernel_class].c_str());
     *ms = *flops = *bytes = 0.0;
     *launches = 0;
     for (auto& t : h->timed) {

@@ -198,12 +198,15 @@ int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_
 /* algorithmic work of one forward over n views: FLOPs and activation bytes (fusion model M1 of
  * SURVEY.md 8d evaluated on this engine's own plan) */
 int df3d_hg_work(const df3d_hg* h, int n, double* flops, double* bytes);
-/* per-kernel-class timing with HIP events recorded on the launch stream around every launch (small overhead:
- * enable it for a measurement pass only).  kernel_class: 0 = 1x1 convolutions, 1 = 3x3 convolutions, 2 = stem,
- * 3 = max-pool, 4 = upsample+add, 5 = fused bottleneck, 6 = fused stack head.  df3d_hg_profile(h, 1) clears previous samples; df3d_hg_profile_read() waits
- * for the events and returns the summed duration (ms), algorithmic FLOPs and bytes, and the launch count. */
+/* per-kernel timing with HIP events recorded on the launch stream around every launch (small overhead: enable it
+ * for a measurement pass only).  Launches are grouped by kernel instantiation, named as rocprofv3 prints them
+ * (e.g. "bottleneck_kernel<float, 256, 128, false>").  df3d_hg_profile(h, 1) clears previous samples;
+ * df3d_hg_profile_count() = number of distinct kernels seen; df3d_hg_profile_read() waits for the events and
+ * returns name, summed duration (ms), algorithmic FLOPs and bytes, and the launch count of kernel `index`. */
 int df3d_hg_profile(df3d_hg* h, int enable);
-int df3d_hg_profile_read(df3d_hg* h, int kernel_class, double* ms, double* flops, double* bytes, int* launches);
+int df3d_hg_profile_count(const df3d_hg* h);
+int df3d_hg_profile_read(df3d_hg* h, int index, char* name_buf, int buflen, double* ms, double* flops, double* bytes,
+                         int* launches);
 /* debugging / layer-wise parity: number of plan steps, and run only steps [0, upto) then copy the
  * tensor produced by step upto-1 (NHWC, engine dtype widened to float32) into out_dev */
 int df3d_hg_num_steps(const df3d_hg* h);

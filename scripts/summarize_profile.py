@@ -8,11 +8,6 @@
 import collections, csv, glob, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLASS = [("conv_mfma_kernel<float, 1,", "f32:conv1x1_mfma"), ("conv_mfma_kernel<float, 9,", "f32:conv3x3_mfma"),
-         ("conv_mfma_kernel<__hip_bfloat16, 1,", "bf16:conv1x1_mfma"), ("conv_mfma_kernel<__hip_bfloat16, 9,", "bf16:conv3x3_mfma"),
-         ("bottleneck_kernel<float", "f32:bottleneck_fused"), ("bottleneck_kernel<__hip_bfloat16", "bf16:bottleneck_fused")]
-
-
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
@@ -51,10 +46,10 @@ def main():
                     continue
                 b = (2 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024
                 w.writerow([k, a["n"], a["FETCH_SIZE"] / a["n"], a["WRITE_SIZE"] / a["n"], b / a["n"]])
-                for pat, name in CLASS:
-                    if pat in k:
-                        cls[name][0] += a["n"]
-                        cls[name][1] += b
+                m = re.match(r"hgk::(\w+<[^(]*>)\(", k)
+                if m:  # key = kernel instantiation exactly as bench.py's roofline.kernel names it
+                    cls[m.group(1)][0] += a["n"]
+                    cls[m.group(1)][1] += b
         for name, (n, b) in cls.items():
             traffic[name] = b / n
         json.dump(traffic, open(tj, "w"), indent=1, sort_keys=True)
