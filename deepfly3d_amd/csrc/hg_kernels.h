@@ -336,6 +336,7 @@ struct StemArgs {
     const float* img;
     void* out;           // NHWC [V, H/2, W/2, 64] (T)
     const float* w;      // [148][64] f32, k-major (row 147 = 0)
+    const void* w_bf16;  // bf16 engine: [64][184] bf16, k' = ky*24 + kx*3 + c (stem_relayout_kernel)
     const float* bias;   // [64]
     int V, H, W;         // input size
 };
@@ -403,6 +404,102 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
             reinterpret_cast<unsigned short*>(p.out)[o + 32 + n] = f32_to_bf16_bits(v1);
         }
     }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// stem for the bf16 engine: the same 7x7/2 convolution on v_mfma_f32_32x32x16_bf16.  K is laid out ky-major
+// with every ky row padded from 21 to 24 taps (k' = ky*24 + kx*3 + c; 7*24 = 168, padded to 176 = 11 MFMA steps),
+// so the 8 K-slots a lane feeds to one MFMA are 8 CONSECUTIVE bf16 values of one patch row (4 ds_read_b32).
+// The f32 image patch is converted to bf16 while it is staged; weights are re-laid [64][176] bf16 in LDS from the
+// same f32 blob the f32 stem uses.  22 MFMAs per wave instead of 148: the kernel becomes load/store-bound.
+// -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_bf16_kernel(StemArgs p) {
+    constexpr int PR = 21, PC = 37, PROW = 120;   // patch row pitch in bf16 elements (111 used; 240 B, a multiple of 16)
+    constexpr int KP = 176, WPITCH = KP + 8;      // weight row: 176 k' + 8 pad (368 B: conflict-free 16-byte reads)
+    __shared__ __attribute__((aligned(16))) unsigned short patch[PR * PROW + 64];
+    __shared__ __attribute__((aligned(16))) unsigned short wl[64 * WPITCH];
+    const int OH = p.H / 2, OW = p.W / 2;
+    const int tiles_x = OW / 16, tiles_y = OH / 8;
+    int b = blockIdx.x;
+    const int tx0 = (b % tiles_x) * 16;
+    b /= tiles_x;
+    const int ty0 = (b % tiles_y) * 8;
+    const int view = b / tiles_y;
+    const int tid = threadIdx.x;
+
+    // weights: the [64][184] bf16 tile was laid out once by stem_relayout_kernel (wl[n][ky*24 + kk] = w[ky*21 + kk][n])
+    for (int i = tid; i < 64 * WPITCH / 8; i += 256)
+        reinterpret_cast<u32x4*>(wl)[i] = reinterpret_cast<const u32x4*>(p.w_bf16)[i];
+    const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
+    const float* img = p.img + (size_t)view * p.H * p.W * 3;
+    for (int i = tid; i < PR * PROW + 64; i += 256) {
+        const int r = i / PROW, cc = i % PROW;
+        const int y = iy0 + r, x = ix0 + cc / 3;
+        float v = 0.0f;
+        if (r < PR && cc < PC * 3 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) v = img[((size_t)y * p.W + x) * 3 + cc % 3];
+        patch[i] = f32_to_bf16_bits(v);
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, half = lane >> 5;
+    const int py = wave * 2 + (m >> 4), px = m & 15;
+    const unsigned short* const abase = patch + (2 * py) * PROW + 6 * px;   // 12*px bytes: 4-byte aligned
+    const unsigned short* const wrow0 = wl + m * WPITCH;
+    const unsigned short* const wrow1 = wl + (32 + m) * WPITCH;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+#pragma unroll
+    for (int g = 0; g < KP / 16; ++g) {
+        const int kp = 16 * g + 8 * half;          // first k' of this lane's 8 slots
+        const int ky = kp / 24, kk = kp % 24;       // 8 consecutive taps of patch row 2*py + ky (kk in {0, 8, 16})
+        u32x4 av = {0u, 0u, 0u, 0u};
+        if (kp < 168) {
+            const unsigned* ap = reinterpret_cast<const unsigned*>(abase + ky * PROW + kk);
+            av[0] = ap[0];
+            av[1] = ap[1];
+            av[2] = ap[2];
+            av[3] = ap[3];   // taps 21..23 of the row multiply zero weights
+        }
+        const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wrow0 + kp);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wrow1 + kp);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
+    }
+    // epilogue: adjacent lanes hold adjacent channels of the same pixel; exchanging one register between lane pairs
+    // lets every lane store TWO channels (4 bytes) of one pixel: even lanes take pixel-register r, odd lanes r + 1
+    const int n = lane & 31;
+    const int odd = lane & 1;
+    const float bias0 = p.bias[n], bias1 = p.bias[32 + n];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const float v0a = fmaxf(acc0[r] + bias0, 0.0f), v0b = fmaxf(acc0[r + 1] + bias0, 0.0f);
+        const float v1a = fmaxf(acc1[r] + bias1, 0.0f), v1b = fmaxf(acc1[r + 1] + bias1, 0.0f);
+        const float g0 = __shfl_xor(odd ? v0a : v0b, 1, 64);   // even gets partner's value for register r, odd for r + 1
+        const float g1 = __shfl_xor(odd ? v1a : v1b, 1, 64);
+        const int rr = r + odd;
+        const int mm = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+        const int oy = ty0 + wave * 2 + (mm >> 4), ox = tx0 + (mm & 15);
+        const size_t o = (((size_t)view * OH + oy) * OW + ox) * 64 + (n & ~1);
+        const unsigned w0 = odd ? pack_bf16x2(g0, v0b) : pack_bf16x2(v0a, g0);
+        const unsigned w1 = odd ? pack_bf16x2(g1, v1b) : pack_bf16x2(v1a, g1);
+        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.out) + o) = w0;
+        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.out) + o + 32) = w1;
+    }
+}
+
+// one-time re-layout of the stem weights for stem_bf16_kernel: f32 [148][64] (k = ky*21 + kk) -> bf16 [64][184]
+__global__ __launch_bounds__(256) void stem_relayout_kernel(const float* __restrict__ w, unsigned short* __restrict__ out) {
+    constexpr int WPITCH = 184;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 64 * WPITCH) return;
+    const int n = i / WPITCH, kp = i % WPITCH;
+    const int ky = kp / 24, kk = kp % 24;
+    float v = 0.0f;
+    if (kp < 168 && kk < 21) v = w[(ky * 21 + kk) * 64 + n];
+    out[i] = f32_to_bf16_bits(v);
 }
 
 // -----------------------------------------------------------------------------------------------------

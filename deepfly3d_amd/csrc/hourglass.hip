@@ -268,7 +268,7 @@ struct df3d_hg {
         st.in = -1;
         st.res = -1;
         st.conv = ConvPlan{49, 3, 64, 3, 64, false, true, false, 0, 0, 0, 0};
-        st.conv.w_off = add_param("conv1", 0, 49, 3, 64, 3, 64, 148 * 64);
+        st.conv.w_off = add_param("conv1", 0, 49, 3, 64, 3, 64, 64 * 184);  // [148][64] f32 used; slot sized for the bf16 [64][184] tile
         st.conv.b_off = add_param("conv1", 1, 49, 3, 64, 3, 64, 64);
         st.out = new_tensor(H / 2, W / 2, 64);
         steps.push_back(st);
@@ -448,14 +448,18 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.img = images;
                 a.out = tptr(st.out);
                 a.w = h->blob + st.conv.w_off;
+                a.w_bf16 = eb == 2 ? wb + st.conv.w_off * eb : nullptr;
                 a.bias = h->blob + st.conv.b_off;
                 a.V = n;
                 a.H = h->H;
                 a.W = h->W;
                 const int blocks = n * (h->H / 2 / 8) * (h->W / 2 / 16);
                 const double opx = (double)n * (h->H / 2) * (h->W / 2);
-                ScopedTimer tm(h, s, std::string("stem_kernel<") + tname + ">", 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb));
-                hipLaunchKernelGGL((stem_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
+                ScopedTimer tm(h, s, eb == 2 ? std::string("stem_bf16_kernel") : std::string("stem_kernel<") + tname + ">", 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb));
+                if constexpr (sizeof(T) == 2)
+                    hipLaunchKernelGGL(stem_bf16_kernel, dim3(blocks), dim3(256), 0, s, a);
+                else
+                    hipLaunchKernelGGL((stem_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
                 DF3D_LAUNCH_CHECK();
                 break;
             }
@@ -674,6 +678,9 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
         DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(lowp_dev) & 255) == 0, "lowp buffer must be 256-byte aligned");
         hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(1024), dim3(256), 0, df3d::as_stream(stream), blob_dev,
                            reinterpret_cast<unsigned short*>(lowp_dev), h->blob_floats);
+        // the bf16 stem wants its weights as a [64][184] bf16 tile: overwrite the stem's slot of the low-precision copy
+        hipLaunchKernelGGL(stem_relayout_kernel, dim3((64 * 184 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
+                           blob_dev + h->steps[0].conv.w_off, reinterpret_cast<unsigned short*>(lowp_dev) + h->steps[0].conv.w_off);
         DF3D_LAUNCH_CHECK();
         h->lowp = lowp_dev;
     }

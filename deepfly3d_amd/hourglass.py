@@ -72,7 +72,7 @@ def pack_state_dict(engine_handle, state_dict):
             if (cout, cin, kh * kw) != (d.cout, d.cin, d.taps):
                 raise ValueError(f"{name}: state_dict shape {w.shape} does not match engine ({d.cout},{d.cin},{d.taps})")
             if d.taps == 49:  # stem: [148][64], k = ky*21 + kx*3 + c
-                packed = np.zeros((148, 64))
+                packed = np.zeros((d.count // 64, 64))  # rows 0..146 used (the slot is larger: see df3d_hip.h)
                 packed[:147] = w.transpose(2, 3, 1, 0).reshape(147, 64)
             else:  # [tap][cout_pad][cin_pad]
                 packed = np.zeros((d.taps, d.cout_pad, d.cin_pad))

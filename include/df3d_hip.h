@@ -156,7 +156,8 @@ int df3d_ba_update_scale(const double* colsq_dev, double* scale_inv_dev, double*
  *      df3d_hg_blob_floats(h) floats at d.offset and uploads it:  df3d_hg_set_weights(h, blob_dev, ...).
  *      Packed layout per convolution: weight [taps][cout_pad][cin_pad] (k contiguous), bias[cout_pad],
  *      and for pre-activated convs in_scale[cin_pad], in_shift[cin_pad] (eval-mode BN as y = x*s + t).
- *      The stem ("conv1", taps = 49) is packed [148][64]: row k = ky*21 + kx*3 + c, 64 outputs contiguous.
+ *      The stem ("conv1", taps = 49) is packed [148][64]: row k = ky*21 + kx*3 + c, 64 outputs contiguous (its slot
+ *      is 184*64 floats: bf16 engines re-lay the low-precision copy as a [64][184] tile; leave the tail zero).
  *      BatchNorms that FOLLOW a convolution are folded into its weight/bias by the caller (the Python packer
  *      deepfly3d_amd/hourglass.py does this in float64).
  *   3. df3d_hg_forward(h, images_dev, n, heatmaps_dev, workspace_dev, workspace_bytes, stream)

@@ -60,7 +60,7 @@ def test_bn_folding_and_packing_reproduce_the_oracle_layer(native_lib):
     got = np.maximum(np.einsum("oc,nchw->nohw", W, a) + b[None, :, None, None], 0)
     assert np.abs(got - ref.numpy()).max() < 1e-5 * np.abs(ref.numpy()).max()
     # stem packing: [148][64], k = ky*21 + kx*3 + c, BN folded
-    ws = params[("conv1", 0)][0].reshape(148, 64)
+    ws = params[("conv1", 0)][0].reshape(184, 64)[:148]
     sd = net.state_dict()
     scale = (sd["bn1.weight"] / torch.sqrt(sd["bn1.running_var"] + 1e-5)).numpy()
     assert np.allclose(ws[2 * 21 + 3 * 3 + 1, 5], sd["conv1.weight"][5, 1, 2, 3].item() * scale[5], rtol=1e-6)
