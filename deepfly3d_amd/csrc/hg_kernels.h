@@ -979,28 +979,44 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
         for (int i = 0; i < 4; ++i) {
             const int n = nh * 128 + i * 32 + l31;
             const float bias = DS ? p.b3[n] + p.bd[n] : p.b3[n];
-            float xr[16];
+            if constexpr (EB == 4) {
+                float xr[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {  // identity skip: all residual loads first (see conv_mfma_kernel)
-                xr[r] = 0.0f;
-                if constexpr (!DS) {
-                    const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;   // pixel index inside the wave's 32
-                    const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n;
-                    if constexpr (EB == 4)
-                        xr[r] = reinterpret_cast<const float*>(xin)[po];
-                    else
-                        xr[r] = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(xin)[po]);
+                for (int r = 0; r < 16; ++r) {  // identity skip: all residual loads first (see conv_mfma_kernel)
+                    xr[r] = 0.0f;
+                    if constexpr (!DS) {
+                        const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;   // pixel index inside the wave's 32
+                        xr[r] = reinterpret_cast<const float*>(xin)[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n];
+                    }
                 }
-            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n;
-                const float v = acc[i][r] + bias + xr[r];
-                if constexpr (EB == 4)
-                    reinterpret_cast<float*>(outp)[po] = v;
-                else
-                    reinterpret_cast<unsigned short*>(outp)[po] = f32_to_bf16_bits(v);
+                for (int r = 0; r < 16; ++r) {
+                    const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n;
+                    reinterpret_cast<float*>(outp)[po] = acc[i][r] + bias + xr[r];
+                }
+            } else {
+                // bf16: lane pairs exchange one register so that each lane owns TWO adjacent channels of one pixel
+                // (even lanes: pixel-register r, odd lanes: r + 1) -> 4-byte residual loads and stores
+                const int odd = lane & 1;
+                size_t po[8];
+                unsigned xr[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int rr = 2 * q + odd;
+                    const int pl = (rr & 3) + 8 * (rr >> 2) + 4 * half;
+                    po[q] = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + (n & ~1);
+                    xr[q] = 0u;
+                    if constexpr (!DS) xr[q] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(xin) + po[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float va = acc[i][2 * q] + bias, vb = acc[i][2 * q + 1] + bias;
+                    const float g = __shfl_xor(odd ? va : vb, 1, 64);
+                    const float lo = (odd ? g : va) + bf16_bits_to_f32((unsigned short)(xr[q] & 0xffffu));
+                    const float hi = (odd ? vb : g) + bf16_bits_to_f32((unsigned short)(xr[q] >> 16));
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(outp) + po[q]) = pack_bf16x2(lo, hi);
+                }
             }
         }
     }
