@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--frames-per-step", type=int, default=32)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--pool-frames", type=int, default=0, help="distinct frames resident in HBM (0 = steps*frames_per_step, capped at 1000)")
+    ap.add_argument("--ba-window", type=int, default=0,
+                    help="BASELINE configs[4]: run one bundle adjustment (HIP kernels + TRF/LSMR driver) per this many frames on "
+                         "geometry-consistent synthetic detections, inside the timed region (0 = fixed calib.pkl, configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
@@ -123,9 +126,25 @@ def main():
         frames[i : i + 64].uniform_(0.0, 1.0, generator=gen)
     outs = pipe.allocate_outputs(total_frames)
 
+    ba_px, ba_runs = None, []
+    if a.ba_window > 0:
+        # geometry-consistent detections: golden-like pose tiled + jitter, projected through the adjusted
+        # cameras of the sample set, quantised to the heat-map grid; the random-weight network output is meaningless for BA
+        from deepfly3d_amd.bundle_adjust import bundle_adjust
+        from deepfly3d_amd.synthetic import synthetic_points2d
+
+        g3 = np.load(os.path.join(ROOT, "tests", "golden", "golden_3d.npz"))
+        rng = np.random.default_rng(rank)
+        pose = g3["points3d_wo_procrustes"]
+        X = np.tile(pose, (a.ba_window // pose.shape[0] + 1, 1, 1))[: a.ba_window] + rng.normal(0, 0.05, size=(a.ba_window, 38, 3))
+        ba_px = synthetic_points2d(X, g3["R"], g3["tvec"], g3["intr"]) * np.array([480.0, 960.0])
+
     def step(i, t0):
         lo = (i * fps_step) % pool
         pipe.run_batch(frames[lo : lo + fps_step], *outs, t0)
+        if ba_px is not None and ((i + 1) * fps_step) // a.ba_window > (i * fps_step) // a.ba_window:
+            _, _, info = bundle_adjust(ba_px, calib["R"], calib["tvec"], calib["intr"], device=dev, return_info=True)
+            ba_runs.append(info["nfev"])
 
     for w in range(a.warmup):
         step(w, 0)
@@ -207,6 +226,8 @@ def main():
                 "frames_per_step": fps_step,
                 "frames_per_gpu": total_frames,
                 "parallelism": f"frame-sharded x{world}, one gather",
+                "bundle_adjust_every_frames": a.ba_window or None,
+                "bundle_adjust_runs_rank0": len(ba_runs) or None,
                 "hourglass_tflops_end_to_end": fl / (ms_step * 1e-3) / 1e12,
                 "hourglass_gbs_algorithmic_end_to_end": by / (ms_step * 1e-3) / 1e9,
             },

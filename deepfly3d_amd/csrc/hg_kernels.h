@@ -614,6 +614,7 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
 struct BottleneckArgs {
     const void* in;     // NHWC [V, H, W, CIN]
     void* out;          // NHWC [V, H, W, 2*PL]
+    void* pool;         // optional NHWC [V, H/2, W/2, 2*PL]: 2x2 max-pool of `out`, written by the same epilogue
     const void* w1;     // [PL][CIN]
     const void* w2;     // [9][PL][PL]
     const void* w3;     // [2*PL][PL]      (K permuted for bf16)
@@ -690,7 +691,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
         const unsigned long long m = __ballot(ok);
         if (lane == 0) valid_lds[wave] = m;
     }
-    if (tid < PL) b2_lds[tid] = p.b2[tid];
 
     // =========================== phase 1: t1 = relu(W1' relu(bn1 x) + b1') on the halo ===================
     {
@@ -739,10 +739,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
             for (int i = 0; i < WP; ++i) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
         };
         f32x16 acc[RT];
+        {
+            const float bias1 = p.b1[ct * 32 + l31];   // bias folded into the accumulator start value
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) acc[i][r] = bias1;
+        }
         load1(0);
         store1(0);
         __syncthreads();
@@ -767,7 +770,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
         // epilogue: bias + ReLU, zero outside the image, into the t1 tile (rows = halo pixels, PL channels).
         // Branch-free: every row (also the 12 pad rows, whose validity bit is 0) is written.
         const int n = ct * 32 + l31;
-        const float bias = p.b1[n];
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             const unsigned vmh = (unsigned)(valid_lds[(rt0 + i) >> 1] >> (((rt0 + i) & 1) * 32 + 4 * half));
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                 const int ro = (r & 3) + 8 * (r >> 2);
                 // select by bit mask (a ?: here makes hipcc emit one branch per register)
                 const unsigned keep = 0u - ((vmh >> ro) & 1u);
-                const float v = __uint_as_float(__float_as_uint(fmaxf(acc[i][r] + bias, 0.0f)) & keep);
+                const float v = __uint_as_float(__float_as_uint(fmaxf(acc[i][r], 0.0f)) & keep);
                 if constexpr (EB == 4)
                     *reinterpret_cast<float*>(trow + ro * C::T1_PITCH) = v;
                 else
@@ -809,11 +811,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
 
     // this wave's 32 pixels: tile rows 2*wave, 2*wave + 1
     const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
+    // t2 accumulators start at b2' (channel of register r in tile m: 32m + (r&3) + 8(r>>2) + 4*half)
     f32x16 t2[NT];
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t2[m][r] = 0.0f;
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + 32 * m + 8 * q + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
+        }
     {
         constexpr int KSTEPS = PL / KE;          // K-steps per tap
         constexpr int NSTEPS = 9 * KSTEPS;
@@ -859,15 +866,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
         }
     }
 
-    // bias + ReLU on t2 (channel of register r in tile m: 32m + (r&3) + 8(r>>2) + 4*half)
+    // ReLU on t2 (the bias was the accumulator start value)
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(b2_lds + 32 * m + 8 * q + 4 * half);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = fmaxf(t2[m][4 * q + e] + bb[e], 0.0f);
-        }
+        for (int r = 0; r < 16; ++r) t2[m][r] = fmaxf(t2[m][r], 0.0f);
 
     // =========================== phase 3: out = W3 t2 (+ Wd x) + b + (x) ==================================
     // halves of 128 output channels; K-step = KE channels of t2 = accumulator registers of one/two tiles
@@ -875,9 +878,38 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
     for (int nh = 0; nh < CO / 128; ++nh) {
         f32x16 acc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const int n = nh * 128 + i * 32 + l31;
+            const float bias = DS ? p.b3[n] + p.bd[n] : p.b3[n];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[i][r] = bias;
+        }
+        // identity skip: the residual values are requested NOW (their latency hides behind the K loop).
+        // fp32: one value per accumulator register; bf16: lane pairs own two adjacent channels of one pixel
+        // (even lanes pixel-register 2q, odd lanes 2q + 1), so loads and stores are 4 bytes wide.
+        constexpr int NRES = DS ? 1 : (EB == 4 ? 64 : 32);
+        unsigned xres[NRES];
+        if constexpr (!DS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = nh * 128 + i * 32 + l31;
+                if constexpr (EB == 4) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        xres[i * 16 + r] = __float_as_uint(reinterpret_cast<const float*>(xin)[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n]);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int rr = 2 * q + (lane & 1);
+                        const int pl = (rr & 3) + 8 * (rr >> 2) + 4 * half;
+                        xres[i * 8 + q] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(xin) +
+                                                                             ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + (n & ~1));
+                    }
+                }
+            }
+        }
         constexpr int NSTEPS = PL / KE;
         const void* w3h = reinterpret_cast<const unsigned char*>(p.w3) + (size_t)nh * 128 * PL * EB;
         load_w(w3h, 128, PL, 0);
@@ -978,44 +1010,57 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = nh * 128 + i * 32 + l31;
-            const float bias = DS ? p.b3[n] + p.bd[n] : p.b3[n];
             if constexpr (EB == 4) {
-                float xr[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {  // identity skip: all residual loads first (see conv_mfma_kernel)
-                    xr[r] = 0.0f;
-                    if constexpr (!DS) {
-                        const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;   // pixel index inside the wave's 32
-                        xr[r] = reinterpret_cast<const float*>(xin)[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n];
-                    }
-                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
                     const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n;
-                    reinterpret_cast<float*>(outp)[po] = acc[i][r] + bias + xr[r];
+                    acc[i][r] += (DS ? 0.0f : __uint_as_float(xres[DS ? 0 : i * 16 + r]));
+                    reinterpret_cast<float*>(outp)[po] = acc[i][r];
+                }
+                if (p.pool) {
+                    // 2x2 max-pool inside the lane: horizontal neighbour = register r^1, vertical neighbour = r^8
+                    float* const pp = reinterpret_cast<float*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                        for (int b2 = 0; b2 < 2; ++b2) {
+                            const int r0 = 2 * a2 + 4 * b2;
+                            const float v = fmaxf(fmaxf(acc[i][r0], acc[i][r0 + 1]), fmaxf(acc[i][r0 + 8], acc[i][r0 + 9]));
+                            const int ppx = a2 + 4 * b2 + 2 * half;
+                            pp[((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + ppx)) * CO + n] = v;
+                        }
                 }
             } else {
-                // bf16: lane pairs exchange one register so that each lane owns TWO adjacent channels of one pixel
-                // (even lanes: pixel-register r, odd lanes: r + 1) -> 4-byte residual loads and stores
                 const int odd = lane & 1;
-                size_t po[8];
-                unsigned xr[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int rr = 2 * q + odd;
                     const int pl = (rr & 3) + 8 * (rr >> 2) + 4 * half;
-                    po[q] = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + (n & ~1);
-                    xr[q] = 0u;
-                    if constexpr (!DS) xr[q] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(xin) + po[q]);
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float va = acc[i][2 * q] + bias, vb = acc[i][2 * q + 1] + bias;
+                    const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + (n & ~1);
+                    const float va = acc[i][2 * q], vb = acc[i][2 * q + 1];
                     const float g = __shfl_xor(odd ? va : vb, 1, 64);
-                    const float lo = (odd ? g : va) + bf16_bits_to_f32((unsigned short)(xr[q] & 0xffffu));
-                    const float hi = (odd ? vb : g) + bf16_bits_to_f32((unsigned short)(xr[q] >> 16));
-                    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(outp) + po[q]) = pack_bf16x2(lo, hi);
+                    const unsigned xr = DS ? 0u : xres[DS ? 0 : i * 8 + q];
+                    const float lo = (odd ? g : va) + bf16_bits_to_f32((unsigned short)(xr & 0xffffu));
+                    const float hi = (odd ? vb : g) + bf16_bits_to_f32((unsigned short)(xr >> 16));
+                    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(outp) + po) = pack_bf16x2(lo, hi);
+                    acc[i][2 * q] = lo;       // keep the paired values for the pooled output
+                    acc[i][2 * q + 1] = hi;
+                }
+                if (p.pool) {
+                    // the two lanes of a pair hold the same channel pair at horizontally adjacent pixels (registers 2q / 2q+1);
+                    // the vertical neighbour is pair q + 4 in the same lane.  Even lanes store the pooled pair.
+                    unsigned short* const pp = reinterpret_cast<unsigned short*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float lo = fmaxf(acc[i][2 * q], acc[i][2 * q + 8]), hi = fmaxf(acc[i][2 * q + 1], acc[i][2 * q + 9]);
+                        lo = fmaxf(lo, __shfl_xor(lo, 1, 64));
+                        hi = fmaxf(hi, __shfl_xor(hi, 1, 64));
+                        // pixel-register 2q (even lane): px = (2q & 3) + 8*((2q >> 2) & 1) + 4*half -> pooled column px / 2
+                        const int ppx = (q & 1) + 4 * (q >> 1) + 2 * half;
+                        if (!odd)
+                            *reinterpret_cast<unsigned*>(pp + ((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + ppx)) * CO + (n & ~1)) = pack_bf16x2(lo, hi);
+                    }
                 }
             }
         }
@@ -1056,7 +1101,7 @@ struct HeadCfg {
     static constexpr int STAGE_A = (256 + 128) * (RBA + 16);         // Wfc rows + r rows
     static constexpr int WSC_PITCH = 256 * EB + 16;
     static constexpr int WSC_BYTES = 32 * WSC_PITCH;
-    static constexpr int RBC = 128;
+    static constexpr int RBC = 128;                                  // phase C staged row bytes
     static constexpr int STAGE_C = 128 * (RBC + 16);
     static constexpr int S1 = 2 * STAGE_A > WSC_BYTES ? 2 * STAGE_A : WSC_BYTES;
     static constexpr int STAGE_BYTES = S1 > 2 * STAGE_C ? S1 : 2 * STAGE_C;
@@ -1274,13 +1319,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void head_kernel(Hea
                                 }
                             }
                 } else {
-                    // y steps: KE = 64 channels = tiles 2s, 2s+1; score step: one 32-channel group
+                    // y steps: KE channels = tiles s*(KE/32) .. +KE/32-1; score step: one 32-channel group
 #pragma unroll
-                    for (int mm = 0; mm < 2; ++mm) {
-                        if (s == YSTEPS && mm == 1) break;
+                    for (int mm = 0; mm < KE / 32; ++mm) {
+                        if (s == YSTEPS && mm >= 1) break;
 #pragma unroll
                         for (int q2 = 0; q2 < 2; ++q2) {
-                            const bf16x8 af = s < YSTEPS ? ypk[s < YSTEPS ? 2 * s + mm : 0][q2] : scpk[q2];
+                            const bf16x8 af = s < YSTEPS ? ypk[s < YSTEPS ? s * (KE / 32) + mm : 0][q2] : scpk[q2];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sw + (i * 32 + l31) * PITCH + (mm * 32 + (2 * q2 + half) * 8) * 2);

@@ -39,6 +39,7 @@ struct Step {
     ConvPlan conv;     // ST_CONV / ST_STEM; for ST_BOTTLENECK: conv = conv1, conv2b = conv2, conv3b = conv3
     ConvPlan conv2b, conv3b, conv4b;  // ST_HEAD: conv = fc, conv2b = score, conv3b = fc_, conv4b = score_
     bool last = false;
+    int pool_out = -1;                // ST_BOTTLENECK: tensor receiving the fused 2x2 max-pool of `out`
 };
 
 struct Allocator {
@@ -89,6 +90,7 @@ struct df3d_hg {
     int rb_override = 0;  // 0 = auto, 64 or 128: staged row bytes per K-step (tuning knob)
     int fuse = 1;         // 1 = 256->128->128->256 bottlenecks at >= 16x32 run as ONE fused kernel
     std::vector<TensorDesc> tensors;
+    std::vector<int> pooled_of;   // tensor id -> id of its max-pooled copy written by the producing fused bottleneck (-1: none)
     std::vector<Step> steps;
     std::vector<df3d_hg_param> params;
     size_t blob_floats = 0;
@@ -119,6 +121,7 @@ struct df3d_hg {
         if (!pitch) pitch = c;
         TensorDesc t{alloc.alloc((size_t)h * w * pitch), h, w, c, pitch};
         tensors.push_back(t);
+        pooled_of.push_back(-1);
         return (int)tensors.size() - 1;
     }
     void free_tensor(int id) {
@@ -174,7 +177,7 @@ struct df3d_hg {
         account_conv((double)ti.h * ti.w, taps, ti.c, cout, res >= 0);
         return st.out;
     }
-    int bottleneck(const std::string& name, int x, int planes) {
+    int bottleneck(const std::string& name, int x, int planes, bool want_pool = false) {
         const int cin = tensors[x].c, cout = 2 * planes;
         const TensorDesc tx = tensors[x];
         const bool shape_ok = (cin == 256 && planes == 128) || (cin == 128 && planes == 128) || (cin == 64 && planes == 64);
@@ -192,6 +195,11 @@ struct df3d_hg {
             if (ds) st.conv4b = plan_conv(name + ".downsample.0", 1, cin, cin, cout, false, false, false);
             st.conv3b = plan_conv(name + ".conv3", 1, planes, planes, cout, false, false, false, dtype == DF3D_DTYPE_BF16 ? 1 : 0);
             st.out = new_tensor(tx.h, tx.w, cout);
+            if (want_pool) {  // the consumer max-pools this tensor: the epilogue writes the pooled copy too (no pool step)
+                st.pool_out = new_tensor(tx.h / 2, tx.w / 2, cout);
+                pooled_of[st.out] = st.pool_out;
+                elems_per_view += (double)tx.h * tx.w * cout * 1.25;  // model M1 still counts the pooling pass
+            }
             steps.push_back(st);
             const double px = (double)tx.h * tx.w;
             account_conv(px, 1, cin, planes, false);
@@ -211,6 +219,7 @@ struct df3d_hg {
         return o;
     }
     int pool(const std::string& name, int x) {
+        if (pooled_of[x] >= 0) return pooled_of[x];  // already produced by the fused bottleneck that wrote x
         const TensorDesc t = tensors[x];
         Step st;
         st.kind = ST_POOL;
@@ -239,7 +248,7 @@ struct df3d_hg {
         const std::string lv = name + "." + std::to_string(n - 1);
         int up1 = bottleneck(lv + ".0.0", x, planes);
         int low = pool(lv + ".pool", x);
-        int low1 = bottleneck(lv + ".1.0", low, planes);
+        int low1 = bottleneck(lv + ".1.0", low, planes, n > 1);
         free_tensor(low);
         int low2;
         if (n > 1)
@@ -256,6 +265,7 @@ struct df3d_hg {
 
     void build() {
         tensors.clear();
+        pooled_of.clear();
         steps.clear();
         params.clear();
         blob_floats = 0;
@@ -275,13 +285,13 @@ struct df3d_hg {
         flops_per_view += 2.0 * (H / 2) * (W / 2) * 147 * 64;
         elems_per_view += (double)H * W * 3 + (double)(H / 2) * (W / 2) * 64;
         int x = st.out;
-        int l1 = bottleneck("layer1.0", x, 64);
+        int l1 = bottleneck("layer1.0", x, 64, true);
         free_tensor(x);
         int p1 = pool("maxpool", l1);
         free_tensor(l1);
         int l2 = bottleneck("layer2.0", p1, 128);
         free_tensor(p1);
-        x = bottleneck("layer3.0", l2, 128);
+        x = bottleneck("layer3.0", l2, 128, true);
         free_tensor(l2);
         for (int s = 0; s < num_stacks; ++s) {
             const std::string S = std::to_string(s);
@@ -501,6 +511,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 BottleneckArgs a;
                 a.in = tptr(st.in);
                 a.out = tptr(st.out);
+                a.pool = st.pool_out >= 0 ? tptr(st.pool_out) : nullptr;
                 a.w1 = wb + st.conv.w_off * eb;
                 a.w2 = wb + st.conv2b.w_off * eb;
                 a.w3 = wb + st.conv3b.w_off * eb;
