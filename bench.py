@@ -107,8 +107,9 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     _native.require_gpu()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    dev_index = local_rank % torch.cuda.device_count()  # (== local_rank on a node with one GPU per rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
 
     fps_step = a.frames_per_step
     sd = synthetic_state_dict(0)

@@ -652,7 +652,7 @@ struct BtCfg {
     static constexpr int STAGED = DS ? (128 + 128) * (RBD + 16) : 0;  // x centre rows + Wd rows
     static constexpr int SMAX = STAGE1 > STAGE2 ? (STAGE1 > STAGED ? STAGE1 : STAGED) : (STAGE2 > STAGED ? STAGE2 : STAGED);
     static constexpr int STAGE_BYTES = (SINGLE ? 1 : 2) * SMAX;
-    static constexpr int MISC = PL * 4 + 64;                       // b2' + validity masks
+    static constexpr int MISC = 64;                                // halo validity masks (3 x 64 bit)
     static constexpr int LDS_BYTES = T1_BYTES + STAGE_BYTES + MISC;
     static constexpr int NT = PL / 32;                             // channel tiles of the intermediates
 };
@@ -669,8 +669,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const t1_lds = smem;
     unsigned char* const stage = smem + C::T1_BYTES;
-    float* const b2_lds = reinterpret_cast<float*>(smem + C::T1_BYTES + C::STAGE_BYTES);
-    unsigned long long* const valid_lds = reinterpret_cast<unsigned long long*>(b2_lds + PL);
+    unsigned long long* const valid_lds = reinterpret_cast<unsigned long long*>(smem + C::T1_BYTES + C::STAGE_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5;          // which 16-byte chunk of a 32-byte K group this lane reads

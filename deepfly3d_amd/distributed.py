@@ -24,7 +24,7 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("DF3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -53,6 +53,8 @@ def _gather_frame_axis(local, frame_axis, ranges, rank, world_size, group=None):
         return local
     longest = max(b - a for a, b in ranges)
     moved = local.movedim(frame_axis, 0).contiguous()
+    if moved.is_cuda and dist.get_backend(group) == "gloo":
+        moved = moved.cpu()  # gloo has no CUDA gather (CPU tests, or several ranks sharing one GPU)
     if moved.shape[0] < longest:
         pad = torch.zeros((longest - moved.shape[0], *moved.shape[1:]), dtype=moved.dtype, device=moved.device)
         moved = torch.cat([moved, pad], dim=0)
