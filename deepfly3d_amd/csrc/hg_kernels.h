@@ -646,6 +646,9 @@ struct BtCfg {
     // workgroups share a CU -- the second one's MFMAs cover the first one's barrier / LDS / memory stalls.
     // fp32: the t1 tile alone is 101 KB, one workgroup per CU, so double-buffer the staging (one barrier per step).
     static constexpr bool SINGLE = EB == 2;
+    // phase-2 weights straight from L2 to registers (no staging, no barriers): measured SLOWER on fp32 (98 vs 112
+    // TFLOP/s: fragment-shaped 32-byte row pieces cost too much in the texture-address path) -- kept off.
+    static constexpr bool DIRECT2 = false;
     static constexpr int RBD = 64;                                 // downsample steps of phase 3 (K = CIN)
     static constexpr int STAGE1 = (BT_HROWS + PL) * (RB1 + 16);    // x rows + W1 rows
     static constexpr int STAGE2 = 128 * (RB2 + 16);                // W2 (PL rows) / W3 (128 rows) 
@@ -820,7 +823,51 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
 #pragma unroll
             for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
         }
-    {
+    if constexpr (C::DIRECT2) {
+        // fp32: the W2 fragments go global/L2 -> registers directly (three 8-channel groups in flight), no LDS
+        // staging and NO barrier in the whole phase: an fp32 MFMA group lasts 1024 cycles, long enough to hide the
+        // L2 latency, and with one workgroup per CU the 36 barrier bubbles of a staged phase 2 were the main loss.
+        // Every wave reads the same 32-byte row pieces, so three of the four requests are L1 hits.
+        constexpr int CPT = PL / 8;             // 8-channel groups per tap
+        constexpr int NC = 9 * CPT;             // 144 (72) groups
+        static_assert(NC % 3 == 0, "pipeline depth");
+        const unsigned char* const wlane = reinterpret_cast<const unsigned char*>(p.w2) + ((size_t)l31 * PL + 4 * half) * EB;
+        auto wload = [&](u32x4 (&w)[NT], int c) {
+            const int tap = c / CPT, kk = c - tap * CPT;
+            const unsigned char* const wp = wlane + ((size_t)tap * PL * PL + kk * 8) * EB;
+#pragma unroll
+            for (int m = 0; m < NT; ++m) w[m] = *reinterpret_cast<const u32x4*>(wp + (size_t)m * 32 * PL * EB);
+        };
+        auto tload = [&](int c) {
+            const int tap = c / CPT, kk = c - tap * CPT;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            return *reinterpret_cast<const u32x4*>(t1_lds + ((py + ky) * BT_HW + (px + kx)) * C::T1_PITCH + kk * 32 + half * 16);
+        };
+        u32x4 wa[NT], wb2[NT], wc[NT];
+        wload(wa, 0);
+        wload(wb2, 1);
+        wload(wc, 2);
+        for (int c = 0; c < NC; c += 3) {
+            {
+                const u32x4 tf = tload(c);
+#pragma unroll
+                for (int m = 0; m < NT; ++m) mfma_chunk<T>(wa[m], tf, t2[m]);
+                if (c + 3 < NC) wload(wa, c + 3);
+            }
+            {
+                const u32x4 tf = tload(c + 1);
+#pragma unroll
+                for (int m = 0; m < NT; ++m) mfma_chunk<T>(wb2[m], tf, t2[m]);
+                if (c + 4 < NC) wload(wb2, c + 4);
+            }
+            {
+                const u32x4 tf = tload(c + 2);
+#pragma unroll
+                for (int m = 0; m < NT; ++m) mfma_chunk<T>(wc[m], tf, t2[m]);
+                if (c + 5 < NC) wload(wc, c + 5);
+            }
+        }
+    } else {
         constexpr int KSTEPS = PL / KE;          // K-steps per tap
         constexpr int NSTEPS = 9 * KSTEPS;
         load_w(p.w2, PL, PL, 0);
@@ -836,27 +883,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
             __builtin_amdgcn_sched_barrier(0);
             const int ky = tap / 3, kx = tap - 3 * ky;
             const unsigned char* const tb = t1_lds + ((py + ky) * BT_HW + (px + kx)) * C::T1_PITCH + kc * RB + half * 16;
-            // fragments of K-group j+1 are requested before the MFMAs of group j (one wave per SIMD: nothing else
-            // hides the LDS latency)
             const unsigned char* const wrow = sw + l31 * PITCH + half * 16;
-            u32x4 tf = *reinterpret_cast<const u32x4*>(tb);
-            u32x4 wf[NT];
-#pragma unroll
-            for (int m = 0; m < NT; ++m) wf[m] = *reinterpret_cast<const u32x4*>(wrow + m * 32 * PITCH);
 #pragma unroll
             for (int j = 0; j < RB / 32; ++j) {
-                u32x4 tfn = tf, wfn[NT];
-                if (j + 1 < RB / 32) {
-                    tfn = *reinterpret_cast<const u32x4*>(tb + (j + 1) * 32);
+                const u32x4 tf = *reinterpret_cast<const u32x4*>(tb + j * 32);
 #pragma unroll
-                    for (int m = 0; m < NT; ++m) wfn[m] = *reinterpret_cast<const u32x4*>(wrow + m * 32 * PITCH + (j + 1) * 32);
-                }
-#pragma unroll
-                for (int m = 0; m < NT; ++m) mfma_chunk<T>(wf[m], tf, t2[m]);
-                if (j + 1 < RB / 32) {
-                    tf = tfn;
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) wf[m] = wfn[m];
+                for (int m = 0; m < NT; ++m) {
+                    const u32x4 wf = *reinterpret_cast<const u32x4*>(wrow + m * 32 * PITCH + j * 32);
+                    mfma_chunk<T>(wf, tf, t2[m]);
                 }
             }
             if (SINGLE && s + 1 < NSTEPS) __syncthreads();
