@@ -654,7 +654,8 @@ struct BtCfg {
     static constexpr int STAGE2 = 128 * (RB2 + 16);                // W2 (PL rows) / W3 (128 rows) 
     static constexpr int STAGED = DS ? (128 + 128) * (RBD + 16) : 0;  // x centre rows + Wd rows
     static constexpr int SMAX = STAGE1 > STAGE2 ? (STAGE1 > STAGED ? STAGE1 : STAGED) : (STAGE2 > STAGED ? STAGE2 : STAGED);
-    static constexpr int STAGE_BYTES = (SINGLE ? 1 : 2) * SMAX;
+    static constexpr int RING = SINGLE ? 1 : 3;                   // phase 2/3 weight buffers (fp32: 3-deep ring, see phase 2)
+    static constexpr int STAGE_BYTES = SINGLE ? SMAX : (2 * SMAX > 3 * STAGE2 ? 2 * SMAX : 3 * STAGE2);
     static constexpr int MISC = 64;                                // halo validity masks (3 x 64 bit)
     static constexpr int LDS_BYTES = T1_BYTES + STAGE_BYTES + MISC;
     static constexpr int NT = PL / 32;                             // channel tiles of the intermediates
@@ -811,6 +812,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
             if (PL == 128 || srow + i * RPP < rows) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
     };
 
+    auto store_w3 = [&](int buf, int rows) {   // same, into slot `buf` of the 3-deep ring (pitch STAGE2)
+        unsigned char* const sw = stage + buf * C::STAGE2;
+#pragma unroll
+        for (int i = 0; i < WPASS; ++i)
+            if (PL == 128 || srow + i * RPP < rows) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
+    };
+
     // this wave's 32 pixels: tile rows 2*wave, 2*wave + 1
     const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
     // t2 accumulators start at b2' (channel of register r in tile m: 32m + (r&3) + 8(r>>2) + 4*half)
@@ -867,7 +875,68 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                 if (c + 5 < NC) wload(wc, c + 5);
             }
         }
+    } else if constexpr (!SINGLE) {
+        // fp32 (one workgroup per CU): 3-deep LDS ring, weights prefetched TWO steps ahead.  During step s the wave
+        //   * computes from buffer s%3, whose first fragments were already read at the end of step s-1,
+        //   * mid-step stores the registers holding step s+2 into buffer (s+2)%3 (last read in step s-1, i.e. before
+        //     the barrier that ended step s-1) and re-issues the global loads for step s+3,
+        //   * reads the first fragments of step s+1 (buffer (s+1)%3, complete since the previous barrier),
+        // so neither the LDS-write nor the LDS-read latency sits between two MFMAs; the single barrier per step only
+        // orders "everyone finished reading buffer s%3" before it is overwritten one step later.
+        constexpr int KSTEPS = PL / KE;
+        constexpr int NSTEPS = 9 * KSTEPS;
+        constexpr int J = RB / 32;
+        auto w2_off = [&](int s) { const int tap = s / KSTEPS; return (size_t)tap * PL * PL + (size_t)(s - tap * KSTEPS) * KE; };
+        auto t1_ptr = [&](int s) {
+            const int tap = s / KSTEPS, kc = s - tap * KSTEPS;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            return t1_lds + ((py + ky) * BT_HW + (px + kx)) * C::T1_PITCH + kc * RB + half * 16;
+        };
+        load_w(p.w2, PL, PL, w2_off(0));
+        store_w3(0, PL);
+        load_w(p.w2, PL, PL, w2_off(1));
+        store_w3(1, PL);
+        load_w(p.w2, PL, PL, w2_off(2));   // stays in registers until the middle of step 0
+        __syncthreads();
+        u32x4 tf = *reinterpret_cast<const u32x4*>(t1_ptr(0));
+        u32x4 wf[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) wf[m] = *reinterpret_cast<const u32x4*>(stage + (m * 32 + l31) * PITCH + half * 16);
+        for (int s = 0; s < NSTEPS; ++s) {
+            const unsigned char* const wrow = stage + (s % 3) * C::STAGE2 + l31 * PITCH + half * 16;
+            const unsigned char* const tb = t1_ptr(s);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                u32x4 tfn, wfn[NT];
+                if (j + 1 < J) {
+                    tfn = *reinterpret_cast<const u32x4*>(tb + (j + 1) * 32);
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) wfn[m] = *reinterpret_cast<const u32x4*>(wrow + m * 32 * PITCH + (j + 1) * 32);
+                } else if (s + 1 < NSTEPS) {   // first fragments of the next step
+                    tfn = *reinterpret_cast<const u32x4*>(t1_ptr(s + 1));
+                    const unsigned char* const wnext = stage + ((s + 1) % 3) * C::STAGE2 + l31 * PITCH + half * 16;
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) wfn[m] = *reinterpret_cast<const u32x4*>(wnext + m * 32 * PITCH);
+                } else {
+                    tfn = tf;
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) wfn[m] = wf[m];
+                }
+#pragma unroll
+                for (int m = 0; m < NT; ++m) mfma_chunk<T>(wf[m], tf, t2[m]);
+                if (j == 1) {
+                    if (s + 2 < NSTEPS) store_w3((s + 2) % 3, PL);
+                    if (s + 3 < NSTEPS) load_w(p.w2, PL, PL, w2_off(s + 3));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                tf = tfn;
+#pragma unroll
+                for (int m = 0; m < NT; ++m) wf[m] = wfn[m];
+            }
+            __syncthreads();
+        }
     } else {
+        // bf16 (two workgroups per CU): one staging buffer, two barriers per K-step
         constexpr int KSTEPS = PL / KE;          // K-steps per tap
         constexpr int NSTEPS = 9 * KSTEPS;
         load_w(p.w2, PL, PL, 0);
@@ -875,7 +944,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
         __syncthreads();
         for (int s = 0; s < NSTEPS; ++s) {
             const int tap = s / KSTEPS, kc = s - tap * KSTEPS;
-            const unsigned char* const sw = stage + (SINGLE ? 0 : (s & 1)) * C::SMAX;
+            const unsigned char* const sw = stage;
             if (s + 1 < NSTEPS) {
                 const int tap1 = (s + 1) / KSTEPS, kc1 = (s + 1) - tap1 * KSTEPS;
                 load_w(p.w2, PL, PL, (size_t)tap1 * PL * PL + (size_t)kc1 * KE);
@@ -893,8 +962,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                     mfma_chunk<T>(wf, tf, t2[m]);
                 }
             }
-            if (SINGLE && s + 1 < NSTEPS) __syncthreads();
-            if (s + 1 < NSTEPS) store_w(SINGLE ? 0 : (s & 1) ^ 1, PL);
+            if (s + 1 < NSTEPS) __syncthreads();
+            if (s + 1 < NSTEPS) store_w(0, PL);
             __syncthreads();
         }
     }
