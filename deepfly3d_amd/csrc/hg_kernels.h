@@ -20,6 +20,9 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_runtime.h>
 
+#ifndef DF3D_ABLATE
+#define DF3D_ABLATE 0
+#endif
 namespace hgk {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
             unsigned char* const sw = sx + X_BYTES;
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
-                u32x4 v = preact_apply<T>(rx[i], coef);  // bn1 + ReLU, deferred past the MFMAs
+                u32x4 v = DF3D_ABLATE == 6 ? rx[i] : preact_apply<T>(rx[i], coef);  // bn1 + ReLU, deferred past the MFMAs
                 const unsigned keep = xok[i] ? 0xffffffffu : 0u;
                 v &= keep;
                 *reinterpret_cast<u32x4*>(sx + (srow + i * RPP) * PITCH + chunk * 16) = v;
@@ -762,6 +765,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                 const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (ct * 32 + l31) * PITCH + j * 32 + half * 16);
 #pragma unroll
                 for (int i = 0; i < RT; ++i) {
+                    if (DF3D_ABLATE == 5) continue;
                     const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * PITCH + j * 32 + half * 16);
                     mfma_chunk<T>(xf, wf, acc[i]);
                 }
@@ -783,6 +787,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                 // select by bit mask (a ?: here makes hipcc emit one branch per register)
                 const unsigned keep = 0u - ((vmh >> ro) & 1u);
                 const float v = __uint_as_float(__float_as_uint(fmaxf(acc[i][r], 0.0f)) & keep);
+                if (DF3D_ABLATE == 7 && r > 0) continue;
                 if constexpr (EB == 4)
                     *reinterpret_cast<float*>(trow + ro * C::T1_PITCH) = v;
                 else
@@ -945,7 +950,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
         for (int s = 0; s < NSTEPS; ++s) {
             const int tap = s / KSTEPS, kc = s - tap * KSTEPS;
             const unsigned char* const sw = stage;
-            if (s + 1 < NSTEPS) {
+            if (DF3D_ABLATE != 2 && s + 1 < NSTEPS) {
                 const int tap1 = (s + 1) / KSTEPS, kc1 = (s + 1) - tap1 * KSTEPS;
                 load_w(p.w2, PL, PL, (size_t)tap1 * PL * PL + (size_t)kc1 * KE);
             }
@@ -953,6 +958,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
             const int ky = tap / 3, kx = tap - 3 * ky;
             const unsigned char* const tb = t1_lds + ((py + ky) * BT_HW + (px + kx)) * C::T1_PITCH + kc * RB + half * 16;
             const unsigned char* const wrow = sw + l31 * PITCH + half * 16;
+            if (DF3D_ABLATE != 1 && DF3D_ABLATE != 4) {
 #pragma unroll
             for (int j = 0; j < RB / 32; ++j) {
                 const u32x4 tf = *reinterpret_cast<const u32x4*>(tb + j * 32);
@@ -962,8 +968,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                     mfma_chunk<T>(wf, tf, t2[m]);
                 }
             }
+            }
+            if (DF3D_ABLATE == 4) continue;   // no compute, no barriers, no LDS writes: only the global loads
             if (s + 1 < NSTEPS) __syncthreads();
-            if (s + 1 < NSTEPS) store_w(0, PL);
+            if (DF3D_ABLATE != 2 && DF3D_ABLATE != 3 && s + 1 < NSTEPS) store_w(0, PL);
             __syncthreads();
         }
     }
@@ -1001,14 +1009,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                         const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
                         xres[i * 16 + r] = __float_as_uint(reinterpret_cast<const float*>(xin)[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n]);
                     }
-                } else {
+                }
+                (void)n;
+            }
+            if constexpr (EB == 2) {
+                // bf16: the epilogue goes through LDS (see below): lane owns, for c = 0..7, the 16-byte chunk (lane & 15)
+                // of wave pixel 4c + (lane >> 4) -> eight 16-byte residual loads
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int rr = 2 * q + (lane & 1);
-                        const int pl = (rr & 3) + 8 * (rr >> 2) + 4 * half;
-                        xres[i * 8 + q] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(xin) +
-                                                                             ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + (n & ~1));
-                    }
+                for (int c = 0; c < 8; ++c) {
+                    const int pw = 4 * c + (lane >> 4);
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin) +
+                        ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CIN + nh * 128 + (lane & 15) * 8);
+                    xres[4 * c + 0] = v[0];
+                    xres[4 * c + 1] = v[1];
+                    xres[4 * c + 2] = v[2];
+                    xres[4 * c + 3] = v[3];
                 }
             }
         }
@@ -1051,6 +1066,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                         for (int e = 0; e < 8; ++e) af[e] = (__bf16)t2[s * (KE / 32) + mm][8 * q2 + e];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
+                            if (DF3D_ABLATE == 9) continue;
                             const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sw + (i * 32 + l31) * PITCH + (mm * 32 + (2 * q2 + half) * 8) * 2);
                             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf, acc[i], 0, 0, 0);
                         }
@@ -1133,36 +1149,51 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                             pp[((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + ppx)) * CO + n] = v;
                         }
                 }
-            } else {
-                const int odd = lane & 1;
+            }
+        }
+        if constexpr (EB == 2) {
+            // bf16 epilogue through LDS: 4-byte-per-lane global stores cost 17 % of the kernel; instead every wave
+            // parks its 32 px x 128 ch tile (bf16) in its own slice of the dead t1 region and streams it out as
+            // 16-byte chunks: per lane 8 x (ds_read_b128 + residual add + global_store_dwordx4), rows fully coalesced.
+            // Only this wave touches its slice, so no barrier is needed (LDS operations of a wave complete in order).
+            constexpr int OP = 128 * 2 + 16;                    // slice row pitch (bytes)
+            unsigned char* const slice = t1_lds + wave * (32 * OP);
+            const int odd = lane & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const int rr = 2 * q + odd;
+                    const int rr = 2 * q + odd;                 // lane pairs exchange one register: see the stem epilogue
                     const int pl = (rr & 3) + 8 * (rr >> 2) + 4 * half;
-                    const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + (n & ~1);
                     const float va = acc[i][2 * q], vb = acc[i][2 * q + 1];
                     const float g = __shfl_xor(odd ? va : vb, 1, 64);
-                    const unsigned xr = DS ? 0u : xres[DS ? 0 : i * 8 + q];
-                    const float lo = (odd ? g : va) + bf16_bits_to_f32((unsigned short)(xr & 0xffffu));
-                    const float hi = (odd ? vb : g) + bf16_bits_to_f32((unsigned short)(xr >> 16));
-                    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(outp) + po) = pack_bf16x2(lo, hi);
-                    acc[i][2 * q] = lo;       // keep the paired values for the pooled output
-                    acc[i][2 * q + 1] = hi;
+                    *reinterpret_cast<unsigned*>(slice + pl * OP + (i * 32 + (l31 & ~1)) * 2) = pack_bf16x2(odd ? g : va, odd ? vb : g);
                 }
-                if (p.pool) {
-                    // the two lanes of a pair hold the same channel pair at horizontally adjacent pixels (registers 2q / 2q+1);
-                    // the vertical neighbour is pair q + 4 in the same lane.  Even lanes store the pooled pair.
-                    unsigned short* const pp = reinterpret_cast<unsigned short*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;
+            unsigned short* const outs = reinterpret_cast<unsigned short*>(outp);
+            u32x4 fin[8];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float lo = fmaxf(acc[i][2 * q], acc[i][2 * q + 8]), hi = fmaxf(acc[i][2 * q + 1], acc[i][2 * q + 9]);
-                        lo = fmaxf(lo, __shfl_xor(lo, 1, 64));
-                        hi = fmaxf(hi, __shfl_xor(hi, 1, 64));
-                        // pixel-register 2q (even lane): px = (2q & 3) + 8*((2q >> 2) & 1) + 4*half -> pooled column px / 2
-                        const int ppx = (q & 1) + 4 * (q >> 1) + 2 * half;
-                        if (!odd)
-                            *reinterpret_cast<unsigned*>(pp + ((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + ppx)) * CO + (n & ~1)) = pack_bf16x2(lo, hi);
-                    }
+            for (int c = 0; c < 8; ++c) {
+                const int pw = 4 * c + (lane >> 4);
+                u32x4 v = *reinterpret_cast<const u32x4*>(slice + pw * OP + (lane & 15) * 16);
+                if constexpr (!DS) {
+                    u32x4 x4 = {xres[4 * c], xres[4 * c + 1], xres[4 * c + 2], xres[4 * c + 3]};
+                    v = add_chunk<T>(v, x4);
+                }
+                fin[c] = v;
+                *reinterpret_cast<u32x4*>(outs + ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CO + nh * 128 + (lane & 15) * 8) = v;
+            }
+            if (p.pool) {
+                // pooled tile row `wave`: horizontal neighbour = lane ^ 16 (pixel +-1), vertical neighbour = chunk c + 4
+                unsigned short* const pp = reinterpret_cast<unsigned short*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    u32x4 m = max_chunk<T>(fin[c], fin[c + 4]);
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(m[e], 16, 64);
+                    m = max_chunk<T>(m, o);
+                    if (((lane >> 4) & 1) == 0)
+                        *reinterpret_cast<u32x4*>(pp + ((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + 2 * c + (lane >> 5))) * CO + nh * 128 + (lane & 15) * 8) = m;
                 }
             }
         }
