@@ -181,7 +181,7 @@ struct df3d_hg {
         const int cin = tensors[x].c, cout = 2 * planes;
         const TensorDesc tx = tensors[x];
         const bool shape_ok = (cin == 256 && planes == 128) || (cin == 128 && planes == 128) || (cin == 64 && planes == 64);
-        if (fuse && shape_ok && tx.h % 8 == 0 && tx.w % 16 == 0 && tx.h >= 16 && tx.w >= 32) {
+        if (fuse && shape_ok && tx.h % 8 == 0 && tx.w % 16 == 0) {
             // the whole block in one kernel (hg_kernels.h: bottleneck_kernel); algorithmic work is accounted
             // exactly as for the separate convolutions (model M1), although far fewer bytes really move
             const bool ds = cin != cout;

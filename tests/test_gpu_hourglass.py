@@ -46,7 +46,7 @@ def test_fp32_every_step_matches_oracle(native_lib, cuda, oracle_net, images, tr
 
     eng = HourglassEngine(oracle_net.state_dict(), dtype="f32", device=cuda, row_bytes=row_bytes, fuse=fuse)
     steps = eng.steps()
-    assert len(steps) == (len(traced) if not fuse else len(traced) - 2 * 17 - 6 - 4 - 6), (len(steps), len(traced))
+    assert len(steps) == (len(traced) if not fuse else len(traced) - 2 * 23 - 6 - 4 - 8), (len(steps), len(traced))
     img = images.to(cuda)
     worst = (0.0, None)
     for k, (name, hwc) in enumerate(steps, start=1):
