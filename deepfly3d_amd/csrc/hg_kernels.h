@@ -20,9 +20,6 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_runtime.h>
 
-#ifndef DF3D_ABLATE
-#define DF3D_ABLATE 0
-#endif
 namespace hgk {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -736,7 +733,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
             unsigned char* const sw = sx + X_BYTES;
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
-                u32x4 v = DF3D_ABLATE == 6 ? rx[i] : preact_apply<T>(rx[i], coef);  // bn1 + ReLU, deferred past the MFMAs
+                u32x4 v = preact_apply<T>(rx[i], coef);  // bn1 + ReLU, deferred past the MFMAs
                 const unsigned keep = xok[i] ? 0xffffffffu : 0u;
                 v &= keep;
                 *reinterpret_cast<u32x4*>(sx + (srow + i * RPP) * PITCH + chunk * 16) = v;
@@ -765,7 +762,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                 const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (ct * 32 + l31) * PITCH + j * 32 + half * 16);
 #pragma unroll
                 for (int i = 0; i < RT; ++i) {
-                    if (DF3D_ABLATE == 5) continue;
                     const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * PITCH + j * 32 + half * 16);
                     mfma_chunk<T>(xf, wf, acc[i]);
                 }
@@ -787,7 +783,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                 // select by bit mask (a ?: here makes hipcc emit one branch per register)
                 const unsigned keep = 0u - ((vmh >> ro) & 1u);
                 const float v = __uint_as_float(__float_as_uint(fmaxf(acc[i][r], 0.0f)) & keep);
-                if (DF3D_ABLATE == 7 && r > 0) continue;
                 if constexpr (EB == 4)
                     *reinterpret_cast<float*>(trow + ro * C::T1_PITCH) = v;
                 else
@@ -950,7 +945,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
         for (int s = 0; s < NSTEPS; ++s) {
             const int tap = s / KSTEPS, kc = s - tap * KSTEPS;
             const unsigned char* const sw = stage;
-            if (DF3D_ABLATE != 2 && s + 1 < NSTEPS) {
+            if (s + 1 < NSTEPS) {
                 const int tap1 = (s + 1) / KSTEPS, kc1 = (s + 1) - tap1 * KSTEPS;
                 load_w(p.w2, PL, PL, (size_t)tap1 * PL * PL + (size_t)kc1 * KE);
             }
@@ -958,7 +953,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
             const int ky = tap / 3, kx = tap - 3 * ky;
             const unsigned char* const tb = t1_lds + ((py + ky) * BT_HW + (px + kx)) * C::T1_PITCH + kc * RB + half * 16;
             const unsigned char* const wrow = sw + l31 * PITCH + half * 16;
-            if (DF3D_ABLATE != 1 && DF3D_ABLATE != 4) {
 #pragma unroll
             for (int j = 0; j < RB / 32; ++j) {
                 const u32x4 tf = *reinterpret_cast<const u32x4*>(tb + j * 32);
@@ -968,10 +962,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                     mfma_chunk<T>(wf, tf, t2[m]);
                 }
             }
-            }
-            if (DF3D_ABLATE == 4) continue;   // no compute, no barriers, no LDS writes: only the global loads
             if (s + 1 < NSTEPS) __syncthreads();
-            if (DF3D_ABLATE != 2 && DF3D_ABLATE != 3 && s + 1 < NSTEPS) store_w(0, PL);
+            if (s + 1 < NSTEPS) store_w(0, PL);
             __syncthreads();
         }
     }
@@ -1066,7 +1058,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                         for (int e = 0; e < 8; ++e) af[e] = (__bf16)t2[s * (KE / 32) + mm][8 * q2 + e];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            if (DF3D_ABLATE == 9) continue;
                             const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sw + (i * 32 + l31) * PITCH + (mm * 32 + (2 * q2 + half) * 8) * 2);
                             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf, acc[i], 0, 0, 0);
                         }

@@ -113,22 +113,33 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
     conf = torch.empty((ncam, T, config["num_predict"], 1), dtype=torch.float32, device=dev)
     heat = [] if return_heatmap else None
     bs = max(1, int(batch_size))
-    for lo in range(0, len(items), bs):
-        chunk = items[lo : lo + bs]
-        frames = np.stack([_read_gray(image_path_for(folder, c, t)) for c, t in chunk])
-        host = torch.from_numpy(frames)
-        if not disable_pin_memory:
-            host = host.pin_memory()
-        fr = host.to(dev, non_blocking=not disable_pin_memory)
-        flip = torch.tensor([1 if c in flip_set else 0 for c, _ in chunk], dtype=torch.uint8)
-        x = preprocess_u8(fr.contiguous(), flip.to(dev), tuple(config["input_shape"]))
-        res = inference_views(x, engine, return_heatmap=return_heatmap)
-        cam = torch.tensor([c for c, _ in chunk], device=dev)
-        tt = torch.tensor([t for _, t in chunk], device=dev)
-        points[cam, tt] = res[0]
-        conf[cam, tt, :, 0] = res[1]
-        if return_heatmap:
-            heat.append(res[2].cpu())
+    # host front-end: JPEG decode is the reference's DataLoader-worker job; here a thread pool decodes chunk k+1
+    # (Pillow releases the GIL) while the GPU works on chunk k
+    from concurrent.futures import ThreadPoolExecutor
+
+    workers = max(1, min(16, (os.cpu_count() or 2) - 1))
+    chunks = [items[lo : lo + bs] for lo in range(0, len(items), bs)]
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        def submit(chunk):
+            return [pool.submit(_read_gray, image_path_for(folder, c, t)) for c, t in chunk]
+
+        pending = submit(chunks[0]) if chunks else []
+        for k, chunk in enumerate(chunks):
+            frames = np.stack([f.result() for f in pending])
+            pending = submit(chunks[k + 1]) if k + 1 < len(chunks) else []
+            host = torch.from_numpy(frames)
+            if not disable_pin_memory:
+                host = host.pin_memory()
+            fr = host.to(dev, non_blocking=not disable_pin_memory)
+            flip = torch.tensor([1 if c in flip_set else 0 for c, _ in chunk], dtype=torch.uint8)
+            x = preprocess_u8(fr.contiguous(), flip.to(dev), tuple(config["input_shape"]))
+            res = inference_views(x, engine, return_heatmap=return_heatmap)
+            cam = torch.tensor([c for c, _ in chunk], device=dev)
+            tt = torch.tensor([t for _, t in chunk], device=dev)
+            points[cam, tt] = res[0]
+            conf[cam, tt, :, 0] = res[1]
+            if return_heatmap:
+                heat.append(res[2].cpu())
     out = [points.cpu().numpy()]
     if return_heatmap:
         hm = torch.cat(heat).numpy()
