@@ -638,19 +638,25 @@ template <typename T, int CIN, int PL, bool DS>
 struct BtCfg {
     static constexpr int EB = Elem<T>::BYTES;
     static constexpr int CO = 2 * PL;
-    static constexpr int T1_PITCH = PL * EB + 16;                  // bytes per halo pixel in the t1 tile
+    // fp32, PL = 128: the t1 tile is built and consumed in TWO halves of 64 channels (phase 1 twice over x, phase 2
+    // accumulates tap x channel-half), which halves its LDS footprint; with a single staging buffer the workgroup
+    // then needs 73 KB instead of 153 KB and two workgroups share a CU, as in bf16.
+    static constexpr bool F32_TWO = true;
+    static constexpr int KSPLIT = (EB == 4 && PL == 128 && F32_TWO) ? 2 : 1;
+    static constexpr int T1W = PL / KSPLIT;                        // channels of t1 resident at a time
+    static constexpr int T1_PITCH = T1W * EB + 16;                 // bytes per halo pixel in the t1 tile
     static constexpr int T1_BYTES = BT_HROWS * T1_PITCH;           // 192 rows: the 12 pad rows make the phase-1 epilogue branch-free
     static constexpr int RB1 = 64;                                 // staged row bytes, phase 1
     static constexpr int RB2 = 128;                                // phases 2 and 3 (K = PL)
     // bf16: ONE staging buffer (two barriers per K-step) so that the workgroup needs < 80 KB of LDS and two
     // workgroups share a CU -- the second one's MFMAs cover the first one's barrier / LDS / memory stalls.
     // fp32: the t1 tile alone is 101 KB, one workgroup per CU, so double-buffer the staging (one barrier per step).
-    static constexpr bool SINGLE = EB == 2;
+    static constexpr bool SINGLE = EB == 2 || F32_TWO;
     // phase-2 weights straight from L2 to registers (no staging, no barriers): measured SLOWER on fp32 (98 vs 112
     // TFLOP/s: fragment-shaped 32-byte row pieces cost too much in the texture-address path) -- kept off.
     static constexpr bool DIRECT2 = false;
     static constexpr int RBD = 64;                                 // downsample steps of phase 3 (K = CIN)
-    static constexpr int STAGE1 = (BT_HROWS + PL) * (RB1 + 16);    // x rows + W1 rows
+    static constexpr int STAGE1 = (BT_HROWS + T1W) * (RB1 + 16);   // x rows + W1 rows
     static constexpr int STAGE2 = 128 * (RB2 + 16);                // W2 (PL rows) / W3 (128 rows) 
     static constexpr int STAGED = DS ? (128 + 128) * (RBD + 16) : 0;  // x centre rows + Wd rows
     static constexpr int SMAX = STAGE1 > STAGE2 ? (STAGE1 > STAGED ? STAGE1 : STAGED) : (STAGE2 > STAGED ? STAGE2 : STAGED);
@@ -662,7 +668,7 @@ struct BtCfg {
 };
 
 template <typename T, int CIN, int PL, bool DS>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kernel(BottleneckArgs p) {
+__global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32_TWO) ? 2 : 1)) void bottleneck_kernel(BottleneckArgs p) {
     using C = BtCfg<T, CIN, PL, DS>;
     constexpr int EB = C::EB;
     constexpr int CO = C::CO;
@@ -695,16 +701,58 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
         if (lane == 0) valid_lds[wave] = m;
     }
 
+    // =========================== phase 2: t2^T = W2' (*) t1 ==============================================
+    // (declarations first: phase 1 and phase 2 alternate when the t1 tile is built in channel parts)
+    constexpr int RB = C::RB2, PITCH = RB + 16, CPR = RB / 16, RPP = 256 / CPR;
+    constexpr int KE = RB / EB;
+    const int chunk = tid % CPR, srow = tid / CPR;
+    constexpr int WPASS = 128 / RPP;   // passes for 128 rows (W3 half); W2 has PL rows
+    u32x4 rw[WPASS];
+    auto load_w = [&](const void* wbase, int rows, size_t row_stride_elems, size_t elem_off) {
+#pragma unroll
+        for (int i = 0; i < WPASS; ++i)
+            if (PL == 128 || srow + i * RPP < rows)  // compile-time true for PL = 128 (all tiles have 128 rows)
+                rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wbase) +
+                                                        ((size_t)(srow + i * RPP) * row_stride_elems + elem_off + chunk * PER16) * EB);
+    };
+    auto store_w = [&](int buf, int rows) {
+        unsigned char* const sw = stage + buf * C::SMAX;
+#pragma unroll
+        for (int i = 0; i < WPASS; ++i)
+            if (PL == 128 || srow + i * RPP < rows) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
+    };
+
+    auto store_w3 = [&](int buf, int rows) {   // same, into slot `buf` of the 3-deep ring (pitch STAGE2)
+        unsigned char* const sw = stage + buf * C::STAGE2;
+#pragma unroll
+        for (int i = 0; i < WPASS; ++i)
+            if (PL == 128 || srow + i * RPP < rows) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
+    };
+
+    // this wave's 32 pixels: tile rows 2*wave, 2*wave + 1
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
+    // t2 accumulators start at b2' (channel of register r in tile m: 32m + (r&3) + 8(r>>2) + 4*half)
+    f32x16 t2[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + 32 * m + 8 * q + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
+        }
     // =========================== phase 1: t1 = relu(W1' relu(bn1 x) + b1') on the halo ===================
-    {
+    // (kh: which T1W-channel part of t1 is produced: rows kh*T1W.. of W1)
+    auto phase1 = [&](int kh) {
         constexpr int RB = C::RB1, PITCH = RB + 16, CPR = RB / 16, RPP = 256 / CPR;   // 4 chunks/row, 64 rows/pass
         constexpr int KE = RB / EB;
-        constexpr int XP = BT_HROWS / RPP, WP = PL / RPP;                              // 3 and 2 (1) passes
+        constexpr int T1W = C::T1W, NT1 = T1W / 32;
+        constexpr int XP = BT_HROWS / RPP, WP = T1W / RPP;                             // 3 and 2 (1) passes
         constexpr int X_BYTES = BT_HROWS * PITCH;
         constexpr int NSTEPS = CIN / KE;
         // wave -> (channel tile ct, row tiles rt0 .. rt0 + RT - 1)
-        constexpr int RT = 6 * NT / 4;
-        const int ct = wave % NT, rt0 = (wave / NT) * RT;
+        constexpr int RT = 6 * NT1 / 4;
+        const int ct = wave % NT1, rt0 = (wave / NT1) * RT;
         const int chunk = tid % CPR, srow = tid / CPR;
         const unsigned char* xp[XP];
         bool xok[XP];
@@ -726,7 +774,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
             for (int i = 0; i < XP; ++i) rx[i] = *reinterpret_cast<const u32x4*>(xp[i] + (size_t)c0 * EB);
 #pragma unroll
             for (int i = 0; i < WP; ++i)
-                rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.w1) + ((size_t)(srow + i * RPP) * CIN + c0) * EB);
+                rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.w1) + ((size_t)(kh * T1W + srow + i * RPP) * CIN + c0) * EB);
         };
         auto store1 = [&](int buf) {
             unsigned char* const sx = stage + buf * C::STAGE1;
@@ -743,7 +791,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
         };
         f32x16 acc[RT];
         {
-            const float bias1 = p.b1[ct * 32 + l31];   // bias folded into the accumulator start value
+            const float bias1 = p.b1[kh * T1W + ct * 32 + l31];   // bias folded into the accumulator start value
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -789,48 +837,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
                     *reinterpret_cast<unsigned short*>(trow + ro * C::T1_PITCH) = f32_to_bf16_bits(v);
             }
         }
-    }
+    };
+
+    phase1(0);
     __syncthreads();
 
-    // =========================== phase 2: t2^T = W2' (*) t1 ==============================================
-    constexpr int RB = C::RB2, PITCH = RB + 16, CPR = RB / 16, RPP = 256 / CPR;
-    constexpr int KE = RB / EB;
-    const int chunk = tid % CPR, srow = tid / CPR;
-    constexpr int WPASS = 128 / RPP;   // passes for 128 rows (W3 half); W2 has PL rows
-    u32x4 rw[WPASS];
-    auto load_w = [&](const void* wbase, int rows, size_t row_stride_elems, size_t elem_off) {
-#pragma unroll
-        for (int i = 0; i < WPASS; ++i)
-            if (PL == 128 || srow + i * RPP < rows)  // compile-time true for PL = 128 (all tiles have 128 rows)
-                rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wbase) +
-                                                        ((size_t)(srow + i * RPP) * row_stride_elems + elem_off + chunk * PER16) * EB);
-    };
-    auto store_w = [&](int buf, int rows) {
-        unsigned char* const sw = stage + buf * C::SMAX;
-#pragma unroll
-        for (int i = 0; i < WPASS; ++i)
-            if (PL == 128 || srow + i * RPP < rows) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
-    };
-
-    auto store_w3 = [&](int buf, int rows) {   // same, into slot `buf` of the 3-deep ring (pitch STAGE2)
-        unsigned char* const sw = stage + buf * C::STAGE2;
-#pragma unroll
-        for (int i = 0; i < WPASS; ++i)
-            if (PL == 128 || srow + i * RPP < rows) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
-    };
-
-    // this wave's 32 pixels: tile rows 2*wave, 2*wave + 1
-    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
-    // t2 accumulators start at b2' (channel of register r in tile m: 32m + (r&3) + 8(r>>2) + 4*half)
-    f32x16 t2[NT];
-#pragma unroll
-    for (int m = 0; m < NT; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + 32 * m + 8 * q + 4 * half);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
-        }
     if constexpr (C::DIRECT2) {
         // fp32: the W2 fragments go global/L2 -> registers directly (three 8-channel groups in flight), no LDS
         // staging and NO barrier in the whole phase: an fp32 MFMA group lasts 1024 cycles, long enough to hide the
@@ -936,35 +947,44 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
             __syncthreads();
         }
     } else {
-        // bf16 (two workgroups per CU): one staging buffer, two barriers per K-step
-        constexpr int KSTEPS = PL / KE;          // K-steps per tap
-        constexpr int NSTEPS = 9 * KSTEPS;
-        load_w(p.w2, PL, PL, 0);
-        store_w(0, PL);
-        __syncthreads();
-        for (int s = 0; s < NSTEPS; ++s) {
-            const int tap = s / KSTEPS, kc = s - tap * KSTEPS;
-            const unsigned char* const sw = stage;
-            if (s + 1 < NSTEPS) {
-                const int tap1 = (s + 1) / KSTEPS, kc1 = (s + 1) - tap1 * KSTEPS;
-                load_w(p.w2, PL, PL, (size_t)tap1 * PL * PL + (size_t)kc1 * KE);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            const unsigned char* const tb = t1_lds + ((py + ky) * BT_HW + (px + kx)) * C::T1_PITCH + kc * RB + half * 16;
-            const unsigned char* const wrow = sw + l31 * PITCH + half * 16;
-#pragma unroll
-            for (int j = 0; j < RB / 32; ++j) {
-                const u32x4 tf = *reinterpret_cast<const u32x4*>(tb + j * 32);
-#pragma unroll
-                for (int m = 0; m < NT; ++m) {
-                    const u32x4 wf = *reinterpret_cast<const u32x4*>(wrow + m * 32 * PITCH + j * 32);
-                    mfma_chunk<T>(wf, tf, t2[m]);
-                }
-            }
-            if (s + 1 < NSTEPS) __syncthreads();
-            if (s + 1 < NSTEPS) store_w(0, PL);
+        // one staging buffer, two barriers per K-step (two workgroups per CU); kh selects the resident t1 channel part
+        auto phase2 = [&](int kh) {
+            constexpr int T1W = C::T1W;
+            constexpr int KSTEPS = T1W / KE;         // K-steps per tap
+            constexpr int NSTEPS = 9 * KSTEPS;
+            load_w(p.w2, PL, PL, (size_t)kh * T1W);
+            store_w(0, PL);
             __syncthreads();
+            for (int s = 0; s < NSTEPS; ++s) {
+                const int tap = s / KSTEPS, kc = s - tap * KSTEPS;
+                const unsigned char* const sw = stage;
+                if (s + 1 < NSTEPS) {
+                    const int tap1 = (s + 1) / KSTEPS, kc1 = (s + 1) - tap1 * KSTEPS;
+                    load_w(p.w2, PL, PL, (size_t)tap1 * PL * PL + (size_t)kh * T1W + (size_t)kc1 * KE);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const unsigned char* const tb = t1_lds + ((py + ky) * BT_HW + (px + kx)) * C::T1_PITCH + kc * RB + half * 16;
+                const unsigned char* const wrow = sw + l31 * PITCH + half * 16;
+#pragma unroll
+                for (int j = 0; j < RB / 32; ++j) {
+                    const u32x4 tf = *reinterpret_cast<const u32x4*>(tb + j * 32);
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) {
+                        const u32x4 wf = *reinterpret_cast<const u32x4*>(wrow + m * 32 * PITCH + j * 32);
+                        mfma_chunk<T>(wf, tf, t2[m]);
+                    }
+                }
+                if (s + 1 < NSTEPS) __syncthreads();
+                if (s + 1 < NSTEPS) store_w(0, PL);
+                __syncthreads();
+            }
+        };
+#pragma unroll 1
+        for (int kh = 0; kh < C::KSPLIT; ++kh) {
+            if (kh > 0) phase1(kh);
+            if (kh > 0) __syncthreads();
+            phase2(kh);
         }
     }
 
@@ -989,13 +1009,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
         // identity skip: the residual values are requested NOW (their latency hides behind the K loop).
         // fp32: one value per accumulator register; bf16: lane pairs own two adjacent channels of one pixel
         // (even lanes pixel-register 2q, odd lanes 2q + 1), so loads and stores are 4 bytes wide.
-        constexpr int NRES = DS ? 1 : (EB == 4 ? 64 : 32);
+        constexpr bool PREFETCH_RES32 = EB == 4 && !C::F32_TWO;   // fp32 at two workgroups per CU: no registers to spare
+        constexpr int NRES = DS ? 1 : (EB == 4 ? (PREFETCH_RES32 ? 64 : 1) : 32);
         unsigned xres[NRES];
         if constexpr (!DS) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n = nh * 128 + i * 32 + l31;
-                if constexpr (EB == 4) {
+                if constexpr (PREFETCH_RES32) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -1120,11 +1141,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void bottleneck_kern
         for (int i = 0; i < 4; ++i) {
             const int n = nh * 128 + i * 32 + l31;
             if constexpr (EB == 4) {
+                if constexpr (!DS && !PREFETCH_RES32) {   // all 16 residual loads of the tile before the first store
+                    float xr[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        xr[r] = reinterpret_cast<const float*>(xin)[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] += xr[r];
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
                     const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n;
-                    acc[i][r] += (DS ? 0.0f : __uint_as_float(xres[DS ? 0 : i * 16 + r]));
+                    if constexpr (!DS && PREFETCH_RES32) acc[i][r] += __uint_as_float(xres[DS || !PREFETCH_RES32 ? 0 : i * 16 + r]);
                     reinterpret_cast<float*>(outp)[po] = acc[i][r];
                 }
                 if (p.pool) {
