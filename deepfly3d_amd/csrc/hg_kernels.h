@@ -731,16 +731,6 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
 
     // this wave's 32 pixels: tile rows 2*wave, 2*wave + 1
     const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
-    // t2 accumulators start at b2' (channel of register r in tile m: 32m + (r&3) + 8(r>>2) + 4*half)
-    f32x16 t2[NT];
-#pragma unroll
-    for (int m = 0; m < NT; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + 32 * m + 8 * q + 4 * half);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
-        }
     // =========================== phase 1: t1 = relu(W1' relu(bn1 x) + b1') on the halo ===================
     // (kh: which T1W-channel part of t1 is produced: rows kh*T1W.. of W1)
     auto phase1 = [&](int kh) {
@@ -841,6 +831,17 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
 
     phase1(0);
     __syncthreads();
+
+    // t2 accumulators start at b2' (channel of register r in tile m: 32m + (r&3) + 8(r>>2) + 4*half)
+    f32x16 t2[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + 32 * m + 8 * q + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
+        }
 
     if constexpr (C::DIRECT2) {
         // fp32: the W2 fragments go global/L2 -> registers directly (three 8-channel groups in flight), no LDS
