@@ -4,7 +4,7 @@ There is NO CPU fallback: if the library is missing or a call fails, this module
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DF3D_LIB") or os.path.join(_HERE, "libdf3d_hip.so")  # DF3D_LIB: developer override (kernel A/B builds)
@@ -59,6 +59,11 @@ PROTOTYPES = {
     "df3d_relayout_19_to_38": (c_int, [c_void_p, POINTER(c_int), c_int, c_void_p, c_void_p]),
     "df3d_triangulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_triangulate_scaled": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "df3d_column_median": (c_int, [c_void_p, c_int, c_longlong, c_longlong, c_void_p, c_void_p]),
+    "df3d_procrustes_work_doubles": (c_longlong, [c_longlong]),
+    "df3d_procrustes": (c_int, [c_void_p, c_longlong, POINTER(c_double), POINTER(c_double), c_void_p, c_void_p, c_longlong, c_void_p]),
+    "df3d_pose_normalize": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_longlong, c_void_p]),
+    "df3d_oneeuro_filter": (c_int, [c_void_p, c_longlong, c_int, c_double, c_double, c_double, c_double, c_longlong, c_double, c_void_p, c_void_p]),
     "df3d_ba_eval": (c_int, [POINTER(BAProblem), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_ba_colsq": (c_int, [POINTER(BAProblem), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_ba_matvec": (c_int, [POINTER(BAProblem), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -7,7 +7,8 @@ MI355X back-end.  Same constructor, methods, attributes, exceptions and result-p
     core.calibrate_calc(min_img_id, max_img_id)                        # reference :229-250
     core.save()
 
-GUI-only methods (manual corrections, error navigation) are out of scope.
+GUI-only methods (interactive correction, error navigation, plotting) are out of scope (SURVEY.md sec. 2 row 1);
+the correction store and `corrected_points2d*` are kept so that stored corrections reach the triangulation.
 """
 import glob
 import os
@@ -25,7 +26,7 @@ from .config import config, load_calibration
 from .db import PoseDB
 from .inference import inference_folder
 from .os_util import get_max_img_id, parse_vid_name
-from .procrustes import procrustes_separate
+from .procrustes import procrustes_separate, video_pose
 
 _KNOWN_ORDERINGS = [
     (r"/CLC/", [0, 6, 5, 4, 3, 2, 1]),
@@ -165,7 +166,13 @@ class Core:
         print(f"Reprojection error is {self.camNet.reprojection_error()}")
 
     def get_points3d(self):
-        raise NotImplementedError("the smoothed/rotated video pose (reference core.py:332-343) is out of scope; use the pkl's points3d")
+        """Pose for the 3-D video: array[image_id][joint_id] = (x, y, z) after Procrustes, median-centring + axis swap
+        and the One-Euro temporal filter (reference :332-343), computed on the device."""
+        return video_pose(np.copy(self.camNet.points3d), device=self.device)
+
+    def save_corrections(self):
+        """Write the manual corrections to the output folder (reference :345-347)."""
+        self.db.dump()
 
     def save(self):
         """Write df3d_result_*.pkl with the reference's schema and key order (reference :349-369)."""
@@ -174,7 +181,7 @@ class Core:
             self.camNet.triangulate()
             pts3d = self.camNet.points3d
             result["points3d_wo_procrustes"] = pts3d
-            result["points3d"] = procrustes_separate(pts3d)
+            result["points3d"] = procrustes_separate(pts3d, device=self.device)
             result = {**self.camNet.summarize(), **result}
         else:
             logger.debug("Triangulation skipped.")
@@ -185,6 +192,24 @@ class Core:
         print(f"Saved results at: {self.save_path}")
 
     # -- helpers --------------------------------------------------------------------------------------
+    def corrected_points2d(self, cam_id, img_id):
+        """Estimated or manually corrected 2-D joints of one image (reference :374-385)."""
+        points2d = self.camNet.cam_list[cam_id][img_id].copy()
+        manual = self.db.manual_corrections()
+        if img_id in manual.get(cam_id, {}):
+            points2d[:] = manual[cam_id][img_id]
+        return points2d
+
+    def corrected_points2d_matrix(self):
+        """results[cam_id][img_id][joint_id] = (row, col) with the manual corrections applied (reference :387-401)."""
+        manual = self.db.manual_corrections()
+        pts2d = self.camNet.points2d
+        for cam_id in range(config["num_cameras"]):
+            for img_id in range(self.num_images):
+                if img_id in manual.get(cam_id, {}):
+                    pts2d[cam_id, img_id, :] = manual[cam_id][img_id]
+        return pts2d
+
     def setup_camera_ordering(self, camera_ordering) -> np.ndarray:
         if camera_ordering is None:
             camera_ordering = find_default_camera_ordering(self.input_folder)

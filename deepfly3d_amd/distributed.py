@@ -77,14 +77,16 @@ def gather_results(points2d, conf, points3d, num_frames, rank, world_size, align
     return p2, cf, p3
 
 
-def assemble_result(points2d, conf, points3d_wo, cameras, camera_ordering):
+def assemble_result(points2d, conf, points3d_wo, cameras, camera_ordering, procrustes=None):
     """Rank-0 epilogue: Procrustes on the full sequence + the reference's result dictionary
-    (schema and key order of reference df3d/core.py:349-369)."""
-    from .procrustes import procrustes_separate
+    (schema and key order of reference df3d/core.py:349-369).  `procrustes` defaults to the
+    device implementation (deepfly3d_amd.procrustes.procrustes_separate: needs the GPU, no CPU fallback)."""
+    if procrustes is None:
+        from .procrustes import procrustes_separate as procrustes
 
     p3 = np.asarray(points3d_wo, np.float64)
     out = {c: {"R": cameras["R"][c], "tvec": cameras["tvec"][c], "distort": cameras["distort"][c], "intr": cameras["intr"][c]} for c in range(7)}
-    out["points3d"] = procrustes_separate(p3)
+    out["points3d"] = procrustes(p3)
     out["points2d"] = np.asarray(points2d, np.float64)
     out["points3d_wo_procrustes"] = p3
     out["camera_ordering"] = np.asarray(camera_ordering)

@@ -64,3 +64,66 @@ def triangulate(P, points2d_px):
         "df3d_triangulate",
     )
     return X
+
+
+def column_median(cols):
+    """cols [ncols, n] float64 cuda -> [ncols] exact medians (numpy.median semantics)."""
+    lib = _native.load()
+    _need(cols, torch.float64, "cols")
+    ncols, n = cols.shape
+    out = torch.empty((ncols,), dtype=torch.float64, device=cols.device)
+    _native.check(lib.df3d_column_median(cols.data_ptr(), ncols, n, n, out.data_ptr(), _stream(cols)), "df3d_column_median")
+    return out
+
+
+def procrustes(points3d, tmpl_seg_med, tmpl_fit_med):
+    """points3d [T, 38, 3] float64 cuda -> registered copy (a9).  tmpl_* are the template's host constants
+    (deepfly3d_amd.procrustes.template_constants)."""
+    lib = _native.load()
+    _need(points3d, torch.float64, "points3d")
+    if points3d.dim() != 3 or tuple(points3d.shape[1:]) != (38, 3):
+        raise ValueError("points3d must be [T, 38, 3]")
+    T = points3d.shape[0]
+    seg = np.ascontiguousarray(tmpl_seg_med, dtype=np.float64)
+    fit = np.ascontiguousarray(tmpl_fit_med, dtype=np.float64)
+    if seg.shape != (2, 12) or fit.shape != (2, 6, 3):
+        raise ValueError("template constants must be [2, 12] and [2, 6, 3]")
+    need = lib.df3d_procrustes_work_doubles(T)
+    work = torch.empty((need,), dtype=torch.float64, device=points3d.device)
+    out = torch.empty_like(points3d)
+    dp = ctypes.POINTER(ctypes.c_double)
+    _native.check(
+        lib.df3d_procrustes(points3d.data_ptr(), T, seg.ctypes.data_as(dp), fit.ctypes.data_as(dp), out.data_ptr(), work.data_ptr(), need,
+                            _stream(points3d)),
+        "df3d_procrustes",
+    )
+    return out
+
+
+def pose_normalize(points3d, rotate=True):
+    """[T, J, 3] float64 cuda -> minus the per-axis median of all points, optionally (x, y, z) -> (x, -z, -y)."""
+    lib = _native.load()
+    _need(points3d, torch.float64, "points3d")
+    T, J, three = points3d.shape
+    if three != 3:
+        raise ValueError("points3d must be [T, J, 3]")
+    work = torch.empty((3,), dtype=torch.float64, device=points3d.device)
+    out = torch.empty_like(points3d)
+    _native.check(lib.df3d_pose_normalize(points3d.data_ptr(), T, J, 1 if rotate else 0, out.data_ptr(), work.data_ptr(), 3, _stream(points3d)),
+                  "df3d_pose_normalize")
+    return out
+
+
+def oneeuro_filter(series, freq=100.0, mincutoff=0.1, beta=2.0, dcutoff=1.0, first_stamp=1, stamp_step=0.1):
+    """series [T, ...] float64 cuda: every trailing element is one channel filtered along T (reference
+    df3d/signal_util.py:69-100 defaults)."""
+    lib = _native.load()
+    _need(series, torch.float64, "series")
+    T = series.shape[0]
+    nch = int(series[0].numel()) if T else 1
+    out = torch.empty_like(series)
+    _native.check(
+        lib.df3d_oneeuro_filter(series.data_ptr(), T, nch, freq, mincutoff, beta, dcutoff, first_stamp, stamp_step, out.data_ptr(), _stream(series)),
+        "df3d_oneeuro_filter",
+    )
+    return out

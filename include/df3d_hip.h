@@ -82,6 +82,36 @@ int df3d_triangulate_scaled(const double* P, const double* pts_norm_dev, double 
                             int T, int J, double* X_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a9  per-side Procrustes registration to the template pose + the `Core.get_points3d` chain.
+ *     Replaces reference df3d/procrustes.py:51-151 (`procrustes_seperate`, call site df3d/core.py:358,340),
+ *     df3d/plot_util.py:85-91 (`normalize_pose_3d`, call site core.py:341) and df3d/signal_util.py:69-100
+ *     (`filter_batch`, call site core.py:342).  All float64, SEQUENCE-GLOBAL (medians over every frame): call
+ *     once on the gathered sequence.  Several small launches on `stream`; `work` is caller-owned scratch.
+ *
+ * df3d_column_median : cols_dev [ncols] columns of n doubles, column c at cols_dev + c*col_stride;
+ *                      out_dev[c] = median (exact order statistic; mean of the two middle values for even n).
+ * df3d_procrustes    : pts_dev / out_dev [T, 38, 3]; tmpl_seg_med HOST [2][12] = per side, median over the
+ *                      template's frames of the 12 leg-segment lengths; tmpl_fit_med HOST [2][6][3] = median of
+ *                      the template's 6 fit joints (side joints 0,1,5,6,10,11).  work_dev >=
+ *                      df3d_procrustes_work_doubles(T) doubles.
+ * df3d_pose_normalize: out = in - median over all T*njoints points (per axis); rotate != 0 additionally maps
+ *                      (x, y, z) -> (x, -z, -y).  work_dev >= 3 doubles.  in == out allowed.
+ * df3d_oneeuro_filter: in/out [T, nch]; one independent One-Euro filter per channel; sample i carries the time
+ *                      stamp (i + first_stamp) * stamp_step and, like the reference, the filter re-derives its
+ *                      sampling frequency from consecutive stamps.  The reference's `filter_batch` is
+ *                      (freq 100, mincutoff 0.1, beta 2.0, dcutoff 1.0, first_stamp 1, stamp_step 0.1).
+ *                      Bit-identical to the reference's float arithmetic.
+ * ---------------------------------------------------------------------------------------------- */
+int df3d_column_median(const double* cols_dev, int ncols, long long n, long long col_stride, double* out_dev, void* stream);
+long long df3d_procrustes_work_doubles(long long T);
+int df3d_procrustes(const double* pts_dev, long long T, const double* tmpl_seg_med, const double* tmpl_fit_med,
+                    double* out_dev, double* work_dev, long long work_doubles, void* stream);
+int df3d_pose_normalize(const double* in_dev, long long T, int njoints, int rotate, double* out_dev, double* work_dev,
+                        long long work_doubles, void* stream);
+int df3d_oneeuro_filter(const double* in_dev, long long T, int nch, double freq, double mincutoff, double beta,
+                        double dcutoff, long long first_stamp, double stamp_step, double* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a7  bundle adjustment building blocks.   Replaces the arithmetic under pyba
  *     CameraNetwork.bundle_adjust(update_intrinsic=False, update_distort=False)
  *     (call site reference df3d/core.py:249).  Unknowns x = [ncam x (rvec, tvec)] ++ [npts x XYZ];

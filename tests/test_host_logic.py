@@ -1,5 +1,5 @@
 """CPU tests of the host-side logic: parameter packing / BN folding, frame sharding, folder discovery, CLI flags,
-Procrustes (product copy) against the reference-executed vectors, result schema."""
+the correction store, result schema."""
 import ctypes
 import os
 import pickle
@@ -9,15 +9,47 @@ import pytest
 import torch
 
 
-def test_procrustes_product_matches_reference_vectors(golden_dir):
-    from deepfly3d_amd.procrustes import procrustes_separate
+def test_procrustes_template_constants(golden_dir):
+    """The only host arithmetic of a9: the constant template reduced to 60 numbers (the transform itself is a
+    device computation: tests/test_gpu_pose3d.py)."""
+    from deepfly3d_amd.procrustes import template_constants
 
-    for name in ("procrustes_golden", "procrustes_jitter"):
-        d = np.load(f"{golden_dir}/{name}.npz")
-        inp = d["inp"].copy()
-        out = procrustes_separate(inp)
-        assert np.abs(out - d["out"]).max() < 1e-12
-        assert np.array_equal(inp, d["inp"])  # unlike the reference's in-place centring, the input is left intact
+    tmpl = np.load(f"{golden_dir}/template.npz")["points3d"]
+    seg, fit = template_constants()
+    assert seg.shape == (2, 12) and fit.shape == (2, 6, 3)
+    legs = tmpl[:, 19:34].reshape(15, 3, 5, 3)
+    assert np.array_equal(seg[1], np.median(np.linalg.norm(np.diff(legs, axis=2), axis=-1).reshape(15, 12), axis=0))
+    assert np.array_equal(fit[0], np.median(tmpl[:, [0, 1, 5, 6, 10, 11]], axis=0))
+    seg2, _ = template_constants(tmpl * 2.0)
+    assert np.allclose(seg2, 2.0 * seg)
+
+
+def test_pose_db_round_trip(tmp_path):
+    """Correction store (reference df3d/db.py): file name, write / read / remove, pixel-scaled deep copy."""
+    from deepfly3d_amd.config import config
+    from deepfly3d_amd.db import PoseDB
+
+    folder = str(tmp_path)
+    db = PoseDB(folder)
+    assert os.path.basename(db.db_path) == "pose_corr_{}.pkl".format(folder.replace("/", "-")) and os.path.exists(db.db_path)
+    assert db.read(0, 3) is None and db.read_modified_joints(0, 3) == [] and not db.has_key(0, 3)
+    pts = np.full((38, 2), 0.5)
+    db.write(pts, 2, 7, True, [4, 5])
+    db.dump()
+    again = PoseDB(folder)
+    assert again.has_key(2, 7) and again.read_modified_joints(2, 7) == [4, 5] and np.array_equal(again.read(2, 7), pts)
+    old_shape = config.get("image_shape")
+    config["image_shape"] = [960, 480]
+    try:
+        mc = again.manual_corrections()
+        assert np.array_equal(mc[2][7], pts * [960, 480]) and np.array_equal(again.read(2, 7), pts)
+    finally:
+        if old_shape is None:
+            config.pop("image_shape")
+        else:
+            config["image_shape"] = old_shape
+    again.remove_corrections(2, 7)
+    assert not again.has_key(2, 7) and 7 not in again.db["train"][2] and 7 not in again.db["modified"][2]
 
 
 def test_package_data_matches_reference_fixtures(golden_dir):
@@ -196,7 +228,11 @@ def test_assemble_result_schema(golden_dir):
 
     g3 = np.load(f"{golden_dir}/golden_3d.npz")
     cams = {k: g3[k] for k in ("R", "tvec", "intr", "distort")}
-    out = assemble_result(g3["points2d"], g3["heatmap_confidence"][..., 0], g3["points3d_wo_procrustes"], cams, g3["camera_ordering"])
+    from oracle import geometry as og
+
+    tmpl = np.load(f"{golden_dir}/template.npz")["points3d"]
+    out = assemble_result(g3["points2d"], g3["heatmap_confidence"][..., 0], g3["points3d_wo_procrustes"], cams, g3["camera_ordering"],
+                          procrustes=lambda p: og.procrustes_separate(p, tmpl))  # device Procrustes: tests/test_gpu_pose3d.py
     assert [str(k) for k in out.keys()] == list(g3["key_order"])
     assert np.abs(out["points3d"] - g3["points3d"]).max() < 1e-12
     assert out["heatmap_confidence"].shape == (7, 15, 19, 1) and out["points2d"].dtype == np.float64

@@ -114,3 +114,19 @@ def test_argmax_oracle_semantics():
     assert pts.dtype == np.float32 and conf.dtype == np.float32
     assert pts[0, 0].tolist() == [3 / 8, 5 / 16] and pts[0, 1].tolist() == [1 / 8, 2 / 16]
     assert pts[1, 2].tolist() == [0.0, 0.0] and conf[0, 0] == 2.0
+
+
+def test_pose_chain_pinned_by_reference_execution(golden_dir):
+    """normalize_pose_3d / filter_batch restatements are bit-identical to the reference's own functions."""
+    from oracle import postprocess as pp
+
+    tmpl = np.load(f"{golden_dir}/template.npz")["points3d"]
+    for name in ("pose_chain_golden", "pose_chain_jitter"):
+        d = np.load(f"{golden_dir}/{name}.npz")
+        p, n, f = pp.pose_chain(d["inp"], tmpl)
+        assert np.abs(p - d["procrustes"]).max() < 1e-12
+        assert np.array_equal(pp.normalize_pose_3d(d["procrustes"]), d["normalized"])
+        assert np.array_equal(pp.oneeuro_filter(d["normalized"]), d["filtered"])
+        assert np.abs(f - d["filtered"]).max() < 1e-12
+    d = np.load(f"{golden_dir}/oneeuro_random.npz")
+    assert np.array_equal(pp.oneeuro_filter(d["inp"][:120]), d["out"][:120])
