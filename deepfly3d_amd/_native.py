@@ -55,6 +55,8 @@ PROTOTYPES = {
     "df3d_device_count": (c_int, []),
     "df3d_device_name": (c_int, [c_int, c_char_p, c_int]),
     "df3d_preprocess_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
+    "df3d_jpeg_work_bytes": (c_size_t, [c_int, c_int, c_int, c_size_t]),
+    "df3d_jpeg_decode_luma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "df3d_heatmap_argmax": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "df3d_relayout_19_to_38": (c_int, [c_void_p, POINTER(c_int), c_int, c_void_p, c_void_p]),
     "df3d_triangulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -1,0 +1,631 @@
+// Input front-end, SURVEY.md 8(f) row 1: baseline JPEG -> luma plane on the device, so that the host only reads
+// file bytes (the reference decodes with libjpeg inside df2d's DataLoader workers; frames are written by ffmpeg,
+// reference df3d/core.py:446-459).  ITU-T T.81 baseline sequential DCT, Huffman, 8 bit; libjpeg's "islow"
+// inverse DCT bit for bit (oracle/jpeg_oracle.c is the CPU restatement, itself pinned against libjpeg-turbo).
+//
+//   jpeg_parse_kernel    one workgroup per file: marker walk out of an LDS window, tables into a per-file
+//                        descriptor, then the entropy-coded segment is un-stuffed (FF00 -> FF) cooperatively
+//                        into a clean byte stream (tile-wise flag / scan / compact)
+//   jpeg_huffman_kernel  one 64-lane wave per file, wave-uniform control flow: the bit buffer lives in scalar
+//                        registers, the next 256 stream bytes in one VGPR (v_readlane), 9-bit code look-up
+//                        tables in LDS; lane i keeps coefficient i of the current block, so a decoded value is a
+//                        compare + select and a finished luma block leaves as one coalesced 128-byte store
+//   jpeg_idct_kernel     one thread per 8x8 luma block: de-quantise, 2 x 8 one-dimensional LL&M passes, clamp
+//
+// Only the luma component is reconstructed (the rig's cameras are monochrome; chroma blocks are entropy-decoded
+// and dropped).  Integer work: results are bit-exact.  Per file the Huffman stage is sequential (latency-bound,
+// ~140 k symbols); throughput comes from one wave per file across the 1 024 SIMDs.
+#include <cstdint>
+
+#include "common.h"
+
+namespace jpg {
+
+enum { ST_OK = 0, ST_TRUNCATED = 1, ST_NOT_JPEG = 2, ST_UNSUPPORTED = 3, ST_CORRUPT = 4, ST_SHAPE = 5 };
+
+struct Meta {
+    int status;
+    int width, height, ncomp;
+    int hmax, vmax;
+    int restart_interval;
+    int comp_h[4], comp_v[4], comp_tq[4], comp_td[4], comp_ta[4];
+    unsigned scan_pos;   // byte offset of the entropy-coded data inside the file
+    unsigned clean_len;  // bytes of the un-stuffed stream
+    int mcus_x, mcus_y;
+    int ybw, ybh;  // luma block grid (MCU padded)
+    unsigned short q[4][64];  // natural order
+    unsigned char qpresent[4];
+    unsigned char dht_present[8];  // [tc*4 + th]
+    unsigned char dht_counts[8][16];
+    unsigned char dht_vals[8][256];
+};
+
+__constant__ unsigned char ZIGZAG[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                         41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                         30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel 1: header parse + un-stuffing.  256 threads per file; every thread runs the (uniform) marker walk on an
+// LDS window of the file, thread 0 writes the descriptor.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int WIN = 4096;
+constexpr int PT = 256;
+
+struct Window {
+    const unsigned char* g;
+    unsigned n, base;
+    unsigned char* lds;
+    __device__ void stage(unsigned pos) {
+        __syncthreads();
+        base = pos & ~15u;
+        for (unsigned i = threadIdx.x * 16; i < WIN; i += PT * 16) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (base + i < n) v = *reinterpret_cast<const uint4*>(g + base + i);  // files are padded to 16 bytes
+            *reinterpret_cast<uint4*>(lds + i) = v;
+        }
+        __syncthreads();
+    }
+    __device__ unsigned get(unsigned pos) {  // uniform
+        if (pos - base >= (unsigned)WIN) stage(pos);
+        return lds[pos - base];
+    }
+    __device__ unsigned get16(unsigned pos) { return (get(pos) << 8) | get(pos + 1); }
+};
+
+__global__ __launch_bounds__(PT) void jpeg_parse_kernel(const unsigned char* __restrict__ files, const unsigned* __restrict__ offsets,
+                                                        const unsigned* __restrict__ sizes, int expect_w, int expect_h,
+                                                        Meta* __restrict__ metas,
+                                                        unsigned char* __restrict__ clean) {
+    __shared__ __attribute__((aligned(16))) unsigned char win_lds[WIN];
+    __shared__ unsigned s_scan[PT];
+    __shared__ unsigned s_total;
+    const int img = blockIdx.x;
+    const unsigned off = offsets[img], n = sizes[img];
+    const unsigned char* d = files + off;
+    Meta* M = metas + img;
+    const int tid = threadIdx.x;
+    Window w{d, n, 0xffffffffu, win_lds};
+    w.stage(0);
+
+    // descriptor defaults (thread 0 owns all scalar fields)
+    if (tid == 0) {
+        M->status = ST_OK;
+        M->restart_interval = 0;
+        M->clean_len = 0;
+        M->hmax = M->vmax = 1;
+        for (int i = 0; i < 4; ++i) M->qpresent[i] = 0;
+        for (int i = 0; i < 8; ++i) M->dht_present[i] = 0;
+    }
+    int status = ST_OK;
+    unsigned i = 2, scan_pos = 0;
+    int width = 0, height = 0, ncomp = 0, hmax = 1, vmax = 1, have_sof = 0;
+    int ch[4] = {1, 1, 1, 1}, cv[4] = {1, 1, 1, 1}, cid[4] = {0, 0, 0, 0};
+    if (n < 4 || w.get(0) != 0xFF || w.get(1) != 0xD8) status = ST_NOT_JPEG;
+    while (status == ST_OK && scan_pos == 0) {
+        if (i + 4 > n) { status = ST_TRUNCATED; break; }
+        if (w.get(i) != 0xFF) { status = ST_CORRUPT; break; }
+        while (i < n && w.get(i) == 0xFF) ++i;
+        if (i >= n) { status = ST_TRUNCATED; break; }
+        const unsigned m = w.get(i++);
+        if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (m == 0xD9) { status = ST_CORRUPT; break; }
+        if (i + 2 > n) { status = ST_TRUNCATED; break; }
+        const unsigned L = w.get16(i);
+        if (L < 2 || i + L > n) { status = ST_TRUNCATED; break; }
+        const unsigned s = i + 2, sl = L - 2;
+        if (m == 0xDB) {
+            unsigned j = 0;
+            while (j < sl && status == ST_OK) {
+                const unsigned b = w.get(s + j);
+                const unsigned pq = b >> 4, tq = b & 15;
+                if (tq > 3 || pq > 1) { status = ST_CORRUPT; break; }
+                ++j;
+                if (j + (pq ? 128 : 64) > sl) { status = ST_CORRUPT; break; }
+                for (int k = 0; k < 64; ++k) {
+                    const unsigned v = pq ? w.get16(s + j) : w.get(s + j);
+                    j += pq ? 2 : 1;
+                    if (tid == 0) M->q[tq][ZIGZAG[k]] = (unsigned short)v;
+                }
+                if (tid == 0) M->qpresent[tq] = 1;
+            }
+        } else if (m == 0xC4) {
+            unsigned j = 0;
+            while (j < sl && status == ST_OK) {
+                if (j + 17 > sl) { status = ST_CORRUPT; break; }
+                const unsigned b = w.get(s + j);
+                const unsigned tc = b >> 4, th = b & 15;
+                if (tc > 1 || th > 3) { status = ST_CORRUPT; break; }
+                unsigned nv = 0;
+                for (int k = 0; k < 16; ++k) {
+                    const unsigned c = w.get(s + j + 1 + k);
+                    nv += c;
+                    if (tid == 0) M->dht_counts[tc * 4 + th][k] = (unsigned char)c;
+                }
+                if (nv > 256 || j + 17 + nv > sl) { status = ST_CORRUPT; break; }
+                for (unsigned k = 0; k < nv; ++k) {
+                    const unsigned v = w.get(s + j + 17 + k);
+                    if (tid == 0) M->dht_vals[tc * 4 + th][k] = (unsigned char)v;
+                }
+                if (tid == 0) M->dht_present[tc * 4 + th] = 1;
+                j += 17 + nv;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (sl < 6) { status = ST_CORRUPT; break; }
+            if (w.get(s) != 8) { status = ST_UNSUPPORTED; break; }
+            height = (int)w.get16(s + 1);
+            width = (int)w.get16(s + 3);
+            ncomp = (int)w.get(s + 5);
+            if (ncomp < 1 || ncomp > 4) { status = ST_UNSUPPORTED; break; }
+            if (sl < 6 + 3u * ncomp || width == 0 || height == 0) { status = ST_CORRUPT; break; }
+            for (int c = 0; c < ncomp; ++c) {
+                cid[c] = (int)w.get(s + 6 + 3 * c);
+                const unsigned hv = w.get(s + 7 + 3 * c);
+                const unsigned tq = w.get(s + 8 + 3 * c);
+                ch[c] = hv >> 4;
+                cv[c] = hv & 15;
+                if (ch[c] < 1 || ch[c] > 4 || cv[c] < 1 || cv[c] > 4 || tq > 3) status = ST_CORRUPT;
+                hmax = max(hmax, ch[c]);
+                vmax = max(vmax, cv[c]);
+                if (tid == 0) M->comp_tq[c] = (int)tq;
+            }
+            have_sof = 1;
+        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            status = ST_UNSUPPORTED;
+        } else if (m == 0xDD) {
+            if (sl < 2) { status = ST_CORRUPT; break; }
+            const unsigned ri = w.get16(s);
+            if (tid == 0) M->restart_interval = (int)ri;
+        } else if (m == 0xDA) {
+            if (!have_sof || sl < 1) { status = ST_CORRUPT; break; }
+            const int ns = (int)w.get(s);
+            if (ns != ncomp) { status = ST_UNSUPPORTED; break; }
+            if (sl < 1 + 2u * ns + 3) { status = ST_CORRUPT; break; }
+            for (int k = 0; k < ns; ++k) {
+                const int id = (int)w.get(s + 1 + 2 * k);
+                const unsigned t = w.get(s + 2 + 2 * k);
+                if (id != cid[k]) status = ST_UNSUPPORTED;
+                if ((t >> 4) > 3 || (t & 15) > 3) status = ST_CORRUPT;
+                if (tid == 0) {
+                    M->comp_td[k] = (int)(t >> 4);
+                    M->comp_ta[k] = (int)(t & 15);
+                }
+            }
+            if (status == ST_OK) scan_pos = i + L;
+            break;
+        }
+        i += L;
+    }
+    if (status == ST_OK && ((expect_w > 0 && expect_w != width) || (expect_h > 0 && expect_h != height))) status = ST_SHAPE;
+    if (ncomp == 1) ch[0] = cv[0] = hmax = vmax = 1;
+    const int mcus_x = status == ST_OK ? (width + 8 * hmax - 1) / (8 * hmax) : 0;
+    const int mcus_y = status == ST_OK ? (height + 8 * vmax - 1) / (8 * vmax) : 0;
+    if (tid == 0) {
+        M->width = width;
+        M->height = height;
+        M->ncomp = ncomp;
+        M->hmax = hmax;
+        M->vmax = vmax;
+        for (int c = 0; c < 4; ++c) {
+            M->comp_h[c] = ch[c];
+            M->comp_v[c] = cv[c];
+        }
+        M->scan_pos = scan_pos;
+        M->mcus_x = mcus_x;
+        M->mcus_y = mcus_y;
+        M->ybw = mcus_x * ch[0];
+        M->ybh = mcus_y * cv[0];
+        M->status = status;
+    }
+    if (status != ST_OK) return;
+
+    // ---- un-stuff [scan_pos, n) into clean + off: drop every 0x00 that follows a 0xFF -----------------
+    unsigned char* out = clean + off;
+    unsigned produced = 0;
+    const unsigned start = scan_pos & ~15u;
+    for (unsigned tile = start; tile < n; tile += PT * 16) {
+        const unsigned p0 = tile + tid * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        unsigned prev = 0;
+        if (p0 < n) {
+            v = *reinterpret_cast<const uint4*>(d + p0);
+            if (p0 > 0) prev = d[p0 - 1];
+        }
+        unsigned char by[16];
+        *reinterpret_cast<uint4*>(by) = v;
+        unsigned keep = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const unsigned pos = p0 + k;
+            const bool ok = pos >= scan_pos && pos < n && !(by[k] == 0 && prev == 0xFF);
+            keep |= (ok ? 1u : 0u) << k;
+            prev = by[k];
+        }
+        const unsigned cnt = __popc(keep);
+        // exclusive scan of cnt over the 256 threads
+        s_scan[tid] = cnt;
+        __syncthreads();
+        for (int o = 1; o < PT; o <<= 1) {
+            const unsigned a = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += a;
+            __syncthreads();
+        }
+        unsigned dst = produced + s_scan[tid] - cnt;
+        if (tid == PT - 1) s_total = s_scan[tid];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (keep & (1u << k)) out[dst++] = by[k];
+        }
+        __syncthreads();
+        produced += s_total;
+        __syncthreads();
+    }
+    // zero padding behind the stream so that the decoder's window loads read defined bytes
+    for (unsigned p = produced + tid; p < n && p < produced + 1024; p += PT) out[p] = 0;
+    if (tid == 0) M->clean_len = produced;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel 2: sequential Huffman decode, one wave per file
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LUT_BITS = 9;
+
+__device__ __forceinline__ unsigned rfl(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+
+struct HuffLds {
+    unsigned short lut[8][1 << LUT_BITS];  // (len << 8) | symbol, 0 = longer than LUT_BITS
+    unsigned limit[8][18];                 // (maxcode[l] + 1) << (16 - l), left-justified 16-bit compare; [17] = 65536
+    int valoff[8][17];                     // valptr[l] - mincode[l]
+    unsigned char vals[8][256];
+};
+
+struct BitReader {
+    const unsigned* words;  // un-stuffed stream as aligned dwords
+    unsigned nwords;        // number of defined dwords (including padding)
+    unsigned long long buf; // left-justified
+    int cnt;
+    int widx;          // next dword inside `win`
+    unsigned wbase;    // dword index of win lane 0
+    unsigned win, nxt; // per lane: dword wbase + lane, wbase + 64 + lane
+    int lane;
+
+    __device__ __forceinline__ unsigned load(unsigned idx) const { return idx < nwords ? words[idx] : 0u; }
+    __device__ void init(const unsigned char* stream, unsigned len_bytes, int ln) {
+        words = reinterpret_cast<const unsigned*>(stream);
+        nwords = (len_bytes + 3) / 4 + 8;
+        lane = ln;
+        wbase = 0;
+        win = load(lane);
+        nxt = load(64 + lane);
+        widx = 0;
+        buf = 0;
+        cnt = 0;
+    }
+    __device__ __forceinline__ void refill() {  // after this cnt >= 33
+        if (cnt <= 32) {
+            unsigned w = (unsigned)__builtin_amdgcn_readlane((int)win, widx);
+            w = __builtin_bswap32(w);
+            buf |= (unsigned long long)w << (32 - cnt);
+            cnt += 32;
+            if (++widx == 64) {
+                widx = 0;
+                wbase += 64;
+                win = nxt;
+                nxt = load(wbase + 64 + lane);
+            }
+        }
+    }
+    __device__ __forceinline__ unsigned peek(int n) const { return (unsigned)(buf >> (64 - n)); }
+    __device__ __forceinline__ void skip(int n) {
+        buf <<= n;
+        cnt -= n;
+    }
+    __device__ __forceinline__ void align_byte() { skip(cnt & 7); }
+};
+
+__device__ __forceinline__ int decode_symbol(BitReader& br, const HuffLds& T, int t) {
+    br.refill();
+    const unsigned e = rfl(T.lut[t][br.peek(LUT_BITS)]);
+    if (e) {
+        br.skip((int)(e >> 8));
+        return (int)(e & 255u);
+    }
+    const unsigned p16 = br.peek(16);
+    int l = LUT_BITS + 1;
+    while (l <= 16 && p16 >= rfl(T.limit[t][l])) ++l;
+    if (l > 16) return -1;
+    const int code = (int)(p16 >> (16 - l));
+    br.skip(l);
+    return (int)rfl(T.vals[t][(rfl((unsigned)T.valoff[t][l]) + code) & 255]);
+}
+
+__device__ __forceinline__ int receive_extend(BitReader& br, int s) {  // s in 1..16, cnt >= s guaranteed by caller
+    const int v = (int)br.peek(s);
+    br.skip(s);
+    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+}
+
+__global__ __launch_bounds__(64) void jpeg_huffman_kernel(Meta* __restrict__ metas, const unsigned* __restrict__ offsets,
+                                                          const unsigned char* __restrict__ clean, short* __restrict__ coef,
+                                                          long long coef_stride) {
+    __shared__ HuffLds T;
+    const int img = blockIdx.x, lane = threadIdx.x;
+    Meta* M = metas + img;
+    if (rfl((unsigned)M->status) != ST_OK) return;
+    const int ncomp = (int)rfl((unsigned)M->ncomp);
+    // ---- tables ------------------------------------------------------------------------------------
+    int bad = 0;
+    for (int t = 0; t < 8; ++t) {
+        if (!rfl(M->dht_present[t])) continue;
+        for (int i = lane; i < (1 << LUT_BITS); i += 64) T.lut[t][i] = 0;
+        T.vals[t][lane] = M->dht_vals[t][lane];
+        T.vals[t][lane + 64] = M->dht_vals[t][lane + 64];
+        T.vals[t][lane + 128] = M->dht_vals[t][lane + 128];
+        T.vals[t][lane + 192] = M->dht_vals[t][lane + 192];
+        __syncthreads();
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+            const int c = (int)rfl(M->dht_counts[t][l - 1]);
+            if (lane == 0) T.valoff[t][l] = k - code;
+            // symbols k .. k+c-1 have codes code .. code+c-1 of length l
+            if (l <= LUT_BITS) {
+                const int span = 1 << (LUT_BITS - l);
+                for (int e = lane; e < c * span; e += 64) {
+                    const int j = e / span;
+                    T.lut[t][((code + j) << (LUT_BITS - l)) + (e - j * span)] = (unsigned short)((l << 8) | M->dht_vals[t][k + j]);
+                }
+            }
+            k += c;
+            code += c;
+            if (code > (1 << l)) bad = 1;
+            if (lane == 0) T.limit[t][l] = (unsigned)code << (16 - l);
+            code <<= 1;
+        }
+        if (lane == 0) T.limit[t][17] = 0x10000u;
+        if (k > 256) bad = 1;
+        __syncthreads();
+    }
+    for (int c = 0; c < ncomp; ++c) {
+        if (!rfl(M->qpresent[M->comp_tq[c]]) || !rfl(M->dht_present[M->comp_td[c]]) || !rfl(M->dht_present[4 + M->comp_ta[c]])) bad = 1;
+    }
+    if (bad) {
+        if (lane == 0) M->status = ST_CORRUPT;
+        return;
+    }
+
+    // ---- scan ----------------------------------------------------------------------------------------
+    BitReader br;
+    br.init(clean + rfl(offsets[img]), rfl(M->clean_len), lane);
+    const int mcus_x = (int)rfl((unsigned)M->mcus_x), mcus_y = (int)rfl((unsigned)M->mcus_y), ybw = (int)rfl((unsigned)M->ybw);
+    const int ri = (int)rfl((unsigned)M->restart_interval);
+    int ch[4], cv[4], td[4], ta[4], pred[4] = {0, 0, 0, 0};
+    for (int c = 0; c < 4; ++c) {
+        ch[c] = (int)rfl((unsigned)M->comp_h[c]);
+        cv[c] = (int)rfl((unsigned)M->comp_v[c]);
+        td[c] = (int)rfl((unsigned)M->comp_td[c]) & 3;
+        ta[c] = 4 + ((int)rfl((unsigned)M->comp_ta[c]) & 3);
+    }
+    // lane i keeps natural-order coefficient i of the current block; kz = its position in the zig-zag sequence
+    int kz = 0;
+    for (int k = 0; k < 64; ++k) kz = ZIGZAG[k] == lane ? k : kz;
+    short* cbase = coef + (long long)img * coef_stride;
+    int restart_left = ri, next_rst = 0, status = ST_OK;
+
+    for (int my = 0; my < mcus_y && status == ST_OK; ++my) {
+        for (int mx = 0; mx < mcus_x && status == ST_OK; ++mx) {
+            if (ri && restart_left == 0) {
+                br.align_byte();
+                br.refill();
+                int guard = 0;
+                while (br.peek(8) == 0xFF && guard++ < 64) {  // marker prefix and fill bytes
+                    br.skip(8);
+                    br.refill();
+                }
+                if ((int)br.peek(8) != 0xD0 + next_rst) {
+                    status = ST_CORRUPT;
+                    break;
+                }
+                br.skip(8);
+                next_rst = (next_rst + 1) & 7;
+                restart_left = ri;
+                pred[0] = pred[1] = pred[2] = pred[3] = 0;
+            }
+            for (int c = 0; c < ncomp && status == ST_OK; ++c) {
+                for (int v = 0; v < cv[c] && status == ST_OK; ++v) {
+                    for (int h = 0; h < ch[c] && status == ST_OK; ++h) {
+                        int mine = 0;
+                        int s = decode_symbol(br, T, td[c]);
+                        if (s < 0 || s > 11) {
+                            status = ST_CORRUPT;
+                            break;
+                        }
+                        if (s) {
+                            br.refill();
+                            pred[c] += receive_extend(br, s);
+                        }
+                        if (kz == 0) mine = pred[c];
+                        int k = 1;
+                        while (k < 64) {
+                            s = decode_symbol(br, T, ta[c]);
+                            if (s < 0) {
+                                status = ST_CORRUPT;
+                                break;
+                            }
+                            const int r = s >> 4, sz = s & 15;
+                            if (sz == 0) {
+                                if (r != 15) break;
+                                k += 16;
+                                continue;
+                            }
+                            k += r;
+                            if (k > 63) {
+                                status = ST_CORRUPT;
+                                break;
+                            }
+                            br.refill();
+                            const int val = receive_extend(br, sz);
+                            if (kz == k) mine = val;
+                            ++k;
+                        }
+                        if (c == 0) {
+                            const int bx = mx * ch[0] + h, by = my * cv[0] + v;
+                            cbase[((long long)by * ybw + bx) * 64 + lane] = (short)mine;
+                        }
+                    }
+                }
+            }
+            if (ri) --restart_left;
+        }
+    }
+    if (status != ST_OK && lane == 0) M->status = status;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel 3: de-quantise + islow inverse DCT, one thread per luma block
+// ---------------------------------------------------------------------------------------------------------
+template <int SHIFT>
+__device__ __forceinline__ void idct_1d(const int (&in)[8], int (&out)[8]) {
+    const int rnd = 1 << (SHIFT - 1);
+    int z1, z2, z3, z4, z5, t0, t1, t2, t3;
+    z2 = in[2];
+    z3 = in[6];
+    z1 = (z2 + z3) * 4433;
+    t2 = z1 + z3 * (-15137);
+    t3 = z1 + z2 * 6270;
+    t0 = (in[0] + in[4]) * 8192;
+    t1 = (in[0] - in[4]) * 8192;
+    const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    t0 = in[7];
+    t1 = in[5];
+    t2 = in[3];
+    t3 = in[1];
+    z1 = t0 + t3;
+    z2 = t1 + t2;
+    z3 = t0 + t2;
+    z4 = t1 + t3;
+    z5 = (z3 + z4) * 9633;
+    t0 *= 2446;
+    t1 *= 16819;
+    t2 *= 25172;
+    t3 *= 12299;
+    z1 *= -7373;
+    z2 *= -20995;
+    z3 *= -16069;
+    z4 *= -3196;
+    z3 += z5;
+    z4 += z5;
+    t0 += z1 + z3;
+    t1 += z2 + z4;
+    t2 += z2 + z3;
+    t3 += z1 + z4;
+    out[0] = (t10 + t3 + rnd) >> SHIFT;
+    out[7] = (t10 - t3 + rnd) >> SHIFT;
+    out[1] = (t11 + t2 + rnd) >> SHIFT;
+    out[6] = (t11 - t2 + rnd) >> SHIFT;
+    out[2] = (t12 + t1 + rnd) >> SHIFT;
+    out[5] = (t12 - t1 + rnd) >> SHIFT;
+    out[3] = (t13 + t0 + rnd) >> SHIFT;
+    out[4] = (t13 - t0 + rnd) >> SHIFT;
+}
+
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(const Meta* __restrict__ metas, const short* __restrict__ coef,
+                                                        long long coef_stride, int n, int width, int height,
+                                                        unsigned char* __restrict__ luma) {
+    const int img = blockIdx.y;
+    const Meta* M = metas + img;
+    if (M->status != ST_OK) return;
+    const int ybw = M->ybw, ybh = M->ybh;
+    const int blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= ybw * ybh) return;
+    const int bx = blk % ybw, by = blk / ybw;
+    if (bx * 8 >= width || by * 8 >= height) return;
+    const short* c = coef + (long long)img * coef_stride + (long long)blk * 64;
+    const unsigned short* q = M->q[M->comp_tq[0]];
+    int ws[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(c + r * 8);
+        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ws[r][2 * j] = (int)(short)(w[j] & 0xffff) * (int)q[r * 8 + 2 * j];
+            ws[r][2 * j + 1] = (int)(short)(w[j] >> 16) * (int)q[r * 8 + 2 * j + 1];
+        }
+    }
+#pragma unroll
+    for (int col = 0; col < 8; ++col) {
+        int in[8], out[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) in[r] = ws[r][col];
+        idct_1d<11>(in, out);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ws[r][col] = out[r];
+    }
+    unsigned char* dst = luma + ((long long)img * height + by * 8) * width + bx * 8;
+    const bool full = bx * 8 + 8 <= width && (width & 7) == 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int out[8];
+        idct_1d<18>(ws[r], out);
+        if (by * 8 + r >= height) break;
+        unsigned px[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) px[x] = (unsigned)min(max(out[x] + 128, 0), 255);
+        if (full) {
+            uint2 pk;
+            pk.x = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+            pk.y = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+            *reinterpret_cast<uint2*>(dst + (long long)r * width) = pk;
+        } else {
+            for (int x = 0; x < 8; ++x)
+                if (bx * 8 + x < width) dst[(long long)r * width + x] = (unsigned char)px[x];
+        }
+    }
+}
+
+inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
+inline long long coef_stride_for(int width, int height) {
+    // worst case sampling 4x4: MCU 32x32 pixels
+    const long long bw = (width + 31) / 32 * 4, bh = (height + 31) / 32 * 4;
+    return bw * bh * 64;
+}
+
+}  // namespace jpg
+
+extern "C" {
+
+size_t df3d_jpeg_work_bytes(int n, int width, int height, size_t total_file_bytes) {
+    if (n < 0 || width <= 0 || height <= 0) return 0;
+    long long b = jpg::align_up((long long)n * sizeof(jpg::Meta), 256);
+    b += jpg::align_up((long long)total_file_bytes + 4096, 256);
+    b += (long long)n * jpg::coef_stride_for(width, height) * 2;
+    return (size_t)b;
+}
+
+int df3d_jpeg_decode_luma(const unsigned char* files_dev, const unsigned* offsets_dev, const unsigned* sizes_dev, int n,
+                          size_t total_file_bytes, int width, int height, unsigned char* luma_dev, int* status_dev, void* work_dev,
+                          size_t work_bytes, void* stream) {
+    DF3D_CHECK_ARG(n >= 0 && width > 0 && height > 0, "bad shape");
+    if (n == 0) return DF3D_OK;
+    DF3D_CHECK_ARG(files_dev && offsets_dev && sizes_dev && luma_dev && status_dev && work_dev, "null pointer");
+    DF3D_CHECK_ARG(((uintptr_t)files_dev & 15) == 0, "files_dev must be 16-byte aligned (and every file offset a multiple of 16)");
+    DF3D_CHECK_ARG(work_bytes >= df3d_jpeg_work_bytes(n, width, height, total_file_bytes), "work buffer too small (df3d_jpeg_work_bytes)");
+    hipStream_t s = df3d::as_stream(stream);
+    char* w = static_cast<char*>(work_dev);
+    jpg::Meta* metas = reinterpret_cast<jpg::Meta*>(w);
+    w += jpg::align_up((long long)n * sizeof(jpg::Meta), 256);
+    unsigned char* clean = reinterpret_cast<unsigned char*>(w);
+    w += jpg::align_up((long long)total_file_bytes + 4096, 256);
+    short* coef = reinterpret_cast<short*>(w);
+    const long long cs = jpg::coef_stride_for(width, height);
+    hipLaunchKernelGGL(jpg::jpeg_parse_kernel, dim3(n), dim3(jpg::PT), 0, s, files_dev, offsets_dev, sizes_dev, width, height, metas, clean);
+    hipLaunchKernelGGL(jpg::jpeg_huffman_kernel, dim3(n), dim3(64), 0, s, metas, offsets_dev, clean, coef, cs);
+    const int blocks = (int)(cs / 64);
+    hipLaunchKernelGGL(jpg::jpeg_idct_kernel, dim3((blocks + 255) / 256, n), dim3(256), 0, s, metas, coef, cs, n, width, height, luma_dev);
+    // status: first int of every descriptor
+    DF3D_HIP(hipMemcpy2DAsync(status_dev, sizeof(int), metas, sizeof(jpg::Meta), sizeof(int), n, hipMemcpyDeviceToDevice, s));
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+}  // extern "C"

@@ -48,6 +48,26 @@ int df3d_preprocess_u8(const unsigned char* img_dev, const unsigned char* flip_d
                        float* out_dev, int OH, int OW, const float* mean3_host, const float* std3_host, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a1  JPEG front-end: n baseline JPEG files -> their luma planes, on the device.
+ *     Replaces the libjpeg decode inside df2d's DataLoader (call site reference df3d/core.py:177-185; the
+ *     frames are ffmpeg-written JPEGs, df3d/core.py:446-459).  Baseline / extended sequential Huffman, 8 bit,
+ *     1-4 components in one interleaved scan, any sampling factors, restart intervals; libjpeg's default
+ *     "islow" inverse DCT, bit-exact.  Only the first (luma) component is reconstructed.
+ * files_dev   the files' bytes in one 16-byte aligned buffer of total_file_bytes (+ 16 readable bytes behind it);
+ *             file i = [offsets[i], offsets[i] + sizes[i]), every offset a multiple of 16, files in
+ *             ascending, non-overlapping order
+ * offsets_dev, sizes_dev  [n] uint32 (device)
+ * luma_dev    [n, height, width] uint8;   every file must be width x height
+ * status_dev  [n] int32: 0 ok, 1 truncated, 2 not a JPEG, 3 unsupported (progressive / arithmetic / 12 bit /
+ *             multi-scan), 4 corrupt, 5 size differs.  Planes of failed files are left untouched.
+ * work_dev    >= df3d_jpeg_work_bytes(n, width, height, total_file_bytes) bytes, 256-byte aligned
+ * ---------------------------------------------------------------------------------------------- */
+size_t df3d_jpeg_work_bytes(int n, int width, int height, size_t total_file_bytes);
+int df3d_jpeg_decode_luma(const unsigned char* files_dev, const unsigned* offsets_dev, const unsigned* sizes_dev, int n,
+                          size_t total_file_bytes, int width, int height, unsigned char* luma_dev, int* status_dev,
+                          void* work_dev, size_t work_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a3  heat-map -> point + confidence.   Replaces df2d's heatmap2points / confidence extraction behind
  *     inference_folder(..., return_confidence=True)          (reference df3d/core.py:177-185,
  *     semantics reference README.md:404: arg-max over (h, w), confidence = the max value).

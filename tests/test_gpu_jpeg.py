@@ -1,0 +1,129 @@
+"""-m gpu parity tests of the device JPEG front-end (C ABI df3d_jpeg_decode_luma) -- integer work, so BIT-EXACT:
+against libjpeg-turbo itself (through Pillow, the library the reference's loaders sit on) and against the C
+oracle, on the reference's own test JPEGs and on encoder-made files that cover the format's corners."""
+import glob
+import io
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import jpeg as oj
+
+pytestmark = pytest.mark.gpu
+
+
+def pil_luma(blob):
+    im = Image.open(io.BytesIO(blob))
+    if im.mode != "L":
+        im.draft("L", im.size)  # libjpeg's own grayscale output of a YCbCr file: the luma plane
+    assert im.mode == "L"
+    return np.asarray(im)
+
+
+def _smooth(rng, h, w, c=None):
+    shape = (h // 4 + 2, w // 4 + 2) + ((c,) if c else ())
+    a = np.kron(rng.random(shape) * 255, np.ones((4, 4) + ((1,) if c else ())))[:h, :w]
+    return (a + rng.normal(0, 6, a.shape)).clip(0, 255).astype(np.uint8)
+
+
+def _encode(img, **kw):
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def test_reference_test_images_bit_exact(native_lib, cuda, golden_dir):
+    from deepfly3d_amd import jpeg
+
+    blobs = [open(p, "rb").read() for p in sorted(glob.glob(f"{golden_dir}/images/*.jpg"))]
+    assert len(blobs) == 14
+    out = jpeg.decode_luma(blobs, 960, 480).cpu().numpy()
+    for i, b in enumerate(blobs):
+        assert np.array_equal(out[i], pil_luma(b))
+        assert np.array_equal(out[i], oj.decode_luma(b))
+        assert np.array_equal(out[i], np.asarray(Image.open(io.BytesIO(b)).convert("L")))  # chroma-neutral: also the RGB->L image
+
+
+@pytest.mark.parametrize("hw", [(8, 8), (16, 16), (17, 33), (100, 75), (1, 1), (7, 250), (480, 960)])
+def test_encoder_matrix_bit_exact(native_lib, cuda, hw):
+    """Qualities 30..100 (8- and 16-entry code lengths, long codes), standard and optimised Huffman tables,
+    grayscale / 4:4:4 / 4:2:2 / 4:2:0, restart intervals, sizes that are not multiples of the MCU."""
+    from deepfly3d_amd import jpeg
+
+    h, w = hw
+    rng = np.random.default_rng(h * 1000 + w)
+    blobs = []
+    for q in (30, 75, 95, 100):
+        for kw in ({}, {"optimize": True}, {"subsampling": 0}, {"subsampling": 1}, {"subsampling": 2}, {"restart_marker_blocks": 5},
+                   {"restart_marker_rows": 1}):
+            for colour in (False, True):
+                if not colour and "subsampling" in kw:
+                    continue
+                blobs.append(_encode(_smooth(rng, h, w, 3 if colour else None), quality=q, **kw))
+    out = jpeg.decode_luma(blobs, w, h).cpu().numpy()
+    for i, b in enumerate(blobs):
+        assert np.array_equal(out[i], oj.decode_luma(b)), f"file {i} differs from the oracle"
+        assert np.array_equal(out[i], pil_luma(b)), f"file {i} differs from libjpeg"
+
+
+def test_noise_images_long_codes(native_lib, cuda):
+    """White noise at quality 100: almost every coefficient non-zero, 16-bit Huffman codes, big magnitudes."""
+    from deepfly3d_amd import jpeg
+
+    rng = np.random.default_rng(3)
+    blobs = [_encode(rng.integers(0, 256, size=(64, 96), dtype=np.uint8), quality=100, optimize=o) for o in (False, True)]
+    blobs += [_encode(rng.integers(0, 256, size=(64, 96, 3), dtype=np.uint8), quality=100, subsampling=2)]
+    out = jpeg.decode_luma(blobs, 96, 64).cpu().numpy()
+    for i, b in enumerate(blobs):
+        assert np.array_equal(out[i], pil_luma(b))
+
+
+def test_large_app_segment_and_fill_bytes(native_lib, cuda):
+    """A 20 KB APP1 segment in front of the tables (longer than the parser's LDS window) and a COM segment."""
+    from deepfly3d_amd import jpeg
+
+    rng = np.random.default_rng(4)
+    b = _encode(_smooth(rng, 48, 64), quality=80)
+    app = b"\xff\xe1" + (20000 + 2).to_bytes(2, "big") + bytes(rng.integers(0, 256, size=20000, dtype=np.uint8))
+    com = b"\xff\xfe" + (5 + 2).to_bytes(2, "big") + b"hello"
+    fat = b[:2] + app + com + b[2:]
+    out = jpeg.decode_luma([fat, b], 64, 48).cpu().numpy()
+    assert np.array_equal(out[0], pil_luma(b)) and np.array_equal(out[1], pil_luma(b))
+
+
+def test_status_codes_and_mixed_batches(native_lib, cuda):
+    from deepfly3d_amd import jpeg
+
+    rng = np.random.default_rng(5)
+    img = _smooth(rng, 40, 56)
+    good = _encode(img, quality=85)
+    progressive = _encode(img, quality=85, progressive=True)
+    other_size = _encode(_smooth(rng, 32, 56), quality=85)
+    not_jpeg = b"\x89PNG\r\n\x1a\n" + bytes(64)
+    cut_header = good[:60]
+    batch = [good, progressive, other_size, not_jpeg, cut_header, good]
+    out, st = jpeg.decode_luma(batch, 56, 40, check=False, return_status=True)
+    assert list(st) == [0, 3, 5, 2, 1, 0]
+    for i, b in enumerate(batch):
+        assert oj.status(b, 56, 40) == st[i]  # the oracle classifies the same way
+    out = out.cpu().numpy()
+    assert np.array_equal(out[0], pil_luma(good)) and np.array_equal(out[5], pil_luma(good))
+    with pytest.raises(jpeg.JpegDecodeError, match="file 1 of the batch: unsupported"):
+        jpeg.decode_luma(batch, 56, 40)
+    # a file cut inside the entropy-coded data decodes the intact MCU rows and never reads out of bounds
+    cut = good[: len(good) * 2 // 3]
+    got, st = jpeg.decode_luma([cut], 56, 40, check=False, return_status=True)
+    assert st[0] == 0 and np.array_equal(got.cpu().numpy()[0][:8], pil_luma(good)[:8])
+    assert jpeg.decode_luma([], 56, 40).shape == (0, 40, 56)
+
+
+def test_many_files_one_call(native_lib, cuda, golden_dir):
+    """224 files (one 32-frame step of the pipeline) in one call; every copy decodes identically."""
+    from deepfly3d_amd import jpeg
+
+    blobs = [open(p, "rb").read() for p in sorted(glob.glob(f"{golden_dir}/images/*.jpg"))] * 16
+    out = jpeg.decode_luma(blobs, 960, 480)
+    ref = out[:14]
+    for r in range(1, 16):
+        assert bool((out[14 * r : 14 * (r + 1)] == ref).all())

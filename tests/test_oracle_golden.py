@@ -130,3 +130,39 @@ def test_pose_chain_pinned_by_reference_execution(golden_dir):
         assert np.abs(f - d["filtered"]).max() < 1e-12
     d = np.load(f"{golden_dir}/oneeuro_random.npz")
     assert np.array_equal(pp.oneeuro_filter(d["inp"][:120]), d["out"][:120])
+
+
+def test_jpeg_oracle_pinned_by_libjpeg(golden_dir):
+    """The C restatement of the baseline luma decode equals libjpeg-turbo (through Pillow) bit for bit on the
+    reference's own test JPEGs and on encoder-made files (tables, sampling, restart intervals, odd sizes)."""
+    import glob
+    import io
+
+    from PIL import Image
+
+    from oracle import jpeg as oj
+
+    def pil_luma(blob):
+        im = Image.open(io.BytesIO(blob))
+        if im.mode != "L":
+            im.draft("L", im.size)
+        return np.asarray(im)
+
+    for p in sorted(glob.glob(f"{golden_dir}/images/*.jpg")):
+        b = open(p, "rb").read()
+        y, coef, nsym = oj.decode_luma(b, with_coefficients=True)
+        assert np.array_equal(y, pil_luma(b)) and coef.shape == (60, 120, 64) and 100000 < nsym < 200000
+    rng = np.random.default_rng(0)
+    for h, w in [(8, 8), (17, 33), (100, 75), (1, 1)]:
+        for q in (30, 95, 100):
+            for kw in ({}, {"optimize": True}, {"subsampling": 0}, {"subsampling": 2}, {"restart_marker_blocks": 5}):
+                for c in (None, 3):
+                    if c is None and "subsampling" in kw:
+                        continue
+                    img = (rng.random((h, w) + ((c,) if c else ())) * 255).astype(np.uint8)
+                    buf = io.BytesIO()
+                    Image.fromarray(img).save(buf, "JPEG", quality=q, **kw)
+                    assert np.array_equal(oj.decode_luma(buf.getvalue()), pil_luma(buf.getvalue()))
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, "JPEG", progressive=True)
+    assert oj.status(buf.getvalue()) == 3 and oj.status(b"nope") == 2
