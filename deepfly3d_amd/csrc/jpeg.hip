@@ -31,6 +31,7 @@ struct Meta {
     int comp_h[4], comp_v[4], comp_tq[4], comp_td[4], comp_ta[4];
     unsigned scan_pos;   // byte offset of the entropy-coded data inside the file
     unsigned clean_len;  // bytes of the un-stuffed stream
+    int par_done;        // the parallel Huffman kernel finished this file (else the sequential one decodes it)
     int mcus_x, mcus_y;
     int ybw, ybh;  // luma block grid (MCU padded)
     unsigned short q[4][64];  // natural order
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(PT) void jpeg_parse_kernel(const unsigned char* __r
         M->status = ST_OK;
         M->restart_interval = 0;
         M->clean_len = 0;
+        M->par_done = 0;
         M->hmax = M->vmax = 1;
         for (int i = 0; i < 4; ++i) M->qpresent[i] = 0;
         for (int i = 0; i < 8; ++i) M->dht_present[i] = 0;
@@ -266,18 +268,309 @@ __global__ __launch_bounds__(PT) void jpeg_parse_kernel(const unsigned char* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// kernel 2: sequential Huffman decode, one wave per file
+// Huffman tables in LDS (shared by both decode kernels)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int LUT_BITS = 9;
-
 __device__ __forceinline__ unsigned rfl(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
+template <int LB>
 struct HuffLds {
-    unsigned short lut[8][1 << LUT_BITS];  // (len << 8) | symbol, 0 = longer than LUT_BITS
-    unsigned limit[8][18];                 // (maxcode[l] + 1) << (16 - l), left-justified 16-bit compare; [17] = 65536
-    int valoff[8][17];                     // valptr[l] - mincode[l]
+    unsigned short lut[8][1 << LB];  // (len << 8) | symbol, 0 = code longer than LB bits (or invalid)
+    unsigned limit[8][18];           // (maxcode[l] + 1) << (16 - l): left-justified 16-bit compare; [17] = 65536
+    int valoff[8][17];               // valptr[l] - mincode[l]
     unsigned char vals[8][256];
 };
+
+// Build every present table; all NT threads of the workgroup call this.  Returns non-zero for an invalid table or
+// when a table a component refers to is missing.
+template <int LB, int NT>
+__device__ int build_tables(const Meta* M, HuffLds<LB>& T, int tid) {
+    int bad = 0;
+    for (int t = 0; t < 8; ++t) {
+        if (!rfl(M->dht_present[t])) continue;
+        for (int i = tid; i < (1 << LB); i += NT) T.lut[t][i] = 0;
+        for (int i = tid; i < 256; i += NT) T.vals[t][i] = M->dht_vals[t][i];
+        __syncthreads();
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+            const int c = (int)rfl(M->dht_counts[t][l - 1]);
+            if (tid == 0) T.valoff[t][l] = k - code;
+            if (l <= LB) {  // symbols k .. k+c-1 have the codes code .. code+c-1 of length l
+                const int span = 1 << (LB - l);
+                for (int e = tid; e < c * span; e += NT) {
+                    const int j = e / span;
+                    T.lut[t][((code + j) << (LB - l)) + (e - j * span)] = (unsigned short)((l << 8) | T.vals[t][(k + j) & 255]);
+                }
+            }
+            k += c;
+            code += c;
+            if (code > (1 << l)) bad = 1;
+            if (tid == 0) T.limit[t][l] = (unsigned)code << (16 - l);
+            code <<= 1;
+        }
+        if (tid == 0) T.limit[t][17] = 0x10000u;
+        if (k > 256) bad = 1;
+        __syncthreads();
+    }
+    const int ncomp = (int)rfl((unsigned)M->ncomp);
+    for (int c = 0; c < ncomp; ++c) {
+        if (!rfl(M->qpresent[M->comp_tq[c]]) || !rfl(M->dht_present[M->comp_td[c]]) || !rfl(M->dht_present[4 + M->comp_ta[c]])) bad = 1;
+    }
+    return bad;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel 2a: parallel Huffman decode by self-synchronisation, 256 lanes per file.
+//
+// The un-stuffed stream is cut into 256 equal chunks.  Pass 0: every lane decodes its chunk from the chunk's
+// first bit as if a block started there; JPEG Huffman streams re-synchronise within a few symbols, so the lane's
+// END state (bit position, coefficient index, block-in-MCU) is almost always right although its beginning is
+// garbage.  Pass j >= 1: every lane restarts from its predecessor's end state of pass j-1; when no start state
+// changes any more the decode equals the sequential one (lane 0 is right by construction, each end state is a
+// function of the start state).  A last pass writes the luma coefficients: the block index of a lane's first block
+// is the prefix sum of the lanes' block counts; DC differences are written and integrated afterwards.
+// Files with restart intervals, files that do not converge within MAX_PASSES, truncated or invalid streams are
+// left to the sequential kernel (2b), which is the exact fall-back: M->par_done tells it what is finished.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PLB = 11;  // look-up bits of the parallel decoder
+constexpr int PNT = 256;
+constexpr int MAX_PASSES = 10;
+
+struct ParCtx {
+    const unsigned* words;    // un-stuffed stream as dwords: global memory (raw byte order) or LDS (already byte-swapped)
+    unsigned nwords;
+    int nbm, c1, c2, c3;      // blocks per MCU and the first block of components 1, 2, 3
+    int td[4], ta[4];
+    unsigned total_y;
+};
+
+// IN_LDS: the whole stream sits byte-swapped in LDS and the 64-bit window is read afresh for every symbol.
+// Otherwise three dwords are kept in registers and the next one is fetched from global memory on a word crossing.
+template <bool IN_LDS>
+struct LaneBits {
+    unsigned wi, w0, w1, w2;
+    __device__ __forceinline__ static unsigned ld(const ParCtx& cx, unsigned i) { return i < cx.nwords ? __builtin_bswap32(cx.words[i]) : 0u; }
+    __device__ __forceinline__ void seek(const ParCtx& cx, unsigned p) {
+        if (IN_LDS) return;
+        wi = p >> 5;
+        w0 = ld(cx, wi);
+        w1 = ld(cx, wi + 1);
+        w2 = ld(cx, wi + 2);
+    }
+    __device__ __forceinline__ unsigned window(const ParCtx& cx, unsigned p) const {  // the 32 bits starting at bit p
+        unsigned a = w0, b = w1;
+        if (IN_LDS) {
+            a = cx.words[p >> 5];
+            b = cx.words[(p >> 5) + 1];
+        }
+        const unsigned long long two = ((unsigned long long)a << 32) | b;
+        return (unsigned)((two << (p & 31)) >> 32);
+    }
+    __device__ __forceinline__ void advance(const ParCtx& cx, unsigned p) {  // p moved by < 32 bits
+        if (IN_LDS) return;
+        if ((p >> 5) != wi) {
+            ++wi;
+            w0 = w1;
+            w1 = w2;
+            w2 = ld(cx, wi + 2);
+        }
+    }
+};
+
+template <bool WRITE, bool IN_LDS>
+__device__ void decode_chunk(const ParCtx& cx, const HuffLds<PLB>& T, const unsigned char* zz, unsigned& p, int& k, int& b,
+                             unsigned end, unsigned& ycount, int& err, unsigned ybase, short* __restrict__ cbase) {
+    LaneBits<IN_LDS> lb;
+    lb.seek(cx, p);
+    ycount = 0;
+    err = 0;
+    while (true) {
+        const bool active = p < end;
+        if (!__any(active)) break;
+        if (active) {
+            const unsigned win = lb.window(cx, p);
+            const bool isdc = k == 0;
+            const int comp = (b >= cx.c1) + (b >= cx.c2) + (b >= cx.c3);
+            const int tdc = comp == 0 ? cx.td[0] : (comp == 1 ? cx.td[1] : (comp == 2 ? cx.td[2] : cx.td[3]));
+            const int tac = comp == 0 ? cx.ta[0] : (comp == 1 ? cx.ta[1] : (comp == 2 ? cx.ta[2] : cx.ta[3]));
+            const int t = isdc ? tdc : tac;
+            unsigned e = T.lut[t][win >> (32 - PLB)];
+            bool invalid = false;
+            if (e == 0) {  // longer than PLB bits: canonical search
+                const unsigned p16 = win >> 16;
+                int l = PLB + 1;
+                while (l <= 16 && p16 >= T.limit[t][l]) ++l;
+                if (l <= 16) {
+                    e = ((unsigned)l << 8) | T.vals[t][(T.valoff[t][l] + (int)(p16 >> (16 - l))) & 255];
+                } else {
+                    e = (16u << 8);  // invalid code: keep moving
+                    invalid = true;
+                }
+            }
+            const int len = (int)(e >> 8), sym = (int)(e & 255u);
+            const int size = isdc ? (sym > 15 ? 15 : sym) : (sym & 15);
+            const int run = isdc ? 0 : (sym >> 4);
+            const unsigned rest = win << len;
+            const unsigned bits = size ? rest >> (32 - size) : 0u;
+            const int val = size ? ((int)bits < (1 << (size - 1)) ? (int)bits - (1 << size) + 1 : (int)bits) : 0;
+            const int kk = k + run;  // coefficient this symbol sets (when size > 0)
+            if (WRITE) {
+                const unsigned j = ybase + ycount;  // luma blocks finished before this symbol
+                if (j < cx.total_y) {               // still inside the image (behind it: marker bytes and padding)
+                    if (invalid || (isdc ? sym > 11 : (size > 0 && kk > 63))) err = 1;
+                    if (comp == 0 && (isdc || size > 0) && kk <= 63) cbase[(long long)j * 64 + zz[kk]] = (short)val;
+                }
+            }
+            const int knext = isdc ? 1 : (sym == 0 ? 64 : kk + 1);
+            if (knext >= 64) {
+                ycount += comp == 0 ? 1u : 0u;
+                b = b + 1 == cx.nbm ? 0 : b + 1;
+                k = 0;
+            } else {
+                k = knext;
+            }
+            p += (unsigned)(len + size);
+            lb.advance(cx, p);
+        }
+    }
+}
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict__ metas, const unsigned* __restrict__ offsets,
+                                                               const unsigned char* __restrict__ clean, short* __restrict__ coef,
+                                                               long long coef_stride, unsigned lds_words) {
+    extern __shared__ unsigned s_stream[];  // IN_LDS: the file's un-stuffed stream, byte-swapped dwords
+    __shared__ HuffLds<PLB> T;
+    __shared__ unsigned s_p[PNT + 1];
+    __shared__ unsigned s_kb[PNT + 1];
+    __shared__ unsigned s_cnt[PNT];
+    __shared__ int s_dc[PNT];
+    __shared__ unsigned char s_zz[64];
+    __shared__ int s_flag;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    Meta* M = metas + img;
+    if (tid == 0) M->par_done = 0;
+    if (rfl((unsigned)M->status) != ST_OK) return;
+    if (rfl((unsigned)M->restart_interval) != 0) return;  // restart markers sit inside the stream: sequential kernel
+    if (build_tables<PLB, PNT>(M, T, tid)) return;         // the sequential kernel reports the error
+    if (tid < 64) s_zz[tid] = ZIGZAG[tid];
+
+    ParCtx cx;
+    const unsigned clean_len = rfl(M->clean_len);
+    cx.words = reinterpret_cast<const unsigned*>(clean + rfl(offsets[img]));
+    cx.nwords = (clean_len + 3) / 4 + 8;
+    if (IN_LDS) {
+        if (cx.nwords + 2 > lds_words) return;  // does not fit: sequential kernel
+        for (unsigned i = tid; i < cx.nwords + 2; i += PNT) s_stream[i] = i < cx.nwords ? __builtin_bswap32(cx.words[i]) : 0u;
+        cx.words = s_stream;
+    }
+    const int ncomp = (int)rfl((unsigned)M->ncomp);
+    int nb[4] = {0, 0, 0, 0};
+    for (int c = 0; c < 4; ++c) {
+        if (c < ncomp) nb[c] = (int)rfl((unsigned)M->comp_h[c]) * (int)rfl((unsigned)M->comp_v[c]);
+        cx.td[c] = (int)rfl((unsigned)M->comp_td[c]) & 3;
+        cx.ta[c] = 4 + ((int)rfl((unsigned)M->comp_ta[c]) & 3);
+    }
+    cx.nbm = nb[0] + nb[1] + nb[2] + nb[3];
+    cx.c1 = ncomp > 1 ? nb[0] : 0x7fffffff;
+    cx.c2 = ncomp > 2 ? nb[0] + nb[1] : 0x7fffffff;
+    cx.c3 = ncomp > 3 ? nb[0] + nb[1] + nb[2] : 0x7fffffff;
+    const unsigned mcus = rfl((unsigned)M->mcus_x) * rfl((unsigned)M->mcus_y);
+    cx.total_y = mcus * (unsigned)nb[0];
+    const unsigned total_bits = clean_len * 8u;
+    unsigned chunk = ((total_bits + PNT - 1) / PNT + 31) & ~31u;
+    if (chunk < 32) chunk = 32;
+    const unsigned nominal = (unsigned)tid * chunk;
+    const unsigned end = min(nominal + chunk, total_bits);
+    short* cbase = coef + (long long)img * coef_stride;
+
+    // start states: speculative (block start at the chunk's first bit)
+    s_p[tid] = min(nominal, total_bits);
+    s_kb[tid] = 0;
+    __syncthreads();
+
+    unsigned p, ycount;
+    int k, b, err;
+    bool converged = false;
+    int passes = 0;
+    for (int pass = 0; pass < MAX_PASSES; ++pass) {
+        passes = pass + 1;
+        p = s_p[tid];
+        k = (int)(s_kb[tid] & 255u);
+        b = (int)(s_kb[tid] >> 8);
+        decode_chunk<false, IN_LDS>(cx, T, s_zz, p, k, b, end, ycount, err, 0u, cbase);
+        __syncthreads();
+        // lane tid's end state is lane tid+1's next start state
+        int changed = 0;
+        if (tid + 1 < PNT) {
+            const unsigned np = p, nkb = (unsigned)k | ((unsigned)b << 8);
+            changed = (s_p[tid + 1] != np) || (s_kb[tid + 1] != nkb);
+            s_p[tid + 1] = np;
+            s_kb[tid + 1] = nkb;
+        }
+        s_cnt[tid] = ycount;
+        if (!__syncthreads_or(changed)) {
+            converged = pass > 0 || PNT == 1;
+            if (pass > 0) break;
+        }
+    }
+    if (!converged) {
+        if (tid == 0) M->par_done = -1;
+        return;
+    }
+    // the counts of the last pass belong to the converged start states: exclusive scan -> first block per lane
+    for (int o = 1; o < PNT; o <<= 1) {
+        const unsigned a = tid >= o ? s_cnt[tid - o] : 0;
+        __syncthreads();
+        s_cnt[tid] += a;
+        __syncthreads();
+    }
+    const unsigned all_y = s_cnt[PNT - 1];
+    if (all_y < cx.total_y) {
+        if (tid == 0) M->par_done = -2;
+        return;
+    }  // the stream ends early: sequential kernel (it feeds zeros like libjpeg's callers expect)
+    const unsigned ybase = s_cnt[tid] - ycount;
+    p = s_p[tid];
+    k = (int)(s_kb[tid] & 255u);
+    b = (int)(s_kb[tid] >> 8);
+    decode_chunk<true, IN_LDS>(cx, T, s_zz, p, k, b, end, ycount, err, ybase, cbase);
+    if (tid == 0) s_flag = 0;
+    __threadfence_block();
+    __syncthreads();
+    if (err) s_flag = 1;
+    __syncthreads();
+    if (s_flag) {
+        if (tid == 0) M->par_done = -3;
+        return;
+    }  // invalid symbols: let the sequential kernel classify the file
+    // integrate the DC differences over the luma blocks in decode order
+    const unsigned per = (cx.total_y + PNT - 1) / PNT;
+    const unsigned j0 = min((unsigned)tid * per, cx.total_y), j1 = min(j0 + per, cx.total_y);
+    int sum = 0;
+    for (unsigned j = j0; j < j1; ++j) sum += cbase[(long long)j * 64];
+    s_dc[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < PNT; o <<= 1) {
+        const int a = tid >= o ? s_dc[tid - o] : 0;
+        __syncthreads();
+        s_dc[tid] += a;
+        __syncthreads();
+    }
+    int run = s_dc[tid] - sum;
+    for (unsigned j = j0; j < j1; ++j) {
+        run += cbase[(long long)j * 64];
+        cbase[(long long)j * 64] = (short)run;
+    }
+    if (tid == 0) M->par_done = passes;  // > 0: done here (the value is the number of synchronisation passes)
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel 2b: sequential Huffman decode, one wave per file (exact fall-back; wave-uniform control flow: the bit
+// buffer lives in scalar registers, the next 256 stream bytes in one VGPR read with v_readlane; lane i keeps
+// coefficient i of the current block, so a decoded value is a compare + select and a finished luma block leaves as
+// one coalesced 128-byte store)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LUT_BITS = 9;
 
 struct BitReader {
     const unsigned* words;  // un-stuffed stream as aligned dwords
@@ -323,7 +616,7 @@ struct BitReader {
     __device__ __forceinline__ void align_byte() { skip(cnt & 7); }
 };
 
-__device__ __forceinline__ int decode_symbol(BitReader& br, const HuffLds& T, int t) {
+__device__ __forceinline__ int decode_symbol(BitReader& br, const HuffLds<LUT_BITS>& T, int t) {
     br.refill();
     const unsigned e = rfl(T.lut[t][br.peek(LUT_BITS)]);
     if (e) {
@@ -348,47 +641,13 @@ __device__ __forceinline__ int receive_extend(BitReader& br, int s) {  // s in 1
 __global__ __launch_bounds__(64) void jpeg_huffman_kernel(Meta* __restrict__ metas, const unsigned* __restrict__ offsets,
                                                           const unsigned char* __restrict__ clean, short* __restrict__ coef,
                                                           long long coef_stride) {
-    __shared__ HuffLds T;
+    __shared__ HuffLds<LUT_BITS> T;
     const int img = blockIdx.x, lane = threadIdx.x;
     Meta* M = metas + img;
     if (rfl((unsigned)M->status) != ST_OK) return;
+    if ((int)rfl((unsigned)M->par_done) > 0) return;  // the parallel kernel finished this file
     const int ncomp = (int)rfl((unsigned)M->ncomp);
-    // ---- tables ------------------------------------------------------------------------------------
-    int bad = 0;
-    for (int t = 0; t < 8; ++t) {
-        if (!rfl(M->dht_present[t])) continue;
-        for (int i = lane; i < (1 << LUT_BITS); i += 64) T.lut[t][i] = 0;
-        T.vals[t][lane] = M->dht_vals[t][lane];
-        T.vals[t][lane + 64] = M->dht_vals[t][lane + 64];
-        T.vals[t][lane + 128] = M->dht_vals[t][lane + 128];
-        T.vals[t][lane + 192] = M->dht_vals[t][lane + 192];
-        __syncthreads();
-        int code = 0, k = 0;
-        for (int l = 1; l <= 16; ++l) {
-            const int c = (int)rfl(M->dht_counts[t][l - 1]);
-            if (lane == 0) T.valoff[t][l] = k - code;
-            // symbols k .. k+c-1 have codes code .. code+c-1 of length l
-            if (l <= LUT_BITS) {
-                const int span = 1 << (LUT_BITS - l);
-                for (int e = lane; e < c * span; e += 64) {
-                    const int j = e / span;
-                    T.lut[t][((code + j) << (LUT_BITS - l)) + (e - j * span)] = (unsigned short)((l << 8) | M->dht_vals[t][k + j]);
-                }
-            }
-            k += c;
-            code += c;
-            if (code > (1 << l)) bad = 1;
-            if (lane == 0) T.limit[t][l] = (unsigned)code << (16 - l);
-            code <<= 1;
-        }
-        if (lane == 0) T.limit[t][17] = 0x10000u;
-        if (k > 256) bad = 1;
-        __syncthreads();
-    }
-    for (int c = 0; c < ncomp; ++c) {
-        if (!rfl(M->qpresent[M->comp_tq[c]]) || !rfl(M->dht_present[M->comp_td[c]]) || !rfl(M->dht_present[4 + M->comp_ta[c]])) bad = 1;
-    }
-    if (bad) {
+    if (build_tables<LUT_BITS, 64>(M, T, lane)) {
         if (lane == 0) M->status = ST_CORRUPT;
         return;
     }
@@ -396,7 +655,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(Meta* __restrict__ met
     // ---- scan ----------------------------------------------------------------------------------------
     BitReader br;
     br.init(clean + rfl(offsets[img]), rfl(M->clean_len), lane);
-    const int mcus_x = (int)rfl((unsigned)M->mcus_x), mcus_y = (int)rfl((unsigned)M->mcus_y), ybw = (int)rfl((unsigned)M->ybw);
+    const int mcus_x = (int)rfl((unsigned)M->mcus_x), mcus_y = (int)rfl((unsigned)M->mcus_y);
     const int ri = (int)rfl((unsigned)M->restart_interval);
     int ch[4], cv[4], td[4], ta[4], pred[4] = {0, 0, 0, 0};
     for (int c = 0; c < 4; ++c) {
@@ -410,6 +669,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(Meta* __restrict__ met
     for (int k = 0; k < 64; ++k) kz = ZIGZAG[k] == lane ? k : kz;
     short* cbase = coef + (long long)img * coef_stride;
     int restart_left = ri, next_rst = 0, status = ST_OK;
+    long long yblock = 0;  // luma blocks in decode order
 
     for (int my = 0; my < mcus_y && status == ST_OK; ++my) {
         for (int mx = 0; mx < mcus_x && status == ST_OK; ++mx) {
@@ -431,46 +691,45 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(Meta* __restrict__ met
                 pred[0] = pred[1] = pred[2] = pred[3] = 0;
             }
             for (int c = 0; c < ncomp && status == ST_OK; ++c) {
-                for (int v = 0; v < cv[c] && status == ST_OK; ++v) {
-                    for (int h = 0; h < ch[c] && status == ST_OK; ++h) {
-                        int mine = 0;
-                        int s = decode_symbol(br, T, td[c]);
-                        if (s < 0 || s > 11) {
+                const int nblk = ch[c] * cv[c];
+                for (int blk = 0; blk < nblk && status == ST_OK; ++blk) {
+                    int mine = 0;
+                    int s = decode_symbol(br, T, td[c]);
+                    if (s < 0 || s > 11) {
+                        status = ST_CORRUPT;
+                        break;
+                    }
+                    if (s) {
+                        br.refill();
+                        pred[c] += receive_extend(br, s);
+                    }
+                    if (kz == 0) mine = pred[c];
+                    int k = 1;
+                    while (k < 64) {
+                        s = decode_symbol(br, T, ta[c]);
+                        if (s < 0) {
                             status = ST_CORRUPT;
                             break;
                         }
-                        if (s) {
-                            br.refill();
-                            pred[c] += receive_extend(br, s);
+                        const int r = s >> 4, sz = s & 15;
+                        if (sz == 0) {
+                            if (r != 15) break;
+                            k += 16;
+                            continue;
                         }
-                        if (kz == 0) mine = pred[c];
-                        int k = 1;
-                        while (k < 64) {
-                            s = decode_symbol(br, T, ta[c]);
-                            if (s < 0) {
-                                status = ST_CORRUPT;
-                                break;
-                            }
-                            const int r = s >> 4, sz = s & 15;
-                            if (sz == 0) {
-                                if (r != 15) break;
-                                k += 16;
-                                continue;
-                            }
-                            k += r;
-                            if (k > 63) {
-                                status = ST_CORRUPT;
-                                break;
-                            }
-                            br.refill();
-                            const int val = receive_extend(br, sz);
-                            if (kz == k) mine = val;
-                            ++k;
+                        k += r;
+                        if (k > 63) {
+                            status = ST_CORRUPT;
+                            break;
                         }
-                        if (c == 0) {
-                            const int bx = mx * ch[0] + h, by = my * cv[0] + v;
-                            cbase[((long long)by * ybw + bx) * 64 + lane] = (short)mine;
-                        }
+                        br.refill();
+                        const int val = receive_extend(br, sz);
+                        if (kz == k) mine = val;
+                        ++k;
+                    }
+                    if (c == 0) {
+                        cbase[yblock * 64 + lane] = (short)mine;
+                        ++yblock;
                     }
                 }
             }
@@ -539,7 +798,9 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const Meta* __restrict__
     if (blk >= ybw * ybh) return;
     const int bx = blk % ybw, by = blk / ybw;
     if (bx * 8 >= width || by * 8 >= height) return;
-    const short* c = coef + (long long)img * coef_stride + (long long)blk * 64;
+    const int h0 = M->comp_h[0], v0 = M->comp_v[0];
+    const int j = ((by / v0) * M->mcus_x + bx / h0) * (h0 * v0) + (by % v0) * h0 + bx % h0;  // decode order: MCU by MCU
+    const short* c = coef + (long long)img * coef_stride + (long long)j * 64;
     const unsigned short* q = M->q[M->comp_tq[0]];
     int ws[8][8];
 #pragma unroll
@@ -603,8 +864,8 @@ size_t df3d_jpeg_work_bytes(int n, int width, int height, size_t total_file_byte
 }
 
 int df3d_jpeg_decode_luma(const unsigned char* files_dev, const unsigned* offsets_dev, const unsigned* sizes_dev, int n,
-                          size_t total_file_bytes, int width, int height, unsigned char* luma_dev, int* status_dev, void* work_dev,
-                          size_t work_bytes, void* stream) {
+                          size_t total_file_bytes, unsigned max_file_bytes, int width, int height, unsigned char* luma_dev, int* status_dev, int* path_dev,
+                          void* work_dev, size_t work_bytes, int flags, void* stream) {
     DF3D_CHECK_ARG(n >= 0 && width > 0 && height > 0, "bad shape");
     if (n == 0) return DF3D_OK;
     DF3D_CHECK_ARG(files_dev && offsets_dev && sizes_dev && luma_dev && status_dev && work_dev, "null pointer");
@@ -619,11 +880,26 @@ int df3d_jpeg_decode_luma(const unsigned char* files_dev, const unsigned* offset
     short* coef = reinterpret_cast<short*>(w);
     const long long cs = jpg::coef_stride_for(width, height);
     hipLaunchKernelGGL(jpg::jpeg_parse_kernel, dim3(n), dim3(jpg::PT), 0, s, files_dev, offsets_dev, sizes_dev, width, height, metas, clean);
+    if (!(flags & 1)) {
+        // the parallel decoder writes only non-zero coefficients
+        DF3D_HIP(hipMemsetAsync(coef, 0, (size_t)n * cs * sizeof(short), s));
+        // stream in LDS when the largest file fits next to the tables (the un-stuffed stream is shorter than the file)
+        const size_t lds_cap = 112 * 1024;
+        const size_t want = ((size_t)max_file_bytes + 3) / 4 * 4 + 64;
+        if (max_file_bytes > 0 && want <= lds_cap) {
+            hipLaunchKernelGGL(jpg::jpeg_huffman_par_kernel<true>, dim3(n), dim3(jpg::PNT), want, s, metas, offsets_dev, clean, coef, cs,
+                               (unsigned)(want / 4));
+        } else {
+            hipLaunchKernelGGL(jpg::jpeg_huffman_par_kernel<false>, dim3(n), dim3(jpg::PNT), 0, s, metas, offsets_dev, clean, coef, cs, 0u);
+        }
+    }
     hipLaunchKernelGGL(jpg::jpeg_huffman_kernel, dim3(n), dim3(64), 0, s, metas, offsets_dev, clean, coef, cs);
     const int blocks = (int)(cs / 64);
     hipLaunchKernelGGL(jpg::jpeg_idct_kernel, dim3((blocks + 255) / 256, n), dim3(256), 0, s, metas, coef, cs, n, width, height, luma_dev);
     // status: first int of every descriptor
     DF3D_HIP(hipMemcpy2DAsync(status_dev, sizeof(int), metas, sizeof(jpg::Meta), sizeof(int), n, hipMemcpyDeviceToDevice, s));
+    if (path_dev)
+        DF3D_HIP(hipMemcpy2DAsync(path_dev, sizeof(int), &metas->par_done, sizeof(jpg::Meta), sizeof(int), n, hipMemcpyDeviceToDevice, s));
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }

@@ -6,8 +6,8 @@
                                       disable_pin_memory=False)
     points2d: (7, T, 19, 2) float32 normalised (row/64, col/128);  conf: (7, T, 19, 1) float32
 
-Pipeline on the device: uint8 frames -> df3d_preprocess_u8 (flip / resize / normalise) -> df3d_hg_forward
-(stacked hourglass) -> df3d_heatmap_argmax.  JPEG decoding is host IO (Pillow).  No CPU compute fallback.
+Pipeline on the device: JPEG bytes -> df3d_jpeg_decode_luma -> df3d_preprocess_u8 (flip / resize / normalise) ->
+df3d_hg_forward (stacked hourglass) -> df3d_heatmap_argmax.  The host lists and reads files.  No CPU fallback.
 
 Weights: a bearpaw/df2d `state_dict` checkpoint (`sh8_deepfly.tar`, reference df3d/config.py:30-32) is looked
 up in $DF3D_WEIGHTS or deepfly3d_amd/weights/.  It is not redistributable offline; for plumbing tests set
@@ -88,16 +88,24 @@ def inference_views(images, engine, return_heatmap=False):
     return (pts, conf, hm) if return_heatmap else (pts, conf)
 
 
-def _read_gray(path):
+def _image_size(path):
+    """(width, height) from the JPEG header (host IO only; pixels are decoded on the device)."""
     from PIL import Image
 
     with Image.open(path) as im:
-        return np.asarray(im.convert("L"))
+        return im.size
+
+
+# views per device batch: the reference's `batch_size` (8) is a lower bound, results do not depend on the batch
+DEVICE_BATCH_VIEWS = 224
 
 
 def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return_confidence=True, max_img_id=None,
                      batch_size=8, disable_pin_memory=False, dtype="f32", device=None, state_dict=None):
-    """Drop-in for df2d.inference.inference_folder (see module docstring)."""
+    """Drop-in for df2d.inference.inference_folder (see module docstring).  Host work: listing and reading the
+    files.  Device work: JPEG decode (csrc/jpeg.hip), flip / resize / normalise, hourglass, arg-max."""
+    from .jpeg import JpegFolderReader
+
     _native.require_gpu()
     if max_img_id is None:
         from .os_util import get_max_img_id
@@ -112,34 +120,27 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
     points = torch.empty((ncam, T, config["num_predict"], 2), dtype=torch.float32, device=dev)
     conf = torch.empty((ncam, T, config["num_predict"], 1), dtype=torch.float32, device=dev)
     heat = [] if return_heatmap else None
-    bs = max(1, int(batch_size))
-    # host front-end: JPEG decode is the reference's DataLoader-worker job; here a thread pool decodes chunk k+1
-    # (Pillow releases the GIL) while the GPU works on chunk k
-    from concurrent.futures import ThreadPoolExecutor
-
-    workers = max(1, min(16, (os.cpu_count() or 2) - 1))
+    bs = max(1, int(batch_size), DEVICE_BATCH_VIEWS if not return_heatmap else 1)
     chunks = [items[lo : lo + bs] for lo in range(0, len(items), bs)]
-    with ThreadPoolExecutor(max_workers=workers) as pool:
-        def submit(chunk):
-            return [pool.submit(_read_gray, image_path_for(folder, c, t)) for c, t in chunk]
-
-        pending = submit(chunks[0]) if chunks else []
+    if not chunks:
+        raise FileNotFoundError(f"no images to process in {folder}")
+    paths = [[image_path_for(folder, c, t) for c, t in chunk] for chunk in chunks]
+    width, height = _image_size(paths[0][0])
+    reader = JpegFolderReader(width, height, dev, pinned=not disable_pin_memory)
+    with torch.cuda.device(dev):
+        reader.prefetch(paths[0])
         for k, chunk in enumerate(chunks):
-            frames = np.stack([f.result() for f in pending])
-            pending = submit(chunks[k + 1]) if k + 1 < len(chunks) else []
-            host = torch.from_numpy(frames)
-            if not disable_pin_memory:
-                host = host.pin_memory()
-            fr = host.to(dev, non_blocking=not disable_pin_memory)
-            flip = torch.tensor([1 if c in flip_set else 0 for c, _ in chunk], dtype=torch.uint8)
-            x = preprocess_u8(fr.contiguous(), flip.to(dev), tuple(config["input_shape"]))
+            luma = reader.decode_next(paths[k + 1] if k + 1 < len(chunks) else None)
+            flip = torch.tensor([1 if c in flip_set else 0 for c, _ in chunk], dtype=torch.uint8).to(dev, non_blocking=True)
+            x = preprocess_u8(luma, flip, tuple(config["input_shape"]))
             res = inference_views(x, engine, return_heatmap=return_heatmap)
-            cam = torch.tensor([c for c, _ in chunk], device=dev)
-            tt = torch.tensor([t for _, t in chunk], device=dev)
+            cam = torch.tensor([c for c, _ in chunk]).to(dev, non_blocking=True)
+            tt = torch.tensor([t for _, t in chunk]).to(dev, non_blocking=True)
             points[cam, tt] = res[0]
             conf[cam, tt, :, 0] = res[1]
             if return_heatmap:
                 heat.append(res[2].cpu())
+        reader.finish()
     out = [points.cpu().numpy()]
     if return_heatmap:
         hm = torch.cat(heat).numpy()

@@ -56,16 +56,22 @@ int df3d_preprocess_u8(const unsigned char* img_dev, const unsigned char* flip_d
  * files_dev   the files' bytes in one 16-byte aligned buffer of total_file_bytes (+ 16 readable bytes behind it);
  *             file i = [offsets[i], offsets[i] + sizes[i]), every offset a multiple of 16, files in
  *             ascending, non-overlapping order
- * offsets_dev, sizes_dev  [n] uint32 (device)
+ * offsets_dev, sizes_dev  [n] uint32 (device);  max_file_bytes = the largest size (host value; 0 = unknown: the
+ *             parallel decoder then reads the stream from global memory instead of staging it in LDS)
  * luma_dev    [n, height, width] uint8;   every file must be width x height
  * status_dev  [n] int32: 0 ok, 1 truncated, 2 not a JPEG, 3 unsupported (progressive / arithmetic / 12 bit /
  *             multi-scan), 4 corrupt, 5 size differs.  Planes of failed files are left untouched.
+ * path_dev    optional [n] int32 (may be NULL): 1 = decoded by the parallel Huffman kernel, 0 = by the sequential one
  * work_dev    >= df3d_jpeg_work_bytes(n, width, height, total_file_bytes) bytes, 256-byte aligned
+ * flags       0, or DF3D_JPEG_SEQUENTIAL: skip the parallel (self-synchronising) Huffman kernel and decode every
+ *             file with the sequential wave-per-file kernel (the exact fall-back the parallel one defers to for
+ *             restart-interval, truncated or invalid streams); results are identical either way
  * ---------------------------------------------------------------------------------------------- */
+#define DF3D_JPEG_SEQUENTIAL 1
 size_t df3d_jpeg_work_bytes(int n, int width, int height, size_t total_file_bytes);
 int df3d_jpeg_decode_luma(const unsigned char* files_dev, const unsigned* offsets_dev, const unsigned* sizes_dev, int n,
-                          size_t total_file_bytes, int width, int height, unsigned char* luma_dev, int* status_dev,
-                          void* work_dev, size_t work_bytes, void* stream);
+                          size_t total_file_bytes, unsigned max_file_bytes, int width, int height, unsigned char* luma_dev, int* status_dev,
+                          int* path_dev, void* work_dev, size_t work_bytes, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a3  heat-map -> point + confidence.   Replaces df2d's heatmap2points / confidence extraction behind

@@ -91,6 +91,17 @@ def test_inference_folder_plumbing(native_lib, cuda, tmp_path, golden_dir, monke
     assert pts.shape == (7, 2, 19, 2) and conf.shape == (7, 2, 19, 1) and pts.dtype == np.float32 and conf.dtype == np.float32
     grid = pts.astype(np.float64) * np.array([64.0, 128.0])
     assert np.array_equal(grid, np.round(grid)) and grid[..., 0].max() < 64 and grid[..., 1].max() < 128
+    # the same frames decoded by libjpeg (Pillow) on the host and pushed through the same device stages: identical
+    # results, i.e. the device JPEG decode is bit-exact inside the real pipeline
+    from PIL import Image
+
+    from deepfly3d_amd import ops
+
+    frames = np.stack([np.asarray(Image.open(os.path.join(folder, f"camera_{c}_img_{t}.jpg")).convert("L")) for c in range(7) for t in range(2)])
+    flip = torch.tensor([1 if c in (4, 5, 6) else 0 for c in range(7) for _ in range(2)], dtype=torch.uint8)
+    x = inference.preprocess_u8(torch.from_numpy(frames).to(cuda), flip.to(cuda), (256, 512))
+    p_ref, c_ref = ops.heatmap_argmax(inference.get_engine().forward(x))
+    assert np.array_equal(p_ref.cpu().numpy().reshape(7, 2, 19, 2), pts) and np.array_equal(c_ref.cpu().numpy().reshape(7, 2, 19, 1), conf)
     pts2, conf2, hm = None, None, None
     out = inference.inference_folder(folder=folder, camera_ids_to_flip=[4, 5, 6], return_heatmap=True, return_confidence=True,
                                      max_img_id=1, batch_size=3, disable_pin_memory=True)

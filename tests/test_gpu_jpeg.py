@@ -33,20 +33,25 @@ def _encode(img, **kw):
     return buf.getvalue()
 
 
-def test_reference_test_images_bit_exact(native_lib, cuda, golden_dir):
+SEQ = pytest.mark.parametrize("sequential", [False, True], ids=["parallel", "sequential"])
+
+
+@SEQ
+def test_reference_test_images_bit_exact(native_lib, cuda, golden_dir, sequential):
     from deepfly3d_amd import jpeg
 
     blobs = [open(p, "rb").read() for p in sorted(glob.glob(f"{golden_dir}/images/*.jpg"))]
     assert len(blobs) == 14
-    out = jpeg.decode_luma(blobs, 960, 480).cpu().numpy()
+    out = jpeg.decode_luma(blobs, 960, 480, sequential=sequential).cpu().numpy()
     for i, b in enumerate(blobs):
         assert np.array_equal(out[i], pil_luma(b))
         assert np.array_equal(out[i], oj.decode_luma(b))
         assert np.array_equal(out[i], np.asarray(Image.open(io.BytesIO(b)).convert("L")))  # chroma-neutral: also the RGB->L image
 
 
+@SEQ
 @pytest.mark.parametrize("hw", [(8, 8), (16, 16), (17, 33), (100, 75), (1, 1), (7, 250), (480, 960)])
-def test_encoder_matrix_bit_exact(native_lib, cuda, hw):
+def test_encoder_matrix_bit_exact(native_lib, cuda, hw, sequential):
     """Qualities 30..100 (8- and 16-entry code lengths, long codes), standard and optimised Huffman tables,
     grayscale / 4:4:4 / 4:2:2 / 4:2:0, restart intervals, sizes that are not multiples of the MCU."""
     from deepfly3d_amd import jpeg
@@ -61,20 +66,21 @@ def test_encoder_matrix_bit_exact(native_lib, cuda, hw):
                 if not colour and "subsampling" in kw:
                     continue
                 blobs.append(_encode(_smooth(rng, h, w, 3 if colour else None), quality=q, **kw))
-    out = jpeg.decode_luma(blobs, w, h).cpu().numpy()
+    out = jpeg.decode_luma(blobs, w, h, sequential=sequential).cpu().numpy()
     for i, b in enumerate(blobs):
         assert np.array_equal(out[i], oj.decode_luma(b)), f"file {i} differs from the oracle"
         assert np.array_equal(out[i], pil_luma(b)), f"file {i} differs from libjpeg"
 
 
-def test_noise_images_long_codes(native_lib, cuda):
+@SEQ
+def test_noise_images_long_codes(native_lib, cuda, sequential):
     """White noise at quality 100: almost every coefficient non-zero, 16-bit Huffman codes, big magnitudes."""
     from deepfly3d_amd import jpeg
 
     rng = np.random.default_rng(3)
     blobs = [_encode(rng.integers(0, 256, size=(64, 96), dtype=np.uint8), quality=100, optimize=o) for o in (False, True)]
     blobs += [_encode(rng.integers(0, 256, size=(64, 96, 3), dtype=np.uint8), quality=100, subsampling=2)]
-    out = jpeg.decode_luma(blobs, 96, 64).cpu().numpy()
+    out = jpeg.decode_luma(blobs, 96, 64, sequential=sequential).cpu().numpy()
     for i, b in enumerate(blobs):
         assert np.array_equal(out[i], pil_luma(b))
 
@@ -92,8 +98,16 @@ def test_large_app_segment_and_fill_bytes(native_lib, cuda):
     assert np.array_equal(out[0], pil_luma(b)) and np.array_equal(out[1], pil_luma(b))
 
 
-def test_status_codes_and_mixed_batches(native_lib, cuda):
-    from deepfly3d_amd import jpeg
+@SEQ
+def test_status_codes_and_mixed_batches(native_lib, cuda, sequential):
+    from deepfly3d_amd import jpeg as jpeg_mod
+
+    class jpeg:  # route every call of this test through the selected Huffman path
+        JpegDecodeError = jpeg_mod.JpegDecodeError
+
+        @staticmethod
+        def decode_luma(*a, **kw):
+            return jpeg_mod.decode_luma(*a, sequential=sequential, **kw)
 
     rng = np.random.default_rng(5)
     img = _smooth(rng, 40, 56)
