@@ -60,7 +60,7 @@ def run(args):
         logger.info("Nothing to do. Check your command-line arguments.")
         return 0
     logger.info(f"\nWorking in {args.input_folder}")
-    core = Core(args.input_folder, args.output_folder, args.num_images_max, args.order, dtype=args.dtype)
+    core = Core(args.input_folder, args.output_folder, args.num_images_max, args.order, dtype=args.dtype, device=getattr(args, "device", None))
     if not args.skip_estimation:
         core.pose2d_estimation(args.batch_size, args.pin_memory_disabled)
         core.save()
@@ -133,10 +133,30 @@ def run_from_file(args):
 
 
 def main(argv=None):
+    """Entry point.  Multi-GPU: `python -m torch.distributed.run --nproc-per-node N -m deepfly3d_amd.cli INPUT ...`
+    (one process per GPU; frames are sharded, rank 0 writes the result)."""
+    import os
+
     args = parse_cli_args(argv)
     setup_logger(args)
     if args.debug:
         return print_debug(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+
+        from . import distributed as dd
+
+        _, _, local_rank = dd.init_from_env()
+        args.device = str(dd.local_device(local_rank))
+        try:
+            return _dispatch(args)
+        finally:
+            dist.barrier()
+            dist.destroy_process_group()
+    return _dispatch(args)
+
+
+def _dispatch(args):
     if args.from_file and args.recursive:
         logger.error('Error: choose an input method between "from file" and "recursive" but not both.')
         return 1

@@ -66,10 +66,17 @@ class Core:
 
     def __init__(self, input_folder: str, output_folder: Optional[str] = None, num_images_max: Optional[int] = None,
                  camera_ordering: List[int] = [0, 1, 2, 3, 4, 5, 6], dtype: str = "f32", device=None):
+        from . import distributed as dd
+
         self.dtype, self.device = dtype, device
+        rank, world = dd.current()
+        self.is_primary = rank == 0  # multi-GPU: rank 0 alone expands videos, calibrates and writes results
         self.input_folder = input_folder
         self.output_folder = self.input_folder + "_df3d" if output_folder is None else output_folder
-        self.expand_videos()
+        if self.is_primary:
+            self.expand_videos()
+        if world > 1:
+            torch.distributed.barrier()  # the frames exist for every rank from here on
         self.fps = self.get_fps()
         self.num_images_max = num_images_max if num_images_max is not None else 0
         self.max_img_id = get_max_img_id(self.input_folder)
@@ -93,7 +100,12 @@ class Core:
         if not hasattr(self, "image_shape"):
             raise ValueError(f"Image shape not specified in config and could not be read from {image0}")
 
-        self.db = PoseDB(self.output_folder)
+        if self.is_primary:
+            self.db = PoseDB(self.output_folder)
+        if world > 1:
+            torch.distributed.barrier()
+        if not self.is_primary:
+            self.db = PoseDB(self.output_folder)  # written by rank 0 above: loaded, not re-created
         self.camera_ordering = self.setup_camera_ordering(camera_ordering)
         self.camNet = None
         self.points2d = None
@@ -148,17 +160,37 @@ class Core:
 
     # -- hot path -------------------------------------------------------------------------------------
     def pose2d_estimation(self, batch_size: int = 8, disable_pin_memory: bool = False):
-        """2-D pose on every frame of every camera, then the 19 -> 38 joint layout (reference :170-203)."""
+        """2-D pose on every frame of every camera, then the 19 -> 38 joint layout (reference :170-203).
+
+        Under `torch.distributed` (one process per GPU) every rank processes a contiguous range of frames and ONE
+        gather brings the results to rank 0, which alone goes on to calibrate and save."""
+        from . import distributed as dd
+
         flip = [cam for idx, cam in enumerate(self.camera_ordering) if idx > 3]
-        points19, self.conf = inference_folder(
+        rank, world = dd.current()
+        t0, t1 = dd.shard_range(self.num_images, world, rank)
+        points19, conf = inference_folder(
             folder=self.input_folder, camera_ids_to_flip=flip, return_heatmap=False, return_confidence=True,
             max_img_id=self.max_img_id, batch_size=batch_size, disable_pin_memory=disable_pin_memory, dtype=self.dtype, device=self.device,
+            frame_range=(t0, t1),
         )
-        self.points2d = relayout_points2d(points19, self.camera_ordering, self.device)
+        points2d = relayout_points2d(points19, self.camera_ordering, self.device) if t1 > t0 else np.zeros((7, 0, 38, 2))
+        if world > 1:
+            dev = torch.device(self.device) if self.device is not None else dd.local_device()
+            p = dd.gather_frames(torch.from_numpy(points2d).to(dev), 1, self.num_images)
+            c = dd.gather_frames(torch.from_numpy(np.ascontiguousarray(conf)).to(dev), 1, self.num_images)
+            self.is_primary = rank == 0
+            if not self.is_primary:
+                self.points2d = self.conf = None
+                return
+            points2d, conf = p.cpu().numpy(), c.cpu().numpy()
+        self.points2d, self.conf = points2d, conf
 
     def calibrate_calc(self, min_img_id, max_img_id):
         """Bundle adjustment from the shipped initial calibration (reference :229-250; like the reference the
         image-id range is accepted and unused)."""
+        if not self.is_primary:
+            return
         calib = load_calibration()
         reordered = {int(cidx): calib[idx] for idx, cidx in enumerate(self.camera_ordering)}
         self.camNet = CameraNetwork(self.points2d * self.image_shape[::-1], calib=reordered, image_path=self._image_path, device=self.device)
@@ -176,6 +208,8 @@ class Core:
 
     def save(self):
         """Write df3d_result_*.pkl with the reference's schema and key order (reference :349-369)."""
+        if not self.is_primary:
+            return
         result = {"points2d": np.copy(self.points2d)}
         if self.camNet is not None and self.camNet.has_calibration():
             self.camNet.triangulate()

@@ -31,6 +31,21 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+def current():
+    """(rank, world_size) of the initialised process group, (0, 1) without one."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def local_device(local_rank=None):
+    """The GPU of this process: cuda:LOCAL_RANK (wrapped when fewer devices are visible, e.g. 2 test ranks on 1 GPU)."""
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = torch.cuda.device_count()
+    return torch.device(f"cuda:{local_rank % n}") if n else torch.device("cpu")
+
+
 def shard_range(num_frames, world_size, rank, align=1):
     """Contiguous frame range [start, stop) of `rank`; boundaries are multiples of `align` (e.g. the 1 000-frame
     bundle-adjustment window) except the last.  Ranges cover [0, num_frames) exactly, in rank order."""
@@ -64,6 +79,12 @@ def _gather_frame_axis(local, frame_axis, ranges, rank, world_size, group=None):
         return None
     parts = [bufs[r][: ranges[r][1] - ranges[r][0]] for r in range(world_size)]
     return torch.cat(parts, dim=0).movedim(0, frame_axis).contiguous()
+
+
+def gather_frames(local, frame_axis, num_frames, align=1, group=None):
+    """Gather a tensor that is sharded along `frame_axis` by `shard_range` to rank 0 (None on the other ranks)."""
+    rank, world = current()
+    return _gather_frame_axis(local, frame_axis, all_ranges(num_frames, world, align), rank, world, group)
 
 
 def gather_results(points2d, conf, points3d, num_frames, rank, world_size, align=1, group=None):

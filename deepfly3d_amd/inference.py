@@ -101,9 +101,11 @@ DEVICE_BATCH_VIEWS = 224
 
 
 def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return_confidence=True, max_img_id=None,
-                     batch_size=8, disable_pin_memory=False, dtype="f32", device=None, state_dict=None):
+                     batch_size=8, disable_pin_memory=False, dtype="f32", device=None, state_dict=None, frame_range=None):
     """Drop-in for df2d.inference.inference_folder (see module docstring).  Host work: listing and reading the
-    files.  Device work: JPEG decode (csrc/jpeg.hip), flip / resize / normalise, hourglass, arg-max."""
+    files.  Device work: JPEG decode (csrc/jpeg.hip), flip / resize / normalise, hourglass, arg-max.
+    `frame_range=(t0, t1)` (multi-GPU sharding) restricts the call to images t0 <= id < t1; the outputs then have
+    t1 - t0 frames."""
     from .jpeg import JpegFolderReader
 
     _native.require_gpu()
@@ -111,12 +113,20 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
         from .os_util import get_max_img_id
 
         max_img_id = get_max_img_id(folder)
-    T = max_img_id + 1
+    t_first, t_stop = (0, max_img_id + 1) if frame_range is None else (int(frame_range[0]), int(frame_range[1]))
+    T = max(0, t_stop - t_first)
     ncam = config["num_cameras"]
+    if T == 0 and frame_range is not None:  # an empty shard
+        out = [np.zeros((ncam, 0, config["num_predict"], 2), np.float32)]
+        if return_heatmap:
+            out.append(np.zeros((ncam, 0, config["num_predict"], config["input_shape"][0] // 4, config["input_shape"][1] // 4), np.float32))
+        if return_confidence:
+            out.append(np.zeros((ncam, 0, config["num_predict"], 1), np.float32))
+        return tuple(out) if len(out) > 1 else out[0]
     engine = get_engine(dtype=dtype, device=device, state_dict=state_dict)
     dev = engine.device
     flip_set = set(int(c) for c in camera_ids_to_flip)
-    items = [(c, t) for c in range(ncam) for t in range(T)]
+    items = [(c, t) for c in range(ncam) for t in range(T)]  # t is relative to t_first
     points = torch.empty((ncam, T, config["num_predict"], 2), dtype=torch.float32, device=dev)
     conf = torch.empty((ncam, T, config["num_predict"], 1), dtype=torch.float32, device=dev)
     heat = [] if return_heatmap else None
@@ -124,7 +134,7 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
     chunks = [items[lo : lo + bs] for lo in range(0, len(items), bs)]
     if not chunks:
         raise FileNotFoundError(f"no images to process in {folder}")
-    paths = [[image_path_for(folder, c, t) for c, t in chunk] for chunk in chunks]
+    paths = [[image_path_for(folder, c, t_first + t) for c, t in chunk] for chunk in chunks]
     width, height = _image_size(paths[0][0])
     reader = JpegFolderReader(width, height, dev, pinned=not disable_pin_memory)
     with torch.cuda.device(dev):

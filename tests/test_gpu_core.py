@@ -169,3 +169,31 @@ def test_frame_sharding_is_bit_consistent(native_lib, cuda, golden_dir):
     assert torch.equal(torch.cat([s0[0], s1[0]], dim=1), whole[0])
     assert torch.equal(torch.cat([s0[1], s1[1]], dim=1), whole[1])
     assert torch.equal(torch.cat([s0[2], s1[2]], dim=0), whole[2])
+
+
+def test_cli_two_ranks_match_one_rank(native_lib, cuda, tmp_path, golden_dir):
+    """`torch.distributed.run --nproc-per-node 2 -m deepfly3d_amd.cli` (two ranks sharing this GPU, gloo for the
+    gather) writes the same result file as the single-process CLI: frames are sharded, rank 0 gathers and saves."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DF3D_SYNTHETIC_WEIGHTS="0", DF3D_DIST_BACKEND="gloo", PYTHONPATH=root)
+    results = []
+    for tag, launcher in (("one", [sys.executable, "-m", "deepfly3d_amd.cli"]),
+                          ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                   "--master-port", "29631", "-m", "deepfly3d_amd.cli"])):
+        base = tmp_path / tag
+        base.mkdir()
+        folder = _sample_folder(base, golden_dir)
+        r = subprocess.run(launcher + [folder, "-n", "2"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        files = [f for f in os.listdir(folder + "_df3d") if f.startswith("df3d_result")]
+        assert len(files) == 1
+        with open(os.path.join(folder + "_df3d", files[0]), "rb") as f:
+            results.append(pickle.load(f))
+    one, two = results
+    assert list(one.keys()) == list(two.keys())
+    for k in ("points2d", "heatmap_confidence", "camera_ordering"):
+        assert np.array_equal(one[k], two[k]), k
+    assert np.allclose(one["points3d_wo_procrustes"], two["points3d_wo_procrustes"], atol=1e-9)
