@@ -1485,7 +1485,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void head_kernel(Hea
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sw + (i * 32 + l31) * PITCH + (mm * 32 + (2 * q2 + half) * 8) * 2);
-                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf, acc[i], 0, 0, 0);
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc[i], 0, 0, 0);  // transposed: rows = channels
                             }
                         }
                     }
@@ -1493,33 +1493,53 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void head_kernel(Hea
                 if (s + 1 <= YSTEPS) storeC((s & 1) ^ 1);
                 __syncthreads();
             }
-            // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4*half of the wave][col = channel nh*128 + 32 i + l31]
+            if constexpr (EB == 4) {
+                // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4*half of the wave][col = channel nh*128 + 32 i + l31]
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = nh * 128 + i * 32 + l31;
-                const float bias = p.bfc_[n] + p.bsc_[n];
-                float xr[16];
+                for (int i = 0; i < 4; ++i) {
+                    const int n = nh * 128 + i * 32 + l31;
+                    const float bias = p.bfc_[n] + p.bsc_[n];
+                    float xr[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    xr[r] = 0.0f;
-                    if (m < p.M) {
-                        if constexpr (EB == 4)
-                            xr[r] = reinterpret_cast<const float*>(p.x)[(size_t)m * 256 + n];
-                        else
-                            xr[r] = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.x)[(size_t)m * 256 + n]);
+                    for (int r = 0; r < 16; ++r) {
+                        const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        xr[r] = m < p.M ? reinterpret_cast<const float*>(p.x)[(size_t)m * 256 + n] : 0.0f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (m < p.M) reinterpret_cast<float*>(p.out)[(size_t)m * 256 + n] = acc[i][r] + bias + xr[r];
                     }
                 }
+            } else {
+                // bf16 epilogue on the TRANSPOSED product: lane = pixel m0 + 32 wave + l31, registers 4q..4q+3 of tile i =
+                // channels nh*128 + 32 i + 8 q + 4 half + {0..3}: four consecutive channels = one 8-byte access
+                const long long m = m0 + wave * 32 + l31;
+                if (m < p.M) {
+                    const unsigned short* const xrow = reinterpret_cast<const unsigned short*>(p.x) + (size_t)m * 256;
+                    unsigned short* const orow = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * 256;
+                    uint2 xv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float v = acc[i][r] + bias + xr[r];
-                    if (m < p.M) {
-                        if constexpr (EB == 4)
-                            reinterpret_cast<float*>(p.out)[(size_t)m * 256 + n] = v;
-                        else
-                            reinterpret_cast<unsigned short*>(p.out)[(size_t)m * 256 + n] = f32_to_bf16_bits(v);
-                    }
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xv[4 * i + q] = *reinterpret_cast<const uint2*>(xrow + nh * 128 + 32 * i + 8 * q + 4 * half);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = nh * 128 + 32 * i + 8 * q + 4 * half;
+                            const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bfc_ + n);
+                            const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bsc_ + n);
+                            const uint2 xx = xv[4 * i + q];
+                            const float x0 = bf16_bits_to_f32((unsigned short)(xx.x & 0xffffu)), x1 = bf16_bits_to_f32((unsigned short)(xx.x >> 16));
+                            const float x2 = bf16_bits_to_f32((unsigned short)(xx.y & 0xffffu)), x3 = bf16_bits_to_f32((unsigned short)(xx.y >> 16));
+                            const float v0 = acc[i][4 * q + 0] + (b1[0] + b2[0]) + x0, v1 = acc[i][4 * q + 1] + (b1[1] + b2[1]) + x1;
+                            const float v2 = acc[i][4 * q + 2] + (b1[2] + b2[2]) + x2, v3 = acc[i][4 * q + 3] + (b1[3] + b2[3]) + x3;
+                            uint2 o;
+                            o.x = (unsigned)f32_to_bf16_bits(v0) | ((unsigned)f32_to_bf16_bits(v1) << 16);
+                            o.y = (unsigned)f32_to_bf16_bits(v2) | ((unsigned)f32_to_bf16_bits(v3) << 16);
+                            *reinterpret_cast<uint2*>(orow + n) = o;
+                        }
                 }
             }
         }
