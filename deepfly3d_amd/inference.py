@@ -129,6 +129,7 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
     items = [(c, t) for c in range(ncam) for t in range(T)]  # t is relative to t_first
     points = torch.empty((ncam, T, config["num_predict"], 2), dtype=torch.float32, device=dev)
     conf = torch.empty((ncam, T, config["num_predict"], 1), dtype=torch.float32, device=dev)
+    points_flat, conf_flat = points.view(ncam * T, config["num_predict"], 2), conf.view(ncam * T, config["num_predict"], 1)
     heat = [] if return_heatmap else None
     bs = max(1, int(batch_size), DEVICE_BATCH_VIEWS if not return_heatmap else 1)
     chunks = [items[lo : lo + bs] for lo in range(0, len(items), bs)]
@@ -141,13 +142,13 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
         reader.prefetch(paths[0])
         for k, chunk in enumerate(chunks):
             luma = reader.decode_next(paths[k + 1] if k + 1 < len(chunks) else None)
-            flip = torch.tensor([1 if c in flip_set else 0 for c, _ in chunk], dtype=torch.uint8).to(dev, non_blocking=True)
+            flip = torch.from_numpy(np.fromiter((1 if c in flip_set else 0 for c, _ in chunk), dtype=np.uint8, count=len(chunk))).to(dev, non_blocking=True)
             x = preprocess_u8(luma, flip, tuple(config["input_shape"]))
             res = inference_views(x, engine, return_heatmap=return_heatmap)
-            cam = torch.tensor([c for c, _ in chunk]).to(dev, non_blocking=True)
-            tt = torch.tensor([t for _, t in chunk]).to(dev, non_blocking=True)
-            points[cam, tt] = res[0]
-            conf[cam, tt, :, 0] = res[1]
+            # items are (camera, frame) in camera-major order = the flat order of points[ncam, T]: contiguous copies
+            lo = k * bs
+            points_flat[lo : lo + len(chunk)] = res[0]
+            conf_flat[lo : lo + len(chunk), :, 0] = res[1]
             if return_heatmap:
                 heat.append(res[2].cpu())
         reader.finish()
