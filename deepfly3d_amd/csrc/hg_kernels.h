@@ -641,39 +641,31 @@ struct BtCfg {
     // fp32, PL = 128: the t1 tile is built and consumed in TWO halves of 64 channels (phase 1 twice over x, phase 2
     // accumulates tap x channel-half), which halves its LDS footprint; with a single staging buffer the workgroup
     // then needs 73 KB instead of 153 KB and two workgroups share a CU, as in bf16.
-    static constexpr bool F32_TWO = true;
-    static constexpr int KSPLIT = (EB == 4 && PL == 128 && F32_TWO) ? 2 : 1;
+    static constexpr int KSPLIT = (EB == 4 && PL == 128) ? 2 : 1;
     static constexpr int T1W = PL / KSPLIT;                        // channels of t1 resident at a time
     static constexpr int T1_PITCH = T1W * EB + 16;                 // bytes per halo pixel in the t1 tile
     static constexpr int T1_BYTES = BT_HROWS * T1_PITCH;           // 192 rows: the 12 pad rows make the phase-1 epilogue branch-free
     static constexpr int RB1 = 64;                                 // staged row bytes, phase 1
     static constexpr int RB2 = 128;                                // phases 2 and 3 (K = PL)
-    // bf16: ONE staging buffer (two barriers per K-step) so that the workgroup needs < 80 KB of LDS and two
-    // workgroups share a CU -- the second one's MFMAs cover the first one's barrier / LDS / memory stalls.
-    // fp32: the t1 tile alone is 101 KB, one workgroup per CU, so double-buffer the staging (one barrier per step).
-    static constexpr bool SINGLE = EB == 2 || F32_TWO;
-    // phase-2 weights straight from L2 to registers (no staging, no barriers): measured SLOWER on fp32 (98 vs 112
-    // TFLOP/s: fragment-shaped 32-byte row pieces cost too much in the texture-address path) -- kept off.
-    static constexpr bool DIRECT2 = false;
+    // ONE staging buffer (two barriers per K-step) so that the workgroup needs < 80 KB of LDS and two workgroups
+    // share a CU -- the second one's MFMAs cover the first one's barrier / LDS / memory stalls.
     static constexpr int RBD = 64;                                 // downsample steps of phase 3 (K = CIN)
     static constexpr int STAGE1 = (BT_HROWS + T1W) * (RB1 + 16);   // x rows + W1 rows
     static constexpr int STAGE2 = 128 * (RB2 + 16);                // W2 (PL rows) / W3 (128 rows) 
     static constexpr int STAGED = DS ? (128 + 128) * (RBD + 16) : 0;  // x centre rows + Wd rows
     static constexpr int SMAX = STAGE1 > STAGE2 ? (STAGE1 > STAGED ? STAGE1 : STAGED) : (STAGE2 > STAGED ? STAGE2 : STAGED);
-    static constexpr int RING = SINGLE ? 1 : 3;                   // phase 2/3 weight buffers (fp32: 3-deep ring, see phase 2)
-    static constexpr int STAGE_BYTES = SINGLE ? SMAX : (2 * SMAX > 3 * STAGE2 ? 2 * SMAX : 3 * STAGE2);
+    static constexpr int STAGE_BYTES = SMAX;
     static constexpr int MISC = 64;                                // halo validity masks (3 x 64 bit)
     static constexpr int LDS_BYTES = T1_BYTES + STAGE_BYTES + MISC;
     static constexpr int NT = PL / 32;                             // channel tiles of the intermediates
 };
 
 template <typename T, int CIN, int PL, bool DS>
-__global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32_TWO) ? 2 : 1)) void bottleneck_kernel(BottleneckArgs p) {
+__global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
     using C = BtCfg<T, CIN, PL, DS>;
     constexpr int EB = C::EB;
     constexpr int CO = C::CO;
     constexpr int NT = C::NT;
-    constexpr bool SINGLE = C::SINGLE;
     constexpr int PER16 = Elem<T>::PER16;
     static_assert(PL == 128 || PL == 64, "planes");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -717,13 +709,6 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
     };
     auto store_w = [&](int buf, int rows) {
         unsigned char* const sw = stage + buf * C::SMAX;
-#pragma unroll
-        for (int i = 0; i < WPASS; ++i)
-            if (PL == 128 || srow + i * RPP < rows) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
-    };
-
-    auto store_w3 = [&](int buf, int rows) {   // same, into slot `buf` of the 3-deep ring (pitch STAGE2)
-        unsigned char* const sw = stage + buf * C::STAGE2;
 #pragma unroll
         for (int i = 0; i < WPASS; ++i)
             if (PL == 128 || srow + i * RPP < rows) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
@@ -791,7 +776,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
         store1(0);
         __syncthreads();
         for (int s = 0; s < NSTEPS; ++s) {
-            const unsigned char* const sx = stage + (SINGLE ? 0 : (s & 1)) * C::STAGE1;
+            const unsigned char* const sx = stage + 0 * C::STAGE1;
             const unsigned char* const sw = sx + X_BYTES;
             if (s + 1 < NSTEPS) load1(s + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -804,8 +789,8 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
                     mfma_chunk<T>(xf, wf, acc[i]);
                 }
             }
-            if (SINGLE && s + 1 < NSTEPS) __syncthreads();  // every wave is done reading the only buffer
-            if (s + 1 < NSTEPS) store1(SINGLE ? 0 : (s & 1) ^ 1);
+            if (s + 1 < NSTEPS) __syncthreads();  // every wave is done reading the only buffer
+            if (s + 1 < NSTEPS) store1(0);
             __syncthreads();
         }
         // epilogue: bias + ReLU, zero outside the image, into the t1 tile (rows = halo pixels, PL channels).
@@ -843,111 +828,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
             for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
         }
 
-    if constexpr (C::DIRECT2) {
-        // fp32: the W2 fragments go global/L2 -> registers directly (three 8-channel groups in flight), no LDS
-        // staging and NO barrier in the whole phase: an fp32 MFMA group lasts 1024 cycles, long enough to hide the
-        // L2 latency, and with one workgroup per CU the 36 barrier bubbles of a staged phase 2 were the main loss.
-        // Every wave reads the same 32-byte row pieces, so three of the four requests are L1 hits.
-        constexpr int CPT = PL / 8;             // 8-channel groups per tap
-        constexpr int NC = 9 * CPT;             // 144 (72) groups
-        static_assert(NC % 3 == 0, "pipeline depth");
-        const unsigned char* const wlane = reinterpret_cast<const unsigned char*>(p.w2) + ((size_t)l31 * PL + 4 * half) * EB;
-        auto wload = [&](u32x4 (&w)[NT], int c) {
-            const int tap = c / CPT, kk = c - tap * CPT;
-            const unsigned char* const wp = wlane + ((size_t)tap * PL * PL + kk * 8) * EB;
-#pragma unroll
-            for (int m = 0; m < NT; ++m) w[m] = *reinterpret_cast<const u32x4*>(wp + (size_t)m * 32 * PL * EB);
-        };
-        auto tload = [&](int c) {
-            const int tap = c / CPT, kk = c - tap * CPT;
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            return *reinterpret_cast<const u32x4*>(t1_lds + ((py + ky) * BT_HW + (px + kx)) * C::T1_PITCH + kk * 32 + half * 16);
-        };
-        u32x4 wa[NT], wb2[NT], wc[NT];
-        wload(wa, 0);
-        wload(wb2, 1);
-        wload(wc, 2);
-        for (int c = 0; c < NC; c += 3) {
-            {
-                const u32x4 tf = tload(c);
-#pragma unroll
-                for (int m = 0; m < NT; ++m) mfma_chunk<T>(wa[m], tf, t2[m]);
-                if (c + 3 < NC) wload(wa, c + 3);
-            }
-            {
-                const u32x4 tf = tload(c + 1);
-#pragma unroll
-                for (int m = 0; m < NT; ++m) mfma_chunk<T>(wb2[m], tf, t2[m]);
-                if (c + 4 < NC) wload(wb2, c + 4);
-            }
-            {
-                const u32x4 tf = tload(c + 2);
-#pragma unroll
-                for (int m = 0; m < NT; ++m) mfma_chunk<T>(wc[m], tf, t2[m]);
-                if (c + 5 < NC) wload(wc, c + 5);
-            }
-        }
-    } else if constexpr (!SINGLE) {
-        // fp32 (one workgroup per CU): 3-deep LDS ring, weights prefetched TWO steps ahead.  During step s the wave
-        //   * computes from buffer s%3, whose first fragments were already read at the end of step s-1,
-        //   * mid-step stores the registers holding step s+2 into buffer (s+2)%3 (last read in step s-1, i.e. before
-        //     the barrier that ended step s-1) and re-issues the global loads for step s+3,
-        //   * reads the first fragments of step s+1 (buffer (s+1)%3, complete since the previous barrier),
-        // so neither the LDS-write nor the LDS-read latency sits between two MFMAs; the single barrier per step only
-        // orders "everyone finished reading buffer s%3" before it is overwritten one step later.
-        constexpr int KSTEPS = PL / KE;
-        constexpr int NSTEPS = 9 * KSTEPS;
-        constexpr int J = RB / 32;
-        auto w2_off = [&](int s) { const int tap = s / KSTEPS; return (size_t)tap * PL * PL + (size_t)(s - tap * KSTEPS) * KE; };
-        auto t1_ptr = [&](int s) {
-            const int tap = s / KSTEPS, kc = s - tap * KSTEPS;
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            return t1_lds + ((py + ky) * BT_HW + (px + kx)) * C::T1_PITCH + kc * RB + half * 16;
-        };
-        load_w(p.w2, PL, PL, w2_off(0));
-        store_w3(0, PL);
-        load_w(p.w2, PL, PL, w2_off(1));
-        store_w3(1, PL);
-        load_w(p.w2, PL, PL, w2_off(2));   // stays in registers until the middle of step 0
-        __syncthreads();
-        u32x4 tf = *reinterpret_cast<const u32x4*>(t1_ptr(0));
-        u32x4 wf[NT];
-#pragma unroll
-        for (int m = 0; m < NT; ++m) wf[m] = *reinterpret_cast<const u32x4*>(stage + (m * 32 + l31) * PITCH + half * 16);
-        for (int s = 0; s < NSTEPS; ++s) {
-            const unsigned char* const wrow = stage + (s % 3) * C::STAGE2 + l31 * PITCH + half * 16;
-            const unsigned char* const tb = t1_ptr(s);
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                u32x4 tfn, wfn[NT];
-                if (j + 1 < J) {
-                    tfn = *reinterpret_cast<const u32x4*>(tb + (j + 1) * 32);
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) wfn[m] = *reinterpret_cast<const u32x4*>(wrow + m * 32 * PITCH + (j + 1) * 32);
-                } else if (s + 1 < NSTEPS) {   // first fragments of the next step
-                    tfn = *reinterpret_cast<const u32x4*>(t1_ptr(s + 1));
-                    const unsigned char* const wnext = stage + ((s + 1) % 3) * C::STAGE2 + l31 * PITCH + half * 16;
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) wfn[m] = *reinterpret_cast<const u32x4*>(wnext + m * 32 * PITCH);
-                } else {
-                    tfn = tf;
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) wfn[m] = wf[m];
-                }
-#pragma unroll
-                for (int m = 0; m < NT; ++m) mfma_chunk<T>(wf[m], tf, t2[m]);
-                if (j == 1) {
-                    if (s + 2 < NSTEPS) store_w3((s + 2) % 3, PL);
-                    if (s + 3 < NSTEPS) load_w(p.w2, PL, PL, w2_off(s + 3));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                tf = tfn;
-#pragma unroll
-                for (int m = 0; m < NT; ++m) wf[m] = wfn[m];
-            }
-            __syncthreads();
-        }
-    } else {
+    {
         // one staging buffer, two barriers per K-step (two workgroups per CU); kh selects the resident t1 channel part
         auto phase2 = [&](int kh) {
             constexpr int T1W = C::T1W;
@@ -1007,25 +888,11 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = bias;
         }
-        // identity skip: the residual values are requested NOW (their latency hides behind the K loop).
-        // fp32: one value per accumulator register; bf16: lane pairs own two adjacent channels of one pixel
-        // (even lanes pixel-register 2q, odd lanes 2q + 1), so loads and stores are 4 bytes wide.
-        constexpr bool PREFETCH_RES32 = EB == 4 && !C::F32_TWO;   // fp32 at two workgroups per CU: no registers to spare
-        constexpr int NRES = DS ? 1 : (EB == 4 ? (PREFETCH_RES32 ? 64 : 1) : 32);
+        // identity skip, bf16: the residual values are requested NOW (their latency hides behind the K loop); fp32 at two
+        // workgroups per CU has no registers to spare and loads them in the epilogue
+        constexpr int NRES = (!DS && EB == 2) ? 32 : 1;
         unsigned xres[NRES];
         if constexpr (!DS) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = nh * 128 + i * 32 + l31;
-                if constexpr (PREFETCH_RES32) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        xres[i * 16 + r] = __float_as_uint(reinterpret_cast<const float*>(xin)[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n]);
-                    }
-                }
-                (void)n;
-            }
             if constexpr (EB == 2) {
                 // bf16: the epilogue goes through LDS (see below): lane owns, for c = 0..7, the 16-byte chunk (lane & 15)
                 // of wave pixel 4c + (lane >> 4) -> eight 16-byte residual loads
@@ -1048,7 +915,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < NSTEPS; ++s) {
-            const unsigned char* const sw = stage + (SINGLE ? 0 : (s & 1)) * C::SMAX;
+            const unsigned char* const sw = stage + 0 * C::SMAX;
             if (s + 1 < NSTEPS) load_w(w3h, 128, PL, (size_t)(s + 1) * KE);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (EB == 4) {
@@ -1085,8 +952,8 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
                         }
                     }
             }
-            if (SINGLE && s + 1 < NSTEPS) __syncthreads();
-            if (s + 1 < NSTEPS) store_w(SINGLE ? 0 : (s & 1) ^ 1, 128);
+            if (s + 1 < NSTEPS) __syncthreads();
+            if (s + 1 < NSTEPS) store_w(0, 128);
             __syncthreads();
         }
         if constexpr (DS) {
@@ -1118,7 +985,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
             stored(0);
             __syncthreads();
             for (int s = 0; s < NSTEPSd; ++s) {
-                const unsigned char* const sx = stage + (SINGLE ? 0 : (s & 1)) * C::SMAX;
+                const unsigned char* const sx = stage + 0 * C::SMAX;
                 const unsigned char* const sw = sx + XBYTES;
                 if (s + 1 < NSTEPSd) loadd(s + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1131,8 +998,8 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
                         mfma_chunk<T>(xf, wf, acc[i]);
                     }
                 }
-                if (SINGLE && s + 1 < NSTEPSd) __syncthreads();
-                if (s + 1 < NSTEPSd) stored(SINGLE ? 0 : (s & 1) ^ 1);
+                if (s + 1 < NSTEPSd) __syncthreads();
+                if (s + 1 < NSTEPSd) stored(0);
                 __syncthreads();
             }
         }
@@ -1142,7 +1009,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
         for (int i = 0; i < 4; ++i) {
             const int n = nh * 128 + i * 32 + l31;
             if constexpr (EB == 4) {
-                if constexpr (!DS && !PREFETCH_RES32) {   // all 16 residual loads of the tile before the first store
+                if constexpr (!DS) {   // all 16 residual loads of the tile before the first store
                     float xr[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -1156,7 +1023,6 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || BtCfg<T, CIN, PL, DS>::F32
                 for (int r = 0; r < 16; ++r) {
                     const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
                     const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n;
-                    if constexpr (!DS && PREFETCH_RES32) acc[i][r] += __uint_as_float(xres[DS || !PREFETCH_RES32 ? 0 : i * 16 + r]);
                     reinterpret_cast<float*>(outp)[po] = acc[i][r];
                 }
                 if (p.pool) {
