@@ -328,12 +328,13 @@ __device__ int build_tables(const Meta* M, HuffLds<LB>& T, int tid) {
 // changes any more the decode equals the sequential one (lane 0 is right by construction, each end state is a
 // function of the start state).  A last pass writes the luma coefficients: the block index of a lane's first block
 // is the prefix sum of the lanes' block counts; DC differences are written and integrated afterwards.
-// Files with restart intervals, files that do not converge within MAX_PASSES, truncated or invalid streams are
+// Files with restart intervals, files that do not converge within MAX_PASSES (every pass fixes at least one more lane), truncated or invalid streams are
 // left to the sequential kernel (2b), which is the exact fall-back: M->par_done tells it what is finished.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int PLB = 11;  // look-up bits of the parallel decoder
 constexpr int PNT = 256;
-constexpr int MAX_PASSES = 10;
+constexpr int MAX_PASSES = 32;  // a pass costs ~0.25 ms, the sequential fall-back ~40 ms per 70 KB file
+constexpr unsigned MIN_CHUNK = 2048;
 
 struct ParCtx {
     const unsigned* words;    // un-stuffed stream as dwords: global memory (raw byte order) or LDS (already byte-swapped)
@@ -477,14 +478,17 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     const unsigned mcus = rfl((unsigned)M->mcus_x) * rfl((unsigned)M->mcus_y);
     cx.total_y = mcus * (unsigned)nb[0];
     const unsigned total_bits = clean_len * 8u;
+    // chunks of at least MIN_CHUNK bits: 4:2:0 streams need ~1 000 bits to re-synchronise (the block-in-MCU index
+    // locks in last), shorter chunks would only add passes; small files simply use fewer lanes
     unsigned chunk = ((total_bits + PNT - 1) / PNT + 31) & ~31u;
-    if (chunk < 32) chunk = 32;
+    if (chunk < MIN_CHUNK) chunk = MIN_CHUNK;
     const unsigned nominal = (unsigned)tid * chunk;
     const unsigned end = min(nominal + chunk, total_bits);
     short* cbase = coef + (long long)img * coef_stride;
 
-    // start states: speculative (block start at the chunk's first bit)
-    s_p[tid] = min(nominal, total_bits);
+    // start states of pass 0: speculative (a block starts there), one chunk AHEAD of the lane's own chunk so that the
+    // decode has a whole extra chunk to synchronise before the end state that matters (lanes 0 and 1 are exact)
+    s_p[tid] = min(tid > 0 ? nominal - chunk : 0u, total_bits);
     s_kb[tid] = 0;
     __syncthreads();
 
@@ -503,7 +507,9 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
         int changed = 0;
         if (tid + 1 < PNT) {
             const unsigned np = p, nkb = (unsigned)k | ((unsigned)b << 8);
-            changed = (s_p[tid + 1] != np) || (s_kb[tid + 1] != nkb);
+            // lanes whose chunk lies behind the stream decode nothing: their start state is irrelevant (and would
+            // otherwise ripple through the idle lanes one lane per pass)
+            changed = (nominal + chunk < total_bits) && ((s_p[tid + 1] != np) || (s_kb[tid + 1] != nkb));
             s_p[tid + 1] = np;
             s_kb[tid + 1] = nkb;
         }

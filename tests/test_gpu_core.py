@@ -197,3 +197,45 @@ def test_cli_two_ranks_match_one_rank(native_lib, cuda, tmp_path, golden_dir):
     for k in ("points2d", "heatmap_confidence", "camera_ordering"):
         assert np.array_equal(one[k], two[k]), k
     assert np.allclose(one["points3d_wo_procrustes"], two["points3d_wo_procrustes"], atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_full_size_workload_properties(native_lib, cuda, golden_dir, dtype):
+    """BASELINE configs[1] / configs[2] at FULL size (1 000 frames x 7 views of 256x512x3, one GPU), checked through
+    size-independent properties: the run is deterministic (bit-identical twice), every frame's result is independent
+    of its position and batch (16 scattered frames re-run one by one are bit-identical), detections lie on the
+    heat-map grid, confidences are finite, and for two frames the whole chain (device heat-maps -> oracle arg-max ->
+    oracle layout -> oracle DLT) reproduces the device output."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.pipeline import FramePipeline
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    T = 1000
+    eng = HourglassEngine(synthetic_state_dict(0), dtype=dtype, device=cuda)
+    c = np.load(f"{golden_dir}/calib.npz")
+    pipe = FramePipeline(eng, c["R"], c["tvec"], c["intr"])
+    gen = torch.Generator(device=cuda).manual_seed(7)
+    frames = torch.rand((T, 7, 256, 512, 3), generator=gen, device=cuda, dtype=torch.float32)
+    first = [t.clone() for t in pipe.run(frames, frames_per_batch=32)]
+    again = pipe.run(frames, frames_per_batch=32)
+    for a, b in zip(first, again):
+        assert torch.equal(a, b)
+    p2, conf, p3 = first
+    assert p2.shape == (7, T, 38, 2) and conf.shape == (7, T, 19) and p3.shape == (T, 38, 3)
+    assert bool(torch.isfinite(conf).all()) and bool(torch.isfinite(p3).all())
+    rng = np.random.default_rng(3)
+    for t in sorted(rng.choice(T, size=16, replace=False).tolist()):
+        q2, qc, q3 = pipe.run(frames[t : t + 1], frames_per_batch=1)
+        assert torch.equal(q2[:, 0], p2[:, t]) and torch.equal(qc[:, 0], conf[:, t]) and torch.equal(q3[0], p3[t])
+    # grid: un-flipped columns are k/128 or 1 - k/128, rows k/64, all in [0, 1]
+    g = p2.cpu().numpy()
+    rows, cols = g[..., 0] * 64.0, g[..., 1] * 128.0
+    assert np.array_equal(rows, np.round(rows)) and np.array_equal(cols, np.round(cols)) and rows.min() >= 0 and rows.max() < 64 and cols.max() <= 128
+    # two frames against the oracle's geometry on the DEVICE heat-maps
+    for t in (0, T - 1):
+        hm = eng.forward(frames[t].contiguous()).cpu().numpy()
+        pts, cf = og.heatmap_argmax(hm)
+        p38 = og.relayout_19_to_38(pts.reshape(7, 1, 19, 2), list(range(7)))
+        assert np.array_equal(p2[:, t].cpu().numpy(), p38[:, 0]) and np.array_equal(conf[:, t].cpu().numpy(), cf)
+        X = og.triangulate_dlt(og.pixels_from_normalised(p38, [960, 480]), og.projection_matrices(c["R"], c["tvec"], c["intr"]))
+        assert np.abs(p3[t].cpu().numpy() - X[0]).max() < 1e-6 * max(1.0, np.abs(X).max())

@@ -141,3 +141,42 @@ def test_many_files_one_call(native_lib, cuda, golden_dir):
     ref = out[:14]
     for r in range(1, 16):
         assert bool((out[14 * r : 14 * (r + 1)] == ref).all())
+
+
+def test_parallel_decoder_paths(native_lib, cuda, golden_dir):
+    """The reference's JPEGs take the parallel (self-synchronising) Huffman kernel, with the stream staged in LDS or
+    read from global memory; restart-interval files fall back to the sequential kernel; all bit-identical."""
+    from deepfly3d_amd import jpeg
+
+    blobs = [open(p, "rb").read() for p in sorted(glob.glob(f"{golden_dir}/images/*.jpg"))]
+    ref = np.stack([pil_luma(b) for b in blobs])
+    out, path = jpeg.decode_luma(blobs, 960, 480, return_path=True)
+    assert np.array_equal(out.cpu().numpy(), ref) and (path > 0).all() and path.max() <= 12  # value = synchronisation passes
+    out, path = jpeg.decode_luma(blobs, 960, 480, return_path=True, stream_in_lds=False)
+    assert np.array_equal(out.cpu().numpy(), ref) and (path > 0).all()
+    out, path = jpeg.decode_luma(blobs, 960, 480, return_path=True, sequential=True)
+    assert np.array_equal(out.cpu().numpy(), ref) and (path == 0).all()
+    rng = np.random.default_rng(8)
+    img = _smooth(rng, 96, 160)
+    col = _smooth(rng, 96, 160, 3)
+    mix = [_encode(img, quality=90, restart_marker_blocks=7), _encode(img, quality=90), _encode(col, quality=90)]
+    out, path = jpeg.decode_luma(mix, 160, 96, return_path=True)
+    # restart markers -> sequential; single-component stream -> parallel; a busy 4:2:0 colour stream may or may not
+    # synchronise its block-in-MCU index within the pass budget (then the sequential kernel decodes it): same pixels
+    assert path[0] == 0 and path[1] > 0
+    for i, b in enumerate(mix):
+        assert np.array_equal(out.cpu().numpy()[i], pil_luma(b))
+
+
+def test_large_files_exceed_the_lds_stage(native_lib, cuda):
+    """Noise at quality 97, 1600x1200: files of several hundred KB, far beyond the 112 KB LDS stage -> the
+    global-memory variant of the parallel kernel; also a larger block grid than the camera frames."""
+    from deepfly3d_amd import jpeg
+
+    rng = np.random.default_rng(9)
+    blobs = [_encode(rng.integers(0, 256, size=(1200, 1600), dtype=np.uint8), quality=97),
+             _encode(_smooth(rng, 1200, 1600, 3), quality=97, subsampling=2)]
+    assert max(len(b) for b in blobs) > 200 * 1024
+    out, path = jpeg.decode_luma(blobs, 1600, 1200, return_path=True)
+    for i, b in enumerate(blobs):
+        assert np.array_equal(out[i].cpu().numpy(), pil_luma(b)), f"file {i} (path {path[i]})"
