@@ -339,7 +339,7 @@ constexpr unsigned MIN_CHUNK = 2048;
 struct ParCtx {
     const unsigned* words;    // un-stuffed stream as dwords: global memory (raw byte order) or LDS (already byte-swapped)
     unsigned nwords;
-    int nbm, c1, c2, c3;      // blocks per MCU and the first block of components 1, 2, 3
+    int nbm;                  // blocks per MCU
     int td[4], ta[4];
     unsigned total_y;
 };
@@ -363,8 +363,8 @@ struct LaneBits {
             a = cx.words[p >> 5];
             b = cx.words[(p >> 5) + 1];
         }
-        const unsigned long long two = ((unsigned long long)a << 32) | b;
-        return (unsigned)((two << (p & 31)) >> 32);
+        const unsigned sh = p & 31u;
+        return sh ? __builtin_amdgcn_alignbit(a, b, 32u - sh) : a;
     }
     __device__ __forceinline__ void advance(const ParCtx& cx, unsigned p) {  // p moved by < 32 bits
         if (IN_LDS) return;
@@ -377,9 +377,10 @@ struct LaneBits {
     }
 };
 
+// blk[b] (LDS): for block b of the MCU  bits 0-2 = DC table slot, bits 3-5 = AC table slot, bit 7 = luma component
 template <bool WRITE, bool IN_LDS>
-__device__ void decode_chunk(const ParCtx& cx, const HuffLds<PLB>& T, const unsigned char* zz, unsigned& p, int& k, int& b,
-                             unsigned end, unsigned& ycount, int& err, unsigned ybase, short* __restrict__ cbase) {
+__device__ void decode_chunk(const ParCtx& cx, const HuffLds<PLB>& T, const unsigned char* zz, const unsigned char* blk, unsigned& p,
+                             int& k, int& b, unsigned end, unsigned& ycount, int& err, unsigned ybase, short* __restrict__ cbase) {
     LaneBits<IN_LDS> lb;
     lb.seek(cx, p);
     ycount = 0;
@@ -390,16 +391,15 @@ __device__ void decode_chunk(const ParCtx& cx, const HuffLds<PLB>& T, const unsi
         if (active) {
             const unsigned win = lb.window(cx, p);
             const bool isdc = k == 0;
-            const int comp = (b >= cx.c1) + (b >= cx.c2) + (b >= cx.c3);
-            const int tdc = comp == 0 ? cx.td[0] : (comp == 1 ? cx.td[1] : (comp == 2 ? cx.td[2] : cx.td[3]));
-            const int tac = comp == 0 ? cx.ta[0] : (comp == 1 ? cx.ta[1] : (comp == 2 ? cx.ta[2] : cx.ta[3]));
-            const int t = isdc ? tdc : tac;
+            const unsigned sel = blk[b];
+            const int t = (int)(isdc ? (sel & 7u) : ((sel >> 3) & 7u));
+            const bool luma = (sel & 0x80u) != 0;
             unsigned e = T.lut[t][win >> (32 - PLB)];
             bool invalid = false;
-            if (e == 0) {  // longer than PLB bits: canonical search
+            if (e == 0) {  // longer than PLB bits: canonical search over the 5 remaining lengths, loads issued together
                 const unsigned p16 = win >> 16;
-                int l = PLB + 1;
-                while (l <= 16 && p16 >= T.limit[t][l]) ++l;
+                const unsigned l12 = T.limit[t][12], l13 = T.limit[t][13], l14 = T.limit[t][14], l15 = T.limit[t][15], l16 = T.limit[t][16];
+                const int l = 12 + (p16 >= l12) + (p16 >= l13) + (p16 >= l14) + (p16 >= l15) + (p16 >= l16);
                 if (l <= 16) {
                     e = ((unsigned)l << 8) | T.vals[t][(T.valoff[t][l] + (int)(p16 >> (16 - l))) & 255];
                 } else {
@@ -418,12 +418,12 @@ __device__ void decode_chunk(const ParCtx& cx, const HuffLds<PLB>& T, const unsi
                 const unsigned j = ybase + ycount;  // luma blocks finished before this symbol
                 if (j < cx.total_y) {               // still inside the image (behind it: marker bytes and padding)
                     if (invalid || (isdc ? sym > 11 : (size > 0 && kk > 63))) err = 1;
-                    if (comp == 0 && (isdc || size > 0) && kk <= 63) cbase[(long long)j * 64 + zz[kk]] = (short)val;
+                    if (luma && (isdc || size > 0) && kk <= 63) cbase[(long long)j * 64 + zz[kk]] = (short)val;
                 }
             }
             const int knext = isdc ? 1 : (sym == 0 ? 64 : kk + 1);
             if (knext >= 64) {
-                ycount += comp == 0 ? 1u : 0u;
+                ycount += luma ? 1u : 0u;
                 b = b + 1 == cx.nbm ? 0 : b + 1;
                 k = 0;
             } else {
@@ -446,6 +446,7 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     __shared__ unsigned s_cnt[PNT];
     __shared__ int s_dc[PNT];
     __shared__ unsigned char s_zz[64];
+    __shared__ unsigned char s_blk[16];
     __shared__ int s_flag;
     const int img = blockIdx.x, tid = threadIdx.x;
     Meta* M = metas + img;
@@ -472,9 +473,13 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
         cx.ta[c] = 4 + ((int)rfl((unsigned)M->comp_ta[c]) & 3);
     }
     cx.nbm = nb[0] + nb[1] + nb[2] + nb[3];
-    cx.c1 = ncomp > 1 ? nb[0] : 0x7fffffff;
-    cx.c2 = ncomp > 2 ? nb[0] + nb[1] : 0x7fffffff;
-    cx.c3 = ncomp > 3 ? nb[0] + nb[1] + nb[2] : 0x7fffffff;
+    if (cx.nbm > 16) return;  // beyond the standard's 10 blocks per MCU: sequential kernel
+    if (tid < 16) {
+        const int c = (tid >= nb[0]) + (tid >= nb[0] + nb[1]) + (tid >= nb[0] + nb[1] + nb[2]);
+        const int tdc = c == 0 ? cx.td[0] : (c == 1 ? cx.td[1] : (c == 2 ? cx.td[2] : cx.td[3]));
+        const int tac = c == 0 ? cx.ta[0] : (c == 1 ? cx.ta[1] : (c == 2 ? cx.ta[2] : cx.ta[3]));
+        s_blk[tid] = (unsigned char)(tdc | (tac << 3) | (c == 0 ? 0x80 : 0));
+    }
     const unsigned mcus = rfl((unsigned)M->mcus_x) * rfl((unsigned)M->mcus_y);
     cx.total_y = mcus * (unsigned)nb[0];
     const unsigned total_bits = clean_len * 8u;
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
         p = s_p[tid];
         k = (int)(s_kb[tid] & 255u);
         b = (int)(s_kb[tid] >> 8);
-        decode_chunk<false, IN_LDS>(cx, T, s_zz, p, k, b, end, ycount, err, 0u, cbase);
+        decode_chunk<false, IN_LDS>(cx, T, s_zz, s_blk, p, k, b, end, ycount, err, 0u, cbase);
         __syncthreads();
         // lane tid's end state is lane tid+1's next start state
         int changed = 0;
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     p = s_p[tid];
     k = (int)(s_kb[tid] & 255u);
     b = (int)(s_kb[tid] >> 8);
-    decode_chunk<true, IN_LDS>(cx, T, s_zz, p, k, b, end, ycount, err, ybase, cbase);
+    decode_chunk<true, IN_LDS>(cx, T, s_zz, s_blk, p, k, b, end, ycount, err, ybase, cbase);
     if (tid == 0) s_flag = 0;
     __threadfence_block();
     __syncthreads();
