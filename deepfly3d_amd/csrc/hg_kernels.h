@@ -1132,7 +1132,7 @@ struct HeadCfg {
 };
 
 template <typename T, bool LAST>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void head_kernel(HeadArgs p) {
+__global__ __launch_bounds__(256, ((sizeof(T) == 2 || LAST) ? 2 : 1)) void head_kernel(HeadArgs p) {
     using C = HeadCfg<T>;
     constexpr int EB = C::EB;
     constexpr int PER16 = Elem<T>::PER16;
