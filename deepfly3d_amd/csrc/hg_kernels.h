@@ -613,6 +613,7 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
 // =====================================================================================================
 struct BottleneckArgs {
     const void* in;     // NHWC [V, H, W, CIN]
+    const void* in2;    // UP: NHWC [V, H/2, W/2, CIN]; the block's input is in + nearest-upsample(in2), rounded to T
     void* out;          // NHWC [V, H, W, 2*PL]
     void* pool;         // optional NHWC [V, H/2, W/2, 2*PL]: 2x2 max-pool of `out`, written by the same epilogue
     const void* w1;     // [PL][CIN]
@@ -660,9 +661,10 @@ struct BtCfg {
     static constexpr int NT = PL / 32;                             // channel tiles of the intermediates
 };
 
-template <typename T, int CIN, int PL, bool DS>
+template <typename T, int CIN, int PL, bool DS, bool UP = false>
 __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
     using C = BtCfg<T, CIN, PL, DS>;
+    static_assert(!UP || !DS, "the upsample-add input exists for the identity-skip block only");
     constexpr int EB = C::EB;
     constexpr int CO = C::CO;
     constexpr int NT = C::NT;
@@ -683,6 +685,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
     const int ty0 = (b % tiles_y) * BT_TH;
     const int view = b / tiles_y;
     const unsigned char* const xin = reinterpret_cast<const unsigned char*>(p.in) + (size_t)view * p.H * p.W * CIN * EB;
+    // UP: the low-resolution addend (the hourglass' up-path: x = in + upsample(in2), what upadd_kernel would have written)
+    const unsigned char* const xin2 = UP ? reinterpret_cast<const unsigned char*>(p.in2) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN * EB : nullptr;
 
     // validity of the 192 halo rows (inside the image?) as three 64-bit masks
     if (tid < BT_HROWS) {
@@ -730,6 +734,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
         const int ct = wave % NT1, rt0 = (wave / NT1) * RT;
         const int chunk = tid % CPR, srow = tid / CPR;
         const unsigned char* xp[XP];
+        const unsigned char* xq[UP ? XP : 1];
         bool xok[XP];
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
@@ -738,8 +743,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
             const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
             xok[i] = hp < BT_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             xp[i] = xin + ((size_t)(xok[i] ? y : 0) * p.W + (xok[i] ? x : 0)) * CIN * EB;
+            if constexpr (UP) xq[i] = xin2 + ((size_t)(xok[i] ? (y >> 1) : 0) * (p.W / 2) + (xok[i] ? (x >> 1) : 0)) * CIN * EB;
         }
         u32x4 rx[XP], rw[WP];
+        u32x4 rb[UP ? XP : 1];
         PreactCoef<T> coef;
         auto load1 = [&](int s) {
             const int c0 = s * KE + chunk * PER16;
@@ -747,6 +754,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
             // out-of-image halo rows read pixel (0,0) (a valid address) and are masked to zero in store1: no branches
 #pragma unroll
             for (int i = 0; i < XP; ++i) rx[i] = *reinterpret_cast<const u32x4*>(xp[i] + (size_t)c0 * EB);
+            if constexpr (UP) {
+#pragma unroll
+                for (int i = 0; i < XP; ++i) rb[i] = *reinterpret_cast<const u32x4*>(xq[i] + (size_t)c0 * EB);
+            }
 #pragma unroll
             for (int i = 0; i < WP; ++i)
                 rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.w1) + ((size_t)(kh * T1W + srow + i * RPP) * CIN + c0) * EB);
@@ -756,7 +767,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
             unsigned char* const sw = sx + X_BYTES;
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
-                u32x4 v = preact_apply<T>(rx[i], coef);  // bn1 + ReLU, deferred past the MFMAs
+                u32x4 v = rx[i];
+                if constexpr (UP) v = add_chunk<T>(v, rb[i]);  // x = in + upsample(in2), rounded like upadd_kernel's output
+                v = preact_apply<T>(v, coef);  // bn1 + ReLU, deferred past the MFMAs
                 const unsigned keep = xok[i] ? 0xffffffffu : 0u;
                 v &= keep;
                 *reinterpret_cast<u32x4*>(sx + (srow + i * RPP) * PITCH + chunk * 16) = v;
@@ -1015,6 +1028,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
                     for (int r = 0; r < 16; ++r) {
                         const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
                         xr[r] = reinterpret_cast<const float*>(xin)[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n];
+                        if constexpr (UP)
+                            xr[r] += reinterpret_cast<const float*>(xin2)[((size_t)(ty0 / 2 + wave) * (p.W / 2) + ((tx0 + (pl & 15)) >> 1)) * CIN + n];
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][r] += xr[r];
@@ -1048,6 +1063,15 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
             constexpr int OP = 128 * 2 + 16;                    // slice row pitch (bytes)
             unsigned char* const slice = t1_lds + wave * (32 * OP);
             const int odd = lane & 1;
+            u32x4 x2[UP ? 8 : 1];
+            if constexpr (UP) {  // low-resolution addend of the residual: pixel (row wave of the half-size tile, column pw/2)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int pw = 4 * c + (lane >> 4);
+                    x2[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin2) +
+                        ((size_t)(ty0 / 2 + wave) * (p.W / 2) + ((tx0 + (pw & 15)) >> 1)) * CIN + nh * 128 + (lane & 15) * 8);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1066,6 +1090,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
                 u32x4 v = *reinterpret_cast<const u32x4*>(slice + pw * OP + (lane & 15) * 16);
                 if constexpr (!DS) {
                     u32x4 x4 = {xres[4 * c], xres[4 * c + 1], xres[4 * c + 2], xres[4 * c + 3]};
+                    if constexpr (UP) x4 = add_chunk<T>(x4, x2[c]);
                     v = add_chunk<T>(v, x4);
                 }
                 fin[c] = v;

@@ -142,3 +142,18 @@ def test_bf16_argmax_agreement_with_fp32(native_lib, cuda, oracle_net, images):
     near = ((p32 - p16).abs() * torch.tensor([64.0, 128.0], device=cuda)).amax(dim=-1).le(2.0).float().mean().item()
     print(f"bf16 vs fp32 arg-max: identical cell {same:.3f}, within 2 cells {near:.3f}")
     assert near >= 0.6  # random-weight heat-maps are nearly flat; trained nets have sharp peaks
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_upsample_add_is_bit_identical(native_lib, cuda, oracle_net, images, dtype):
+    """The upsample + add folded into the consuming bottleneck (default for bf16) against the separate upadd kernel:
+    8 launches fewer, bit-identical heat-maps -- the sum is rounded to the engine dtype exactly as upadd_kernel would
+    have stored it."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
+    x = images.to(cuda)
+    on = HourglassEngine(sd, dtype=dtype, device=cuda, fuse_upadd=True)
+    off = HourglassEngine(sd, dtype=dtype, device=cuda, fuse_upadd=False)
+    assert len(off.steps()) - len(on.steps()) == 8
+    assert torch.equal(on.forward(x), off.forward(x))
