@@ -549,7 +549,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.W = ti.w;
                 const int cin = st.conv.cin, pl = st.conv.cout;
                 const double px = (double)n * ti.h * ti.w;
-                ScopedTimer tm(h, s, std::string("bottleneck_kernel<") + tname + ", " + std::to_string(cin) + ", " + std::to_string(pl) + ", " + (ds ? "true" : "false") + ">",
+                ScopedTimer tm(h, s, std::string("bottleneck_kernel<") + tname + ", " + std::to_string(cin) + ", " + std::to_string(pl) + ", " + (ds ? "true" : "false") + ", " + (a.in2 ? "true" : "false") + ">",
                                2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + (ds ? 2.0 * cin * pl : 0.0)), px * eb * (cin + 2.0 * pl));
                 const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
                 if (int rc = launch_bottleneck<T>(a, cin, pl, blocks, s)) return rc;
