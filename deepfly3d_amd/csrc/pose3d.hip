@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void median_kernel(const double* __restrict__ 
         s_rank[0] = (n - 1) / 2;
         s_rank[1] = n / 2;
     }
+    const bool dense = inner_n >= n;
     unsigned long long mask = 0;
     for (int pass = 7; pass >= 0; --pass) {
         const int shift = 8 * pass;
@@ -54,7 +55,15 @@ __global__ __launch_bounds__(256) void median_kernel(const double* __restrict__ 
         const unsigned long long p0 = s_prefix[0], p1 = s_prefix[1];
         const bool same = p0 == p1;
         for (long long i = tid; i < n; i += 256) {
-            const long long o = i / inner_n, r = i - o * inner_n;
+            long long o, r;
+            if (dense) {  // one run of n elements: no index arithmetic
+                o = 0;
+                r = i;
+            } else {      // 32-bit division (n < 2^31 is checked by the callers): a 64-bit one costs more than the load
+                const unsigned q = (unsigned)i / (unsigned)inner_n;
+                o = q;
+                r = (long long)((unsigned)i - q * (unsigned)inner_n);
+            }
             const unsigned long long k = order_key(col[o * outer_stride + r * inner_stride]);
             const unsigned int bin = (unsigned int)(k >> shift) & 255u;
             if ((k & mask) == p0) atomicAdd(&hist[0][bin], 1u);
@@ -313,7 +322,7 @@ extern "C" {
 
 int df3d_column_median(const double* cols, int ncols, long long n, long long col_stride, double* out, void* stream) {
     DF3D_CHECK_ARG(cols && out, "null pointer");
-    DF3D_CHECK_ARG(ncols >= 0 && n >= 1, "need ncols >= 0 and n >= 1");
+    DF3D_CHECK_ARG(ncols >= 0 && n >= 1 && n < (1LL << 31), "need ncols >= 0 and 1 <= n < 2^31");
     if (ncols == 0) return DF3D_OK;
     hipLaunchKernelGGL(median_kernel, dim3(ncols, 1), dim3(256), 0, df3d::as_stream(stream), cols, n, n, 1LL, 0LL, col_stride, 0LL, out);
     DF3D_LAUNCH_CHECK();
@@ -325,7 +334,7 @@ long long df3d_procrustes_work_doubles(long long T) { return T < 0 ? 0 : work_do
 int df3d_procrustes(const double* pts, long long T, const double* tmpl_seg_med, const double* tmpl_fit_med, double* out,
                     double* work, long long work_len, void* stream) {
     DF3D_CHECK_ARG(pts && out && work && tmpl_seg_med && tmpl_fit_med, "null pointer");
-    DF3D_CHECK_ARG(T >= 1, "need at least one frame");
+    DF3D_CHECK_ARG(T >= 1 && T * 38 < (1LL << 31), "need 1 <= T < 2^31 / 38 frames");
     DF3D_CHECK_ARG(work_len >= work_doubles(T), "work buffer too small (df3d_procrustes_work_doubles)");
     hipStream_t s = df3d::as_stream(stream);
     Template tm;
@@ -349,7 +358,7 @@ int df3d_procrustes(const double* pts, long long T, const double* tmpl_seg_med, 
 int df3d_pose_normalize(const double* in, long long T, int njoints, int rotate, double* out, double* work, long long work_len,
                         void* stream) {
     DF3D_CHECK_ARG(in && out && work, "null pointer");
-    DF3D_CHECK_ARG(T >= 1 && njoints >= 1, "need T >= 1 and njoints >= 1");
+    DF3D_CHECK_ARG(T >= 1 && njoints >= 1 && T * njoints < (1LL << 31), "need T >= 1, njoints >= 1 and T * njoints < 2^31");
     DF3D_CHECK_ARG(work_len >= 3, "work buffer needs 3 doubles");
     hipStream_t s = df3d::as_stream(stream);
     const long long TJ = T * njoints;
