@@ -14,7 +14,6 @@ import glob
 import os
 import pickle
 import re
-import subprocess
 from typing import List, Optional
 
 import numpy as np
@@ -25,7 +24,7 @@ from .camera_network import CameraNetwork
 from .config import config, load_calibration
 from .db import PoseDB
 from .inference import inference_folder
-from .os_util import get_max_img_id, parse_vid_name
+from .os_util import camera_videos, extract_frames, get_max_img_id, parse_frame_rate, parse_vid_name, probe_frame_rate
 from .procrustes import procrustes_separate, video_pose
 
 _KNOWN_ORDERINGS = [
@@ -62,7 +61,7 @@ def relayout_points2d(points19, camera_ordering, device=None):
 
 
 class Core:
-    """Main interface to the 2-D and 3-D pose estimation (reference df3d/core.py:62)."""
+    """Main interface to the 2-D and 3-D pose estimation (same surface as reference df3d/core.py:62)."""
 
     def __init__(self, input_folder: str, output_folder: Optional[str] = None, num_images_max: Optional[int] = None,
                  camera_ordering: List[int] = [0, 1, 2, 3, 4, 5, 6], dtype: str = "f32", device=None):
@@ -71,65 +70,80 @@ class Core:
         self.dtype, self.device = dtype, device
         rank, world = dd.current()
         self.is_primary = rank == 0  # multi-GPU: rank 0 alone expands videos, calibrates and writes results
+
+        def everyone_waits():
+            if world > 1:
+                torch.distributed.barrier()
+
         self.input_folder = input_folder
-        self.output_folder = self.input_folder + "_df3d" if output_folder is None else output_folder
+        self.output_folder = output_folder if output_folder is not None else self.input_folder + "_df3d"
         if self.is_primary:
             self.expand_videos()
-        if world > 1:
-            torch.distributed.barrier()  # the frames exist for every rank from here on
+        everyone_waits()  # the frames exist for every rank from here on
         self.fps = self.get_fps()
-        self.num_images_max = num_images_max if num_images_max is not None else 0
-        self.max_img_id = get_max_img_id(self.input_folder)
-        if self.num_images_max > 0:
-            self.num_images = min(self.num_images_max, self.max_img_id + 1)
-            self.max_img_id = self.num_images - 1
-        else:
-            self.num_images = self.max_img_id + 1
-        self._image_path = os.path.join(self.input_folder, "camera_{cam_id}_img_{img_id}.jpg")
-        image0 = self._image_path.format(cam_id=0, img_id=0)
-        if "image_shape" in config:
-            self.image_shape = config["image_shape"]
-        if os.path.exists(image0):
-            from PIL import Image
 
-            with Image.open(image0) as im:
-                shape0 = [im.size[0], im.size[1]]  # [W, H]
-            if "image_shape" in config and shape0 != self.image_shape:
-                raise ValueError(f"Actual image shape {shape0} does not match config.py image shape {self.image_shape}")
-            self.image_shape = config["image_shape"] = shape0
-        if not hasattr(self, "image_shape"):
-            raise ValueError(f"Image shape not specified in config and could not be read from {image0}")
+        # frame range: ids 0 .. max_img_id, optionally cut to the first num_images_max
+        self.num_images_max = num_images_max or 0
+        last = get_max_img_id(self.input_folder)
+        self.num_images = min(self.num_images_max, last + 1) if self.num_images_max > 0 else last + 1
+        self.max_img_id = self.num_images - 1
+
+        self._image_path = os.path.join(self.input_folder, "camera_{cam_id}_img_{img_id}.jpg")
+        self.image_shape = self._resolve_image_shape(self._image_path.format(cam_id=0, img_id=0))
 
         if self.is_primary:
-            self.db = PoseDB(self.output_folder)
-        if world > 1:
-            torch.distributed.barrier()
+            self.db = PoseDB(self.output_folder)  # creates pose_corr_*.pkl on first use, like the reference
+        everyone_waits()
         if not self.is_primary:
             self.db = PoseDB(self.output_folder)  # written by rank 0 above: loaded, not re-created
         self.camera_ordering = self.setup_camera_ordering(camera_ordering)
-        self.camNet = None
-        self.points2d = None
-        self.points3d = None
-        self.conf = None
-        if os.path.exists(self.save_path):  # resume from an earlier result (reference :109-126)
-            with open(self.save_path, "rb") as f:
-                prev = pickle.load(f)
-            self.points2d = prev["points2d"]
-            self.conf = prev["heatmap_confidence"]
-            if "points3d" in prev:
-                self.points3d = prev["points3d"]
-            self.camNet = CameraNetwork(prev["points2d"] * self.image_shape[::-1], calib=prev, image_path=self._image_path, device=self.device)
+        self.camNet = self.points2d = self.points3d = self.conf = None
+        if os.path.exists(self.save_path):
+            self._resume(self.save_path)
+
+    @staticmethod
+    def _resolve_image_shape(first_image):
+        """[W, H] of the recording: read from the first frame, cross-checked with a configured shape, remembered in
+        the config (reference df3d/core.py:84-100: same precedence, same ValueErrors)."""
+        configured = config.get("image_shape")
+        if os.path.exists(first_image):
+            from PIL import Image
+
+            with Image.open(first_image) as im:
+                actual = list(im.size)
+            if configured is not None and actual != configured:
+                raise ValueError(f"Actual image shape {actual} does not match config.py image shape {configured}")
+            config["image_shape"] = actual
+            return actual
+        if configured is None:
+            raise ValueError(f"Image shape not specified in config and could not be read from {first_image}")
+        return configured
+
+    def _resume(self, result_file):
+        """Re-open an earlier result: its poses and the cameras it holds (reference df3d/core.py:109-126)."""
+        with open(result_file, "rb") as f:
+            earlier = pickle.load(f)
+        self.points2d, self.conf = earlier["points2d"], earlier["heatmap_confidence"]
+        self.points3d = earlier.get("points3d", self.points3d)
+        pixels = earlier["points2d"] * self.image_shape[::-1]
+        self.camNet = CameraNetwork(pixels, calib=earlier, image_path=self._image_path, device=self.device)
 
     # -- properties -----------------------------------------------------------------------------------
+    @staticmethod
+    def _as_directory(path, create=False):
+        if create:
+            os.makedirs(path, exist_ok=True)
+        path = os.path.abspath(path).rstrip("/")
+        assert os.path.isdir(path), f"Not a directory {path}"
+        return path
+
     @property
     def input_folder(self):
         return self._input_folder
 
     @input_folder.setter
     def input_folder(self, value):
-        value = os.path.abspath(value).rstrip("/")
-        assert os.path.isdir(value), f"Not a directory {value}"
-        self._input_folder = value
+        self._input_folder = self._as_directory(value)
 
     @property
     def output_folder(self):
@@ -137,10 +151,7 @@ class Core:
 
     @output_folder.setter
     def output_folder(self, value):
-        os.makedirs(value, exist_ok=True)
-        value = os.path.abspath(value).rstrip("/")
-        assert os.path.isdir(value), f"Not a directory {value}"
-        self._output_folder = value
+        self._output_folder = self._as_directory(value, create=True)
 
     @property
     def number_of_joints(self):
@@ -156,7 +167,8 @@ class Core:
 
     @property
     def save_path(self):
-        return os.path.join(self.output_folder, "df3d_result_{}.pkl".format(self.input_folder.replace("/", "_")))
+        flat = self.input_folder.replace("/", "_")
+        return os.path.join(self.output_folder, f"df3d_result_{flat}.pkl")
 
     # -- hot path -------------------------------------------------------------------------------------
     def pose2d_estimation(self, batch_size: int = 8, disable_pin_memory: bool = False):
@@ -226,67 +238,60 @@ class Core:
         print(f"Saved results at: {self.save_path}")
 
     # -- helpers --------------------------------------------------------------------------------------
+    def _correction_for(self, corrections, cam_id, img_id):
+        return corrections.get(cam_id, {}).get(img_id)
+
     def corrected_points2d(self, cam_id, img_id):
-        """Estimated or manually corrected 2-D joints of one image (reference :374-385)."""
-        points2d = self.camNet.cam_list[cam_id][img_id].copy()
-        manual = self.db.manual_corrections()
-        if img_id in manual.get(cam_id, {}):
-            points2d[:] = manual[cam_id][img_id]
-        return points2d
+        """Joints of one image in pixels: the manual correction when one is stored, else the estimate
+        (reference df3d/core.py:374-385)."""
+        estimate = self.camNet.cam_list[cam_id][img_id].copy()
+        fix = self._correction_for(self.db.manual_corrections(), cam_id, img_id)
+        if fix is not None:
+            estimate[:] = fix
+        return estimate
 
     def corrected_points2d_matrix(self):
-        """results[cam_id][img_id][joint_id] = (row, col) with the manual corrections applied (reference :387-401)."""
-        manual = self.db.manual_corrections()
-        pts2d = self.camNet.points2d
-        for cam_id in range(config["num_cameras"]):
-            for img_id in range(self.num_images):
-                if img_id in manual.get(cam_id, {}):
-                    pts2d[cam_id, img_id, :] = manual[cam_id][img_id]
-        return pts2d
+        """results[cam_id][img_id][joint_id] = (row, col), stored corrections written over the camera network's
+        estimates -- in place, like the reference (df3d/core.py:387-401)."""
+        corrections = self.db.manual_corrections()
+        everything = self.camNet.points2d
+        for cam_id, per_image in corrections.items():
+            for img_id, fix in per_image.items():
+                if cam_id < config["num_cameras"] and img_id < self.num_images:
+                    everything[cam_id, img_id, :] = fix
+        return everything
 
     def setup_camera_ordering(self, camera_ordering) -> np.ndarray:
-        if camera_ordering is None:
-            camera_ordering = find_default_camera_ordering(self.input_folder)
-        return np.array(camera_ordering)
+        order = find_default_camera_ordering(self.input_folder) if camera_ordering is None else camera_ordering
+        return np.array(order)
 
     def get_image(self, cam_id, img_id):
         return self.camNet.cam_list[cam_id].get_image(img_id)
 
     def get_fps(self):
-        rates = []
-        for vid in glob.glob(os.path.join(self.input_folder, "camera_?.mp4")):
-            cmd = ["ffprobe", "-v", "error", "-select_streams", "v:0", "-show_entries", "stream=avg_frame_rate", "-of",
-                   "default=noprint_wrappers=1:nokey=1", vid]
-            try:
-                rates.append(subprocess.check_output(cmd, text=True))
-            except Exception:
+        """Frame rate of the first camera video ffprobe can read, None without videos or without ffprobe."""
+        for video in camera_videos(self.input_folder):
+            cmd, answer = probe_frame_rate(video)
+            if answer is None:
                 logger.warning(f"Command failed: {' '.join(cmd)}")
-                break
-        if not rates:
-            return None
-        rate = rates[0]
-        try:
-            return float(rate)
-        except ValueError:
-            pass
-        try:
-            num, den = map(int, rate.split("/"))
-            return num / den if den else None
-        except ValueError:
-            logger.warning(f'Could not parse framerate "{rate}" returned by ffprobe, so setting fps to None.')
-            return None
+                return None
+            rate = parse_frame_rate(answer)
+            if rate is None:
+                logger.warning(f'Could not parse framerate "{answer}" returned by ffprobe, so setting fps to None.')
+            return rate
+        return None
 
     def expand_videos(self):
-        """camera_x.mp4 -> camera_x_img_y.jpg through ffmpeg when the frames are not there yet (reference :446-459)."""
-        for vid in glob.glob(os.path.join(self.input_folder, "camera_?.mp4")):
-            cam_id = parse_vid_name(os.path.basename(vid))
-            have = any(os.path.exists(os.path.join(self.input_folder, f"camera_{cam_id}_img_{n}.jpg")) for n in ("0", "000000"))
-            if not have:
-                subprocess.call(f"ffmpeg -nostats -loglevel error -i {vid} -qscale:v 2 -start_number 0 {self.input_folder}/camera_{cam_id}_img_%d.jpg  < /dev/null", shell=True)
+        """camera_x.mp4 -> camera_x_img_y.jpg through ffmpeg for cameras whose frames are not there yet."""
+        for video in camera_videos(self.input_folder):
+            cam_id = parse_vid_name(os.path.basename(video))
+            first_frames = (os.path.join(self.input_folder, f"camera_{cam_id}_img_{n}.jpg") for n in ("0", "000000"))
+            if not any(os.path.exists(f) for f in first_frames):
+                extract_frames(video, self.input_folder, cam_id)
 
     def delete_images(self):
-        """Remove expanded frames of cameras whose .mp4 is present (reference :461-475)."""
-        for vid in glob.glob(os.path.join(self.input_folder, "camera_[0-9].mp4")):
-            cam_id = parse_vid_name(os.path.basename(vid))
-            for img in glob.glob(os.path.join(self.input_folder, f"camera_{cam_id}_img_*.jpg")):
-                os.remove(img)
+        """Remove the expanded frames of every camera that still has its .mp4."""
+        for video in camera_videos(self.input_folder, any_id=False):
+            cam_id = parse_vid_name(os.path.basename(video))
+            for frame in glob.glob(os.path.join(self.input_folder, f"camera_{cam_id}_img_*.jpg")):
+                os.remove(frame)

@@ -48,3 +48,42 @@ def parse_img_name(name):
 def parse_vid_name(name):
     m = re.match(r"camera_(\d+)", name.replace(".mp4", ""))
     return int(m[1])
+
+
+# ---- camera_<id>.mp4 companions of an image folder (reference df3d/core.py:405-475) -------------------------------
+def camera_videos(folder, any_id=True):
+    """Sorted `camera_<c>.mp4` files of `folder` (`any_id=False`: single-digit ids only, the reference's delete rule)."""
+    import glob
+
+    return sorted(glob.glob(os.path.join(folder, "camera_?.mp4" if any_id else "camera_[0-9].mp4")))
+
+
+def probe_frame_rate(video):
+    """Average frame rate string ffprobe reports for the first video stream, or None when ffprobe is unusable."""
+    import subprocess
+
+    cmd = ["ffprobe", "-v", "error", "-select_streams", "v:0", "-show_entries", "stream=avg_frame_rate",
+           "-of", "default=noprint_wrappers=1:nokey=1", video]
+    try:
+        return cmd, subprocess.check_output(cmd, text=True)
+    except Exception:
+        return cmd, None
+
+
+def parse_frame_rate(text):
+    """'30' -> 30.0, '30000/1001' -> 29.97, '0/0' or garbage -> None."""
+    text = text.strip()
+    for convert in (float, lambda t: (lambda n, d: n / d if d else None)(*map(int, t.split("/")))):
+        try:
+            return convert(text)
+        except (ValueError, TypeError):
+            continue
+    return None
+
+
+def extract_frames(video, folder, cam_id):
+    """ffmpeg: camera_<c>.mp4 -> camera_<c>_img_<n>.jpg, numbered from 0, quality scale 2."""
+    import subprocess
+
+    pattern = os.path.join(folder, f"camera_{cam_id}_img_%d.jpg")
+    return subprocess.call(f"ffmpeg -nostats -loglevel error -i {video} -qscale:v 2 -start_number 0 {pattern}  < /dev/null", shell=True)
