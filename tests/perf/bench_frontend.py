@@ -1,6 +1,6 @@
 """Input front-end measurement: JPEG files -> frames/s, PCIe and file IO included.
 
-  python scripts/bench_frontend.py [--frames 256] [--out profiles/r01_frontend.json]
+  python tests/perf/bench_frontend.py [--frames 256] [--out profiles/r01_frontend.json]
 
 Builds a folder of `frames` x 7 camera JPEGs by repeating the reference's 14 sample images (tests/golden/images),
 then reports
@@ -22,7 +22,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from deepfly3d_amd import inference, jpeg  # noqa: E402
 
 
@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    here = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     root = tempfile.mkdtemp(prefix="df3d_frontend_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     folder = os.path.join(root, "images")
     os.makedirs(folder)

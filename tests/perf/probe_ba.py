@@ -1,6 +1,6 @@
-"""BA timing probe: python scripts/probe_ba.py [frames]"""
+"""BA timing probe: python tests/perf/probe_ba.py [frames]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from deepfly3d_amd.bundle_adjust import bundle_adjust
 from deepfly3d_amd.synthetic import synthetic_points2d

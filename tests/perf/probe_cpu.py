@@ -1,5 +1,5 @@
 import os, time, torch, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import hourglass_torch as oh
 print("cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
 for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
