@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the DeepFly3D per-frame hot path on MI355X (BASELINE.json metric: frames/sec, 7-view 2D -> 3D).
 
-    python bench.py --gpus 1 --steps 32 --warmup 3
+    python bench.py --gpus 1 --steps 8 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): per GPU `steps x frames_per_step` synthetic frames (default 32 x 32 = 1 024),
+Workload (BASELINE.json configs[1]): per GPU `steps x frames_per_step` synthetic frames (default 8 x 128 = 1 024),
 each 7 views of 256 x 512 x 3 float32, seeded and resident in HBM before the timed region; 2-stack hourglass in
 fp32 with seeded synthetic weights (no checkpoints offline); fixed calib.pkl cameras.  One "step" = one batch of
 `frames_per_step` frames through the whole path: hourglass -> arg-max/confidence -> 19->38 layout -> DLT.
@@ -32,9 +32,9 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-per-step", type=int, default=128)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--pool-frames", type=int, default=0, help="distinct frames resident in HBM (0 = steps*frames_per_step, capped at 1000)")
     ap.add_argument("--ba-window", type=int, default=0,

@@ -97,7 +97,7 @@ def _image_size(path):
 
 
 # views per device batch: the reference's `batch_size` (8) is a lower bound, results do not depend on the batch
-DEVICE_BATCH_VIEWS = 224
+DEVICE_BATCH_VIEWS = 896
 
 
 def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return_confidence=True, max_img_id=None,

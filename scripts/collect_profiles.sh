@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/r01
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for dt in f32 bf16; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${dt}_stats" -o bench -- python "$R/bench.py" --dtype $dt --steps 16 --no-cpu-baseline > "$OUT/${dt}_bench_profiled.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${dt}_stats" -o bench -- python "$R/bench.py" --dtype $dt --steps 8 --no-cpu-baseline > "$OUT/${dt}_bench_profiled.log" 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${dt}_fetch" -o pmc -- python "$R/bench.py" --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${dt}_write" -o pmc -- python "$R/bench.py" --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
   find "$OUT" -name "*kernel_trace.csv" -delete
