@@ -132,7 +132,10 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
     points_flat, conf_flat = points.view(ncam * T, config["num_predict"], 2), conf.view(ncam * T, config["num_predict"], 1)
     heat = [] if return_heatmap else None
     bs = max(1, int(batch_size), DEVICE_BATCH_VIEWS if not return_heatmap else 1)
-    chunks = [items[lo : lo + bs] for lo in range(0, len(items), bs)]
+    # a short first batch gets the GPU going while the reader threads fetch the first full-size one
+    first = min(bs, 224)
+    starts = [0] + list(range(first, len(items), bs))
+    chunks = [items[lo:hi] for lo, hi in zip(starts, starts[1:] + [len(items)]) if hi > lo]
     if not chunks:
         raise FileNotFoundError(f"no images to process in {folder}")
     paths = [[image_path_for(folder, c, t_first + t) for c, t in chunk] for chunk in chunks]
@@ -146,7 +149,7 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
             x = preprocess_u8(luma, flip, tuple(config["input_shape"]))
             res = inference_views(x, engine, return_heatmap=return_heatmap)
             # items are (camera, frame) in camera-major order = the flat order of points[ncam, T]: contiguous copies
-            lo = k * bs
+            lo = starts[k]
             points_flat[lo : lo + len(chunk)] = res[0]
             conf_flat[lo : lo + len(chunk), :, 0] = res[1]
             if return_heatmap:
