@@ -222,8 +222,11 @@ def main():
             "dtype": a.dtype,
             "data": "synthetic (seeded uniform frames resident in HBM, seeded synthetic hourglass weights, data/calib.pkl cameras)",
             "config": {
-                "workload": f"BASELINE configs[{1 if a.dtype == 'f32' else 2}]: {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {a.dtype}, "
-                            "arg-max + 38-joint layout + fp64 DLT with fixed calib.pkl",
+                "workload": (f"BASELINE configs[4] (per-GPU share): {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {a.dtype}, "
+                             f"arg-max + 38-joint layout + fp64 DLT, bundle-adjustment re-calibration every {a.ba_window} frames"
+                             if a.ba_window else
+                             f"BASELINE configs[{1 if a.dtype == 'f32' else 2}]: {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {a.dtype}, "
+                             "arg-max + 38-joint layout + fp64 DLT with fixed calib.pkl"),
                 "frames_per_step": fps_step,
                 "frames_per_gpu": total_frames,
                 "parallelism": f"frame-sharded x{world}, one gather",
