@@ -18,8 +18,9 @@ OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 LIB_PATH = os.path.join(HERE, "libdf3d_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
-# pose3d.hip reproduces the reference's float64 recurrences bit for bit: no multiply-add fusion there
-FILE_FLAGS = {"pose3d.hip": ["-ffp-contract=off"]}
+# pose3d.hip and ba_lsmr.hip reproduce float64 scalar recurrences (One-Euro filter, LSMR rotations) exactly as the
+# CPU reference arithmetic rounds them: no multiply-add fusion there
+FILE_FLAGS = {"pose3d.hip": ["-ffp-contract=off"], "ba_lsmr.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc():

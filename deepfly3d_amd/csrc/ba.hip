@@ -14,6 +14,7 @@
 #include <cmath>
 
 #include "common.h"
+#include "ba_lsmr.h"
 
 namespace {
 
@@ -167,16 +168,7 @@ __global__ __launch_bounds__(256) void ba_matvec_kernel(df3d_ba_problem p, const
     *reinterpret_cast<double2*>(y + 2 * (size_t)i) = out;
 }
 
-// fixed-order block reduction of one double per thread (256 threads): wave butterflies then 4 -> 1 in LDS
-__device__ __forceinline__ double block_reduce_256(double v, double* lds4) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) lds4[wave] = v;
-    __syncthreads();
-    return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
-}
+using df3d_lsmr::block_reduce_256;
 
 // stage 1 of J^T u (SQUARE = false) or of the column norms (SQUARE = true), camera columns only:
 // partial[(c * NCHUNK + chunk) * 6 + k]
@@ -333,6 +325,54 @@ __global__ __launch_bounds__(256) void absmax_kernel(const double* __restrict__ 
         __syncthreads();
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = lds[0];
+}
+
+// ---- LSMR vector kernels that take their coefficients from the device-resident state (no-ops once it has stopped) ----
+// WHICH = 0:  u = t - alpha * u   (t = A v);   WHICH = 1:  v = t - beta * v   (t = A^T u, only when beta > 0)
+template <int WHICH>
+__global__ __launch_bounds__(256) void lsmr_bidiag_kernel(const df3d_lsmr::State* __restrict__ st, const double* __restrict__ t,
+                                                          double* __restrict__ y, size_t n, double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    if (st->istop || (WHICH == 1 && !st->beta_pos)) return;
+    const double b = WHICH == 0 ? -st->alpha : -st->beta;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double v = 1.0 * t[i];
+        v += b * y[i];
+        y[i] = v;
+        acc += v * v;
+    }
+    const double tot = block_reduce_256(acc, lds4);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// WHICH = 0:  u *= 1/beta;   WHICH = 1:  v *= 1/alpha   (both only when beta > 0)
+template <int WHICH>
+__global__ __launch_bounds__(256) void lsmr_scale_kernel(const df3d_lsmr::State* __restrict__ st, double* __restrict__ x, size_t n) {
+    if (st->istop || !st->beta_pos) return;
+    const double a = WHICH == 0 ? st->inv_beta : st->inv_alpha;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = a * x[i];
+}
+
+// hbar = h - c1*hbar ; x += c2*hbar ; h = v - c3*h ; partial sum(x^2)
+__global__ __launch_bounds__(256) void lsmr_update_dev_kernel(const df3d_lsmr::State* __restrict__ st, double* __restrict__ hbar,
+                                                              double* __restrict__ h, double* __restrict__ x,
+                                                              const double* __restrict__ v, size_t n, double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    if (st->istop) return;
+    const double c1 = st->c1, c2 = st->c2, c3 = st->c3;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double hi = h[i];
+        const double hb = hi - c1 * hbar[i];
+        const double xi = x[i] + c2 * hb;
+        hbar[i] = hb;
+        x[i] = xi;
+        h[i] = v[i] - c3 * hi;
+        acc += xi * xi;
+    }
+    const double tot = block_reduce_256(acc, lds4);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
 inline int grid_for(size_t n) {
@@ -537,104 +577,85 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
     if (alpha > 0)
         if (int rc = df3d_vec_axpby(1.0 / alpha, v, 0.0, nullptr, v, n, stream)) return rc;
 
-    int itn = 0, istop = 0;
-    double zetabar = alpha * beta, alphabar = alpha;
-    double rho = 1, rhobar = 1, cbar = 1, sbar = 0;
+    // ---- iterations: every scalar of the recurrence lives in `st` on the device; the host only enqueues kernels and
+    // looks at (istop, itn) once per CHUNK iterations (kernels of iterations past the stop are no-ops), instead of three
+    // synchronous read-backs per iteration
+    df3d_lsmr::State init{};
+    init.alpha = alpha;
+    init.beta = beta;
+    init.rho = init.rhobar = init.cbar = 1;
+    init.sbar = 0;
+    init.zeta = 0;
+    init.zetabar = alpha * beta;
+    init.alphabar = alpha;
+    init.betadd = beta;
+    init.betad = 0;
+    init.rhodold = 1;
+    init.tautildeold = init.thetatilde = init.dd = 0;
+    init.normA2 = alpha * alpha;
+    init.maxrbar = 0;
+    init.minrbar = 1e100;
+    init.normA = std::sqrt(init.normA2);
+    init.condA = 1;
+    init.normx = 0;
+    init.normr = beta;
+    init.normar = alpha * beta;
+    init.normb = normb;
+    init.damp = damp;
+    init.atol = atol;
+    init.btol = btol;
+    init.ctol = conlim > 0 ? 1.0 / conlim : 0.0;
+    init.inv_beta = init.inv_alpha = 1.0;
+    init.itn = 0;
+    init.istop = 0;
+    init.maxiter = maxiter;
+    init.beta_pos = 1;
     DF3D_HIP(hipMemcpyAsync(h, v, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-    double betadd = beta, betad = 0, rhodold = 1, tautildeold = 0, thetatilde = 0, zeta = 0, dd = 0;
-    double normA2 = alpha * alpha, maxrbar = 0, minrbar = 1e100;
-    double normA = std::sqrt(normA2), condA = 1, normx = 0;
-    const double ctol = conlim > 0 ? 1.0 / conlim : 0.0;
-    double normr = beta, normar = alpha * beta;
 
-    auto finish = [&]() {
-        info_host[0] = istop;
-        info_host[1] = itn;
-        info_host[2] = normr;
-        info_host[3] = normar;
-        info_host[4] = normA;
-        info_host[5] = condA;
-        info_host[6] = normx;
+    auto finish = [&](const df3d_lsmr::State& f) {
+        info_host[0] = f.istop;
+        info_host[1] = f.itn;
+        info_host[2] = f.normr;
+        info_host[3] = f.normar;
+        info_host[4] = f.normA;
+        info_host[5] = f.condA;
+        info_host[6] = f.normx;
         info_host[7] = 0;
         return DF3D_OK;
     };
-    if (normar == 0 || normb == 0) {
+    if (init.normar == 0 || normb == 0) {
         DF3D_HIP(hipStreamSynchronize(s));
-        return finish();
+        return finish(init);
     }
+    static_assert(sizeof(df3d_lsmr::State) <= 64 * sizeof(double), "state must fit behind the reduction scratch");
+    df3d_lsmr::State* st = reinterpret_cast<df3d_lsmr::State*>(result + 8);
+    DF3D_HIP(hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, s));
+    DF3D_HIP(hipStreamSynchronize(s));  // `init` is on the stack
 
-    while (itn < maxiter) {
-        ++itn;
-        // u = A v - alpha u ; beta = |u|
-        if (int rc = launch_matvec(p, Jc, Jp, d_dev, v, tmp_m, s)) return rc;
-        if (int rc = sumsq_axpby(1.0, tmp_m, -alpha, u, u, m, gm, &ss)) return rc;
-        beta = std::sqrt(ss);
-        if (beta > 0) {
-            if (int rc = df3d_vec_axpby(1.0 / beta, u, 0.0, nullptr, u, m, stream)) return rc;
-            // v = A^T u - beta v ; alpha = |v|
+    constexpr int CHUNK = 16;
+    df3d_lsmr::State now = init;
+    for (int done = 0; done < maxiter && now.istop == 0; done += CHUNK) {
+        const int todo = maxiter - done < CHUNK ? maxiter - done : CHUNK;
+        for (int it = 0; it < todo; ++it) {
+            // u = A v - alpha u ; beta = |u| ; u /= beta
+            if (int rc = launch_matvec(p, Jc, Jp, d_dev, v, tmp_m, s)) return rc;
+            hipLaunchKernelGGL(lsmr_bidiag_kernel<0>, dim3(gm), dim3(256), 0, s, st, tmp_m, u, m, red);
+            df3d_lsmr::launch_step_a(st, red, gm, s);
+            hipLaunchKernelGGL(lsmr_scale_kernel<0>, dim3(gm), dim3(256), 0, s, st, u, m);
+            // v = A^T u - beta v ; alpha = |v| ; rotations ; v /= alpha
             if (int rc = launch_rmatvec(p, Jc, Jp, d_dev, u, tmp_n, scratch, s)) return rc;
-            if (int rc = sumsq_axpby(1.0, tmp_n, -beta, v, v, n, gn, &ss)) return rc;
-            alpha = std::sqrt(ss);
-            if (alpha > 0)
-                if (int rc = df3d_vec_axpby(1.0 / alpha, v, 0.0, nullptr, v, n, stream)) return rc;
+            hipLaunchKernelGGL(lsmr_bidiag_kernel<1>, dim3(gn), dim3(256), 0, s, st, tmp_n, v, n, red);
+            df3d_lsmr::launch_step_b(st, red, gn, s);
+            hipLaunchKernelGGL(lsmr_scale_kernel<1>, dim3(gn), dim3(256), 0, s, st, v, n);
+            // hbar, x, h ; |x| ; stopping tests
+            hipLaunchKernelGGL(lsmr_update_dev_kernel, dim3(gn), dim3(256), 0, s, st, hbar, h, x_dev, v, n, red);
+            df3d_lsmr::launch_step_c(st, red, gn, s);
         }
-        double chat, shat, alphahat;
-        sym_ortho(alphabar, damp, chat, shat, alphahat);
-        const double rhoold = rho;
-        double c, sn;
-        sym_ortho(alphahat, beta, c, sn, rho);
-        const double thetanew = sn * alpha;
-        alphabar = c * alpha;
-        const double rhobarold = rhobar, zetaold = zeta;
-        const double thetabar = sbar * rho;
-        const double rhotemp = cbar * rho;
-        sym_ortho(cbar * rho, thetanew, cbar, sbar, rhobar);
-        zeta = cbar * zetabar;
-        zetabar = -sbar * zetabar;
-        // hbar = h - c1 hbar ; x += c2 hbar ; h = v - c3 h ; normx
-        hipLaunchKernelGGL(lsmr_update_kernel, dim3(gn), dim3(256), 0, s, thetabar * rho / (rhoold * rhobarold),
-                           zeta / (rho * rhobar), thetanew / rho, hbar, h, x_dev, v, n, red);
-        hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, red, gn, result);
         DF3D_LAUNCH_CHECK();
-        if (int rc = read_back(result, &ss, s)) return rc;
-        normx = std::sqrt(ss);
-
-        const double betaacute = chat * betadd;
-        const double betacheck = -shat * betadd;
-        const double betahat = c * betaacute;
-        betadd = -sn * betaacute;
-        const double thetatildeold = thetatilde;
-        double ctildeold, stildeold, rhotildeold;
-        sym_ortho(rhodold, thetabar, ctildeold, stildeold, rhotildeold);
-        thetatilde = stildeold * rhobar;
-        rhodold = ctildeold * rhobar;
-        betad = -stildeold * betad + ctildeold * betahat;
-        tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold;
-        const double taud = (zeta - thetatilde * tautildeold) / rhodold;
-        dd += betacheck * betacheck;
-        normr = std::sqrt(dd + (betad - taud) * (betad - taud) + betadd * betadd);
-        normA2 += beta * beta;
-        normA = std::sqrt(normA2);
-        normA2 += alpha * alpha;
-        maxrbar = std::fmax(maxrbar, rhobarold);
-        if (itn > 1) minrbar = std::fmin(minrbar, rhobarold);
-        condA = std::fmax(maxrbar, rhotemp) / std::fmin(minrbar, rhotemp);
-        normar = std::fabs(zetabar);
-        const double test1 = normr / normb;
-        const double test2 = (normA * normr) != 0 ? normar / (normA * normr) : INFINITY;
-        const double test3 = 1.0 / condA;
-        const double t1 = test1 / (1 + normA * normx / normb);
-        const double rtol = btol + atol * normA * normx / normb;
-        if (itn >= maxiter) istop = 7;
-        if (1 + test3 <= 1) istop = 6;
-        if (1 + test2 <= 1) istop = 5;
-        if (1 + t1 <= 1) istop = 4;
-        if (test3 <= ctol) istop = 3;
-        if (test2 <= atol) istop = 2;
-        if (test1 <= rtol) istop = 1;
-        if (istop > 0) break;
+        DF3D_HIP(hipMemcpyAsync(&now, st, sizeof(now), hipMemcpyDeviceToHost, s));
+        DF3D_HIP(hipStreamSynchronize(s));
     }
-    return finish();
+    return finish(now);
 }
 
 }  // extern "C"

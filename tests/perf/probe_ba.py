@@ -6,7 +6,7 @@ from deepfly3d_amd.bundle_adjust import bundle_adjust
 from deepfly3d_amd.synthetic import synthetic_points2d
 from deepfly3d_amd.config import load_calibration
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-g3 = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "golden_3d.npz"))
+g3 = np.load(os.path.join(os.path.dirname(__file__), "..", "golden", "golden_3d.npz"))
 cal = load_calibration()
 c = {k: np.stack([cal[i][k] for i in range(7)]) for k in ("R", "tvec", "intr")}
 rng = np.random.default_rng(0)
