@@ -180,7 +180,9 @@ int df3d_ba_rmatvec(const df3d_ba_problem* p, const double* Jc_dev, const double
                     const double* u_dev, double* w_dev, double* scratch_dev, void* stream);
 
 /* LSMR on A = J*diag(d) with Tikhonov `damp`, the inner solve of scipy's TRF (tr_solver='lsmr').
- * Synchronous (reads scalars back every iteration).  x_dev[n] receives the solution.
+ * Synchronous: returns when the solve has stopped.  The scalar recurrence is kept on the device; the host enqueues 16
+ * iterations at a time and then reads the stop flag (kernels of iterations past the stop are no-ops).  x_dev[n]
+ * receives the solution.
  * work_dev: at least df3d_ba_lsmr_work_doubles(p) doubles (includes the scratch).  info_host[8] =
  * {istop, itn, normr, normar, normA, condA, normx, 0}. */
 size_t df3d_ba_lsmr_work_doubles(const df3d_ba_problem* p);
