@@ -47,6 +47,18 @@ def test_calibration_like_the_reference_test(native_lib, cuda, tmp_path, golden_
     assert saved["camera_ordering"].dtype == np.int64 and np.array_equal(saved["camera_ordering"], g3["camera_ordering"])
     assert np.array_equal(saved["points2d"], g3["points2d"]) and np.array_equal(saved["heatmap_confidence"], g3["heatmap_confidence"])
     assert abs(core.camNet.reprojection_error() - 2.94) < 0.05
+    # Core.get_points3d (reference df3d/core.py:332-343): Procrustes -> median-centre + axis swap -> One-Euro filter, against
+    # the chain executed with the reference's own functions on the golden pose (the pose here comes from OUR bundle
+    # adjustment, 1.5e-6 mm from the golden one)
+    chain = np.load(f"{golden_dir}/pose_chain_golden.npz")
+    video_pose = core.get_points3d()
+    assert video_pose.shape == (15, 38, 3) and np.abs(video_pose - chain["filtered"]).max() < 1e-4
+    # stored corrections reach corrected_points2d (pixel units, like the reference's PoseDB.manual_corrections)
+    fix = np.full((38, 2), 0.25)
+    core.db.write(fix, 2, 3, True, [0])
+    assert np.allclose(core.corrected_points2d(2, 3), fix * np.array([960, 480]))
+    assert np.allclose(core.corrected_points2d(2, 4), core.camNet.cam_list[2][4])
+    core.save_corrections()
     config.pop("image_shape", None)
 
 
