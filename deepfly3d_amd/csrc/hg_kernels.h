@@ -746,7 +746,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
             if constexpr (UP) xq[i] = xin2 + ((size_t)(xok[i] ? (y >> 1) : 0) * (p.W / 2) + (xok[i] ? (x >> 1) : 0)) * CIN * EB;
         }
         u32x4 rx[XP], rw[WP];
-        u32x4 rb[UP ? XP : 1];
+        u32x4 rb[(UP && EB == 2) ? XP : 1];
+        int c0_late = 0;
         PreactCoef<T> coef;
         auto load1 = [&](int s) {
             const int c0 = s * KE + chunk * PER16;
@@ -754,10 +755,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
             // out-of-image halo rows read pixel (0,0) (a valid address) and are masked to zero in store1: no branches
 #pragma unroll
             for (int i = 0; i < XP; ++i) rx[i] = *reinterpret_cast<const u32x4*>(xp[i] + (size_t)c0 * EB);
-            if constexpr (UP) {
+            if constexpr (UP && EB == 2) {
 #pragma unroll
                 for (int i = 0; i < XP; ++i) rb[i] = *reinterpret_cast<const u32x4*>(xq[i] + (size_t)c0 * EB);
             }
+            if constexpr (UP && EB == 4) c0_late = c0;
 #pragma unroll
             for (int i = 0; i < WP; ++i)
                 rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.w1) + ((size_t)(kh * T1W + srow + i * RPP) * CIN + c0) * EB);
@@ -768,7 +770,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
                 u32x4 v = rx[i];
-                if constexpr (UP) v = add_chunk<T>(v, rb[i]);  // x = in + upsample(in2), rounded like upadd_kernel's output
+                // x = in + upsample(in2), rounded like upadd_kernel's output.  bf16 prefetched the addend with x; fp32 (no
+                // registers to spare beside its 254) fetches it here: a 4x re-used, L2-resident tensor
+                if constexpr (UP && EB == 2) v = add_chunk<T>(v, rb[i]);
+                if constexpr (UP && EB == 4) v = add_chunk<T>(v, *reinterpret_cast<const u32x4*>(xq[i] + (size_t)c0_late * EB));
                 v = preact_apply<T>(v, coef);  // bn1 + ReLU, deferred past the MFMAs
                 const unsigned keep = xok[i] ? 0xffffffffu : 0u;
                 v &= keep;
@@ -1028,8 +1033,16 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
                     for (int r = 0; r < 16; ++r) {
                         const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
                         xr[r] = reinterpret_cast<const float*>(xin)[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n];
-                        if constexpr (UP)
-                            xr[r] += reinterpret_cast<const float*>(xin2)[((size_t)(ty0 / 2 + wave) * (p.W / 2) + ((tx0 + (pl & 15)) >> 1)) * CIN + n];
+                    }
+                    if constexpr (UP) {
+                        // the wave's two tile rows share ONE half-resolution row and neighbouring columns one pixel: registers
+                        // r, r^1, r^8, r^9 take the same addend -> 4 loads per tile, key = bits 1 and 2 of r
+                        float t4[4];
+#pragma unroll
+                        for (int key = 0; key < 4; ++key)
+                            t4[key] = reinterpret_cast<const float*>(xin2)[((size_t)(ty0 / 2 + wave) * (p.W / 2) + tx0 / 2 + (key & 1) + 4 * (key >> 1) + 2 * half) * CIN + n];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) xr[r] += t4[((r >> 1) & 1) + 2 * ((r >> 2) & 1)];
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][r] += xr[r];
@@ -1063,10 +1076,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
             constexpr int OP = 128 * 2 + 16;                    // slice row pitch (bytes)
             unsigned char* const slice = t1_lds + wave * (32 * OP);
             const int odd = lane & 1;
-            u32x4 x2[UP ? 8 : 1];
-            if constexpr (UP) {  // low-resolution addend of the residual: pixel (row wave of the half-size tile, column pw/2)
+            u32x4 x2[UP ? 4 : 1];
+            if constexpr (UP) {  // low-resolution addend of the residual: pixel (row wave of the half-size tile, column pw/2);
+                                 // chunks c and c + 4 (the tile row below) share it
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
+                for (int c = 0; c < 4; ++c) {
                     const int pw = 4 * c + (lane >> 4);
                     x2[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin2) +
                         ((size_t)(ty0 / 2 + wave) * (p.W / 2) + ((tx0 + (pw & 15)) >> 1)) * CIN + nh * 128 + (lane & 15) * 8);
@@ -1090,7 +1104,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
                 u32x4 v = *reinterpret_cast<const u32x4*>(slice + pw * OP + (lane & 15) * 16);
                 if constexpr (!DS) {
                     u32x4 x4 = {xres[4 * c], xres[4 * c + 1], xres[4 * c + 2], xres[4 * c + 3]};
-                    if constexpr (UP) x4 = add_chunk<T>(x4, x2[c]);
+                    if constexpr (UP) x4 = add_chunk<T>(x4, x2[c & 3]);
                     v = add_chunk<T>(v, x4);
                 }
                 fin[c] = v;

@@ -108,7 +108,7 @@ class HourglassEngine:
         _native.check(self.lib.df3d_hg_set_input(self.h, height, width), "df3d_hg_set_input")
         if not fuse:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"fuse", 0), "df3d_hg_set_option")
-        if fuse_upadd is not None:  # default: the library's choice (on for bf16, off for f32)
+        if fuse_upadd is not None:  # default: the library's choice (on)
             _native.check(self.lib.df3d_hg_set_option(self.h, b"fuse_upadd", 1 if fuse_upadd else 0), "df3d_hg_set_option")
         if row_bytes:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"row_bytes", row_bytes), "df3d_hg_set_option")

@@ -249,7 +249,7 @@ size_t df3d_hg_blob_floats(const df3d_hg* h);
 size_t df3d_hg_lowp_bytes(const df3d_hg* h);
 int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void* stream);
 /* knobs: "fuse" = 1 (default) | 0: run 256->128->128->256 bottlenecks as one fused kernel -- must be set before
- * the weights (it changes the manifest);  "fuse_upadd" = 1 (default for bf16) | 0 (default for f32): the hourglass'
+ * the weights (it changes the manifest);  "fuse_upadd" = 1 (default) | 0: the hourglass'
  * nearest-upsample + add is folded into the input load of the bottleneck that consumes the sum (same results bit
  * for bit; set before the weights);  "row_bytes" = 0 (auto) | 64 | 128 bytes staged per operand row per K-step */
 int df3d_hg_set_option(df3d_hg* h, const char* key, int value);

@@ -39,14 +39,15 @@ def _rel_err(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("fuse,row_bytes", [(True, 0), (False, 0), (False, 64)])
-def test_fp32_every_step_matches_oracle(native_lib, cuda, oracle_net, images, traced, fuse, row_bytes):
+@pytest.mark.parametrize("fuse,row_bytes,fuse_upadd", [(True, 0, True), (True, 0, False), (False, 0, False), (False, 64, False)])
+def test_fp32_every_step_matches_oracle(native_lib, cuda, oracle_net, images, traced, fuse, row_bytes, fuse_upadd):
     """Every plan step (fused bottlenecks: the block output; unfused: every convolution) against the oracle."""
     from deepfly3d_amd.hourglass import HourglassEngine
 
-    eng = HourglassEngine(oracle_net.state_dict(), dtype="f32", device=cuda, row_bytes=row_bytes, fuse=fuse)
+    eng = HourglassEngine(oracle_net.state_dict(), dtype="f32", device=cuda, row_bytes=row_bytes, fuse=fuse, fuse_upadd=fuse_upadd)
     steps = eng.steps()
-    assert len(steps) == (len(traced) if not fuse else len(traced) - 2 * 23 - 6 - 4 - 8), (len(steps), len(traced))
+    expect = len(traced) if not fuse else len(traced) - 2 * 23 - 6 - 4 - 8 - (8 if fuse_upadd else 0)
+    assert len(steps) == expect, (len(steps), len(traced))
     img = images.to(cuda)
     worst = (0.0, None)
     for k, (name, hwc) in enumerate(steps, start=1):
