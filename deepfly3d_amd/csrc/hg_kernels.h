@@ -1171,7 +1171,7 @@ struct HeadCfg {
 };
 
 template <typename T, bool LAST>
-__global__ __launch_bounds__(256, ((sizeof(T) == 2 || LAST) ? 2 : 1)) void head_kernel(HeadArgs p) {
+__global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
     using C = HeadCfg<T>;
     constexpr int EB = C::EB;
     constexpr int PER16 = Elem<T>::PER16;
@@ -1319,7 +1319,11 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || LAST) ? 2 : 1)) void head_
         // ================= phase C: x_new = x + Wfc_ y + Wsc_ score + biases ==============================
         constexpr int RB = C::RBC, PITCH = RB + 16, CPR = RB / 16, RPP = 256 / CPR;   // 8 chunks per row, 32 rows per pass
         constexpr int KE = RB / EB;
-        constexpr int WPASS = 128 / RPP;
+        // output channels per pass: fp32 64 (two accumulator tiles: with y's 128 registers the kernel then fits 256 VGPRs and
+        // two workgroups share a CU), bf16 128
+        constexpr int NI = EB == 4 ? 2 : 4;
+        constexpr int CH = NI * 32, NPASS = 256 / CH;
+        constexpr int WPASS = CH / RPP;
         constexpr int YSTEPS = 256 / KE;          // K-steps over y (8 for f32, 4 for bf16); one more step for score
         const int chunk = tid % CPR, srow = tid / CPR;
         u32x4 rw[WPASS];
@@ -1333,7 +1337,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || LAST) ? 2 : 1)) void head_
             for (int i = 0; i < WPASS; ++i) {
                 u32x4 v = {0u, 0u, 0u, 0u};
                 if (!is_sc || chunk * PER16 < 32)
-                    v = *reinterpret_cast<const u32x4*>(base + ((size_t)(nh * 128 + srow + i * RPP) * stride + koff + chunk * PER16) * EB);
+                    v = *reinterpret_cast<const u32x4*>(base + ((size_t)(nh * CH + srow + i * RPP) * stride + koff + chunk * PER16) * EB);
                 rw[i] = v;
             }
         };
@@ -1350,10 +1354,10 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || LAST) ? 2 : 1)) void head_
                 for (int e = 0; e < 8; ++e) scpk[q2][e] = (__bf16)sc[8 * q2 + e];
         }
 #pragma unroll 1
-        for (int nh = 0; nh < 2; ++nh) {
-            f32x16 acc[4];
+        for (int nh = 0; nh < NPASS; ++nh) {
+            f32x16 acc[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
             loadC(nh, 0);
@@ -1371,7 +1375,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || LAST) ? 2 : 1)) void head_
 #pragma unroll
                         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
+                            for (int i = 0; i < NI; ++i) {
                                 const f32x4 wf = *reinterpret_cast<const f32x4*>(sw + (i * 32 + l31) * PITCH + (4 * q2 + 2 * jj + half) * 16);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
@@ -1388,7 +1392,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || LAST) ? 2 : 1)) void head_
                         for (int q2 = 0; q2 < 2; ++q2) {
                             const bf16x8 af = s < YSTEPS ? ypk[s < YSTEPS ? s * (KE / 32) + mm : 0][q2] : scpk[q2];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
+                            for (int i = 0; i < NI; ++i) {
                                 const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sw + (i * 32 + l31) * PITCH + (mm * 32 + (2 * q2 + half) * 8) * 2);
                                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc[i], 0, 0, 0);  // transposed: rows = channels
                             }
@@ -1401,8 +1405,8 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || LAST) ? 2 : 1)) void head_
             if constexpr (EB == 4) {
                 // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4*half of the wave][col = channel nh*128 + 32 i + l31]
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n = nh * 128 + i * 32 + l31;
+                for (int i = 0; i < NI; ++i) {
+                    const int n = nh * CH + i * 32 + l31;
                     const float bias = p.bfc_[n] + p.bsc_[n];
                     float xr[16];
 #pragma unroll
@@ -1425,14 +1429,14 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 || LAST) ? 2 : 1)) void head_
                     unsigned short* const orow = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * 256;
                     uint2 xv[16];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < NI; ++i)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) xv[4 * i + q] = *reinterpret_cast<const uint2*>(xrow + nh * 128 + 32 * i + 8 * q + 4 * half);
+                        for (int q = 0; q < 4; ++q) xv[4 * i + q] = *reinterpret_cast<const uint2*>(xrow + nh * CH + 32 * i + 8 * q + 4 * half);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < NI; ++i)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int n = nh * 128 + 32 * i + 8 * q + 4 * half;
+                            const int n = nh * CH + 32 * i + 8 * q + 4 * half;
                             const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bfc_ + n);
                             const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bsc_ + n);
                             const uint2 xx = xv[4 * i + q];
