@@ -17,7 +17,8 @@ Python modules on seeded inputs:
                        procrustes.py:51-89) on the golden and on a seeded
                        perturbed 3-D sequence.
 
-Nothing in tests/, bench.py or smoke() reads /root/reference at run time; they
+No -m gpu test, bench.py or smoke() reads /root/reference at run time (tests/test_shims.py, a CPU test of the import
+seam, does and is skipped where the checkout is absent); they
 read only these npz files.  No reference source text is stored here.
 """
 import os
