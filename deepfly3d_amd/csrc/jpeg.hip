@@ -31,7 +31,8 @@ struct Meta {
     int comp_h[4], comp_v[4], comp_tq[4], comp_td[4], comp_ta[4];
     unsigned scan_pos;   // byte offset of the entropy-coded data inside the file
     unsigned clean_len;  // bytes of the un-stuffed stream
-    int par_done;        // the parallel Huffman kernel finished this file (else the sequential one decodes it)
+    int par_done;        // > 0: the parallel Huffman kernel finished this file (= its synchronisation passes); <= 0: the
+                         // sequential kernel decodes it (-1 no convergence, -2 stream ends early, -3 invalid symbols)
     int mcus_x, mcus_y;
     int ybw, ybh;  // luma block grid (MCU padded)
     unsigned short q[4][64];  // natural order

@@ -61,7 +61,9 @@ int df3d_preprocess_u8(const unsigned char* img_dev, const unsigned char* flip_d
  * luma_dev    [n, height, width] uint8;   every file must be width x height
  * status_dev  [n] int32: 0 ok, 1 truncated, 2 not a JPEG, 3 unsupported (progressive / arithmetic / 12 bit /
  *             multi-scan), 4 corrupt, 5 size differs.  Planes of failed files are left untouched.
- * path_dev    optional [n] int32 (may be NULL): 1 = decoded by the parallel Huffman kernel, 0 = by the sequential one
+ * path_dev    optional [n] int32 (may be NULL): > 0 = decoded by the parallel Huffman kernel (the value is its number of
+ *             synchronisation passes); <= 0 = by the sequential one (0: restart intervals / sequential requested / table
+ *             problem, -1: no convergence, -2: stream ends early, -3: invalid symbols)
  * work_dev    >= df3d_jpeg_work_bytes(n, width, height, total_file_bytes) bytes, 256-byte aligned
  * flags       0, or DF3D_JPEG_SEQUENTIAL: skip the parallel (self-synchronising) Huffman kernel and decode every
  *             file with the sequential wave-per-file kernel (the exact fall-back the parallel one defers to for
