@@ -236,3 +236,56 @@ def test_assemble_result_schema(golden_dir):
     assert [str(k) for k in out.keys()] == list(g3["key_order"])
     assert np.abs(out["points3d"] - g3["points3d"]).max() < 1e-12
     assert out["heatmap_confidence"].shape == (7, 15, 19, 1) and out["points2d"].dtype == np.float64
+
+
+def _fake_tool(bin_dir, name, body):
+    path = os.path.join(bin_dir, name)
+    with open(path, "w") as f:
+        f.write("#!/bin/bash\n" + body)
+    os.chmod(path, 0o755)
+
+
+def test_core_with_videos_fps_and_delete_images(tmp_path, golden_dir, monkeypatch):
+    """Mirror of reference tests/test_df3d.py: test_load_core_with_videos / test_delete_images, with stand-in ffmpeg /
+    ffprobe executables (the image has neither): a folder that only holds camera_x.mp4 is expanded to frames once, the
+    frame rate comes from ffprobe's avg_frame_rate, --delete-images removes the frames and keeps the videos."""
+    from deepfly3d_amd.config import config
+    from deepfly3d_amd.core import Core
+
+    bin_dir = tmp_path / "bin"
+    bin_dir.mkdir()
+    src = os.path.join(golden_dir, "images")
+    log = tmp_path / "ffmpeg_calls.log"
+    _fake_tool(str(bin_dir), "ffprobe", 'echo "30000/1001"\n')
+    _fake_tool(str(bin_dir), "ffmpeg", f'''
+while [ $# -gt 0 ]; do if [ "$1" = "-i" ]; then vid="$2"; fi; last="$1"; shift; done
+cam=$(basename "$vid" .mp4); cam=${{cam#camera_}}
+echo "$vid" >> {log}
+for n in 0 1; do cp {src}/camera_${{cam}}_img_$n.jpg "$(printf "$last" $n)"; done
+''')
+    monkeypatch.setenv("PATH", f"{bin_dir}:{os.environ['PATH']}")
+    config.pop("image_shape", None)
+    folder = tmp_path / "working"
+    folder.mkdir()
+    for c in range(7):
+        (folder / f"camera_{c}.mp4").write_bytes(b"not really a video")
+    core = Core(str(folder), None, 0, [0, 1, 2, 3, 4, 5, 6])
+    assert core.num_images == 2 and core.max_img_id == 1 and core.image_shape == [960, 480]
+    assert core.output_folder == str(folder) + "_df3d" and os.path.isdir(core.output_folder)
+    assert abs(core.fps - 30000 / 1001) < 1e-12
+    assert len(open(log).read().split()) == 7
+    Core(str(folder), None, 0, [0, 1, 2, 3, 4, 5, 6])  # frames are there now: no second expansion
+    assert len(open(log).read().split()) == 7
+    assert len(list(folder.glob("camera_*_img_*.jpg"))) == 14
+    core.delete_images()
+    assert not list(folder.glob("camera_*.jpg")) and len(list(folder.glob("camera_*.mp4"))) == 7
+    # frame-rate strings ffprobe may print
+    from deepfly3d_amd.os_util import parse_frame_rate
+
+    assert parse_frame_rate("25\n") == 25.0 and parse_frame_rate("0/0") is None and parse_frame_rate("n/a") is None
+    # no ffprobe at all -> fps None, like the reference when the command fails
+    os.remove(bin_dir / "ffprobe")
+    monkeypatch.setenv("PATH", str(bin_dir))
+    (folder / "camera_0_img_0.jpg").write_bytes(open(os.path.join(src, "camera_0_img_0.jpg"), "rb").read())
+    assert Core(str(folder), None, 0, [0, 1, 2, 3, 4, 5, 6]).fps is None
+    config.pop("image_shape", None)
