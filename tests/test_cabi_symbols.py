@@ -55,7 +55,25 @@ def test_argument_validation_without_gpu(native_lib):
     # forward before weights are set is a state error, never a silent success
     rc = native_lib.df3d_hg_forward(h, ctypes.c_void_p(256), 1, ctypes.c_void_p(256), ctypes.c_void_p(256), 1 << 40, None)
     assert rc == -3 and b"weights" in native_lib.df3d_last_error()
+    assert native_lib.df3d_hg_set_option(h, b"fuse_upadd", 2) == -1 and native_lib.df3d_hg_set_option(h, b"no_such_knob", 1) == -1
     native_lib.df3d_hg_destroy(h)
+    # front-end and sequence tail
+    p16 = ctypes.c_void_p(4096)
+    assert native_lib.df3d_jpeg_work_bytes(4, 960, 480, 300000) > 4 * 921600 and native_lib.df3d_jpeg_work_bytes(-1, 960, 480, 0) == 0
+    rc = native_lib.df3d_jpeg_decode_luma(ctypes.c_void_p(4100), p16, p16, 1, 1000, 1000, 960, 480, p16, p16, None, p16, 1 << 30, 0, None)
+    assert rc == -1 and b"16-byte aligned" in native_lib.df3d_last_error()
+    rc = native_lib.df3d_jpeg_decode_luma(p16, p16, p16, 1, 1000, 1000, 960, 480, p16, p16, None, p16, 16, 0, None)
+    assert rc == -1 and b"work buffer too small" in native_lib.df3d_last_error()
+    assert native_lib.df3d_jpeg_decode_luma(None, None, None, 0, 0, 0, 960, 480, None, None, None, None, 0, 0, None) == 0  # empty batch
+    assert native_lib.df3d_column_median(p16, 1, 0, 0, p16, None) == -1
+    assert native_lib.df3d_procrustes_work_doubles(1000) >= 60 * 1000
+    two = (ctypes.c_double * 24)()
+    six = (ctypes.c_double * 36)()
+    assert native_lib.df3d_procrustes(p16, 0, two, six, p16, p16, 1 << 20, None) == -1
+    assert native_lib.df3d_procrustes(p16, 10, two, six, p16, p16, 8, None) == -1 and b"work buffer" in native_lib.df3d_last_error()
+    assert native_lib.df3d_pose_normalize(p16, 10, 38, 1, p16, p16, 2, None) == -1
+    assert native_lib.df3d_oneeuro_filter(p16, 10, 114, 0.0, 0.1, 2.0, 1.0, 1, 0.1, p16, None) == -1
+    assert native_lib.df3d_oneeuro_filter(None, 0, 114, 100.0, 0.1, 2.0, 1.0, 1, 0.1, None, None) == 0  # no frames
 
 
 def test_engine_plan_accounting(native_lib):
