@@ -313,6 +313,13 @@ def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None):
 
 
 def bundle_adjust(points2d_px, R, tvec, intr, device="cuda:0", return_info=False):
+    """See _bundle_adjust; runs with `device` as the current HIP device (kernels launch on the current device)."""
+    _native.require_gpu()
+    with torch.cuda.device(torch.device(device)):
+        return _bundle_adjust(points2d_px, R, tvec, intr, device, return_info)
+
+
+def _bundle_adjust(points2d_px, R, tvec, intr, device, return_info):
     """points2d_px (ncam, T, J, 2) float64 (row_px, col_px); R (ncam,3,3), tvec (ncam,3), intr (ncam,3,3).
     Returns adjusted (R, tvec) as float64 numpy arrays (+ solver info)."""
     _native.require_gpu()

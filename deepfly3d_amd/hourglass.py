@@ -165,11 +165,12 @@ class HourglassEngine:
         if out is None:
             out = torch.empty((n, self.num_classes, self.height // 4, self.width // 4), dtype=torch.float32, device=self.device)
         ws = self._workspace(n)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        _native.check(
-            self.lib.df3d_hg_forward(self.h, images.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
-            "df3d_hg_forward",
-        )
+        with torch.cuda.device(self.device):  # kernels launch on the current HIP device
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _native.check(
+                self.lib.df3d_hg_forward(self.h, images.data_ptr(), n, out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                "df3d_hg_forward",
+            )
         return out
 
     def forward_upto(self, images, upto):
@@ -181,9 +182,10 @@ class HourglassEngine:
         shape = (n, c, h, w) if last_nchw else (n, h, w, c)
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
         ws = self._workspace(n)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        _native.check(
-            self.lib.df3d_hg_forward_upto(self.h, images.data_ptr(), n, upto, out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
-            "df3d_hg_forward_upto",
-        )
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _native.check(
+                self.lib.df3d_hg_forward_upto(self.h, images.data_ptr(), n, upto, out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                "df3d_hg_forward_upto",
+            )
         return out

@@ -73,11 +73,12 @@ def preprocess_u8(frames_u8, flip, out_hw=(256, 512)):
     fl = None
     if flip is not None:
         fl = flip.to(device=frames_u8.device, dtype=torch.uint8).contiguous()
-    _native.check(
-        lib.df3d_preprocess_u8(frames_u8.data_ptr(), fl.data_ptr() if fl is not None else None, n, H, W, C, out.data_ptr(), out_hw[0], out_hw[1],
-                               mean, std, torch.cuda.current_stream(frames_u8.device).cuda_stream),
-        "df3d_preprocess_u8",
-    )
+    with torch.cuda.device(frames_u8.device):  # kernels launch on the current HIP device
+        _native.check(
+            lib.df3d_preprocess_u8(frames_u8.data_ptr(), fl.data_ptr() if fl is not None else None, n, H, W, C, out.data_ptr(), out_hw[0], out_hw[1],
+                                   mean, std, torch.cuda.current_stream(frames_u8.device).cuda_stream),
+            "df3d_preprocess_u8",
+        )
     return out
 
 

@@ -54,12 +54,13 @@ def decode_luma(blobs, width, height, device=None, check=True, return_status=Fal
     path = torch.zeros((n,), dtype=torch.int32, device=dev) if return_path else None
     need = lib.df3d_jpeg_work_bytes(n, width, height, total)
     work = torch.empty((need,), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    _native.check(
-        lib.df3d_jpeg_decode_luma(files_dev.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), n, total, int(sizes.max()) if stream_in_lds else 0, width, height, out.data_ptr(),
-                                  status.data_ptr(), path.data_ptr() if return_path else None, work.data_ptr(), need, 1 if sequential else 0, stream),
-        "df3d_jpeg_decode_luma",
-    )
+    with torch.cuda.device(dev):  # kernels launch on the current HIP device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _native.check(
+            lib.df3d_jpeg_decode_luma(files_dev.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), n, total, int(sizes.max()) if stream_in_lds else 0, width, height, out.data_ptr(),
+                                      status.data_ptr(), path.data_ptr() if return_path else None, work.data_ptr(), need, 1 if sequential else 0, stream),
+            "df3d_jpeg_decode_luma",
+        )
     if check or return_status:
         st = status.cpu().numpy()
         if check and st.any():
@@ -149,12 +150,13 @@ class JpegFolderReader:
             need = self.lib.df3d_jpeg_work_bytes(n, self.width, self.height, total)
             if self.work is None or self.work.numel() < need:
                 self.work = torch.empty((need,), dtype=torch.uint8, device=self.dev)
-            _native.check(
-                self.lib.df3d_jpeg_decode_luma(files_dev.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), n, total, int(sizes.max()), self.width,
-                                               self.height, out.data_ptr(), status.data_ptr(), None, self.work.data_ptr(), self.work.numel(), 0,
-                                               torch.cuda.current_stream(self.dev).cuda_stream),
-                "df3d_jpeg_decode_luma",
-            )
+            with torch.cuda.device(self.dev):
+                _native.check(
+                    self.lib.df3d_jpeg_decode_luma(files_dev.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), n, total, int(sizes.max()), self.width,
+                                                   self.height, out.data_ptr(), status.data_ptr(), None, self.work.data_ptr(), self.work.numel(), 0,
+                                                   torch.cuda.current_stream(self.dev).cuda_stream),
+                    "df3d_jpeg_decode_luma",
+                )
             self.statuses.append((status, paths))
         if next_paths is not None:
             self.prefetch(next_paths)

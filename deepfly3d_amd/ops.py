@@ -15,11 +15,28 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _on_tensor_device(fn):
+    """Kernels are launched on the calling thread's CURRENT HIP device: make that the device of the first tensor
+    argument, so a process that drives several GPUs (or one that never called torch.cuda.set_device) stays correct."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kw)
+        return fn(*args, **kw)
+
+    return wrapper
+
+
 def _need(t, dtype, name):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
         raise ValueError(f"{name} must be a contiguous {dtype} CUDA tensor")
 
 
+@_on_tensor_device
 def heatmap_argmax(heatmaps):
     """heatmaps [n, J, H, W] float32 (cuda) -> (points [n, J, 2] float32 (row/H, col/W), conf [n, J] float32)."""
     lib = _native.load()
@@ -34,6 +51,7 @@ def heatmap_argmax(heatmaps):
     return pts, conf
 
 
+@_on_tensor_device
 def relayout_19_to_38(points19, camera_ordering):
     """points19 [7, T, 19, 2] float32 (cuda) -> [7, T, 38, 2] float64 (reference df3d/core.py:187-203)."""
     lib = _native.load()
@@ -47,6 +65,7 @@ def relayout_19_to_38(points19, camera_ordering):
     return out
 
 
+@_on_tensor_device
 def triangulate(P, points2d_px):
     """P [ncam, 3, 4] float64 (numpy or tensor), points2d_px [ncam, T, J, 2] float64 cuda (row_px, col_px)
     -> X [T, J, 3] float64 cuda; zeros where fewer than two cameras see the joint."""
@@ -66,6 +85,7 @@ def triangulate(P, points2d_px):
     return X
 
 
+@_on_tensor_device
 def column_median(cols):
     """cols [ncols, n] float64 cuda -> [ncols] exact medians (numpy.median semantics)."""
     lib = _native.load()
@@ -76,6 +96,7 @@ def column_median(cols):
     return out
 
 
+@_on_tensor_device
 def procrustes(points3d, tmpl_seg_med, tmpl_fit_med):
     """points3d [T, 38, 3] float64 cuda -> registered copy (a9).  tmpl_* are the template's host constants
     (deepfly3d_amd.procrustes.template_constants)."""
@@ -100,6 +121,7 @@ def procrustes(points3d, tmpl_seg_med, tmpl_fit_med):
     return out
 
 
+@_on_tensor_device
 def pose_normalize(points3d, rotate=True):
     """[T, J, 3] float64 cuda -> minus the per-axis median of all points, optionally (x, y, z) -> (x, -z, -y)."""
     lib = _native.load()
@@ -114,6 +136,7 @@ def pose_normalize(points3d, rotate=True):
     return out
 
 
+@_on_tensor_device
 def oneeuro_filter(series, freq=100.0, mincutoff=0.1, beta=2.0, dcutoff=1.0, first_stamp=1, stamp_step=0.1):
     """series [T, ...] float64 cuda: every trailing element is one channel filtered along T (reference
     df3d/signal_util.py:69-100 defaults)."""

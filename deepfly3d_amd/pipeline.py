@@ -41,11 +41,12 @@ class FramePipeline:
         p38 = ops.relayout_19_to_38(pts_ct, self.order)  # [7, F, 38, 2] f64
         out_points2d[:, t0 : t0 + F] = p38
         X = torch.empty((F, 38, 3), dtype=torch.float64, device=self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        _native.check(
-            self.lib.df3d_triangulate_scaled(self.P.ctypes.data_as(ctypes.c_void_p), p38.data_ptr(), self.H, self.W, 7, F, 38, X.data_ptr(), stream),
-            "df3d_triangulate_scaled",
-        )
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _native.check(
+                self.lib.df3d_triangulate_scaled(self.P.ctypes.data_as(ctypes.c_void_p), p38.data_ptr(), self.H, self.W, 7, F, 38, X.data_ptr(), stream),
+                "df3d_triangulate_scaled",
+            )
         out_points3d[t0 : t0 + F] = X
 
     def allocate_outputs(self, T):
