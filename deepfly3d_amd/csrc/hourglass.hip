@@ -372,15 +372,22 @@ struct df3d_hg {
 
 namespace {
 
+// hipFuncSetAttribute acts on the CURRENT device: remember per device (bit i of `mask`) where it has been applied
+inline bool first_use_on_this_device(unsigned& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) return true;
+    const bool first = !(mask & (1u << dev));
+    mask |= 1u << dev;
+    return first;
+}
+
 template <typename T, int TAPS, int BN, int RB>
 int launch_conv_t(const ConvArgs& a, hipStream_t s) {
     constexpr int LDS = 2 * (BM + BN) * (RB + 16);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned attr_done = 0;
+    if (first_use_on_this_device(attr_done))
         DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<T, TAPS, BN, RB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
     const long long mt = (a.M + BM - 1) / BM;
     dim3 grid((unsigned)mt, (unsigned)(a.cout / BN));
     hipLaunchKernelGGL((conv_mfma_kernel<T, TAPS, BN, RB>), grid, dim3(256), LDS, s, a);
@@ -444,12 +451,10 @@ struct ScopedTimer {
 template <typename T, int CIN, int PL, bool DS, bool UP = false>
 int launch_bottleneck_t(const BottleneckArgs& a, int blocks, hipStream_t s) {
     using C = BtCfg<T, CIN, PL, DS>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned attr_done = 0;
+    if (first_use_on_this_device(attr_done))
         DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<T, CIN, PL, DS, UP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        attr_done = true;
-    }
     hipLaunchKernelGGL((bottleneck_kernel<T, CIN, PL, DS, UP>), dim3(blocks), dim3(256), C::LDS_BYTES, s, a);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
@@ -573,11 +578,9 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.M = (long long)n * ti.h * ti.w;
                 a.HW = ti.h * ti.w;
                 const void* fn = st.last ? reinterpret_cast<const void*>(head_kernel<T, true>) : reinterpret_cast<const void*>(head_kernel<T, false>);
-                static bool attr_done[2] = {false, false};
-                if (!attr_done[st.last]) {
+                static unsigned attr_done[2] = {0, 0};
+                if (first_use_on_this_device(attr_done[st.last]))
                     DF3D_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, HeadCfg<T>::LDS_BYTES));
-                    attr_done[st.last] = true;
-                }
                 const double mm = (double)a.M;
                 const double fl = 2.0 * mm * (256.0 * 256 + 256.0 * 19 + (st.last ? 0.0 : 256.0 * 256 + 19.0 * 256));
                 ScopedTimer tm(h, s, std::string("head_kernel<") + tname + ", " + (st.last ? "true" : "false") + ">", fl,
