@@ -166,3 +166,21 @@ def test_jpeg_oracle_pinned_by_libjpeg(golden_dir):
     buf = io.BytesIO()
     Image.fromarray(img).save(buf, "JPEG", progressive=True)
     assert oj.status(buf.getvalue()) == 3 and oj.status(b"nope") == 2
+
+
+def test_hourglass_oracle_has_the_surveyed_architecture():
+    """No reference vector can exercise the network (nely-df2d and its weights are not in the checkout: parity
+    unpinned), but its SHAPE is pinned: the torch restatement has the counts SURVEY.md App. B derives from the reference's
+    constants (df3d/config.py:18,33,36): 102 convolutions, 6.73 M parameters, 19 heat-maps at 1/4 resolution from the last of 2 stacks."""
+    import torch
+
+    from oracle import hourglass_torch as oh
+
+    net = oh.build(seed=0)
+    convs = [m for m in net.modules() if isinstance(m, torch.nn.Conv2d)]
+    assert len(convs) == 102
+    assert sum(p.numel() for p in net.parameters()) == 6733222
+    with torch.no_grad():
+        out = net(torch.zeros(1, 3, 64, 128))
+    assert tuple(out.shape) == (1, 19, 16, 32)  # the last stack's heat-maps (what df2d's inference consumes)
+    assert net.num_stacks == 2 if hasattr(net, "num_stacks") else True
