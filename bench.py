@@ -10,9 +10,19 @@ each 7 views of 256 x 512 x 3 float32, seeded and resident in HBM before the tim
 fp32 with seeded synthetic weights (no checkpoints offline); fixed calib.pkl cameras.  One "step" = one batch of
 `frames_per_step` frames through the whole path: hourglass -> arg-max/confidence -> 19->38 layout -> DLT.
 N > 1: every rank owns its own frame range (weak scaling) and the per-frame results are gathered to rank 0 once
-(RCCL), inside the timed region.  Rank 0 prints ONE JSON line.
+(RCCL, one packed `dist.gather`), inside the timed region.  Rank 0 prints ONE JSON line.
+
+The line's headline is configs[1] (fp32).  At N = 1 the same process then times configs[2] (bf16 hourglass, same
+frames) and attaches it as `config2_bf16` with its own roofline, so both precisions are under the driver's clock.
+
+    python bench.py --rank-share 8 --stream-frames 100000 [--ba-window 1000] [--force-collective]
+runs ONE rank's share of BASELINE configs[3] / configs[4] on the one GPU at hand: rank 0's frame range of the
+100 k-frame stream sharded over 8 ranks (aligned to the bundle-adjustment window), streamed through the resident
+frame pool, one bundle adjustment per window interleaved, and -- with --force-collective -- the single packed gather
+executed on a 1-rank RCCL process group, all inside the timed region.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,6 +37,9 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 PEAK_HBM_GBS = 8000.0
+# which roof binds the hourglass per dtype (fp32: AI 55.6 FLOP/B > 19.7 balance -> FLOP-bound;
+# bf16 on MFMA: 323.7 MB/view of activation traffic in the fusion model M1 -> HBM-bound)
+BOUND = {"f32": "mfma", "bf16": "hbm"}
 
 
 def parse():
@@ -36,12 +49,18 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-step", type=int, default=128)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
-    ap.add_argument("--pool-frames", type=int, default=0, help="distinct frames resident in HBM (0 = steps*frames_per_step, capped at 1000)")
+    ap.add_argument("--pool-frames", type=int, default=0, help="distinct frames resident in HBM (0 = steps*frames_per_step, capped at 1024)")
     ap.add_argument("--ba-window", type=int, default=0,
                     help="BASELINE configs[4]: run one bundle adjustment (HIP kernels + TRF/LSMR driver) per this many frames on "
                          "geometry-consistent synthetic detections, inside the timed region (0 = fixed calib.pkl, configs[1])")
+    ap.add_argument("--rank-share", type=int, default=0,
+                    help="run rank 0's share of a --stream-frames stream sharded over this many ranks (configs[3]/[4] on one GPU); overrides --steps")
+    ap.add_argument("--stream-frames", type=int, default=100000)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1: create a 1-rank process group (RCCL) and execute the packed gather anyway")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the attached configs[2] (bf16) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -56,6 +75,17 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return max(1, n)
+
+
+def kernel_source_sha():
+    """sha256 over the HIP sources: profiles/traffic.json records the value it was collected with (no .git on the GPU box)."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "deepfly3d_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(state_dict, frames_cpu, calib, target_seconds):
@@ -94,6 +124,58 @@ def cpu_baseline(state_dict, frames_cpu, calib, target_seconds):
     }
 
 
+def measure_roofline(engine, dtype, run_steps, nprof):
+    """HIP events around every launch of each kernel class (same stream), over `nprof` steps; the dominant kernel
+    priced against the roof SURVEY.md 8(d) assigns to this dtype."""
+    import ctypes
+
+    from deepfly3d_amd import _native
+
+    lib = _native.load()
+    _native.check(lib.df3d_hg_profile(engine.h, 1))
+    run_steps(nprof)
+    torch.cuda.synchronize()
+    per = []
+    buf = ctypes.create_string_buffer(128)
+    for k in range(lib.df3d_hg_profile_count(engine.h)):
+        ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        _native.check(lib.df3d_hg_profile_read(engine.h, k, buf, 128, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n)))
+        if n.value:
+            per.append({"kernel": buf.value.decode(), "launches": n.value, "avg_us": 1e3 * ms.value / n.value, "total_ms": ms.value,
+                        "tflops": fl.value / ms.value / 1e9, "gbs_algorithmic": by.value / ms.value / 1e6})
+    per.sort(key=lambda d: -d["total_ms"])
+    _native.check(lib.df3d_hg_profile(engine.h, 0))
+    dom = per[0]
+    traffic = traffic_src = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = tj.get(dom["kernel"])
+        traffic_src = (tj.get("_meta") or {}).get("kernel_source_sha")
+    bound = BOUND[dtype]
+    roof = {
+        "bound": bound,
+        "kernel": dom["kernel"],
+        "achieved": dom["tflops"] if bound == "mfma" else dom["gbs_algorithmic"],
+        "peak": PEAK_TFLOPS[dtype] if bound == "mfma" else PEAK_HBM_GBS,
+        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+        "algorithmic_bytes_model": "M1 (SURVEY.md 8d): every convolution reads its input and writes its output once",
+        "traffic": traffic,  # HBM bytes per launch from rocprofv3 PMC passes ((2 x FETCH_SIZE + WRITE_SIZE) x 1024), profiles/traffic.json
+        "traffic_kernel_source_sha": traffic_src,
+        "traffic_is_current": (traffic_src == kernel_source_sha()) if traffic_src else None,
+        "avg_launch_us": dom["avg_us"],
+        "mfma_tflops": dom["tflops"],
+        "mfma_frac": dom["tflops"] / PEAK_TFLOPS[dtype],
+        "hbm_gbs_algorithmic": dom["gbs_algorithmic"],
+        "hbm_frac_algorithmic": dom["gbs_algorithmic"] / PEAK_HBM_GBS,
+        "hbm_gbs_pmc": (traffic / (dom["avg_us"] * 1e-6) / 1e9) if traffic else None,
+        "kernels": per,
+    }
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    return roof
+
+
 def main():
     a = parse()
     from deepfly3d_amd import _native
@@ -110,16 +192,26 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()  # (== local_rank on a node with one GPU per rank)
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
+    if a.force_collective and world == 1 and not torch.distributed.is_initialized():
+        port = int(os.environ.get("MASTER_PORT", "29517"))
+        torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    collective = dd.collective_needed(world, a.force_collective)
 
     fps_step = a.frames_per_step
+    align = a.ba_window if a.ba_window > 0 else 1
+    if a.rank_share > 0:
+        t0, t1 = dd.shard_range(a.stream_frames, a.rank_share, 0, align)
+        total_frames = t1 - t0
+        a.steps = -(-total_frames // fps_step)
+    else:
+        total_frames = a.steps * fps_step
     sd = synthetic_state_dict(0)
     engine = HourglassEngine(sd, dtype=a.dtype, device=dev)
     cal = load_calibration()
     calib = {k: np.stack([cal[c][k] for c in range(7)]) for k in ("R", "tvec", "intr", "distort")}
     pipe = FramePipeline(engine, calib["R"], calib["tvec"], calib["intr"])
 
-    total_frames = a.steps * fps_step
-    pool = a.pool_frames or min(total_frames, 1024)
+    pool = a.pool_frames or min(a.steps * fps_step, 1024)
     pool = max(fps_step, (pool // fps_step) * fps_step)
     gen = torch.Generator(device=dev).manual_seed(rank)
     frames = torch.empty((pool, 7, 256, 512, 3), dtype=torch.float32, device=dev)
@@ -127,35 +219,51 @@ def main():
         frames[i : i + 64].uniform_(0.0, 1.0, generator=gen)
     outs = pipe.allocate_outputs(total_frames)
 
-    ba_px, ba_runs = None, []
+    ba_px, ba_runs, ba_cams = None, [], []
     if a.ba_window > 0:
-        # geometry-consistent detections: golden-like pose tiled + jitter, projected through the adjusted
-        # cameras of the sample set, quantised to the heat-map grid; the random-weight network output is meaningless for BA
+        # geometry-consistent detections, one set per window: golden-like pose tiled + jitter, projected through
+        # the adjusted cameras of the sample set, quantised to the heat-map grid (the random-weight network output is
+        # meaningless for BA); prepared before the timed region like the frames
         from deepfly3d_amd.bundle_adjust import bundle_adjust
-        from deepfly3d_amd.synthetic import synthetic_points2d
+        from deepfly3d_amd.synthetic import synthetic_ba_window
 
         g3 = np.load(os.path.join(ROOT, "tests", "golden", "golden_3d.npz"))
-        rng = np.random.default_rng(rank)
-        pose = g3["points3d_wo_procrustes"]
-        X = np.tile(pose, (a.ba_window // pose.shape[0] + 1, 1, 1))[: a.ba_window] + rng.normal(0, 0.05, size=(a.ba_window, 38, 3))
-        ba_px = synthetic_points2d(X, g3["R"], g3["tvec"], g3["intr"]) * np.array([480.0, 960.0])
+        nwin = -(-total_frames // a.ba_window)
+        ba_px = [synthetic_ba_window(g3["points3d_wo_procrustes"], g3["R"], g3["tvec"], g3["intr"], min(a.ba_window, total_frames - w * a.ba_window), rank, w)
+                 for w in range(nwin)]
 
-    def step(i, t0):
-        lo = (i * fps_step) % pool
-        pipe.run_batch(frames[lo : lo + fps_step], *outs, t0)
-        if ba_px is not None and ((i + 1) * fps_step) // a.ba_window > (i * fps_step) // a.ba_window:
-            _, _, info = bundle_adjust(ba_px, calib["R"], calib["tvec"], calib["intr"], device=dev, return_info=True)
-            ba_runs.append(info["nfev"])
+    def step(i, pipeline=pipe, record=True):
+        f0 = i * fps_step
+        n = min(fps_step, total_frames - f0)
+        lo = f0 % pool
+        pipeline.run_batch(frames[lo : lo + n], *outs, f0)
+        # a window closes with this batch (the last window of the share may be shorter)
+        if ba_px is not None and ((f0 + n) // a.ba_window > f0 // a.ba_window or (f0 + n == total_frames and total_frames % a.ba_window)):
+            Rn, tn, info = bundle_adjust(ba_px[(f0 + n - 1) // a.ba_window], calib["R"], calib["tvec"], calib["intr"], device=dev, return_info=True)
+            if record:
+                ba_runs.append(info["nfev"])
+                ba_cams.append(np.concatenate([Rn.reshape(7, 9), tn.reshape(7, 3)], axis=1))
+
+    def gather():
+        if not collective:
+            return
+        cams = None
+        if a.ba_window > 0:
+            cams = torch.from_numpy(np.stack(ba_cams) if ba_cams else np.zeros((0, 7, 12))).to(dev)
+        nf = total_frames * world
+        if a.ba_window > 0 and total_frames % a.ba_window and world > 1:
+            raise SystemExit("per-GPU frames must be a multiple of --ba-window when N > 1")
+        return dd.gather_results(*outs, num_frames=nf, rank=rank, world_size=world, align=align, cameras=cams, force_collective=a.force_collective)
 
     for w in range(a.warmup):
-        step(w, 0)
+        step(w % a.steps, record=False)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     t_start = time.perf_counter()
     for i in range(a.steps):
-        step(i, i * fps_step)
-    gathered = dd.gather_results(*outs, num_frames=total_frames * world, rank=rank, world_size=world)
+        step(i)
+    gathered = gather()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -164,50 +272,59 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    gather_ok = None
+    if collective and rank == 0 and world == 1:  # the 1-rank collective must hand back exactly what went in
+        gather_ok = all(torch.equal(g, o) for g, o in zip(gathered[:3], outs))
 
     roof = None
     if not a.no_roofline and rank == 0:
-        # same stream, HIP events around every launch of each kernel class, over a few steps
-        lib = _native.load()
-        import ctypes
-
-        _native.check(lib.df3d_hg_profile(engine.h, 1))
         nprof = min(a.steps, 4)
-        for i in range(nprof):
-            step(i, i * fps_step)
+        saved_ba, ba_px = ba_px, None  # kernel timing only
+        roof = measure_roofline(engine, a.dtype, lambda n: [step(i, record=False) for i in range(n)], nprof)
+        ba_px = saved_ba
+
+    # configs[2] (bf16 hourglass, same frames and geometry) in the same process, under the same driver clock
+    leg = None
+    if a.dtype == "f32" and world == 1 and not a.no_bf16_leg and a.rank_share == 0 and a.ba_window == 0:
+        e16 = HourglassEngine(sd, dtype="bf16", device=dev)
+        p16 = FramePipeline(e16, calib["R"], calib["tvec"], calib["intr"])
+        for w in range(max(1, a.warmup)):
+            step(w % a.steps, pipeline=p16, record=False)
         torch.cuda.synchronize()
-        per = []
-        buf = ctypes.create_string_buffer(128)
-        for k in range(lib.df3d_hg_profile_count(engine.h)):
-            ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-            _native.check(lib.df3d_hg_profile_read(engine.h, k, buf, 128, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n)))
-            if n.value:
-                per.append({"kernel": buf.value.decode(), "launches": n.value, "avg_us": 1e3 * ms.value / n.value, "total_ms": ms.value,
-                            "tflops": fl.value / ms.value / 1e9, "gbs_algorithmic": by.value / ms.value / 1e6})
-        per.sort(key=lambda d: -d["total_ms"])
-        _native.check(lib.df3d_hg_profile(engine.h, 0))
-        dom = max(per, key=lambda d: d["total_ms"])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(dom["kernel"])
-        compute_bound = dom["kernel"].startswith(("conv", "stem", "bottleneck", "head"))
-        roof = {
-            "bound": "mfma" if compute_bound else "hbm",
-            "kernel": dom["kernel"],
-            "achieved": dom["tflops"] if compute_bound else dom["gbs_algorithmic"],
-            "peak": PEAK_TFLOPS[a.dtype] if compute_bound else PEAK_HBM_GBS,
-            "unit": "TFLOP/s" if compute_bound else "GB/s",
-            "traffic": traffic,
-            "avg_launch_us": dom["avg_us"],
-            "kernels": per,
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i, pipeline=p16, record=False)
+        torch.cuda.synchronize()
+        el16 = time.perf_counter() - t0
+        fl16, by16 = e16.work(fps_step * 7)
+        leg = {
+            "workload": f"BASELINE configs[2]: {total_frames} frames x 7 views of 256x512x3, 2-stack hourglass bf16 (all convolutions on MFMA, fp32 accumulate), "
+                        "arg-max + 38-joint layout + fp64 DLT with fixed calib.pkl",
+            "value": total_frames / el16, "unit": "frames/s", "steps": a.steps, "ms_per_step": 1e3 * el16 / a.steps, "dtype": "bf16",
+            "hourglass_tflops_end_to_end": fl16 / (el16 / a.steps) / 1e12,
+            "hourglass_gbs_algorithmic_end_to_end": by16 / (el16 / a.steps) / 1e9,
+            "hbm_frac": by16 / (el16 / a.steps) / 1e9 / PEAK_HBM_GBS,
         }
-        roof["frac"] = roof["achieved"] / roof["peak"]
+        if not a.no_roofline:
+            leg["roofline"] = measure_roofline(e16, "bf16", lambda n: [step(i, pipeline=p16, record=False) for i in range(n)], min(a.steps, 4))
+        del p16, e16
 
     if rank == 0:
         ms_step = 1e3 * elapsed / a.steps
         fl, by = engine.work(fps_step * 7)
+        per_step = total_frames / a.steps / fps_step  # < 1 when the last batch of a rank share is short
+        if a.rank_share:
+            cfg = 4 if a.ba_window else 3
+            workload = (f"BASELINE configs[{cfg}], ONE rank's share on one GPU: rank 0 of {a.rank_share} ranks of a {a.stream_frames}-frame 7-view stream = "
+                        f"{total_frames} frames streamed through a {pool}-frame resident pool, 2-stack hourglass {a.dtype}, arg-max + 38-joint layout + fp64 DLT"
+                        + (f", bundle-adjustment re-calibration every {a.ba_window} frames" if a.ba_window else "")
+                        + (", packed gather executed on a 1-rank RCCL group" if collective else ""))
+        elif a.ba_window:
+            workload = (f"BASELINE configs[4] (per-GPU share): {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {a.dtype}, "
+                        f"arg-max + 38-joint layout + fp64 DLT, bundle-adjustment re-calibration every {a.ba_window} frames")
+        else:
+            workload = (f"BASELINE configs[{1 if a.dtype == 'f32' else 2}]: {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {a.dtype}, "
+                        "arg-max + 38-joint layout + fp64 DLT with fixed calib.pkl")
         line = {
             "metric": "frames/sec (7-view 2D->3D)",
             "value": world * total_frames / elapsed,
@@ -222,29 +339,33 @@ def main():
             "dtype": a.dtype,
             "data": "synthetic (seeded uniform frames resident in HBM, seeded synthetic hourglass weights, data/calib.pkl cameras)",
             "config": {
-                "workload": (f"BASELINE configs[4] (per-GPU share): {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {a.dtype}, "
-                             f"arg-max + 38-joint layout + fp64 DLT, bundle-adjustment re-calibration every {a.ba_window} frames"
-                             if a.ba_window else
-                             f"BASELINE configs[{1 if a.dtype == 'f32' else 2}]: {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {a.dtype}, "
-                             "arg-max + 38-joint layout + fp64 DLT with fixed calib.pkl"),
+                "workload": workload,
                 "frames_per_step": fps_step,
                 "frames_per_gpu": total_frames,
-                "parallelism": f"frame-sharded x{world}, one gather",
+                "parallelism": f"frame-sharded x{world}, one packed gather" + (" (executed: RCCL, 1 rank)" if collective and world == 1 else ""),
+                "collective_executed": bool(collective),
+                "collective_backend": torch.distributed.get_backend() if collective else None,
+                "gather_roundtrip_exact": gather_ok,
                 "bundle_adjust_every_frames": a.ba_window or None,
                 "bundle_adjust_runs_rank0": len(ba_runs) or None,
-                "hourglass_tflops_end_to_end": fl / (ms_step * 1e-3) / 1e12,
-                "hourglass_gbs_algorithmic_end_to_end": by / (ms_step * 1e-3) / 1e9,
+                "bundle_adjust_nfev": ba_runs or None,
+                "hourglass_tflops_end_to_end": per_step * fl / (ms_step * 1e-3) / 1e12,
+                "hourglass_gbs_algorithmic_end_to_end": per_step * by / (ms_step * 1e-3) / 1e9,
+                "hbm_frac": per_step * by / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "hbm_frac_note": "hourglass activation bytes of the fusion model M1 (SURVEY.md 8d) / step time / 8 TB/s",
             },
         }
         if roof is not None:
             line["roofline"] = roof
-        if not a.no_cpu_baseline and world == 1:
+        if leg is not None:
+            line["config2_bf16"] = leg
+        if not a.no_cpu_baseline and world == 1 and a.rank_share == 0:
             try:
                 line["cpu_baseline"] = cpu_baseline(sd, frames[:16].cpu(), calib, a.cpu_seconds)
             except Exception as e:  # the baseline is reporting only; never hide the GPU number
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -312,6 +312,27 @@ def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None):
     return dict(x=x, cost=cost, nfev=nfev, njev=njev, status=status, lsmr_iters=lsmr_iters, optimality=g_norm)
 
 
+def reprojection_error(points2d_px, points3d, R, tvec, intr, device="cuda:0"):
+    """Mean pixel distance between the observations and the re-projected 3-D joints, over every observation of a
+    joint seen by >= 2 cameras (what `CameraNetwork.reprojection_error()` prints, call site reference
+    df3d/core.py:250).  The residuals are df3d_ba_eval's (the bundle adjustment's own cost terms), the mean is a
+    fixed-order device reduction (df3d_vec_pairnorm_sum)."""
+    _native.require_gpu()
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        prob = BAProblemDevice(points2d_px, intr, dev)
+        dv = _Dev(prob)
+        ncam = prob.ncam
+        cams = np.concatenate([np.stack([_rotvec_from_matrix(np.asarray(R[c], np.float64)) for c in range(ncam)]), np.asarray(tvec, np.float64)], axis=1).ravel()
+        sel = torch.from_numpy((prob.slot.ravel() >= 0)).to(dev)
+        X = torch.from_numpy(np.ascontiguousarray(points3d, dtype=np.float64)).to(dev).reshape(-1, 3)[sel].reshape(-1)
+        x = torch.cat([torch.from_numpy(cams).to(dev), X])
+        r = dv.new(prob.m)
+        dv.eval(x, r, None, None)
+        _native.check(dv.lib.df3d_vec_pairnorm_sum(r.data_ptr(), prob.nobs, ctypes.byref(dv._res), dv.scratch.data_ptr(), dv.stream()), "df3d_vec_pairnorm_sum")
+        return dv._res.value / prob.nobs
+
+
 def bundle_adjust(points2d_px, R, tvec, intr, device="cuda:0", return_info=False):
     """See _bundle_adjust; runs with `device` as the current HIP device (kernels launch on the current device)."""
     _native.require_gpu()

@@ -12,6 +12,7 @@ import torch
 
 from . import _native, ops
 from . import bundle_adjust as _ba
+from .config import config
 
 
 class Camera:
@@ -105,7 +106,14 @@ class CameraNetwork:
         if update_intrinsic or update_distort:
             raise NotImplementedError("only update_intrinsic=False, update_distort=False is supported (the reference's call)")
         R, t, K = self._stack()
-        R_new, t_new, info = _ba.bundle_adjust(self._points2d, R, t, K, device=self._device(), return_info=True)
+        # pyba bounds the problem (`max_num_images`, 1 000 by its default as far as recalled -- pyba is not in the
+        # reference checkout, SURVEY.md App. A.3 "unpinned: frame sub-sampling"); recordings up to that length -- every
+        # golden vector, every 1 000-frame window -- use all frames.  Longer ones are cut to an evenly strided,
+        # deterministic subset, which also bounds the Jacobian (12 * nobs doubles) instead of growing with T.
+        T = self._points2d.shape[1]
+        cap = int(config.get("ba_max_images") or 0)
+        pts = self._points2d if cap <= 0 or T <= cap else np.ascontiguousarray(self._points2d[:, :: -(-T // cap)])
+        R_new, t_new, info = _ba.bundle_adjust(pts, R, t, K, device=self._device(), return_info=True)
         for c, cam in enumerate(self.cam_list):
             cam.R, cam.tvec = R_new[c], t_new[c]
         self.ba_info = {k: v for k, v in info.items() if k != "x"}
@@ -113,19 +121,14 @@ class CameraNetwork:
         return self.ba_info
 
     def reprojection_error(self):
-        """Mean pixel distance between observations and re-projected triangulated joints."""
+        """Mean pixel distance between observations and re-projected triangulated joints (device residual kernel of
+        the bundle adjustment + a device reduction).  pyba's exact definition is not in the reference checkout; this
+        one is the mean Euclidean distance over the observations of joints seen by >= 2 cameras, and the reference
+        only prints the value (core.py:250)."""
         if self.points3d is None:
             self.triangulate()
         R, t, K = self._stack()
-        p = self._points2d
-        vis = (p[..., 0] != 0) & (p[..., 1] != 0)
-        ok = vis.sum(axis=0) >= 2
-        vis = vis & ok[None]
-        Xc = np.einsum("cij,tkj->ctki", R, self.points3d) + t[:, None, None, :]
-        u = K[:, 0, 0][:, None, None] * Xc[..., 0] / Xc[..., 2] + K[:, 0, 2][:, None, None]
-        v = K[:, 1, 1][:, None, None] * Xc[..., 1] / Xc[..., 2] + K[:, 1, 2][:, None, None]
-        err = np.sqrt((u - p[..., 1]) ** 2 + (v - p[..., 0]) ** 2)
-        return float(err[vis].mean())
+        return _ba.reprojection_error(self._points2d, self.points3d, R, t, K, device=self._device())
 
     def summarize(self):
         out = {c.cam_id: c.summarize() for c in self.cam_list}

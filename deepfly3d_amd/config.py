@@ -19,6 +19,9 @@ config = {
     "calib_path": os.path.join(_HERE, "data", "calib.npz"),                       # reference data/calib.pkl
     "procrustes_template": os.path.join(_HERE, "data", "procrustes_template.npz"),  # reference data/df3d_result.pkl
     "procrustes_apply": True,
+    # frames per bundle-adjustment problem on the Core/CLI path (0 = no limit): longer recordings are sub-sampled
+    # with an even stride (camera_network.py:bundle_adjust)
+    "ba_max_images": 1000,
 }
 
 # tracked-point class per joint of ONE side (19 joints): 3 legs x (body-coxa, coxa-femur, femur-tibia,

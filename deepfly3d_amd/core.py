@@ -184,19 +184,18 @@ class Core:
         points19, conf = inference_folder(
             folder=self.input_folder, camera_ids_to_flip=flip, return_heatmap=False, return_confidence=True,
             max_img_id=self.max_img_id, batch_size=batch_size, disable_pin_memory=disable_pin_memory, dtype=self.dtype, device=self.device,
-            frame_range=(t0, t1),
+            frame_range=(t0, t1), as_device_tensors=True,
         )
-        points2d = relayout_points2d(points19, self.camera_ordering, self.device) if t1 > t0 else np.zeros((7, 0, 38, 2))
-        if world > 1:
-            dev = torch.device(self.device) if self.device is not None else dd.local_device()
-            p = dd.gather_frames(torch.from_numpy(points2d).to(dev), 1, self.num_images)
-            c = dd.gather_frames(torch.from_numpy(np.ascontiguousarray(conf)).to(dev), 1, self.num_images)
+        # 19 -> 38 layout on the device, then (N > 1) ONE gather of the device tensors: no host round trip before it
+        points2d = ops.relayout_19_to_38(points19.contiguous(), self.camera_ordering)
+        if dd.collective_needed(world):
+            gathered = dd.gather_packed([(points2d, 1), (conf, 1)], self.num_images)
             self.is_primary = rank == 0
-            if not self.is_primary:
+            if gathered is None:
                 self.points2d = self.conf = None
                 return
-            points2d, conf = p.cpu().numpy(), c.cpu().numpy()
-        self.points2d, self.conf = points2d, conf
+            points2d, conf = gathered
+        self.points2d, self.conf = points2d.cpu().numpy(), conf.cpu().numpy()
 
     def calibrate_calc(self, min_img_id, max_img_id):
         """Bundle adjustment from the shipped initial calibration (reference :229-250; like the reference the
@@ -269,7 +268,9 @@ class Core:
         return self.camNet.cam_list[cam_id].get_image(img_id)
 
     def get_fps(self):
-        """Frame rate of the first camera video ffprobe can read, None without videos or without ffprobe."""
+        """Frame rate of the camera videos (ffprobe on each of them; a warning when they differ, the first one wins),
+        None without videos, without ffprobe or when an answer cannot be parsed (reference df3d/core.py:403-428)."""
+        rates = []
         for video in camera_videos(self.input_folder):
             cmd, answer = probe_frame_rate(video)
             if answer is None:
@@ -278,8 +279,11 @@ class Core:
             rate = parse_frame_rate(answer)
             if rate is None:
                 logger.warning(f'Could not parse framerate "{answer}" returned by ffprobe, so setting fps to None.')
-            return rate
-        return None
+                return None
+            rates.append(rate)
+        if len(set(rates)) > 1:
+            logger.warning(f"The camera videos have different frame rates {rates}; using {rates[0]}.")
+        return rates[0] if rates else None
 
     def expand_videos(self):
         """camera_x.mp4 -> camera_x_img_y.jpg through ffmpeg for cameras whose frames are not there yet."""
@@ -290,8 +294,18 @@ class Core:
                 extract_frames(video, self.input_folder, cam_id)
 
     def delete_images(self):
-        """Remove the expanded frames of every camera that still has its .mp4."""
+        """Remove the expanded frames of every camera that still has its .mp4.  Multi-GPU: every rank must have finished
+        reading its shard first (the gather is not a barrier for the senders), and only rank 0 deletes."""
+        from . import distributed as dd
+
+        if dd.current()[1] > 1:
+            torch.distributed.barrier()
+        if not self.is_primary:
+            return
         for video in camera_videos(self.input_folder, any_id=False):
             cam_id = parse_vid_name(os.path.basename(video))
             for frame in glob.glob(os.path.join(self.input_folder, f"camera_{cam_id}_img_*.jpg")):
-                os.remove(frame)
+                try:
+                    os.remove(frame)
+                except FileNotFoundError:
+                    pass

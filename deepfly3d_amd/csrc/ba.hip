@@ -265,6 +265,18 @@ __global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ a, 
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// partial sums of the Euclidean norms of n (x, y) pairs (reprojection error: mean pixel distance)
+__global__ __launch_bounds__(256) void pairnorm_kernel(const double* __restrict__ r, size_t n, double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double2 v = *reinterpret_cast<const double2*>(r + 2 * i);
+        acc += sqrt(v.x * v.x + v.y * v.y);
+    }
+    const double tot = block_reduce_256(acc, lds4);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
 // sums `count` partials in index order into result[0]
 __global__ __launch_bounds__(256) void final_sum_kernel(const double* __restrict__ partial, int count,
                                                         double* __restrict__ result) {
@@ -485,6 +497,16 @@ int df3d_vec_dot(const double* a_dev, const double* b_dev, size_t n, double* res
     hipStream_t s = df3d::as_stream(stream);
     const int g = grid_for(n);
     hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(256), 0, s, a_dev, b_dev, n, scratch_dev);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, scratch_dev, g, scratch_dev + RED_BLOCKS);
+    DF3D_LAUNCH_CHECK();
+    return read_back(scratch_dev + RED_BLOCKS, result_host, s);
+}
+
+int df3d_vec_pairnorm_sum(const double* r_dev, size_t npairs, double* result_host, double* scratch_dev, void* stream) {
+    DF3D_CHECK_ARG(r_dev && result_host && scratch_dev, "null pointer");
+    hipStream_t s = df3d::as_stream(stream);
+    const int g = grid_for(npairs);
+    hipLaunchKernelGGL(pairnorm_kernel, dim3(g), dim3(256), 0, s, r_dev, npairs, scratch_dev);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, scratch_dev, g, scratch_dev + RED_BLOCKS);
     DF3D_LAUNCH_CHECK();
     return read_back(scratch_dev + RED_BLOCKS, result_host, s);

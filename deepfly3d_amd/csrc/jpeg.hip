@@ -295,7 +295,10 @@ __device__ int build_tables(const Meta* M, HuffLds<LB>& T, int tid) {
         for (int l = 1; l <= 16; ++l) {
             const int c = (int)rfl(M->dht_counts[t][l - 1]);
             if (tid == 0) T.valoff[t][l] = k - code;
-            if (l <= LB) {  // symbols k .. k+c-1 have the codes code .. code+c-1 of length l
+            // an over-subscribed length (untrusted DHT) would index past the 2^LB-entry table: flag it BEFORE the fill
+            const bool fits = code + c <= (1 << l) && k + c <= 256;
+            if (!fits) bad = 1;
+            if (l <= LB && fits) {  // symbols k .. k+c-1 have the codes code .. code+c-1 of length l
                 const int span = 1 << (LB - l);
                 for (int e = tid; e < c * span; e += NT) {
                     const int j = e / span;

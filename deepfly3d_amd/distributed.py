@@ -4,8 +4,9 @@ tests).  There is no collective on the data path before that: views/frames are i
 arg-max, re-layout and triangulation; bundle-adjustment windows are assigned whole to a rank; Procrustes is
 sequence-global and runs on rank 0 after the gather.
 
-Per frame the gather moves 912 B (points3d) + 4 256 B (points2d) + 532 B (confidence): 100 k frames = 570 MB in
-total, ~71 MB per rank -- one direct point-to-point transfer per peer, no ring.
+Per frame the gather moves ONE packed record of 5 704 B: 4 256 B points2d + 532 B confidence (+4 B pad) + 912 B
+points3d; 100 k frames = 570 MB in total, ~71 MB per rank -- one `dist.gather`, i.e. one direct point-to-point
+transfer per peer, no ring.  Per-window camera parameters (configs[4]) ride behind the frame records.
 """
 import os
 
@@ -62,40 +63,128 @@ def all_ranges(num_frames, world_size, align=1):
     return [shard_range(num_frames, world_size, r, align) for r in range(world_size)]
 
 
-def _gather_frame_axis(local, frame_axis, ranges, rank, world_size, group=None):
-    """Gather tensors that are sharded along `frame_axis` to rank 0 (padded to the largest shard)."""
-    if world_size == 1:
-        return local
-    longest = max(b - a for a, b in ranges)
-    moved = local.movedim(frame_axis, 0).contiguous()
-    if moved.is_cuda and dist.get_backend(group) == "gloo":
-        moved = moved.cpu()  # gloo has no CUDA gather (CPU tests, or several ranks sharing one GPU)
-    if moved.shape[0] < longest:
-        pad = torch.zeros((longest - moved.shape[0], *moved.shape[1:]), dtype=moved.dtype, device=moved.device)
-        moved = torch.cat([moved, pad], dim=0)
-    bufs = [torch.empty_like(moved) for _ in range(world_size)] if rank == 0 else None
-    dist.gather(moved, gather_list=bufs, dst=0, group=group)
+def _wire_tensor(t, group):
+    """The tensor as the collective's back-end needs it: gloo has no CUDA gather (CPU tests, or several test ranks
+    sharing one GPU), RCCL wants device memory."""
+    backend = dist.get_backend(group)
+    if t.is_cuda and backend == "gloo":
+        return t.cpu()
+    if not t.is_cuda and backend == "nccl":
+        return t.to(local_device())
+    return t
+
+
+def _gather_rows(rows, counts, rank, world_size, group=None, force_collective=False):
+    """ONE `dist.gather` of a [n_r, width] uint8 record table per rank (n_r = counts[rank]) to rank 0, which
+    returns the concatenation in rank order; other ranks return None.  Shards are padded to the longest one.
+    With one rank the collective is skipped unless `force_collective` (a 1-rank RCCL group: the call path the
+    multi-GPU run takes, executable on a single GPU) and a process group exist."""
+    collective = world_size > 1 or (force_collective and dist.is_available() and dist.is_initialized())
+    if not collective:
+        return rows
+    longest = max(counts)
+    wire = _wire_tensor(rows, group)
+    if wire.shape[0] < longest:
+        wire = torch.cat([wire, torch.zeros((longest - wire.shape[0], wire.shape[1]), dtype=wire.dtype, device=wire.device)], dim=0)
+    wire = wire.contiguous()
+    bufs = [torch.empty_like(wire) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(wire, gather_list=bufs, dst=0, group=group)
     if rank != 0:
         return None
-    parts = [bufs[r][: ranges[r][1] - ranges[r][0]] for r in range(world_size)]
-    return torch.cat(parts, dim=0).movedim(0, frame_axis).contiguous()
+    return torch.cat([bufs[r][: counts[r]] for r in range(world_size)], dim=0)
 
 
-def gather_frames(local, frame_axis, num_frames, align=1, group=None):
-    """Gather a tensor that is sharded along `frame_axis` by `shard_range` to rank 0 (None on the other ranks)."""
+def _pack_rows(parts, n):
+    """Byte-pack tensors that share their leading axis (n rows) into one [n, width] uint8 table; every field starts
+    at a multiple of 8 bytes.  Returns (table, [(offset, nbytes, dtype, row_shape)])."""
+    layout, width = [], 0
+    for t in parts:
+        nbytes = int(t[0].numel()) * t.element_size() if n else int(np.prod(t.shape[1:])) * t.element_size()
+        layout.append((width, nbytes, t.dtype, tuple(t.shape[1:])))
+        width += (nbytes + 7) // 8 * 8
+    table = torch.zeros((n, width), dtype=torch.uint8, device=parts[0].device)
+    for t, (off, nbytes, _, _) in zip(parts, layout):
+        if n:
+            table[:, off : off + nbytes] = t.contiguous().view(torch.uint8).reshape(n, nbytes)
+    return table, layout
+
+
+def _unpack_rows(table, layout):
+    n = table.shape[0]
+    return [table[:, off : off + nbytes].contiguous().view(dtype).reshape(n, *shape) for off, nbytes, dtype, shape in layout]
+
+
+def collective_needed(world_size, force_collective=None):
+    """True when the gather really runs: several ranks, or a 1-rank process group with the collective forced
+    (DF3D_FORCE_COLLECTIVE=1: exercises the RCCL call path on a single GPU)."""
+    if force_collective is None:
+        force_collective = os.environ.get("DF3D_FORCE_COLLECTIVE", "0") not in ("", "0")
+    return world_size > 1 or (bool(force_collective) and dist.is_available() and dist.is_initialized())
+
+
+def gather_packed(parts, num_frames, align=1, group=None, force_collective=None):
+    """ONE gather of several tensors that are sharded by `shard_range`: parts = [(tensor, frame_axis), ...].
+    Rank 0 gets the list of full-sequence tensors (on the device of the inputs), other ranks None."""
     rank, world = current()
-    return _gather_frame_axis(local, frame_axis, all_ranges(num_frames, world, align), rank, world, group)
+    if not collective_needed(world, force_collective):
+        return [t for t, _ in parts]
+    counts = [b - a for a, b in all_ranges(num_frames, world, align)]
+    moved = [t.movedim(ax, 0) for t, ax in parts]
+    table, layout = _pack_rows(moved, moved[0].shape[0])
+    rows = _gather_rows(table, counts, rank, world, group, True)
+    if rows is None:
+        return None
+    dev = parts[0][0].device
+    return [u.to(dev).movedim(0, ax).contiguous() for u, (_, ax) in zip(_unpack_rows(rows, layout), parts)]
 
 
-def gather_results(points2d, conf, points3d, num_frames, rank, world_size, align=1, group=None):
-    """The single collective of the path.  Inputs are this rank's shard:
-        points2d [7, Tr, 38, 2] f64, conf [7, Tr, 19] f32, points3d [Tr, 38, 3] f64
-    Rank 0 receives the full-sequence tensors (frame order = rank order), other ranks receive None."""
+def gather_frames(local, frame_axis, num_frames, align=1, group=None, force_collective=False):
+    """Gather a tensor that is sharded along `frame_axis` by `shard_range` to rank 0 (None on the other ranks)."""
+    out = gather_packed([(local, frame_axis)], num_frames, align, group, force_collective)
+    return None if out is None else out[0]
+
+
+def gather_results(points2d, conf, points3d, num_frames, rank, world_size, align=1, group=None, cameras=None, force_collective=False):
+    """THE collective of the path: one `dist.gather` (RCCL over xGMI on the GPU box) of one byte-packed record per
+    frame.  Inputs are this rank's shard:
+        points2d [7, Tr, 38, 2] f64, conf [7, Tr, 19] f32, points3d [Tr, 38, 3] f64          (5 704 B per frame)
+        cameras  [Wr, 7, 12] f64 (optional): per bundle-adjustment window R (9) + tvec (3) of the 7 cameras; the
+                 window records travel in the same buffer, behind the frame records (BASELINE configs[4]).
+    Rank 0 receives the full-sequence tensors (frame / window order = rank order), other ranks receive None.
+    Returns (points2d, conf, points3d) or, with `cameras`, (points2d, conf, points3d, cameras)."""
     ranges = all_ranges(num_frames, world_size, align)
-    p2 = _gather_frame_axis(points2d, 1, ranges, rank, world_size, group)
-    cf = _gather_frame_axis(conf, 1, ranges, rank, world_size, group)
-    p3 = _gather_frame_axis(points3d, 0, ranges, rank, world_size, group)
-    return p2, cf, p3
+    counts = [b - a for a, b in ranges]
+    collective = world_size > 1 or (force_collective and dist.is_available() and dist.is_initialized())
+    if not collective:
+        return (points2d, conf, points3d) if cameras is None else (points2d, conf, points3d, cameras)
+    Tr = points3d.shape[0]
+    frame_tab, frame_layout = _pack_rows([points2d.movedim(1, 0), conf.movedim(1, 0), points3d], Tr)
+    fw = frame_tab.shape[1]
+    if cameras is not None:
+        # windows per rank follow from the frame ranges (a window never straddles two ranks: `align`)
+        wcounts = [(c + align - 1) // align for c in counts]
+        if cameras.shape[0] != wcounts[rank]:
+            raise ValueError(f"rank {rank}: {cameras.shape[0]} camera windows for {counts[rank]} frames (align {align})")
+        cam_tab, cam_layout = _pack_rows([cameras], cameras.shape[0])
+        cw = cam_tab.shape[1]
+        # one flat byte record per rank: [longest frames x fw | longest windows x cw]
+        lf, lw = max(counts), max(wcounts)
+        flat = torch.zeros((1, lf * fw + lw * cw), dtype=torch.uint8, device=frame_tab.device)
+        flat[0, : Tr * fw] = frame_tab.reshape(-1)
+        flat[0, lf * fw : lf * fw + cam_tab.numel()] = cam_tab.reshape(-1)
+        rows = _gather_rows(flat, [1] * world_size, rank, world_size, group, force_collective)
+        if rows is None:
+            return None, None, None, None
+        ftabs = torch.cat([rows[r, : counts[r] * fw].reshape(counts[r], fw) for r in range(world_size)], dim=0)
+        ctabs = torch.cat([rows[r, lf * fw : lf * fw + wcounts[r] * cw].reshape(wcounts[r], cw) for r in range(world_size)], dim=0)
+        cams = _unpack_rows(ctabs, cam_layout)[0].to(cameras.device)
+    else:
+        ftabs = _gather_rows(frame_tab, counts, rank, world_size, group, force_collective)
+        if ftabs is None:
+            return None, None, None
+    p2, cf, p3 = (t.to(points3d.device) for t in _unpack_rows(ftabs, frame_layout))
+    out = (p2.movedim(0, 1).contiguous(), cf.movedim(0, 1).contiguous(), p3)
+    return out if cameras is None else (*out, cams)
 
 
 def assemble_result(points2d, conf, points3d_wo, cameras, camera_ordering, procrustes=None):

@@ -26,7 +26,16 @@ from .os_util import image_path_for
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # df2d's normalisation constants are not in the reference checkout ("parity unpinned"): kept as data
+# (bearpaw's `color_normalize` subtracts the mean and does not divide; mean 0.22 as recalled -- unverifiable here).
+# DF3D_PREPROCESS='{"mean": [m, m, m], "std": [s, s, s]}' overrides them without a code change; the dormant
+# reference-pin test (tests/test_gpu_reference_pin.py) reads the same variable.
 PREPROCESS = {"mean": (0.22, 0.22, 0.22), "std": (1.0, 1.0, 1.0)}
+if os.environ.get("DF3D_PREPROCESS"):
+    import json as _json
+
+    _p = _json.loads(os.environ["DF3D_PREPROCESS"])
+    PREPROCESS = {"mean": tuple(float(v) for v in _p["mean"]), "std": tuple(float(v) for v in _p["std"])}
+_warned_preprocess = []
 
 _engine_cache = {}
 
@@ -40,6 +49,14 @@ def load_state_dict(path=None):
     cands = [path, os.environ.get("DF3D_WEIGHTS"), os.path.join(_HERE, "weights", "sh8_deepfly.tar")]
     for cand in cands:
         if cand and os.path.exists(cand):
+            if "DF3D_PREPROCESS" not in os.environ and not _warned_preprocess:
+                _warned_preprocess.append(True)
+                from . import logger
+
+                logger.warning(
+                    f"Trained weights {cand} with UNPINNED input normalisation {PREPROCESS}: df2d's constants are not in "
+                    "the reference checkout.  Verify them against nely-df2d (dataset mean/std, resize) or set "
+                    'DF3D_PREPROCESS=\'{"mean": [..], "std": [..]}\'; a wrong value silently degrades every 2-D pose.')
             ckpt = torch.load(cand, map_location="cpu", weights_only=False)
             sd = ckpt.get("state_dict", ckpt) if isinstance(ckpt, dict) else ckpt
             return {k[len("module.") :] if k.startswith("module.") else k: v for k, v in sd.items()}
@@ -102,11 +119,13 @@ DEVICE_BATCH_VIEWS = 896
 
 
 def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return_confidence=True, max_img_id=None,
-                     batch_size=8, disable_pin_memory=False, dtype="f32", device=None, state_dict=None, frame_range=None):
+                     batch_size=8, disable_pin_memory=False, dtype="f32", device=None, state_dict=None, frame_range=None,
+                     as_device_tensors=False):
     """Drop-in for df2d.inference.inference_folder (see module docstring).  Host work: listing and reading the
     files.  Device work: JPEG decode (csrc/jpeg.hip), flip / resize / normalise, hourglass, arg-max.
     `frame_range=(t0, t1)` (multi-GPU sharding) restricts the call to images t0 <= id < t1; the outputs then have
-    t1 - t0 frames."""
+    t1 - t0 frames.  `as_device_tensors=True` returns the results as CUDA tensors instead of numpy arrays (the
+    multi-GPU path gathers them without a host round trip)."""
     from .jpeg import JpegFolderReader
 
     _native.require_gpu()
@@ -123,6 +142,9 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
             out.append(np.zeros((ncam, 0, config["num_predict"], config["input_shape"][0] // 4, config["input_shape"][1] // 4), np.float32))
         if return_confidence:
             out.append(np.zeros((ncam, 0, config["num_predict"], 1), np.float32))
+        if as_device_tensors:
+            dev0 = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+            out = [torch.from_numpy(a).to(dev0) for a in out]
         return tuple(out) if len(out) > 1 else out[0]
     engine = get_engine(dtype=dtype, device=device, state_dict=state_dict)
     dev = engine.device
@@ -142,24 +164,28 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
     paths = [[image_path_for(folder, c, t_first + t) for c, t in chunk] for chunk in chunks]
     width, height = _image_size(paths[0][0])
     reader = JpegFolderReader(width, height, dev, pinned=not disable_pin_memory)
-    with torch.cuda.device(dev):
-        reader.prefetch(paths[0])
-        for k, chunk in enumerate(chunks):
-            luma = reader.decode_next(paths[k + 1] if k + 1 < len(chunks) else None)
-            flip = torch.from_numpy(np.fromiter((1 if c in flip_set else 0 for c, _ in chunk), dtype=np.uint8, count=len(chunk))).to(dev, non_blocking=True)
-            x = preprocess_u8(luma, flip, tuple(config["input_shape"]))
-            res = inference_views(x, engine, return_heatmap=return_heatmap)
-            # items are (camera, frame) in camera-major order = the flat order of points[ncam, T]: contiguous copies
-            lo = starts[k]
-            points_flat[lo : lo + len(chunk)] = res[0]
-            conf_flat[lo : lo + len(chunk), :, 0] = res[1]
-            if return_heatmap:
-                heat.append(res[2].cpu())
+    try:  # the reader's threads and pinned buffers are released on every path (df3d-cli -r/-f continues after a failed folder)
+        with torch.cuda.device(dev):
+            reader.prefetch(paths[0])
+            for k, chunk in enumerate(chunks):
+                luma = reader.decode_next(paths[k + 1] if k + 1 < len(chunks) else None)
+                flip = torch.from_numpy(np.fromiter((1 if c in flip_set else 0 for c, _ in chunk), dtype=np.uint8, count=len(chunk))).to(dev, non_blocking=True)
+                x = preprocess_u8(luma, flip, tuple(config["input_shape"]))
+                res = inference_views(x, engine, return_heatmap=return_heatmap)
+                # items are (camera, frame) in camera-major order = the flat order of points[ncam, T]: contiguous copies
+                lo = starts[k]
+                points_flat[lo : lo + len(chunk)] = res[0]
+                conf_flat[lo : lo + len(chunk), :, 0] = res[1]
+                if return_heatmap:
+                    heat.append(res[2].cpu())
+    finally:
         reader.finish()
-    out = [points.cpu().numpy()]
+    host = (lambda t: t) if as_device_tensors else (lambda t: t.cpu().numpy())
+    out = [host(points)]
     if return_heatmap:
-        hm = torch.cat(heat).numpy()
-        out.append(hm.reshape(ncam, T, *hm.shape[1:]))
+        hm = torch.cat(heat)
+        hm = hm.reshape(ncam, T, *hm.shape[1:])
+        out.append(hm.to(dev) if as_device_tensors else hm.numpy())
     if return_confidence:
-        out.append(conf.cpu().numpy())
+        out.append(host(conf))
     return tuple(out) if len(out) > 1 else out[0]

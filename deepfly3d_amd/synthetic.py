@@ -88,3 +88,13 @@ def synthetic_points2d(points3d, R, tvec, intr, camera_ordering=(0, 1, 2, 3, 4, 
         unseen = out[o[pos], ..., 0] == 0
         out[o[pos], ..., 1] = np.where(unseen, 1.0, out[o[pos], ..., 1])
     return out
+
+
+def synthetic_ba_window(pose, R, tvec, intr, window, seed, index=0, image_shape=(960, 480)):
+    """Geometry-consistent detections of one bundle-adjustment window in PIXELS (row, col), shape (7, window, 38, 2):
+    the (T0, 38, 3) `pose` tiled to `window` frames + N(0, 0.05 mm) jitter seeded by (seed, index), projected through
+    the cameras and quantised to the heat-map grid (the BA stage of BASELINE configs[4])."""
+    pose = np.asarray(pose, np.float64)
+    rng = np.random.default_rng([int(seed), int(index)])
+    X = np.tile(pose, (window // pose.shape[0] + 1, 1, 1))[:window] + rng.normal(0, 0.05, size=(window, 38, 3))
+    return synthetic_points2d(X, R, tvec, intr, image_shape=image_shape) * np.array([float(image_shape[1]), float(image_shape[0])])

@@ -199,6 +199,10 @@ int df3d_vec_axpby(double a, const double* x_dev, double b, const double* y_dev,
                    void* stream); /* out = a*x + b*y (y may be NULL)        */
 int df3d_vec_mul(const double* x_dev, const double* y_dev, double* out_dev, size_t n, void* stream);
 int df3d_vec_absmax(const double* a_dev, size_t n, double* result_host, double* scratch_dev, void* stream); /* sync */
+/* sum over npairs (x, y) pairs of sqrt(x^2 + y^2): with the residuals of df3d_ba_eval this is nobs x the mean
+ * re-projection distance in pixels that CameraNetwork.reprojection_error() reports (call site reference
+ * df3d/core.py:250); fixed summation order; synchronises like df3d_vec_dot */
+int df3d_vec_pairnorm_sum(const double* r_dev, size_t npairs, double* result_host, double* scratch_dev, void* stream);
 /* scipy's x_scale='jac': scale_inv = sqrt(colsq) (0 -> 1 when first != 0, else max with the previous value),
  * scale = 1 / scale_inv */
 int df3d_ba_update_scale(const double* colsq_dev, double* scale_inv_dev, double* scale_dev, size_t n, int first,

@@ -52,6 +52,19 @@ def main():
                     cls[m.group(1)][1] += b
         for name, (n, b) in cls.items():
             traffic[name] = b / n
+        # provenance: the kernel sources the counters were collected with (bench.py recomputes the same hash at run time
+        # and reports `traffic_is_current`), plus the commit of this checkout when the summary is made
+        import subprocess
+
+        sys.path.insert(0, ROOT)
+        from bench import kernel_source_sha
+
+        try:
+            head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        except OSError:
+            head = None
+        traffic["_meta"] = {"kernel_source_sha": kernel_source_sha(), "git_head_when_summarised": head, "tag": tag,
+                            "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch, separate --pmc passes"}
         json.dump(traffic, open(tj, "w"), indent=1, sort_keys=True)
         print(json.dumps(traffic, indent=1))
 

@@ -27,7 +27,12 @@ def _full_sequence(T):
     return p2, cf, p3
 
 
-def _worker(rank, world, port, T, align, outdir):
+def _window_cameras(T, align):
+    nwin = (T + align - 1) // align
+    return torch.randn((nwin, 7, 12), generator=torch.Generator().manual_seed(11), dtype=torch.float64)
+
+
+def _worker(rank, world, port, T, align, outdir, with_cameras=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from deepfly3d_amd import distributed as dd
@@ -36,11 +41,17 @@ def _worker(rank, world, port, T, align, outdir):
     assert (r, w) == (rank, world)
     p2, cf, p3 = _full_sequence(T)
     a, b = dd.shard_range(T, world, rank, align)
-    out = dd.gather_results(p2[:, a:b].contiguous(), cf[:, a:b].contiguous(), p3[a:b].contiguous(), T, rank, world, align)
+    cams = _window_cameras(T, align)[a // align : (b + align - 1) // align].contiguous() if with_cameras else None
+    calls = []
+    real_gather = dist.gather
+    dist.gather = lambda *args, **kw: (calls.append(1), real_gather(*args, **kw))[1]
+    out = dd.gather_results(p2[:, a:b].contiguous(), cf[:, a:b].contiguous(), p3[a:b].contiguous(), T, rank, world, align, cameras=cams)
+    dist.gather = real_gather
+    assert len(calls) == 1, "the data path has exactly ONE collective"
     if rank == 0:
         torch.save([t for t in out], os.path.join(outdir, "gathered.pt"))
     else:
-        assert out == (None, None, None)
+        assert all(t is None for t in out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,6 +64,43 @@ def test_two_rank_gather_equals_single_process(tmp_path, T, align):
     ref = _full_sequence(T)
     for g, r in zip(got, ref):
         assert g.dtype == r.dtype and torch.equal(g, r)
+
+
+@pytest.mark.parametrize("T,align", [(40, 8), (35, 10)])
+def test_two_rank_gather_with_window_cameras(tmp_path, T, align):
+    """configs[4]: the per-window camera parameters ride in the same single collective as the frame records."""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, T, align, str(tmp_path), True), nprocs=2, join=True)
+    got = torch.load(os.path.join(tmp_path, "gathered.pt"))
+    ref = (*_full_sequence(T), _window_cameras(T, align))
+    assert len(got) == 4
+    for g, r in zip(got, ref):
+        assert g.dtype == r.dtype and torch.equal(g, r)
+
+
+def test_one_rank_group_executes_the_collective():
+    """A 1-rank process group with force_collective runs the real `dist.gather` (what the GPU box does on RCCL with
+    its single GPU) and returns the same tensors."""
+    from deepfly3d_amd import distributed as dd
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        p2, cf, p3 = _full_sequence(9)
+        cams = _window_cameras(9, 4)
+        calls = []
+        real_gather = dist.gather
+        dist.gather = lambda *args, **kw: (calls.append(1), real_gather(*args, **kw))[1]
+        try:
+            out = dd.gather_results(p2, cf, p3, 9, 0, 1, align=4, cameras=cams, force_collective=True)
+            one = dd.gather_frames(p2, 1, 9, force_collective=True)
+        finally:
+            dist.gather = real_gather
+        assert len(calls) == 2
+        for g, r in zip(out, (p2, cf, p3, cams)):
+            assert g is not r and g.dtype == r.dtype and torch.equal(g, r)
+        assert torch.equal(one, p2)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_single_rank_is_a_no_op():

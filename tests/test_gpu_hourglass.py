@@ -71,12 +71,87 @@ def test_fp32_forward_heatmaps_and_argmax(native_lib, cuda, oracle_net, images, 
     assert _rel_err(hm.cpu(), ref) < FP32_TOL
     pts, conf = ops.heatmap_argmax(hm)
     rp, rc = og.heatmap_argmax(ref.numpy())
-    agree = np.mean(np.all(pts.cpu().numpy() == rp, axis=-1))
-    assert agree >= 0.97, f"arg-max agreement {agree}"  # near-ties may flip (SURVEY.md sec. 7 'hard parts')
+    _assert_argmax_parity(pts.cpu().numpy(), ref.numpy(), rp, FP32_TOL)
     np.testing.assert_allclose(conf.cpu().numpy(), rc, rtol=0, atol=FP32_TOL * float(ref.abs().max()))
     # batch-size independence: one view alone gives bit-identical heat-maps
     hm1 = eng.forward(images[:1].contiguous().to(cuda))
     assert torch.equal(hm1[0], hm[0])
+
+
+def _assert_argmax_parity(pts, ref_hm, ref_pts, tol):
+    """The rigorous form of "same cell as the oracle": wherever the oracle's own margin (top-1 minus the best other cell)
+    exceeds twice the numerical error bound `tol * max|heat-map|` the cell MUST be identical; on a nearer tie the
+    device may pick another cell only if the oracle's value there is within that bound of the maximum."""
+    n, j, h, w = ref_hm.shape
+    flat = ref_hm.reshape(n, j, -1)
+    bound = 2.0 * tol * np.abs(ref_hm).max()
+    top2 = -np.partition(-flat, 1, axis=-1)[..., :2]
+    decided = (top2[..., 0] - top2[..., 1]) > bound
+    same = np.all(pts == ref_pts, axis=-1)
+    assert same[decided].all(), f"{(~same[decided]).sum()} decided maps with a different arg-max cell"
+    idx = np.rint(pts[..., 0] * h).astype(np.int64) * w + np.rint(pts[..., 1] * w).astype(np.int64)
+    picked = np.take_along_axis(flat, idx[..., None], axis=-1)[..., 0]
+    assert np.all(top2[..., 0] - picked <= bound)
+    return float(same.mean()), float(decided.mean())
+
+
+@pytest.fixture(scope="module")
+def peaked(oracle_net, golden_dir):
+    """Inputs optimised so that the seeded network's heat-maps have ONE sharp peak per joint map (tests/golden/
+    make_peaked_input.py): what a trained network's output looks like, with the whole network in the loop."""
+    d = np.load(f"{golden_dir}/peaked_input.npz")
+    x = torch.from_numpy(d["images_u8"].astype(np.float32) / 255.0)[..., None].expand(-1, -1, -1, 3).contiguous()
+    ref = oh.forward_nhwc(oracle_net, x)
+    rp, rc = og.heatmap_argmax(ref.numpy())
+    planted = d["planted"].astype(np.float32) / np.array([64.0, 128.0], dtype=np.float32)
+    assert np.array_equal(rp, planted), "the oracle peaks at the planted cells"
+    flat = ref.reshape(*ref.shape[:2], -1)
+    top2 = flat.topk(2, dim=-1).values
+    margin = ((top2[..., 0] - top2[..., 1]) / ref.abs().max()).numpy()
+    return dict(x=x, ref=ref, pts=rp, conf=rc, margin=margin)
+
+
+def test_peaked_heatmaps_fp32_identical_cells(native_lib, cuda, oracle_net, peaked):
+    """north_star's 2-D bar (points2d within 1e-4 px = the same heat-map cell) on peaked heat-maps: the fp32 engine
+    returns the oracle's cell for 100 % of the joints, the peak value within 2e-3 (the reference's confidence bar,
+    reference tests/test_df3d.py:167-178) -- in heat-map units, although these peaks are O(10), not O(1)."""
+    from deepfly3d_amd import ops
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    assert peaked["margin"].min() > 100 * FP32_TOL, peaked["margin"].min()
+    eng = HourglassEngine(oracle_net.state_dict(), dtype="f32", device=cuda)
+    hm = eng.forward(peaked["x"].to(cuda))
+    assert _rel_err(hm.cpu(), peaked["ref"]) < FP32_TOL
+    pts, conf = ops.heatmap_argmax(hm)
+    assert np.array_equal(pts.cpu().numpy(), peaked["pts"]), "fp32: identical arg-max cell for every joint"
+    np.testing.assert_allclose(conf.cpu().numpy(), peaked["conf"], rtol=0, atol=2e-3)
+    print(f"peaked fp32: 38/38 identical cells, max |conf diff| {np.abs(conf.cpu().numpy() - peaked['conf']).max():.2e} "
+          f"(peaks {peaked['conf'].min():.1f}..{peaked['conf'].max():.1f}, smallest relative margin {peaked['margin'].min():.3f})")
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_peaked_heatmaps_bf16_cells(native_lib, cuda, oracle_net, peaked, fuse):
+    """BASELINE configs[2] (bf16 activations + weights, fp32 accumulate) on the peaked maps: identical arg-max cell for
+    >= 99 % of the joints (here: all whose margin exceeds the bf16 error), the rest within one cell; the peak VALUE
+    carries bf16's accumulated rounding (~1e-2 relative through 100 convolutions), so the reference's 2e-3 confidence
+    bar is met by the fp32 engine only -- asserted here at the bf16 tolerance and reported."""
+    from deepfly3d_amd import ops
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    eng = HourglassEngine(oracle_net.state_dict(), dtype="bf16", device=cuda, fuse=fuse)
+    hm = eng.forward(peaked["x"].to(cuda))
+    err = _rel_err(hm.cpu(), peaked["ref"])
+    assert err < BF16_TOL
+    pts, conf = ops.heatmap_argmax(hm)
+    pts, conf = pts.cpu().numpy(), conf.cpu().numpy()
+    same = np.all(pts == peaked["pts"], axis=-1)
+    cells = np.abs(pts - peaked["pts"]) * np.array([64.0, 128.0])
+    rel_conf = np.abs(conf - peaked["conf"]).max() / np.abs(peaked["ref"].numpy()).max()
+    print(f"peaked bf16 (fuse={fuse}): identical cell {same.mean():.4f}, worst cell distance {cells.max():.0f}, heat-map rel err {err:.3e}, conf rel err {rel_conf:.3e}")
+    assert same.mean() >= 0.99
+    assert same[peaked["margin"] > 2 * BF16_TOL].all()
+    assert cells.max() <= 1.0
+    assert rel_conf < BF16_TOL
 
 
 def test_fp32_work_accounting(native_lib, cuda, oracle_net):
@@ -142,7 +217,9 @@ def test_bf16_argmax_agreement_with_fp32(native_lib, cuda, oracle_net, images):
     same = (p32 == p16).all(dim=-1).float().mean().item()
     near = ((p32 - p16).abs() * torch.tensor([64.0, 128.0], device=cuda)).amax(dim=-1).le(2.0).float().mean().item()
     print(f"bf16 vs fp32 arg-max: identical cell {same:.3f}, within 2 cells {near:.3f}")
-    assert near >= 0.6  # random-weight heat-maps are nearly flat; trained nets have sharp peaks
+    # random-weight heat-maps of random images are nearly flat (the peaked-map tests above are the parity statement); the
+    # floors are the measured rates (identical 0.42, within two cells 0.66 on these 38 maps) less a margin
+    assert same >= 0.35 and near >= 0.6
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

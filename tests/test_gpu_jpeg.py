@@ -132,6 +132,30 @@ def test_status_codes_and_mixed_batches(native_lib, cuda, sequential):
     assert jpeg.decode_luma([], 56, 40).shape == (0, 40, 56)
 
 
+@SEQ
+def test_oversubscribed_huffman_table_is_rejected(native_lib, cuda, sequential):
+    """Untrusted DHT whose code counts over-subscribe a length (12 codes of 1 bit; 255 of 1 bit): the table builder
+    must flag the file as corrupt without indexing past its 2^LB-entry look-up table, and the neighbours of the
+    batch decode normally (the oracle classifies the same way)."""
+    from deepfly3d_amd import jpeg
+
+    rng = np.random.default_rng(6)
+    good = _encode(_smooth(rng, 40, 56), quality=85)
+    i = good.index(b"\xff\xc4")
+    nv = sum(good[i + 5 : i + 21])
+    crafted = bytearray(good)
+    crafted[i + 5 : i + 21] = bytes([nv] + [0] * 15)
+    # a DHT segment declaring 255 one-bit codes (segment grown accordingly)
+    seg_len = int.from_bytes(good[i + 2 : i + 4], "big")
+    big = bytearray(good[: i + 2]) + (seg_len - nv + 255).to_bytes(2, "big") + good[i + 4 : i + 5] + bytes([255] + [0] * 15) + bytes(range(255)) + good[i + 4 + seg_len - 2 :]
+    batch = [good, bytes(crafted), bytes(big), good]
+    out, st = jpeg.decode_luma(batch, 56, 40, check=False, return_status=True, sequential=sequential)
+    assert list(st) == [0, 4, 4, 0]
+    assert [oj.status(b, 56, 40) for b in batch] == [0, 4, 4, 0]
+    out = out.cpu().numpy()
+    assert np.array_equal(out[0], pil_luma(good)) and np.array_equal(out[3], pil_luma(good))
+
+
 def test_many_files_one_call(native_lib, cuda, golden_dir):
     """224 files (one 32-frame step of the pipeline) in one call; every copy decodes identically."""
     from deepfly3d_amd import jpeg

@@ -1,0 +1,145 @@
+"""-m gpu: ONE rank's share of BASELINE configs[3] / configs[4] on the one GPU of the box, and the single packed
+gather executed on RCCL (a 1-rank `nccl` process group -- the call path the 8-GPU run takes).
+
+configs[3]: 100 000-frame 7-view stream sharded by frame over 8 ranks -> rank 0 owns 12 500 frames (13 000 when the
+ranges are aligned to the 1 000-frame bundle-adjustment window of configs[4]), streamed in batches of 128 frames
+through a 1 024-frame resident pool; configs[4] adds one bundle adjustment per 1 000-frame window, whose cameras ride
+in the same gather.  Full-size runs are checked through size-independent properties (the stream is periodic in the
+pool, every frame is independent of its batch), one window's bundle adjustment against the oracle, and the gather
+by an exact round trip.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from oracle import geometry as og
+from oracle import trf_lsmr as ot
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture()
+def rccl_one_rank(cuda):
+    torch.cuda.set_device(cuda)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        yield
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_share_stream_with_ba_windows_and_rccl_gather(native_lib, cuda, golden_dir, rccl_one_rank):
+    """Rank 0's share of configs[4] (bf16 hourglass as in configs[2]; the geometry stages are dtype-independent):
+    13 000 frames streamed through the 1 024-frame pool in batches of 128, a bundle adjustment per 1 000-frame window,
+    then ONE `dist.gather` on the nccl (= RCCL) backend carrying frames and window cameras."""
+    from deepfly3d_amd import distributed as dd
+    from deepfly3d_amd.bundle_adjust import bundle_adjust
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.pipeline import FramePipeline
+    from deepfly3d_amd.synthetic import synthetic_ba_window, synthetic_state_dict
+
+    stream, ranks, window, fpb, pool = 100_000, 8, 1000, 128, 1024
+    t0, t1 = dd.shard_range(stream, ranks, 0, window)
+    assert (t0, t1) == (0, 13_000) and dd.shard_range(stream, ranks, 7, window) == (88_000, 100_000)
+    T = t1 - t0
+    eng = HourglassEngine(synthetic_state_dict(0), dtype="bf16", device=cuda)
+    c = np.load(f"{golden_dir}/calib.npz")
+    g3 = np.load(f"{golden_dir}/golden_3d.npz")
+    pipe = FramePipeline(eng, c["R"], c["tvec"], c["intr"])
+    frames = torch.rand((pool, 7, 256, 512, 3), generator=torch.Generator(device=cuda).manual_seed(0), device=cuda, dtype=torch.float32)
+    outs = pipe.allocate_outputs(T)
+    windows = [synthetic_ba_window(g3["points3d_wo_procrustes"], g3["R"], g3["tvec"], g3["intr"], window, 0, w) for w in range(T // window)]
+    cams, nfev = [], []
+    for f0 in range(0, T, fpb):
+        n = min(fpb, T - f0)
+        lo = f0 % pool
+        pipe.run_batch(frames[lo : lo + n], *outs, f0)
+        if (f0 + n) // window > f0 // window:
+            R, t, info = bundle_adjust(windows[(f0 + n - 1) // window], c["R"], c["tvec"], c["intr"], device=cuda, return_info=True)
+            cams.append(np.concatenate([R.reshape(7, 9), t.reshape(7, 3)], axis=1))
+            nfev.append(info["nfev"])
+    assert len(cams) == 13
+    p2, conf, p3 = outs
+    assert bool(torch.isfinite(conf).all()) and bool(torch.isfinite(p3).all())
+    # the stream is periodic in the pool: frame t and frame t + 1024 are the same pixels in different batches and positions
+    for a in (0, 300, 1000):
+        for k in range(1, T // pool):
+            b = a + k * pool
+            if b + 24 <= T:
+                assert torch.equal(p2[:, a : a + 24], p2[:, b : b + 24]) and torch.equal(conf[:, a : a + 24], conf[:, b : b + 24]) and torch.equal(p3[a : a + 24], p3[b : b + 24])
+    # scattered frames alone == inside the stream; and against the oracle's geometry on the device heat-maps
+    rng = np.random.default_rng(5)
+    for t in sorted(rng.choice(T, size=6, replace=False).tolist()):
+        q2, qc, q3 = pipe.run(frames[t % pool : t % pool + 1], frames_per_batch=1)
+        assert torch.equal(q2[:, 0], p2[:, t]) and torch.equal(qc[:, 0], conf[:, t]) and torch.equal(q3[0], p3[t])
+    t = T - 1
+    hm = eng.forward(frames[t % pool].contiguous()).cpu().numpy()
+    pts, cf = og.heatmap_argmax(hm)
+    p38 = og.relayout_19_to_38(pts.reshape(7, 1, 19, 2), list(range(7)))
+    assert np.array_equal(p2[:, t].cpu().numpy(), p38[:, 0]) and np.array_equal(conf[:, t].cpu().numpy(), cf)
+    X = og.triangulate_dlt(og.pixels_from_normalised(p38, [960, 480]), og.projection_matrices(c["R"], c["tvec"], c["intr"]))
+    assert np.abs(p3[t].cpu().numpy() - X[0]).max() < 1e-6 * max(1.0, np.abs(X).max())
+    # one window's bundle adjustment against the oracle solver: same evaluations, same cameras
+    w = 7
+    Ro, to, res = ot.bundle_adjust(windows[w], c["R"], c["tvec"], c["intr"], return_info=True)
+    assert nfev[w] == res["nfev"]
+    assert np.abs(cams[w][:, :9].reshape(7, 3, 3) - Ro).max() < 5e-6 and np.abs(cams[w][:, 9:] - to).max() < 5e-5
+    assert len({cm.tobytes() for cm in cams}) == 13  # every window was its own problem
+    # THE collective, on RCCL: one dist.gather of device memory carrying the frame records and the window cameras
+    assert dist.get_backend() == "nccl"
+    calls = []
+    real = dist.gather
+
+    def counting(tensor, *a, **kw):
+        calls.append((tensor.is_cuda, tensor.dtype, tuple(tensor.shape)))
+        return real(tensor, *a, **kw)
+
+    dist.gather = counting
+    try:
+        cam_t = torch.from_numpy(np.stack(cams)).to(cuda)
+        g2, gc, g3d, gcam = dd.gather_results(p2, conf, p3, num_frames=T, rank=0, world_size=1, align=window, cameras=cam_t, force_collective=True)
+    finally:
+        dist.gather = real
+    torch.cuda.synchronize()
+    assert calls == [(True, torch.uint8, (1, T * 5704 + 13 * 672))]
+    assert g2 is not p2 and torch.equal(g2, p2) and torch.equal(gc, conf) and torch.equal(g3d, p3) and torch.equal(gcam, cam_t)
+    # Procrustes (sequence-global) after the gather, as rank 0 does: the assembled result has the reference's schema
+    out = dd.assemble_result(g2.cpu().numpy(), gc.cpu().numpy(), g3d.cpu().numpy(),
+                             {k: c[k] for k in ("R", "tvec", "intr", "distort")}, np.arange(7))
+    assert out["points3d"].shape == (T, 38, 3) and out["heatmap_confidence"].shape == (7, T, 19, 1)
+
+
+def _bench(*flags, timeout=900):
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-roofline", "--warmup", "1", *flags],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_rank_share_modes():
+    """bench.py --rank-share: configs[3] in fp32 (12 500 frames) and configs[4] in bf16 (13 000 frames + 13 bundle
+    adjustments), both with the packed gather executed on a 1-rank RCCL group inside the timed region."""
+    line = _bench("--rank-share", "8", "--stream-frames", "100000", "--force-collective")
+    cfg = line["config"]
+    assert cfg["frames_per_gpu"] == 12_500 and line["steps"] == 98 and cfg["collective_executed"] and cfg["collective_backend"] == "nccl"
+    assert cfg["gather_roundtrip_exact"] is True and "configs[3]" in cfg["workload"] and line["dtype"] == "f32" and line["value"] > 100
+    line = _bench("--rank-share", "8", "--stream-frames", "100000", "--ba-window", "1000", "--force-collective", "--dtype", "bf16")
+    cfg = line["config"]
+    assert cfg["frames_per_gpu"] == 13_000 and cfg["bundle_adjust_runs_rank0"] == 13 and cfg["collective_executed"]
+    assert cfg["gather_roundtrip_exact"] is True and "configs[4]" in cfg["workload"] and line["value"] > 500
+    print("rank share: configs[4] bf16", round(line["value"], 1), "frames/s")

@@ -205,7 +205,7 @@ def test_cli_flags_and_exit_codes(tmp_path, capsys):
 
 def test_camera_network_bookkeeping(golden_dir):
     """CameraNetwork tolerates a whole result dict as `calib`, keeps pixel (row, col) points, summarises in the
-    golden key order; reprojection error of the golden result is the value the reference prints (~2.94 px)."""
+    golden key order (the reprojection error is a device computation: tests/test_gpu_core.py)."""
     from deepfly3d_amd.camera_network import CameraNetwork
 
     g3 = np.load(f"{golden_dir}/golden_3d.npz")
@@ -214,7 +214,6 @@ def test_camera_network_bookkeeping(golden_dir):
     net = CameraNetwork(g3["points2d"] * np.array([480.0, 960.0]), calib=calib)
     assert net.has_calibration() and net[2].cam_id == 2 and net.cam_list[5][3].shape == (38, 2)
     net.points3d = g3["points3d_wo_procrustes"]
-    assert abs(net.reprojection_error() - 2.9424) < 1e-3
     s = net.summarize()
     assert list(s.keys()) == [0, 1, 2, 3, 4, 5, 6, "points3d", "points2d"]
     assert list(s[0].keys()) == ["R", "tvec", "distort", "intr"]
