@@ -239,7 +239,8 @@ def main():
         pipeline.run_batch(frames[lo : lo + n], *outs, f0)
         # a window closes with this batch (the last window of the share may be shorter)
         if ba_px is not None and ((f0 + n) // a.ba_window > f0 // a.ba_window or (f0 + n == total_frames and total_frames % a.ba_window)):
-            Rn, tn, info = bundle_adjust(ba_px[(f0 + n - 1) // a.ba_window], calib["R"], calib["tvec"], calib["intr"], device=dev, return_info=True)
+            closed = (f0 + n) // a.ba_window - 1 if (f0 + n) // a.ba_window > f0 // a.ba_window else len(ba_px) - 1
+            Rn, tn, info = bundle_adjust(ba_px[closed], calib["R"], calib["tvec"], calib["intr"], device=dev, return_info=True)
             if record:
                 ba_runs.append(info["nfev"])
                 ba_cams.append(np.concatenate([Rn.reshape(7, 9), tn.reshape(7, 3)], axis=1))

@@ -69,7 +69,7 @@ def test_rank_share_stream_with_ba_windows_and_rccl_gather(native_lib, cuda, gol
         lo = f0 % pool
         pipe.run_batch(frames[lo : lo + n], *outs, f0)
         if (f0 + n) // window > f0 // window:
-            R, t, info = bundle_adjust(windows[(f0 + n - 1) // window], c["R"], c["tvec"], c["intr"], device=cuda, return_info=True)
+            R, t, info = bundle_adjust(windows[(f0 + n) // window - 1], c["R"], c["tvec"], c["intr"], device=cuda, return_info=True)
             cams.append(np.concatenate([R.reshape(7, 9), t.reshape(7, 3)], axis=1))
             nfev.append(info["nfev"])
     assert len(cams) == 13
