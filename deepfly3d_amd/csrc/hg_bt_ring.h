@@ -1,0 +1,435 @@
+// bf16 fused pre-activation bottleneck 256 -> 128 -> 128 -> 256 (identity skip) with the WEIGHTS streamed by LDS-DMA.
+//
+// Same tile (8 x 16 output pixels, 10 x 18 halo), same wave -> tile mapping, same MFMA K order as
+// hg_kernels.h:bottleneck_kernel<bf16, 256, 128, false, UP> -- the results are bit-identical -- but the 416 KB of
+// weights a tile consumes (W1 64 KB, W2 288 KB, W3 64 KB: 2.7 x the activation bytes of the tile) no longer travel
+// global -> VGPR -> ds_write behind two barriers per K-step.  Instead:
+//
+//   * the engine keeps, per bottleneck, a "weight stream": 52 stages x 8 KB, every stage the exact LDS image of one
+//     K-slice (128 rows x 32 bf16) in a bank-conflict-free order (bt_ring_pack_kernel, at set_weights time);
+//   * the kernel copies stage s + 3 into a 4-deep LDS ring with global_load_lds_dwordx4 (asynchronous, no VGPRs, no
+//     VALU, no ds_write) while the MFMAs consume stage s: ONE barrier per stage, counted s_waitcnt vmcnt(N) only
+//     (the DMA queue is never drained inside a tile), 24 KB of weights in flight per workgroup;
+//   * x (phase 1) is staged through registers as before (it needs bn1 + ReLU and, UP, the upsample add) but three
+//     K-steps ahead, into a 3-deep LDS ring that lives in the not-yet-written t1 region, one barrier per step; the
+//     bn1 scale / shift vectors sit in LDS so that no other vector-memory operation sits in the in-order queue.
+//
+// LDS per workgroup: ring 32 KB (4 stages) + t1 45 KB (180 rows x 256 B, XOR-swizzled instead of padded) + coefficients
+// 2.5 KB + masks = 81 472 B -> two workgroups per CU.
+//
+// Stage image (8 KB): row r (0..127), 16-byte chunk c (0..3) at byte (r >> 2) * 256 + ((((r & 3) << 2 | c) ^ ((r >> 3) & 3)) << 4).
+// An MFMA fragment read (ds_read_b128; 32 consecutive rows, one chunk per lane half) then touches 16 distinct 16-byte
+// slots of the 256-byte bank row in each of the instruction's four lane groups.
+//
+// vmcnt discipline: gfx950 retires vector-memory operations (loads, stores, LDS-DMA) in issue order, so
+// "s_waitcnt vmcnt(N)" with N = the number of operations issued AFTER stage s's two DMA pieces guarantees that stage s
+// has landed for this wave; the barrier that follows makes that true for all four waves.  A smaller N is always safe.
+#pragma once
+#include "hg_kernels.h"
+
+namespace hgk {
+
+struct BtRingArgs {
+    const void* in;       // NHWC bf16 [V, H, W, 256]
+    const void* in2;      // UP: NHWC bf16 [V, H/2, W/2, 256]; the block's input is in + nearest-upsample(in2), rounded to bf16
+    void* out;            // NHWC bf16 [V, H, W, 256]
+    void* pool;           // optional NHWC bf16 [V, H/2, W/2, 256]
+    const void* wstream;  // BR_NSTAGE x BR_STAGE_BYTES: pre-swizzled stage images (bt_ring_pack_kernel)
+    const float* b1;      // [128] (bn2 folded)
+    const float* b2;      // [128] (bn3 folded)
+    const float* b3;      // [256]
+    const float* s1;      // [256] bn1 scale
+    const float* t1;      // [256] bn1 shift
+    int V, H, W;
+};
+
+constexpr int BR_STAGE_BYTES = 8192;                     // 128 rows x 64 bytes (32 bf16 of K)
+constexpr int BR_RING = 4;
+constexpr int BR_W1_STAGES = 8, BR_W2_STAGES = 36, BR_W3_STAGES = 8;
+constexpr int BR_NSTAGE = BR_W1_STAGES + BR_W2_STAGES + BR_W3_STAGES;   // 52
+constexpr int BR_T1_PITCH = 128 * 2;                    // bytes per halo pixel of the t1 tile: no padding, 16-byte chunks XOR-swizzled
+constexpr int BR_T1_BYTES = BT_HALO * BR_T1_PITCH;      // 46 080 (the 12 pad rows of the sixth MFMA row tile are not stored)
+constexpr int BR_XPITCH = 64 + 16;                      // staged x rows: 32 channels + pad
+constexpr int BR_XSTAGE = BT_HROWS * BR_XPITCH;         // 15 360; three of them inside the t1 region
+constexpr int BR_RING_BYTES = BR_RING * BR_STAGE_BYTES;
+constexpr int BR_COEF_BYTES = 512 * 4 + 128 * 4;        // phase 1: bn1 scale [256] | shift [256]; afterwards b2 [128] | b3 [256]; then b1 [128]
+constexpr int BR_LDS_BYTES = BR_RING_BYTES + BR_T1_BYTES + BR_COEF_BYTES + 64;
+// chunk k (8 channels) of halo pixel hp sits in 16-byte slot k ^ ((hp % 18) & 15) of its 256-byte row: the 16 lanes of a
+// ds_read_b128 lane group read 16 different tile columns, hence 16 different slots
+__device__ __forceinline__ int br_t1_swz(int hp) { return (hp % BT_HW) & 15; }
+static_assert(3 * BR_XSTAGE <= BR_T1_BYTES, "the x ring lives inside the t1 region");
+static_assert(2 * BR_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+
+__host__ __device__ constexpr int br_swz(int r, int c) { return (r >> 2) * 256 + (((((r & 3) << 2) | c) ^ ((r >> 3) & 3)) << 4); }
+
+// bf16 blob -> weight stream of one bottleneck.  One thread per 16-byte chunk: 52 stages x 128 rows x 4 chunks.
+__global__ __launch_bounds__(256) void bt_ring_pack_kernel(const unsigned short* __restrict__ w1, const unsigned short* __restrict__ w2,
+                                                           const unsigned short* __restrict__ w3, unsigned char* __restrict__ stream) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= BR_NSTAGE * 512) return;
+    const int s = idx >> 9, r = (idx >> 2) & 127, c = idx & 3;
+    const unsigned short* src;
+    if (s < BR_W1_STAGES) {
+        src = w1 + (size_t)r * 256 + 32 * s + 8 * c;                          // W1 [128][256], K slice s
+    } else if (s < BR_W1_STAGES + BR_W2_STAGES) {
+        const int tap = (s - BR_W1_STAGES) >> 2, kc = (s - BR_W1_STAGES) & 3;
+        src = w2 + ((size_t)tap * 128 + r) * 128 + 32 * kc + 8 * c;           // W2 [9][128][128]
+    } else {
+        const int nh = (s - BR_W1_STAGES - BR_W2_STAGES) >> 2, kc = (s - BR_W1_STAGES - BR_W2_STAGES) & 3;
+        src = w3 + ((size_t)nh * 128 + r) * 128 + 32 * kc + 8 * c;            // W3 [256][128] (K already permuted by the host packer)
+    }
+    *reinterpret_cast<u32x4*>(stream + (size_t)s * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(src);
+}
+
+// LDS-DMA of one 8 KB stage: this wave's two 1 KB pieces (lane l's 16 bytes land at dst + 16 l; dst wave-uniform, in M0).
+// sbase (uniform) + voff (per lane, 32 bit) is the source address.  The instruction's immediate offset is added to the
+// global address AND to the LDS address, so the second piece needs no second M0 value.  M0 is saved and restored inside
+// the statement.
+__device__ __forceinline__ void br_glds_stage(const void* sbase, unsigned voff, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(dst)
+                 : "memory");
+}
+// s_waitcnt vmcnt(n) for a value that is a compile-time constant after unrolling (the switch folds away)
+__device__ __forceinline__ void br_wait_vm(int n) {
+#define BR_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        BR_W(0) BR_W(1) BR_W(2) BR_W(3) BR_W(4) BR_W(5) BR_W(6) BR_W(7) BR_W(8) BR_W(9) BR_W(10) BR_W(11) BR_W(12) BR_W(13)
+        BR_W(14) BR_W(15) BR_W(16) BR_W(17) BR_W(18) BR_W(19) BR_W(20) BR_W(21) BR_W(22) BR_W(23) BR_W(24) BR_W(25) BR_W(26)
+        BR_W(27) BR_W(28) BR_W(29) BR_W(30) BR_W(31) BR_W(32) BR_W(33) BR_W(34) BR_W(35) BR_W(36) BR_W(37) BR_W(38) BR_W(39) BR_W(40)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef BR_W
+}
+// workgroup barrier that does NOT drain the vector-memory queue (a __syncthreads() beside pending LDS-DMA waits vmcnt(0))
+__device__ __forceinline__ void br_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifdef DF3D_BT_TIMING
+// development build only (scripts/probe_ring.py): per-phase shader-cycle sums of wave 0 of every workgroup
+__device__ unsigned long long br_dbg[8];
+#define BR_STAMP(k)                                                              \
+    do {                                                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+        if (tid == 0) atomicAdd(&br_dbg[k], now_ - stamp_);                      \
+        stamp_ = now_;                                                           \
+    } while (0)
+#else
+#define BR_STAMP(k) do { } while (0)
+#endif
+
+template <bool UP>
+__global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
+    using T = __hip_bfloat16;
+    constexpr int CIN = 256, CO = 256, NT = 4;
+    constexpr int LX = UP ? 6 : 3;   // vector-memory loads per thread and x step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const ring = smem;
+    unsigned char* const t1_lds = smem + BR_RING_BYTES;
+    float* const coef_lds = reinterpret_cast<float*>(smem + BR_RING_BYTES + BR_T1_BYTES);
+    unsigned long long* const valid_lds = reinterpret_cast<unsigned long long*>(smem + BR_RING_BYTES + BR_T1_BYTES + BR_COEF_BYTES);
+    const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef DF3D_BT_TIMING
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tiles_x = p.W / BT_TW, tiles_y = p.H / BT_TH;
+    int b = blockIdx.x;
+    const int tx0 = (b % tiles_x) * BT_TW;
+    b /= tiles_x;
+    const int ty0 = (b % tiles_y) * BT_TH;
+    const int view = b / tiles_y;
+    const unsigned char* const xin = reinterpret_cast<const unsigned char*>(p.in) + (size_t)view * p.H * p.W * CIN * 2;
+    const unsigned char* const xin2 = UP ? reinterpret_cast<const unsigned char*>(p.in2) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN * 2 : nullptr;
+
+    // ---- the weight ring ----------------------------------------------------------------------------------
+    const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
+    auto ring_issue = [&](int s) {   // stage s -> ring slot s % 4; this wave copies pieces 2 wave, 2 wave + 1
+        const unsigned dst = ring_addr + (unsigned)(s % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048;
+        br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)s * BR_STAGE_BYTES, wvoff, dst);
+    };
+    // fragment addresses inside a stage: rows 32 m + l31, chunk 2 j + half (+ slot * 8192 + m * 2048 as immediates)
+    const unsigned char* const wf0 = ring + br_swz(l31, half);
+    const unsigned char* const wf1 = ring + br_swz(l31, 2 + half);
+
+    // bn1 coefficients and b1 -> LDS; b2 / b3 wait in two registers and replace the bn1 coefficients after phase 1
+    // (the only plain loads before the ring starts); halo validity masks
+    //   coef_lds: phase 1: [0..255] scale, [256..511] shift; afterwards [0..127] b2, [128..383] b3;  [512..639] b1
+    coef_lds[tid] = p.s1[tid];
+    coef_lds[256 + tid] = p.t1[tid];
+    if (tid < 128) coef_lds[512 + tid] = p.b1[tid];
+    const float late_b2 = p.b2[tid & 127], late_b3 = p.b3[tid];
+    const float* const b1_lds = coef_lds + 512;
+    const float* const b2_lds = coef_lds;
+    const float* const b3_lds = coef_lds + 128;
+    if (tid < BT_HROWS) {
+        const int hy = tid / BT_HW, hx = tid % BT_HW;
+        const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+        const bool ok = tid < BT_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) valid_lds[wave] = m;
+    }
+    ring_issue(0);
+    ring_issue(1);
+    ring_issue(2);
+
+    // ---- phase 1: t1^T = relu(W1' relu(bn1 x)^T + b1') on the halo --------------------------------------------
+    // x staging: thread -> (row = (tid + 256 i) >> 2, 16-byte chunk = tid & 3) of a 32-channel K step
+    constexpr int XP = 3;
+    const int xchunk = tid & 3;
+    const unsigned char* xp[XP];
+    const unsigned char* xq[UP ? XP : 1];
+    unsigned xkeep[XP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const int hp = (tid >> 2) + 64 * i;
+        const int hy = hp / BT_HW, hx = hp % BT_HW;
+        const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+        const bool ok = hp < BT_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        xkeep[i] = ok ? 0xffffffffu : 0u;
+        xp[i] = xin + (((size_t)(ok ? y : 0) * p.W + (ok ? x : 0)) * CIN + xchunk * 8) * 2;
+        if constexpr (UP) xq[i] = xin2 + (((size_t)(ok ? (y >> 1) : 0) * (p.W / 2) + (ok ? (x >> 1) : 0)) * CIN + xchunk * 8) * 2;
+    }
+    u32x4 rx[3][XP];
+    u32x4 rb[UP ? 3 : 1][XP];
+    auto loadx = [&](int s, int slot) {   // out-of-image halo rows read pixel (0, 0) (a valid address) and are masked in storex
+#pragma unroll
+        for (int i = 0; i < XP; ++i) rx[slot][i] = *reinterpret_cast<const u32x4*>(xp[i] + s * 64);
+        if constexpr (UP) {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) rb[slot][i] = *reinterpret_cast<const u32x4*>(xq[i] + s * 64);
+        }
+    };
+    auto storex = [&](int s, int slot) {
+        PreactCoef<T> coef;
+        const int c0 = s * 32 + xchunk * 8;
+        coef.s[0] = *reinterpret_cast<const f32x4*>(coef_lds + c0);
+        coef.s[1] = *reinterpret_cast<const f32x4*>(coef_lds + c0 + 4);
+        coef.t[0] = *reinterpret_cast<const f32x4*>(coef_lds + 256 + c0);
+        coef.t[1] = *reinterpret_cast<const f32x4*>(coef_lds + 256 + c0 + 4);
+        unsigned char* const sx = t1_lds + (s % 3) * BR_XSTAGE;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            u32x4 v = rx[slot][i];
+            if constexpr (UP) v = add_chunk<T>(v, rb[slot][i]);   // x = in + upsample(in2), rounded like upadd_kernel's output
+            v = preact_apply<T>(v, coef);
+            v &= xkeep[i];
+            *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * BR_XPITCH + xchunk * 16) = v;
+        }
+    };
+    loadx(0, 0);
+    loadx(1, 1);
+    loadx(2, 2);
+
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;   // this wave's 32 pixels (phases 2, 3)
+    {
+        // wave w owns t1 channels 32 w .. 32 w + 31 for all six halo row tiles.  The product is formed TRANSPOSED (A = W1
+        // rows, B = x rows: D[channel][halo pixel]) so that a lane ends up with four consecutive channels of ONE pixel per
+        // register group -> 8-byte LDS stores into the t1 tile, no cross-lane traffic.  Same products, same K order.
+        const int ct = wave;
+        f32x16 acc[6];
+        br_barrier();   // coefficients, b1 and masks visible
+        BR_STAMP(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {   // register 4 t + e <-> channel 32 ct + 8 t + 4 half + e
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b1_lds + ct * 32 + 8 * t + 4 * half);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][4 * t + e] = bb[e];
+        }
+#pragma unroll
+        for (int s = 0; s < BR_W1_STAGES; ++s) {
+            storex(s, s % 3);
+            // operations issued after stage s's DMA pieces (see the file header): the next two stages' pieces and the x loads
+            // of the steps issued since
+            br_wait_vm(s == 0 ? 4 + 3 * LX : s == 1 ? 4 + 4 * LX : s == 2 ? 4 + 5 * LX : 4 + LX + (s + 1 < 8 ? LX : 0) + (s + 2 < 8 ? LX : 0));
+            br_barrier();
+            ring_issue(s + 3);
+            if (s + 3 < BR_W1_STAGES) loadx(s + 3, s % 3);
+            const unsigned char* const sx = t1_lds + (s % 3) * BR_XSTAGE;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + ct * 2048);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + (i * 32 + l31) * BR_XPITCH + j * 32 + half * 16);
+                    mfma_chunk<T>(wf, xf, acc[i]);
+                }
+            }
+        }
+        br_barrier();   // every wave is done with the x ring: the t1 tile may overwrite it
+        BR_STAMP(1);
+        // epilogue: ReLU (the bias was the start value), zero outside the image, 8-byte stores into the swizzled t1 tile
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int hp = i * 32 + l31;
+            const unsigned keep = 0u - (unsigned)((valid_lds[i >> 1] >> ((i & 1) * 32 + l31)) & 1ull);
+            unsigned char* const trow = t1_lds + hp * BR_T1_PITCH + half * 8;
+            const int sw = br_t1_swz(hp);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint2 w;
+                w.x = pack_bf16x2(fmaxf(acc[i][4 * t + 0], 0.0f), fmaxf(acc[i][4 * t + 1], 0.0f)) & keep;
+                w.y = pack_bf16x2(fmaxf(acc[i][4 * t + 2], 0.0f), fmaxf(acc[i][4 * t + 3], 0.0f)) & keep;
+                if (i < 5 || hp < BT_HALO) *reinterpret_cast<uint2*>(trow + (((ct * 4 + t) ^ sw) << 4)) = w;
+            }
+        }
+        // the bn1 coefficients are dead: b2 / b3 take their place (read after the next barrier)
+        if (tid < 128) coef_lds[tid] = late_b2;
+        coef_lds[128 + tid] = late_b3;
+    }
+
+    BR_STAMP(2);
+    // ---- phase 2: t2^T = W2' (*) t1 (fully unrolled: every LDS address is one register + an immediate) -----------
+    f32x16 t2[NT];
+    const unsigned char* const t1_lane = t1_lds + (py * BT_HW + px) * BR_T1_PITCH;
+    unsigned tsw[3];   // ((tile column + kx) & 15 ^ half) << 4: the swizzle term of this lane's t1 fragment, per kx
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) tsw[kx] = (unsigned)((((px + kx) & 15) ^ half) << 4);
+#pragma unroll
+    for (int s = BR_W1_STAGES; s < BR_W1_STAGES + BR_W2_STAGES; ++s) {
+        br_wait_vm(4);     // only stages s + 1, s + 2 may still be in flight
+        br_barrier();      // (first iteration: also publishes the t1 tile and b2 / b3)
+        ring_issue(s + 3);
+        if (s == BR_W1_STAGES) {   // t2 accumulators start at b2' (channel of register r in tile m: 32 m + (r & 3) + 8 (r >> 2) + 4 half)
+#pragma unroll
+            for (int m = 0; m < NT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b2_lds + 32 * m + 8 * q + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
+                }
+        }
+        const int q = s - BR_W1_STAGES, tap = q >> 2, kc = q & 3;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            // chunk (4 kc + 2 j + half) ^ swizzle = ((4 kc + 2 j) << 4) ^ tsw[kx]   (4 kc + 2 j is even)
+            const u32x4 tf = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + m * 2048);
+                mfma_chunk<T>(wf, tf, t2[m]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t2[m][r] = fmaxf(t2[m][r], 0.0f);
+
+    BR_STAMP(3);
+    // ---- phase 3: out^T = W3 t2^T + b3 (+ x) -------------------------------------------------------------------
+    // transposed like phase 1 (A = W3 rows, B = the t2 registers): accumulator register 4 t + e of channel tile i holds, for
+    // pixel l31 of the wave, output channel 128 nh + 32 i + 8 t + 4 half + e -> 8-byte stores into the wave's LDS slice
+    unsigned char* const outp = reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * CO * 2;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+        f32x16 acc[4];
+        unsigned xres[32];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const int s = BR_W1_STAGES + BR_W2_STAGES + 4 * nh + kc;
+            // operations issued after stage s's pieces: the next two stages (4), the 8 residual loads of this half (issued in its
+            // first step, after that step's DMA), and -- second half -- the first half's epilogue (8 stores, UP: 4 loads; the
+            // optional 4 pool stores are left out, which only makes the wait conservative)
+            constexpr int E0 = 8 + (UP ? 4 : 0);
+            const int nwait = nh == 0 ? (kc == 0 ? 4 : 12) : (kc == 0 ? 4 + E0 : kc == 1 ? 4 + E0 + 8 : kc == 2 ? 2 + E0 + 8 : 8);
+            br_wait_vm(nwait);
+            br_barrier();
+            if (s + 3 < BR_NSTAGE) ring_issue(s + 3);
+            if (kc == 0) {
+                // residual values requested now: lane owns, for c = 0..7, chunk (lane & 15) of wave pixel 4 c + (lane >> 4)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int pw = 4 * c + (lane >> 4);
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin) +
+                        ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CIN + nh * 128 + (lane & 15) * 8);
+                    xres[4 * c + 0] = v[0];
+                    xres[4 * c + 1] = v[1];
+                    xres[4 * c + 2] = v[2];
+                    xres[4 * c + 3] = v[3];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x4 bb = *reinterpret_cast<const f32x4*>(b3_lds + nh * 128 + i * 32 + 8 * t + 4 * half);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][4 * t + e] = bb[e];
+                    }
+            }
+            // t2 tile kc, registers 8 q2 .. 8 q2 + 7 <-> packed W3 K positions 32 kc + 16 q2 + 8 half .. (host K order, kperm)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                bf16x8 tf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tf[e] = (__bf16)t2[kc][8 * q2 + e];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>((q2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, tf, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        BR_STAMP(4 + 2 * nh);
+        // epilogue through LDS (the t1 region is dead): every wave parks its 32 px x 128 ch tile in its own slice (8-byte stores:
+        // a lane owns four consecutive channels of its pixel per register group) and streams it out as 16-byte chunks with the
+        // residual added; rows fully coalesced.  Only this wave touches its slice.
+        constexpr int OP = 128 * 2 + 16;
+        unsigned char* const slice = t1_lds + wave * (32 * OP);
+        u32x4 x2[UP ? 4 : 1];
+        if constexpr (UP) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int pw = 4 * c + (lane >> 4);
+                x2[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin2) +
+                    ((size_t)(ty0 / 2 + wave) * (p.W / 2) + ((tx0 + (pw & 15)) >> 1)) * CIN + nh * 128 + (lane & 15) * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint2 w;
+                w.x = pack_bf16x2(acc[i][4 * t + 0], acc[i][4 * t + 1]);
+                w.y = pack_bf16x2(acc[i][4 * t + 2], acc[i][4 * t + 3]);
+                *reinterpret_cast<uint2*>(slice + l31 * OP + (i * 32 + 8 * t + 4 * half) * 2) = w;
+            }
+        unsigned short* const outs = reinterpret_cast<unsigned short*>(outp);
+        u32x4 fin[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int pw = 4 * c + (lane >> 4);
+            u32x4 v = *reinterpret_cast<const u32x4*>(slice + pw * OP + (lane & 15) * 16);
+            u32x4 x4 = {xres[4 * c], xres[4 * c + 1], xres[4 * c + 2], xres[4 * c + 3]};
+            if constexpr (UP) x4 = add_chunk<T>(x4, x2[c & 3]);
+            v = add_chunk<T>(v, x4);
+            fin[c] = v;
+            *reinterpret_cast<u32x4*>(outs + ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CO + nh * 128 + (lane & 15) * 8) = v;
+        }
+        if (p.pool) {
+            unsigned short* const pp = reinterpret_cast<unsigned short*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                u32x4 m = max_chunk<T>(fin[c], fin[c + 4]);
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(m[e], 16, 64);
+                m = max_chunk<T>(m, o);
+                if (((lane >> 4) & 1) == 0)
+                    *reinterpret_cast<u32x4*>(pp + ((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + 2 * c + (lane >> 5))) * CO + nh * 128 + (lane & 15) * 8) = m;
+            }
+        }
+        BR_STAMP(5 + 2 * nh);
+    }
+}
+
+}  // namespace hgk

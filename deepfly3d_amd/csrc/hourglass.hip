@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "hg_kernels.h"
+#include "hg_bt_ring.h"
 
 using namespace hgk;
 
@@ -41,6 +42,7 @@ struct Step {
     bool last = false;
     int pool_out = -1;                // ST_BOTTLENECK: tensor receiving the fused 2x2 max-pool of `out`
     int in2 = -1;                     // ST_BOTTLENECK: low-resolution addend of the input (fused upsample + add)
+    long long wstream = -1;           // ST_BOTTLENECK, bf16 256 -> 128 -> 128 -> 256: byte offset of its weight stream behind the bf16 blob
 };
 
 struct Allocator {
@@ -91,6 +93,8 @@ struct df3d_hg {
     int rb_override = 0;  // 0 = auto, 64 or 128: staged row bytes per K-step (tuning knob)
     int fuse = 1;         // 1 = 256->128->128->256 bottlenecks at >= 16x32 run as ONE fused kernel
     int fuse_upadd = 0;   // 1 = the hourglass' upsample + add is folded into the consuming bottleneck's input load (default: on)
+    int ring = 1;         // 1 = bf16 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring.h)
+    size_t stream_bytes = 0;  // weight streams of all ring bottlenecks (behind the bf16 copy of the blob)
     std::vector<TensorDesc> tensors;
     std::vector<int> pooled_of;   // tensor id -> id of its max-pooled copy written by the producing fused bottleneck (-1: none)
     std::vector<Step> steps;
@@ -118,6 +122,7 @@ struct df3d_hg {
     std::vector<hipEvent_t> event_pool;
 
     int elem_bytes() const { return dtype == DF3D_DTYPE_BF16 ? 2 : 4; }
+    size_t stream_base() const { return (blob_floats * 2 + 255) & ~size_t(255); }  // byte offset of the weight streams in the lowp buffer
 
     int new_tensor(int h, int w, int c, int pitch = 0) {
         if (!pitch) pitch = c;
@@ -204,6 +209,10 @@ struct df3d_hg {
             st.conv2b = plan_conv(name + ".conv2", 9, planes, planes, planes, false, true, false);
             if (ds) st.conv4b = plan_conv(name + ".downsample.0", 1, cin, cin, cout, false, false, false);
             st.conv3b = plan_conv(name + ".conv3", 1, planes, planes, cout, false, false, false, dtype == DF3D_DTYPE_BF16 ? 1 : 0);
+            if (ring && dtype == DF3D_DTYPE_BF16 && cin == 256 && planes == 128) {
+                st.wstream = (long long)stream_bytes;
+                stream_bytes += (size_t)BR_NSTAGE * BR_STAGE_BYTES;
+            }
             st.out = new_tensor(tx.h, tx.w, cout);
             if (want_pool) {  // the consumer max-pools this tensor: the epilogue writes the pooled copy too (no pool step)
                 st.pool_out = new_tensor(tx.h / 2, tx.w / 2, cout);
@@ -287,6 +296,7 @@ struct df3d_hg {
         steps.clear();
         params.clear();
         blob_floats = 0;
+        stream_bytes = 0;
         alloc = Allocator();
         flops_per_view = elems_per_view = 0;
         // stem
@@ -554,6 +564,26 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.W = ti.w;
                 const int cin = st.conv.cin, pl = st.conv.cout;
                 const double px = (double)n * ti.h * ti.w;
+                if (eb == 2 && st.wstream >= 0) {
+                    BtRingArgs r;
+                    r.in = a.in; r.in2 = a.in2; r.out = a.out; r.pool = a.pool;
+                    r.wstream = wb + h->stream_base() + st.wstream;
+                    r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.s1 = a.s1; r.t1 = a.t1;
+                    r.V = n; r.H = ti.h; r.W = ti.w;
+                    ScopedTimer tm(h, s, std::string("bottleneck_ring_kernel<") + (a.in2 ? "true" : "false") + ">",
+                                   2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl));
+                    const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
+                    static unsigned attr_done[2] = {0, 0};
+                    const void* fn = a.in2 ? reinterpret_cast<const void*>(bottleneck_ring_kernel<true>) : reinterpret_cast<const void*>(bottleneck_ring_kernel<false>);
+                    if (first_use_on_this_device(attr_done[a.in2 ? 1 : 0]))
+                        DF3D_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BR_LDS_BYTES));
+                    if (a.in2)
+                        hipLaunchKernelGGL((bottleneck_ring_kernel<true>), dim3(blocks), dim3(256), BR_LDS_BYTES, s, r);
+                    else
+                        hipLaunchKernelGGL((bottleneck_ring_kernel<false>), dim3(blocks), dim3(256), BR_LDS_BYTES, s, r);
+                    DF3D_LAUNCH_CHECK();
+                    break;
+                }
                 ScopedTimer tm(h, s, std::string("bottleneck_kernel<") + tname + ", " + std::to_string(cin) + ", " + std::to_string(pl) + ", " + (ds ? "true" : "false") + ", " + (a.in2 ? "true" : "false") + ">",
                                2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + (ds ? 2.0 * cin * pl : 0.0)), px * eb * (cin + 2.0 * pl));
                 const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
@@ -637,6 +667,15 @@ int check_forward_args(df3d_hg* h, const float* images, int n, void* ws, size_t 
 
 extern "C" {
 
+#ifdef DF3D_BT_TIMING
+// development build only: read and clear the per-phase cycle sums of bottleneck_ring_kernel
+int df3d_dbg_ring_cycles(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hgk::br_dbg), 64) != hipSuccess) return -1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(hgk::br_dbg), z, 64) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int df3d_hg_create(int dtype, int num_stacks, df3d_hg** out) {
     DF3D_CHECK_ARG(out != nullptr, "null out");
     DF3D_CHECK_ARG(dtype == DF3D_DTYPE_F32 || dtype == DF3D_DTYPE_BF16, "dtype must be DF3D_DTYPE_F32 or DF3D_DTYPE_BF16");
@@ -689,6 +728,13 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
         h->build();
         return DF3D_OK;
     }
+    if (!strcmp(key, "ring")) {
+        DF3D_CHECK_ARG(value == 0 || value == 1, "ring must be 0 or 1");
+        DF3D_CHECK_ARG(h->blob == nullptr, "set 'ring' before df3d_hg_set_weights (it changes the low-precision buffer)");
+        h->ring = value;
+        h->build();
+        return DF3D_OK;
+    }
     if (!strcmp(key, "row_bytes")) {
         DF3D_CHECK_ARG(value == 0 || value == 64 || value == 128, "row_bytes must be 0, 64 or 128");
         h->rb_override = value;
@@ -711,7 +757,7 @@ size_t df3d_hg_blob_floats(const df3d_hg* h) { return h ? h->blob_floats : 0; }
 
 size_t df3d_hg_lowp_bytes(const df3d_hg* h) {
     if (!h || h->dtype != DF3D_DTYPE_BF16) return 0;
-    return h->blob_floats * 2;
+    return h->stream_base() + h->stream_bytes;   // bf16 copy of the blob + the pre-swizzled weight streams of the ring bottlenecks
 }
 
 int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void* stream) {
@@ -725,6 +771,14 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
         // the bf16 stem wants its weights as a [64][184] bf16 tile: overwrite the stem's slot of the low-precision copy
         hipLaunchKernelGGL(stem_relayout_kernel, dim3((64 * 184 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
                            blob_dev + h->steps[0].conv.w_off, reinterpret_cast<unsigned short*>(lowp_dev) + h->steps[0].conv.w_off);
+        // weight streams of the ring bottlenecks: stage-by-stage LDS images (hg_bt_ring.h), from the bf16 copy
+        for (const Step& st : h->steps) {
+            if (st.kind != ST_BOTTLENECK || st.wstream < 0) continue;
+            const unsigned short* lp = reinterpret_cast<const unsigned short*>(lowp_dev);
+            hipLaunchKernelGGL(bt_ring_pack_kernel, dim3((BR_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
+                               lp + st.conv.w_off, lp + st.conv2b.w_off, lp + st.conv3b.w_off,
+                               reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
+        }
         DF3D_LAUNCH_CHECK();
         h->lowp = lowp_dev;
     }

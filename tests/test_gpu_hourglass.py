@@ -235,3 +235,27 @@ def test_fused_upsample_add_is_bit_identical(native_lib, cuda, oracle_net, image
     off = HourglassEngine(sd, dtype=dtype, device=cuda, fuse_upadd=False)
     assert len(off.steps()) - len(on.steps()) == 8
     assert torch.equal(on.forward(x), off.forward(x))
+
+
+@pytest.mark.parametrize("height,width,n", [(256, 512, 3), (128, 256, 2), (64, 192, 1)])
+def test_bf16_weight_ring_bottleneck_is_bit_identical(native_lib, cuda, oracle_net, height, width, n):
+    """The LDS-DMA weight-ring form of the bf16 256 -> 128 -> 128 -> 256 bottleneck (csrc/hg_bt_ring.h: weights streamed as
+    pre-swizzled stage images through a 3-deep ring, one barrier per stage) against the register-staged kernel it replaces:
+    same MFMA K order, so every plan step and the heat-maps must be BIT-identical (also with the fused upsample + add, the
+    fused pooling output, image borders and tile counts that are not powers of two)."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
+    img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(3 * height + width), dtype=torch.float32).to(cuda)
+    on = HourglassEngine(sd, dtype="bf16", device=cuda, height=height, width=width, ring=True)
+    off = HourglassEngine(sd, dtype="bf16", device=cuda, height=height, width=width, ring=False)
+    steps = on.steps()
+    assert steps == off.steps()
+    for k in range(1, len(steps) + 1):
+        a, b = on.forward_upto(img, k), off.forward_upto(img, k)
+        assert torch.equal(a, b), f"step {k} {steps[k - 1][0]} differs: max |diff| {(a - b).abs().max().item():.3e}"
+    assert torch.equal(on.forward(img), off.forward(img))
+    # repeated launches are deterministic (no dependence on DMA timing)
+    first = on.forward(img).clone()
+    for _ in range(3):
+        assert torch.equal(on.forward(img), first)
