@@ -7,9 +7,10 @@
 //
 //   * the engine keeps, per bottleneck, a "weight stream": 52 stages x 8 KB, every stage the exact LDS image of one
 //     K-slice (128 rows x 32 bf16) in a bank-conflict-free order (bt_ring_pack_kernel, at set_weights time);
-//   * the kernel copies stage s + 3 into a 4-deep LDS ring with global_load_lds_dwordx4 (asynchronous, no VGPRs, no
-//     VALU, no ds_write) while the MFMAs consume stage s: ONE barrier per stage, counted s_waitcnt vmcnt(N) only
-//     (the DMA queue is never drained inside a tile), 24 KB of weights in flight per workgroup;
+//   * the kernel copies the stages into a 4-slot LDS ring with global_load_lds_dwordx4 (asynchronous, no VGPRs, no VALU,
+//     no ds_write) while the MFMAs consume earlier ones: phase 1 one stage per barrier, three stages ahead; phases 2 and 3
+//     TWO stages per barrier (16 MFMAs per wave between barriers), the next pair requested right after the barrier into the
+//     slots just released; counted s_waitcnt vmcnt(N) only, 16-24 KB of weights in flight per workgroup;
 //   * x (phase 1) is staged through registers as before (it needs bn1 + ReLU and, UP, the upsample add) but three
 //     K-steps ahead, into a 3-deep LDS ring that lives in the not-yet-written t1 region, one barrier per step; the
 //     bn1 scale / shift vectors sit in LDS so that no other vector-memory operation sits in the in-order queue.
@@ -106,6 +107,27 @@ __device__ __forceinline__ void br_wait_vm(int n) {
 }
 // workgroup barrier that does NOT drain the vector-memory queue (a __syncthreads() beside pending LDS-DMA waits vmcnt(0))
 __device__ __forceinline__ void br_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// max(x, 0) on two packed bf16: as signed 16-bit integers a negative float is a negative integer, so one v_pk_max_i16 does
+// both halves (and needs no NaN-canonicalising v_max before it, which hipcc puts in front of every fmaxf on an MFMA result)
+__device__ __forceinline__ unsigned br_relu_pk(unsigned packed) {
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(packed));
+    return r;
+}
+// bn1 + ReLU on one 16-byte chunk of 8 bf16: y = max(x * s + t, 0), rounded to bf16 (rounding and max(., 0) commute)
+__device__ __forceinline__ u32x4 br_preact(u32x4 raw, const PreactCoef<__hip_bfloat16>& k) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = bf16_bits_to_f32((unsigned short)(raw[i] & 0xffffu));
+        const float hi = bf16_bits_to_f32((unsigned short)(raw[i] >> 16));
+        const float a = fmaf(lo, k.s[i >> 1][(2 * i) & 3], k.t[i >> 1][(2 * i) & 3]);
+        const float b = fmaf(hi, k.s[i >> 1][(2 * i + 1) & 3], k.t[i >> 1][(2 * i + 1) & 3]);
+        o[i] = br_relu_pk(pack_bf16x2(a, b));
+    }
+    return o;
+}
 
 #ifdef DF3D_BT_TIMING
 // development build only (scripts/probe_ring.py): per-phase shader-cycle sums of wave 0 of every workgroup
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
         for (int i = 0; i < XP; ++i) {
             u32x4 v = rx[slot][i];
             if constexpr (UP) v = add_chunk<T>(v, rb[slot][i]);   // x = in + upsample(in2), rounded like upadd_kernel's output
-            v = preact_apply<T>(v, coef);
+            v = br_preact(v, coef);
             v &= xkeep[i];
             *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * BR_XPITCH + xchunk * 16) = v;
         }
@@ -275,8 +297,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 uint2 w;
-                w.x = pack_bf16x2(fmaxf(acc[i][4 * t + 0], 0.0f), fmaxf(acc[i][4 * t + 1], 0.0f)) & keep;
-                w.y = pack_bf16x2(fmaxf(acc[i][4 * t + 2], 0.0f), fmaxf(acc[i][4 * t + 3], 0.0f)) & keep;
+                w.x = br_relu_pk(pack_bf16x2(acc[i][4 * t + 0], acc[i][4 * t + 1])) & keep;
+                w.y = br_relu_pk(pack_bf16x2(acc[i][4 * t + 2], acc[i][4 * t + 3])) & keep;
                 if (i < 5 || hp < BT_HALO) *reinterpret_cast<uint2*>(trow + (((ct * 4 + t) ^ sw) << 4)) = w;
             }
         }
@@ -292,12 +314,22 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     unsigned tsw[3];   // ((tile column + kx) & 15 ^ half) << 4: the swizzle term of this lane's t1 fragment, per kx
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) tsw[kx] = (unsigned)((((px + kx) & 15) ^ half) << 4);
+    // two stages per barrier: the pair (s0, s0 + 1) was requested one double-step earlier, the pair after it goes into the two
+    // slots the previous double-step has just released
 #pragma unroll
-    for (int s = BR_W1_STAGES; s < BR_W1_STAGES + BR_W2_STAGES; ++s) {
-        br_wait_vm(4);     // only stages s + 1, s + 2 may still be in flight
-        br_barrier();      // (first iteration: also publishes the t1 tile and b2 / b3)
-        ring_issue(s + 3);
-        if (s == BR_W1_STAGES) {   // t2 accumulators start at b2' (channel of register r in tile m: 32 m + (r & 3) + 8 (r >> 2) + 4 half)
+    for (int d = 0; d < BR_W2_STAGES / 2; ++d) {
+        const int s0 = BR_W1_STAGES + 2 * d;
+#if !defined(BR_ABL) || BR_ABL != 4
+        br_wait_vm(d == 0 ? 2 : 0);   // d = 0: phase 1 has already requested stage 10
+        br_barrier();                 // (first iteration: also publishes the t1 tile and b2 / b3)
+#else
+        if (d == 0) { br_wait_vm(2); br_barrier(); }
+#endif
+#if !defined(BR_ABL) || BR_ABL != 3
+        if (d > 0) ring_issue(s0 + 2);
+        ring_issue(s0 + 3);
+#endif
+        if (d == 0) {   // t2 accumulators start at b2' (channel of register r in tile m: 32 m + (r & 3) + 8 (r >> 2) + 4 half)
 #pragma unroll
             for (int m = 0; m < NT; ++m)
 #pragma unroll
@@ -307,23 +339,39 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
                     for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
                 }
         }
-        const int q = s - BR_W1_STAGES, tap = q >> 2, kc = q & 3;
-        const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            // chunk (4 kc + 2 j + half) ^ swizzle = ((4 kc + 2 j) << 4) ^ tsw[kx]   (4 kc + 2 j is even)
-            const u32x4 tf = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
+        for (int u = 0; u < 2; ++u) {
+            const int s = s0 + u;
+            const int q = s - BR_W1_STAGES, tap = q >> 2, kc = q & 3;
+            const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-            for (int m = 0; m < NT; ++m) {
-                const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + m * 2048);
-                mfma_chunk<T>(wf, tf, t2[m]);
+            for (int j = 0; j < 2; ++j) {
+                // chunk (4 kc + 2 j + half) ^ swizzle = ((4 kc + 2 j) << 4) ^ tsw[kx]   (4 kc + 2 j is even)
+                const u32x4 tf = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+#if defined(BR_ABL) && BR_ABL == 2   // ablation: no weight fragment reads
+                    const u32x4 wf = tf;
+#else
+                    const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + m * 2048);
+#endif
+#if defined(BR_ABL) && BR_ABL == 1   // ablation: no MFMAs (the fragments stay live)
+                    asm volatile("" ::"v"(wf), "v"(tf));
+#else
+                    mfma_chunk<T>(wf, tf, t2[m]);
+#endif
+                }
             }
         }
     }
+    // ReLU + rounding to bf16 once: the B operands of phase 3 (tile kc, registers 8 q2 .. 8 q2 + 7 -> four dwords)
+    u32x4 t2f[NT][2];
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t2[m][r] = fmaxf(t2[m][r], 0.0f);
+        for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t2f[m][q2][e] = br_relu_pk(pack_bf16x2(t2[m][8 * q2 + 2 * e], t2[m][8 * q2 + 2 * e + 1]));
 
     BR_STAMP(3);
     // ---- phase 3: out^T = W3 t2^T + b3 (+ x) -------------------------------------------------------------------
@@ -335,17 +383,19 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
         f32x16 acc[4];
         unsigned xres[32];
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            const int s = BR_W1_STAGES + BR_W2_STAGES + 4 * nh + kc;
-            // operations issued after stage s's pieces: the next two stages (4), the 8 residual loads of this half (issued in its
-            // first step, after that step's DMA), and -- second half -- the first half's epilogue (8 stores, UP: 4 loads; the
-            // optional 4 pool stores are left out, which only makes the wait conservative)
+        for (int dd = 0; dd < 2; ++dd) {
+            const int s0 = BR_W1_STAGES + BR_W2_STAGES + 4 * nh + 2 * dd;
+            // operations issued after the pair's DMA pieces: the 8 residual loads of this half (requested in its first
+            // double-step, after the DMA), or the first half's epilogue (8 stores, UP: 4 loads; the optional 4 pool stores
+            // are left out, which only makes the wait conservative)
             constexpr int E0 = 8 + (UP ? 4 : 0);
-            const int nwait = nh == 0 ? (kc == 0 ? 4 : 12) : (kc == 0 ? 4 + E0 : kc == 1 ? 4 + E0 + 8 : kc == 2 ? 2 + E0 + 8 : 8);
-            br_wait_vm(nwait);
+            br_wait_vm(dd == 1 ? 8 : nh == 0 ? 0 : E0);
             br_barrier();
-            if (s + 3 < BR_NSTAGE) ring_issue(s + 3);
-            if (kc == 0) {
+            if (s0 + 3 < BR_NSTAGE) {
+                ring_issue(s0 + 2);
+                ring_issue(s0 + 3);
+            }
+            if (dd == 0) {
                 // residual values requested now: lane owns, for c = 0..7, chunk (lane & 15) of wave pixel 4 c + (lane >> 4)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -366,16 +416,18 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
                         for (int e = 0; e < 4; ++e) acc[i][4 * t + e] = bb[e];
                     }
             }
-            // t2 tile kc, registers 8 q2 .. 8 q2 + 7 <-> packed W3 K positions 32 kc + 16 q2 + 8 half .. (host K order, kperm)
 #pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-                bf16x8 tf;
+            for (int u = 0; u < 2; ++u) {
+                const int kc = 2 * dd + u, s = s0 + u;
+                // t2 tile kc, registers 8 q2 .. 8 q2 + 7 <-> packed W3 K positions 32 kc + 16 q2 + 8 half .. (host K order, kperm)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) tf[e] = (__bf16)t2[kc][8 * q2 + e];
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const bf16x8 tf = __builtin_bit_cast(bf16x8, t2f[kc][q2]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>((q2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, tf, acc[i], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) {
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>((q2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, tf, acc[i], 0, 0, 0);
+                    }
                 }
             }
         }
