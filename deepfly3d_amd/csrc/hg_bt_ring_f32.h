@@ -1,0 +1,349 @@
+// fp32 fused pre-activation bottleneck 256 -> 128 -> 128 -> 256 (identity skip) with the weights streamed by LDS-DMA:
+// the fp32 sibling of hg_bt_ring.h (same 4-slot ring of 8 KB stage images, same swizzles, same barrier discipline).
+//
+// Same tile, wave -> tile mapping and MFMA K order as hg_kernels.h:bottleneck_kernel<float, 256, 128, false, UP>, whose
+// results it reproduces bit for bit.  As there, the t1 tile is built and consumed in two 64-channel halves (kh), so a tile
+// walks the stage sequence
+//     kh = 0:  8 x W1 (two 16-float K steps of the half's 64 rows per stage), 36 x W2 (tap, 16-float K slice of the half)
+//     kh = 1:  the same for the second half
+//     16 x W3 (output half nh, 16-float K slice)                                     = 104 stages, 832 KB per tile.
+// What the ring buys in fp32 (an MFMA-bound kernel: 64 cycles per v_mfma_f32_32x32x2_f32): no weight registers (the
+// register-staged kernel sits at 254 VGPRs), one barrier per 24-32 MFMAs instead of two, the residual values requested a
+// whole double-step before they are used, bn1 coefficients / biases in LDS, and 16-byte LDS stores of the transposed t1 tile.
+//
+// Waits: every ring wait allows exactly the DMA pieces of the stages requested after the awaited one (2 per stage); plain
+// loads issued in between only make that wait conservative (steps are 1 500-2 000 cycles long, so that costs nothing).
+// gfx950 retires vector-memory operations in issue order (see hg_bt_ring.h).
+#pragma once
+#include "hg_bt_ring.h"
+
+namespace hgk {
+
+constexpr int BRF_W1_STAGES = 8, BRF_W2_STAGES = 36, BRF_KH_STAGES = BRF_W1_STAGES + BRF_W2_STAGES, BRF_W3_STAGES = 16;
+constexpr int BRF_NSTAGE = 2 * BRF_KH_STAGES + BRF_W3_STAGES;   // 104
+
+// fp32 blob -> weight stream of one bottleneck.  One thread per 16-byte chunk (4 floats): 104 stages x 512 chunks.
+__global__ __launch_bounds__(256) void bt_ring_pack_f32_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                               const float* __restrict__ w3, unsigned char* __restrict__ stream) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= BRF_NSTAGE * 512) return;
+    const int s = idx >> 9, rem = idx & 511, c = rem & 3;
+    const float* src;
+    int dst;
+    if (s < 2 * BRF_KH_STAGES) {
+        const int kh = s / BRF_KH_STAGES, q = s % BRF_KH_STAGES;
+        if (q < BRF_W1_STAGES) {   // two K steps (16 floats each) of W1 rows 64 kh .. 64 kh + 63
+            const int sub = rem >> 8, n = (rem >> 2) & 63, ks = 2 * q + sub;
+            src = w1 + (size_t)(kh * 64 + n) * 256 + 16 * ks + 4 * c;
+            dst = sub * 4096 + br_swz(n, c);
+        } else {
+            const int tap = (q - BRF_W1_STAGES) >> 2, kc = (q - BRF_W1_STAGES) & 3, r = rem >> 2;
+            src = w2 + ((size_t)tap * 128 + r) * 128 + kh * 64 + 16 * kc + 4 * c;
+            dst = br_swz(r, c);
+        }
+    } else {
+        const int k = s - 2 * BRF_KH_STAGES, nh = k >> 3, k8 = k & 7, r = rem >> 2;
+        src = w3 + ((size_t)nh * 128 + r) * 128 + 16 * k8 + 4 * c;
+        dst = br_swz(r, c);
+    }
+    *reinterpret_cast<u32x4*>(stream + (size_t)s * BR_STAGE_BYTES + dst) = *reinterpret_cast<const u32x4*>(src);
+}
+
+// max(x, 0) without the NaN-canonicalising v_max hipcc puts in front of fmaxf on MFMA results
+__device__ __forceinline__ float br_relu(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+template <bool UP>
+__global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs p) {
+    using T = float;
+    constexpr int CIN = 256, CO = 256, NT = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const ring = smem;
+    unsigned char* const t1_lds = smem + BR_RING_BYTES;
+    float* const coef_lds = reinterpret_cast<float*>(smem + BR_RING_BYTES + BR_T1_BYTES);   // [0..255] bn1 scale, [256..511] shift (later b3), [512..639] b1
+    unsigned long long* const valid_lds = reinterpret_cast<unsigned long long*>(smem + BR_RING_BYTES + BR_T1_BYTES + BR_COEF_BYTES);
+    const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tiles_x = p.W / BT_TW, tiles_y = p.H / BT_TH;
+    int b = blockIdx.x;
+    const int tx0 = (b % tiles_x) * BT_TW;
+    b /= tiles_x;
+    const int ty0 = (b % tiles_y) * BT_TH;
+    const int view = b / tiles_y;
+    const unsigned char* const xin = reinterpret_cast<const unsigned char*>(p.in) + (size_t)view * p.H * p.W * CIN * 4;
+    const unsigned char* const xin2 = UP ? reinterpret_cast<const unsigned char*>(p.in2) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN * 4 : nullptr;
+
+    // ---- the weight ring (every stage index below is a compile-time constant: all loops are unrolled) ----------------------
+    const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
+    auto ring_issue = [&](int s) {   // stage s -> ring slot s % 4; this wave copies pieces 2 wave, 2 wave + 1
+        if (s < BRF_NSTAGE) {
+            const unsigned dst = ring_addr + (unsigned)(s % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048;
+            br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)s * BR_STAGE_BYTES, wvoff, dst);
+        }
+    };
+    const unsigned char* const wf0 = ring + br_swz(l31, half);
+    const unsigned char* const wf1 = ring + br_swz(l31, 2 + half);
+
+    // coefficients -> LDS, t2 start values (b2) straight into the accumulators, b3 waits in a register until bn1 is dead
+    coef_lds[tid] = p.s1[tid];
+    coef_lds[256 + tid] = p.t1[tid];
+    if (tid < 128) coef_lds[512 + tid] = p.b1[tid];
+    const float late_b3 = p.b3[tid];
+    const float* const b1_lds = coef_lds + 512;
+    const float* const b3_lds = coef_lds + 256;
+    f32x16 t2[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + 32 * m + 8 * q + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
+        }
+    if (tid < BT_HROWS) {
+        const int hy = tid / BT_HW, hx = tid % BT_HW;
+        const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+        const bool ok = tid < BT_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) valid_lds[wave] = m;
+    }
+    ring_issue(0);
+    ring_issue(1);
+    ring_issue(2);
+
+    // x staging: thread -> (row = (tid + 256 i) >> 2, 16-byte chunk = tid & 3) of a 16-float K step
+    constexpr int XP = 3;
+    const int xchunk = tid & 3;
+    const unsigned char* xp[XP];
+    const unsigned char* xq[UP ? XP : 1];
+    unsigned xkeep[XP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const int hp = (tid >> 2) + 64 * i;
+        const int hy = hp / BT_HW, hx = hp % BT_HW;
+        const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+        const bool ok = hp < BT_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        xkeep[i] = ok ? 0xffffffffu : 0u;
+        xp[i] = xin + (((size_t)(ok ? y : 0) * p.W + (ok ? x : 0)) * CIN + xchunk * 4) * 4;
+        if constexpr (UP) xq[i] = xin2 + (((size_t)(ok ? (y >> 1) : 0) * (p.W / 2) + (ok ? (x >> 1) : 0)) * CIN + xchunk * 4) * 4;
+    }
+    constexpr int DX = UP ? 2 : 3;   // K steps of x requested ahead (registers); the LDS x ring has three slots either way
+    u32x4 rx[DX][XP];
+    u32x4 rb[UP ? DX : 1][XP];
+    auto loadx = [&](int s, int slot) {
+#pragma unroll
+        for (int i = 0; i < XP; ++i) rx[slot][i] = *reinterpret_cast<const u32x4*>(xp[i] + s * 64);
+        if constexpr (UP) {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) rb[slot][i] = *reinterpret_cast<const u32x4*>(xq[i] + s * 64);
+        }
+    };
+    auto storex = [&](int s, int slot) {
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(coef_lds + s * 16 + xchunk * 4);
+        const f32x4 ct_ = *reinterpret_cast<const f32x4*>(coef_lds + 256 + s * 16 + xchunk * 4);
+        unsigned char* const sx = t1_lds + (s % 3) * BR_XSTAGE;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            f32x4 v = __builtin_bit_cast(f32x4, rx[slot][i]);
+            if constexpr (UP) v += __builtin_bit_cast(f32x4, rb[slot][i]);   // x = in + upsample(in2), what upadd_kernel would have stored
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(br_relu(fmaf(v[e], cs[e], ct_[e]))) & xkeep[i];
+            *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * BR_XPITCH + xchunk * 16) = o;
+        }
+    };
+
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;   // this wave's 32 pixels (phases 2, 3)
+    const unsigned char* const t1_lane = t1_lds + (py * BT_HW + px) * BR_T1_PITCH;
+    unsigned tsw[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) tsw[kx] = (unsigned)((((px + kx) & 15) ^ half) << 4);
+    // phase 1: wave -> channel tile ct (of the half's two) and row tiles rt0 .. rt0 + 2
+    const int ct = wave & 1, rt0 = (wave >> 1) * 3;
+
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const int base = kh * BRF_KH_STAGES;
+        // ---- phase 1 (half kh): t1^T = relu(W1' relu(bn1 x)^T + b1') on the halo, 16 K steps of 16 floats ---------------
+#pragma unroll
+        for (int k = 0; k < DX; ++k) loadx(k, k);
+        br_barrier();   // kh = 0: coefficients / masks visible; kh = 1: every wave has finished reading the first t1 half
+        f32x16 acc[3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {   // register 4 t + e <-> channel 64 kh + 32 ct + 8 t + 4 half + e
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b1_lds + kh * 64 + ct * 32 + 8 * t + 4 * half);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][4 * t + e] = bb[e];
+        }
+#pragma unroll
+        for (int xs = 0; xs < 16; ++xs) {
+            storex(xs, xs % DX);
+            const int st = base + (xs >> 1);     // W1 stage of this step: two K steps per stage
+            // stages requested after `st` so far: st + 1, st + 2 (only st + 1 at the start of the second half, whose first
+            // two stages were requested by the last double-step of the first half's phase 2)
+            if ((xs & 1) == 0) br_wait_vm(kh == 1 && xs == 0 ? 2 : 4);
+            br_barrier();
+            if ((xs & 1) == 0) {
+                if (kh == 1 && xs == 0) ring_issue(st + 2);
+                ring_issue(st + 3);
+            }
+            if (xs + DX < 16) loadx(xs + DX, xs % DX);
+            const unsigned char* const sx = t1_lds + (xs % 3) * BR_XSTAGE;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (st % BR_RING) * BR_STAGE_BYTES + (xs & 1) * 4096 + ct * 2048);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * BR_XPITCH + j * 32 + half * 16);
+                    mfma_chunk<T>(wf, xf, acc[i]);
+                }
+            }
+        }
+        br_barrier();   // every wave is done with the x ring: the t1 half may overwrite it
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int hp = (rt0 + i) * 32 + l31;
+            const unsigned keep = 0u - (unsigned)((valid_lds[(rt0 + i) >> 1] >> (((rt0 + i) & 1) * 32 + l31)) & 1ull);
+            unsigned char* const trow = t1_lds + hp * BR_T1_PITCH;
+            const int sw = br_t1_swz(hp);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                u32x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(br_relu(acc[i][4 * t + e])) & keep;
+                if (hp < BT_HALO) *reinterpret_cast<u32x4*>(trow + (((ct * 8 + 2 * t + half) ^ sw) << 4)) = w;
+            }
+        }
+        if (kh == 1) coef_lds[256 + tid] = late_b3;   // bn1 is dead: b3 takes the shift vector's place (read in phase 3)
+
+        // ---- phase 2 (half kh): t2^T += W2'[:, half] (*) t1 half, two stages per barrier --------------------------------
+#pragma unroll
+        for (int d = 0; d < BRF_W2_STAGES / 2; ++d) {
+            const int s0 = base + BRF_W1_STAGES + 2 * d;
+            br_wait_vm(d == 0 ? 2 : 0);   // d = 0: phase 1 has already requested stage s0 + 2
+            br_barrier();                 // (first iteration: also publishes the t1 half)
+            if (d > 0) ring_issue(s0 + 2);
+            ring_issue(s0 + 3);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s = s0 + u;
+                const int q = s - base - BRF_W1_STAGES, tap = q >> 2, kc = q & 3;
+                const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32x4 tf = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) {
+                        const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + m * 2048);
+                        mfma_chunk<T>(wf, tf, t2[m]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t2[m][r] = br_relu(t2[m][r]);
+
+    // ---- phase 3: out = W3 relu(t2) + b3 + x  (rows = the wave's pixels, columns = channels, as in the register-staged
+    //      kernel: its epilogue -- residual add, 4-byte stores of 128 contiguous bytes per pixel, in-lane pooling -- is kept) ----
+    unsigned char* const outp = reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * CO * 4;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+        f32x16 acc[4];
+        float xr[2][16];   // residual values of channel tiles 0 and 1, requested during the last two double-steps
+        auto load_res = [&](int i, float (&dst)[16]) {
+            const int n = nh * 128 + i * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                dst[r] = reinterpret_cast<const float*>(xin)[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n];
+            }
+        };
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            const int s0 = 2 * BRF_KH_STAGES + 8 * nh + 2 * dd;
+            br_wait_vm(0);   // the pair was requested a whole double-step ago
+            br_barrier();
+            ring_issue(s0 + 2);
+            ring_issue(s0 + 3);
+            if (dd >= 2) load_res(dd - 2, xr[dd - 2]);
+            if (dd == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float bias = b3_lds[nh * 128 + i * 32 + l31];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] = bias;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k8 = 2 * dd + u, s = s0 + u, tile = k8 >> 1, q2 = k8 & 1;
+                // registers 8 q2 + 4 jj + e of t2 tile `tile` hold channels 32 tile + 16 q2 + 8 jj + 4 half + e: 16-byte chunk 2 jj + half of the stage
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(t2[tile][8 * q2 + 4 * jj + e], wf[e], acc[i], 0, 0, 0);
+                    }
+            }
+        }
+        // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4 half of the wave][col = channel nh*128 + 32 i + l31]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = nh * 128 + i * 32 + l31;
+            float xv[16];
+            if (i < 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xv[r] = xr[i][r];
+            } else {
+                load_res(i, xv);
+            }
+            if constexpr (UP) {
+                // the wave's two tile rows share ONE half-resolution row and neighbouring columns one pixel: registers r, r^1, r^8,
+                // r^9 take the same addend -> 4 loads per tile, key = bits 1 and 2 of r
+                float t4[4];
+#pragma unroll
+                for (int key = 0; key < 4; ++key)
+                    t4[key] = reinterpret_cast<const float*>(xin2)[((size_t)(ty0 / 2 + wave) * (p.W / 2) + tx0 / 2 + (key & 1) + 4 * (key >> 1) + 2 * half) * CIN + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xv[r] += t4[((r >> 1) & 1) + 2 * ((r >> 2) & 1)];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] += xv[r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n;
+                reinterpret_cast<float*>(outp)[po] = acc[i][r];
+            }
+            if (p.pool) {
+                // 2x2 max-pool inside the lane: horizontal neighbour = register r^1, vertical neighbour = r^8
+                float* const pp = reinterpret_cast<float*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;
+#pragma unroll
+                for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        const int r0 = 2 * a2 + 4 * b2;
+                        const float v = fmaxf(fmaxf(acc[i][r0], acc[i][r0 + 1]), fmaxf(acc[i][r0 + 8], acc[i][r0 + 9]));
+                        const int ppx = a2 + 4 * b2 + 2 * half;
+                        pp[((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + ppx)) * CO + n] = v;
+                    }
+            }
+        }
+    }
+}
+
+}  // namespace hgk

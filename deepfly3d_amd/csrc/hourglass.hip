@@ -15,6 +15,7 @@
 #include "common.h"
 #include "hg_kernels.h"
 #include "hg_bt_ring.h"
+#include "hg_bt_ring_f32.h"
 
 using namespace hgk;
 
@@ -93,7 +94,7 @@ struct df3d_hg {
     int rb_override = 0;  // 0 = auto, 64 or 128: staged row bytes per K-step (tuning knob)
     int fuse = 1;         // 1 = 256->128->128->256 bottlenecks at >= 16x32 run as ONE fused kernel
     int fuse_upadd = 0;   // 1 = the hourglass' upsample + add is folded into the consuming bottleneck's input load (default: on)
-    int ring = 1;         // 1 = bf16 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring.h)
+    int ring = 1;         // 1 = the 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring*.h)
     size_t stream_bytes = 0;  // weight streams of all ring bottlenecks (behind the bf16 copy of the blob)
     std::vector<TensorDesc> tensors;
     std::vector<int> pooled_of;   // tensor id -> id of its max-pooled copy written by the producing fused bottleneck (-1: none)
@@ -122,7 +123,8 @@ struct df3d_hg {
     std::vector<hipEvent_t> event_pool;
 
     int elem_bytes() const { return dtype == DF3D_DTYPE_BF16 ? 2 : 4; }
-    size_t stream_base() const { return (blob_floats * 2 + 255) & ~size_t(255); }  // byte offset of the weight streams in the lowp buffer
+    // byte offset of the weight streams in the caller's "lowp" buffer: behind the bf16 copy of the blob (bf16), at its start (f32)
+    size_t stream_base() const { return dtype == DF3D_DTYPE_BF16 ? (blob_floats * 2 + 255) & ~size_t(255) : 0; }
 
     int new_tensor(int h, int w, int c, int pitch = 0) {
         if (!pitch) pitch = c;
@@ -209,9 +211,9 @@ struct df3d_hg {
             st.conv2b = plan_conv(name + ".conv2", 9, planes, planes, planes, false, true, false);
             if (ds) st.conv4b = plan_conv(name + ".downsample.0", 1, cin, cin, cout, false, false, false);
             st.conv3b = plan_conv(name + ".conv3", 1, planes, planes, cout, false, false, false, dtype == DF3D_DTYPE_BF16 ? 1 : 0);
-            if (ring && dtype == DF3D_DTYPE_BF16 && cin == 256 && planes == 128) {
+            if (ring && cin == 256 && planes == 128) {   // weights through the LDS-DMA ring (hg_bt_ring.h, hg_bt_ring_f32.h)
                 st.wstream = (long long)stream_bytes;
-                stream_bytes += (size_t)BR_NSTAGE * BR_STAGE_BYTES;
+                stream_bytes += (size_t)(dtype == DF3D_DTYPE_BF16 ? BR_NSTAGE : BRF_NSTAGE) * BR_STAGE_BYTES;
             }
             st.out = new_tensor(tx.h, tx.w, cout);
             if (want_pool) {  // the consumer max-pools this tensor: the epilogue writes the pooled copy too (no pool step)
@@ -564,23 +566,27 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.W = ti.w;
                 const int cin = st.conv.cin, pl = st.conv.cout;
                 const double px = (double)n * ti.h * ti.w;
-                if (eb == 2 && st.wstream >= 0) {
+                if (st.wstream >= 0) {
                     BtRingArgs r;
                     r.in = a.in; r.in2 = a.in2; r.out = a.out; r.pool = a.pool;
-                    r.wstream = wb + h->stream_base() + st.wstream;
+                    r.wstream = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream;
                     r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.s1 = a.s1; r.t1 = a.t1;
                     r.V = n; r.H = ti.h; r.W = ti.w;
-                    ScopedTimer tm(h, s, std::string("bottleneck_ring_kernel<") + (a.in2 ? "true" : "false") + ">",
+                    ScopedTimer tm(h, s, std::string(eb == 2 ? "bottleneck_ring_kernel<" : "bottleneck_ring_f32_kernel<") + (a.in2 ? "true" : "false") + ">",
                                    2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl));
                     const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
-                    static unsigned attr_done[2] = {0, 0};
-                    const void* fn = a.in2 ? reinterpret_cast<const void*>(bottleneck_ring_kernel<true>) : reinterpret_cast<const void*>(bottleneck_ring_kernel<false>);
-                    if (first_use_on_this_device(attr_done[a.in2 ? 1 : 0]))
-                        DF3D_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BR_LDS_BYTES));
-                    if (a.in2)
-                        hipLaunchKernelGGL((bottleneck_ring_kernel<true>), dim3(blocks), dim3(256), BR_LDS_BYTES, s, r);
-                    else
-                        hipLaunchKernelGGL((bottleneck_ring_kernel<false>), dim3(blocks), dim3(256), BR_LDS_BYTES, s, r);
+                    static unsigned attr_done[4] = {0, 0, 0, 0};
+                    const int which = (eb == 2 ? 0 : 2) + (a.in2 ? 1 : 0);
+                    const void* fns[4] = {reinterpret_cast<const void*>(bottleneck_ring_kernel<false>), reinterpret_cast<const void*>(bottleneck_ring_kernel<true>),
+                                          reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<false>), reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<true>)};
+                    if (first_use_on_this_device(attr_done[which]))
+                        DF3D_HIP(hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, BR_LDS_BYTES));
+                    switch (which) {
+                        case 0: hipLaunchKernelGGL((bottleneck_ring_kernel<false>), dim3(blocks), dim3(256), BR_LDS_BYTES, s, r); break;
+                        case 1: hipLaunchKernelGGL((bottleneck_ring_kernel<true>), dim3(blocks), dim3(256), BR_LDS_BYTES, s, r); break;
+                        case 2: hipLaunchKernelGGL((bottleneck_ring_f32_kernel<false>), dim3(blocks), dim3(256), BR_LDS_BYTES, s, r); break;
+                        default: hipLaunchKernelGGL((bottleneck_ring_f32_kernel<true>), dim3(blocks), dim3(256), BR_LDS_BYTES, s, r); break;
+                    }
                     DF3D_LAUNCH_CHECK();
                     break;
                 }
@@ -756,8 +762,9 @@ int df3d_hg_param_desc(const df3d_hg* h, int i, df3d_hg_param* out) {
 size_t df3d_hg_blob_floats(const df3d_hg* h) { return h ? h->blob_floats : 0; }
 
 size_t df3d_hg_lowp_bytes(const df3d_hg* h) {
-    if (!h || h->dtype != DF3D_DTYPE_BF16) return 0;
-    return h->stream_base() + h->stream_bytes;   // bf16 copy of the blob + the pre-swizzled weight streams of the ring bottlenecks
+    if (!h) return 0;
+    // bf16: bf16 copy of the blob + the pre-swizzled weight streams of the ring bottlenecks; f32: the weight streams only
+    return h->stream_base() + h->stream_bytes;
 }
 
 int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void* stream) {
@@ -777,6 +784,17 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
             const unsigned short* lp = reinterpret_cast<const unsigned short*>(lowp_dev);
             hipLaunchKernelGGL(bt_ring_pack_kernel, dim3((BR_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
                                lp + st.conv.w_off, lp + st.conv2b.w_off, lp + st.conv3b.w_off,
+                               reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
+        }
+        DF3D_LAUNCH_CHECK();
+        h->lowp = lowp_dev;
+    } else if (h->stream_bytes) {
+        DF3D_CHECK_ARG(lowp_dev != nullptr, "the engine needs a df3d_hg_lowp_bytes() device buffer for its weight streams");
+        DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(lowp_dev) & 255) == 0, "lowp buffer must be 256-byte aligned");
+        for (const Step& st : h->steps) {
+            if (st.kind != ST_BOTTLENECK || st.wstream < 0) continue;
+            hipLaunchKernelGGL(bt_ring_pack_f32_kernel, dim3((BRF_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
+                               blob_dev + st.conv.w_off, blob_dev + st.conv2b.w_off, blob_dev + st.conv3b.w_off,
                                reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
         }
         DF3D_LAUNCH_CHECK();

@@ -110,7 +110,7 @@ class HourglassEngine:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"fuse", 0), "df3d_hg_set_option")
         if fuse_upadd is not None:  # default: the library's choice (on)
             _native.check(self.lib.df3d_hg_set_option(self.h, b"fuse_upadd", 1 if fuse_upadd else 0), "df3d_hg_set_option")
-        if ring is not None:  # default: the library's choice (bf16: LDS-DMA weight ring in the 256 -> 128 -> 128 -> 256 bottlenecks)
+        if ring is not None:  # default: the library's choice (LDS-DMA weight ring in the 256 -> 128 -> 128 -> 256 bottlenecks)
             _native.check(self.lib.df3d_hg_set_option(self.h, b"ring", 1 if ring else 0), "df3d_hg_set_option")
         if row_bytes:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"row_bytes", row_bytes), "df3d_hg_set_option")

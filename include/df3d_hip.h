@@ -251,7 +251,10 @@ int df3d_hg_set_input(df3d_hg* h, int height, int width);
 int df3d_hg_num_params(const df3d_hg* h);
 int df3d_hg_param_desc(const df3d_hg* h, int i, df3d_hg_param* out);
 size_t df3d_hg_blob_floats(const df3d_hg* h);
-/* bf16 engines keep a bf16 copy of the blob: lowp_dev must hold df3d_hg_lowp_bytes(h) bytes (NULL for f32). */
+/* Engine-private device copies of the weights, made by df3d_hg_set_weights in a caller-owned buffer of
+ * df3d_hg_lowp_bytes(h) bytes (256-byte aligned; NULL is accepted when that size is 0): the bf16 copy of the blob (bf16
+ * engines) and, for both dtypes, the "weight streams" of the 256 -> 128 -> 128 -> 256 bottlenecks -- their weights repacked
+ * as the sequence of 8 KB LDS images the kernel pulls through its LDS-DMA ring (option "ring", default 1). */
 size_t df3d_hg_lowp_bytes(const df3d_hg* h);
 int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void* stream);
 /* knobs: "fuse" = 1 (default) | 0: run 256->128->128->256 bottlenecks as one fused kernel -- must be set before

@@ -237,18 +237,19 @@ def test_fused_upsample_add_is_bit_identical(native_lib, cuda, oracle_net, image
     assert torch.equal(on.forward(x), off.forward(x))
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
 @pytest.mark.parametrize("height,width,n", [(256, 512, 3), (128, 256, 2), (64, 192, 1)])
-def test_bf16_weight_ring_bottleneck_is_bit_identical(native_lib, cuda, oracle_net, height, width, n):
-    """The LDS-DMA weight-ring form of the bf16 256 -> 128 -> 128 -> 256 bottleneck (csrc/hg_bt_ring.h: weights streamed as
-    pre-swizzled stage images through a 3-deep ring, one barrier per stage) against the register-staged kernel it replaces:
-    same MFMA K order, so every plan step and the heat-maps must be BIT-identical (also with the fused upsample + add, the
-    fused pooling output, image borders and tile counts that are not powers of two)."""
+def test_weight_ring_bottleneck_is_bit_identical(native_lib, cuda, oracle_net, height, width, n, dtype):
+    """The LDS-DMA weight-ring form of the 256 -> 128 -> 128 -> 256 bottleneck (csrc/hg_bt_ring.h, hg_bt_ring_f32.h: weights
+    streamed as pre-swizzled stage images through a 4-slot LDS ring, counted vmcnt waits) against the register-staged kernel
+    it replaces: same MFMA K order, so every plan step and the heat-maps must be BIT-identical (also with the fused
+    upsample + add, the fused pooling output, image borders and tile counts that are not powers of two)."""
     from deepfly3d_amd.hourglass import HourglassEngine
 
     sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
     img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(3 * height + width), dtype=torch.float32).to(cuda)
-    on = HourglassEngine(sd, dtype="bf16", device=cuda, height=height, width=width, ring=True)
-    off = HourglassEngine(sd, dtype="bf16", device=cuda, height=height, width=width, ring=False)
+    on = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, ring=True)
+    off = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, ring=False)
     steps = on.steps()
     assert steps == off.steps()
     for k in range(1, len(steps) + 1):
