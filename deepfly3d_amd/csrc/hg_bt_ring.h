@@ -161,7 +161,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int tiles_x = p.W / BT_TW, tiles_y = p.H / BT_TH;
-    int b = blockIdx.x;
+    // XCD-aware tile order (speed only): workgroup b runs on XCD b % 8, so XCD x takes the x-th contiguous eighth of the tiles and
+    // the 64 workgroups resident on it work on neighbouring tiles, whose halos then meet in that XCD's L2 (bijective for any grid)
+    int b;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
     const int tx0 = (b % tiles_x) * BT_TW;
     b /= tiles_x;
     const int ty0 = (b % tiles_y) * BT_TH;
@@ -217,11 +223,16 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
         xp[i] = xin + (((size_t)(ok ? y : 0) * p.W + (ok ? x : 0)) * CIN + xchunk * 8) * 2;
         if constexpr (UP) xq[i] = xin2 + (((size_t)(ok ? (y >> 1) : 0) * (p.W / 2) + (ok ? (x >> 1) : 0)) * CIN + xchunk * 8) * 2;
     }
-    u32x4 rx[3][XP];
-    u32x4 rb[UP ? 3 : 1][XP];
+    constexpr int DX = UP ? 2 : 3;   // K steps of x requested ahead (registers); the LDS x ring has three slots either way
+    u32x4 rx[DX][XP];
+    u32x4 rb[UP ? DX : 1][XP];
     auto loadx = [&](int s, int slot) {   // out-of-image halo rows read pixel (0, 0) (a valid address) and are masked in storex
 #pragma unroll
+#if defined(BR_ABL) && BR_ABL == 5   // ablation: no x loads (registers only)
+        for (int i = 0; i < XP; ++i) rx[slot][i] = u32x4{(unsigned)s, (unsigned)tid, 0u, 0u};
+#else
         for (int i = 0; i < XP; ++i) rx[slot][i] = *reinterpret_cast<const u32x4*>(xp[i] + s * 64);
+#endif
         if constexpr (UP) {
 #pragma unroll
             for (int i = 0; i < XP; ++i) rb[slot][i] = *reinterpret_cast<const u32x4*>(xq[i] + s * 64);
@@ -239,14 +250,15 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
         for (int i = 0; i < XP; ++i) {
             u32x4 v = rx[slot][i];
             if constexpr (UP) v = add_chunk<T>(v, rb[slot][i]);   // x = in + upsample(in2), rounded like upadd_kernel's output
+#if !defined(BR_ABL) || BR_ABL != 6   // ablation 6: no bn1 + ReLU arithmetic
             v = br_preact(v, coef);
+#endif
             v &= xkeep[i];
             *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * BR_XPITCH + xchunk * 16) = v;
         }
     };
-    loadx(0, 0);
-    loadx(1, 1);
-    loadx(2, 2);
+#pragma unroll
+    for (int k = 0; k < DX; ++k) loadx(k, k);
 
     const int py = 2 * wave + (l31 >> 4), px = l31 & 15;   // this wave's 32 pixels (phases 2, 3)
     {
@@ -267,23 +279,30 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
         }
 #pragma unroll
         for (int s = 0; s < BR_W1_STAGES; ++s) {
-            storex(s, s % 3);
-            // operations issued after stage s's DMA pieces (see the file header): the next two stages' pieces and the x loads
-            // of the steps issued since
-            br_wait_vm(s == 0 ? 4 + 3 * LX : s == 1 ? 4 + 4 * LX : s == 2 ? 4 + 5 * LX : 4 + LX + (s + 1 < 8 ? LX : 0) + (s + 2 < 8 ? LX : 0));
+            storex(s, s % DX);
+            // operations issued after stage s's DMA pieces (see the file header): the next two stages' pieces (4) and the x
+            // loads requested since -- the prologue's DX steps for s < 3, then one step's worth per K step while any remain
+            auto cx = [](int k) { return k < BR_W1_STAGES ? LX : 0; };
+            br_wait_vm(s == 0 ? 4 + DX * LX : s == 1 ? 4 + DX * LX + cx(DX) : s == 2 ? 4 + DX * LX + cx(DX) + cx(DX + 1)
+                                                                               : 4 + cx(s - 3 + DX) + cx(s - 2 + DX) + cx(s - 1 + DX));
             br_barrier();
             ring_issue(s + 3);
-            if (s + 3 < BR_W1_STAGES) loadx(s + 3, s % 3);
+            if (s + DX < BR_W1_STAGES) loadx(s + DX, s % DX);
             const unsigned char* const sx = t1_lds + (s % 3) * BR_XSTAGE;
+            // both K halves' fragments are requested before the first MFMA (see phase 2: hipcc would serialise read -> MFMA)
+            u32x4 wfr[2], xfr[2][6];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + ct * 2048);
+                wfr[j] = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + ct * 2048);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + (i * 32 + l31) * BR_XPITCH + j * 32 + half * 16);
-                    mfma_chunk<T>(wf, xf, acc[i]);
-                }
+                for (int i = 0; i < 6; ++i) xfr[j][i] = *reinterpret_cast<const u32x4*>(sx + (i * 32 + l31) * BR_XPITCH + j * 32 + half * 16);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) mfma_chunk<T>(wfr[j], xfr[j][i], acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         br_barrier();   // every wave is done with the x ring: the t1 tile may overwrite it
         BR_STAMP(1);
@@ -339,29 +358,40 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
                     for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
                 }
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int s = s0 + u;
+        // The four (stage, K half) groups of the double-step, software-pipelined by hand: the five fragments of group g + 1 are
+        // requested BEFORE the four MFMAs of group g (hipcc otherwise re-uses one register quad for every weight fragment and
+        // serialises ds_read -> wait -> MFMA, which leaves the LDS latency exposed in front of every MFMA).
+        u32x4 tfr[2], wfr[2][NT];
+        auto load_group = [&](int g, int buf) {
+            const int s = s0 + (g >> 1), j = g & 1;
             const int q = s - BR_W1_STAGES, tap = q >> 2, kc = q & 3;
             const int ky = tap / 3, kx = tap - 3 * ky;
+            // chunk (4 kc + 2 j + half) ^ swizzle = ((4 kc + 2 j) << 4) ^ tsw[kx]   (4 kc + 2 j is even)
+            tfr[buf] = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                // chunk (4 kc + 2 j + half) ^ swizzle = ((4 kc + 2 j) << 4) ^ tsw[kx]   (4 kc + 2 j is even)
-                const u32x4 tf = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
+            for (int m = 0; m < NT; ++m)
+                wfr[buf][m] = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + m * 2048);
+        };
+        load_group(0, 0);
 #pragma unroll
-                for (int m = 0; m < NT; ++m) {
-#if defined(BR_ABL) && BR_ABL == 2   // ablation: no weight fragment reads
-                    const u32x4 wf = tf;
-#else
-                    const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + m * 2048);
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) load_group(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef BR_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
 #endif
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
 #if defined(BR_ABL) && BR_ABL == 1   // ablation: no MFMAs (the fragments stay live)
-                    asm volatile("" ::"v"(wf), "v"(tf));
+                asm volatile("" ::"v"(wfr[g & 1][m]), "v"(tfr[g & 1]));
 #else
-                    mfma_chunk<T>(wf, tf, t2[m]);
+                mfma_chunk<T>(wfr[g & 1][m], tfr[g & 1], t2[m]);
 #endif
-                }
             }
+#ifdef BR_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ReLU + rounding to bf16 once: the B operands of phase 3 (tile kc, registers 8 q2 .. 8 q2 + 7 -> four dwords)
@@ -416,19 +446,24 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
                         for (int e = 0; e < 4; ++e) acc[i][4 * t + e] = bb[e];
                     }
             }
+            // four (stage, K half) groups, the weight fragments of group g + 1 requested before the MFMAs of group g
+            // t2 tile kc, registers 8 q2 .. 8 q2 + 7 <-> packed W3 K positions 32 kc + 16 q2 + 8 half .. (host K order, kperm)
+            bf16x8 w3r[2][4];
+            auto load_w3 = [&](int g, int buf) {
+                const int s = s0 + (g >> 1), q2 = g & 1;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int kc = 2 * dd + u, s = s0 + u;
-                // t2 tile kc, registers 8 q2 .. 8 q2 + 7 <-> packed W3 K positions 32 kc + 16 q2 + 8 half .. (host K order, kperm)
+                for (int i = 0; i < 4; ++i)
+                    w3r[buf][i] = *reinterpret_cast<const bf16x8*>((q2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
+            };
+            load_w3(0, 0);
 #pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) {
-                    const bf16x8 tf = __builtin_bit_cast(bf16x8, t2f[kc][q2]);
+            for (int g = 0; g < 4; ++g) {
+                if (g < 3) load_w3(g + 1, (g + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 tf = __builtin_bit_cast(bf16x8, t2f[2 * dd + (g >> 1)][g & 1]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>((q2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, tf, acc[i], 0, 0, 0);
-                    }
-                }
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3r[g & 1][i], tf, acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         BR_STAMP(4 + 2 * nh);

@@ -68,10 +68,19 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
     const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
 
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef DF3D_BT_TIMING
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int tiles_x = p.W / BT_TW, tiles_y = p.H / BT_TH;
-    int b = blockIdx.x;
+    // XCD-aware tile order (speed only): workgroup b runs on XCD b % 8, so XCD x takes the x-th contiguous eighth of the tiles and
+    // the 64 workgroups resident on it work on neighbouring tiles, whose halos then meet in that XCD's L2 (bijective for any grid)
+    int b;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
     const int tx0 = (b % tiles_x) * BT_TW;
     b /= tiles_x;
     const int ty0 = (b % tiles_y) * BT_TH;
@@ -174,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
 #pragma unroll
         for (int k = 0; k < DX; ++k) loadx(k, k);
         br_barrier();   // kh = 0: coefficients / masks visible; kh = 1: every wave has finished reading the first t1 half
+        BR_STAMP(kh == 0 ? 0 : 3);
         f32x16 acc[3];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {   // register 4 t + e <-> channel 64 kh + 32 ct + 8 t + 4 half + e
@@ -208,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
             }
         }
         br_barrier();   // every wave is done with the x ring: the t1 half may overwrite it
+        BR_STAMP(1);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int hp = (rt0 + i) * 32 + l31;
@@ -223,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
             }
         }
         if (kh == 1) coef_lds[256 + tid] = late_b3;   // bn1 is dead: b3 takes the shift vector's place (read in phase 3)
+        BR_STAMP(2);
 
         // ---- phase 2 (half kh): t2^T += W2'[:, half] (*) t1 half, two stages per barrier --------------------------------
 #pragma unroll
@@ -249,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
             }
         }
     }
+    BR_STAMP(3);
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
@@ -300,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
                     }
             }
         }
+        BR_STAMP(4 + 2 * nh);
         // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4 half of the wave][col = channel nh*128 + 32 i + l31]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -343,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
                     }
             }
         }
+        BR_STAMP(5 + 2 * nh);
     }
 }
 

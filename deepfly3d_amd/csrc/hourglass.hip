@@ -579,13 +579,17 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                     const int which = (eb == 2 ? 0 : 2) + (a.in2 ? 1 : 0);
                     const void* fns[4] = {reinterpret_cast<const void*>(bottleneck_ring_kernel<false>), reinterpret_cast<const void*>(bottleneck_ring_kernel<true>),
                                           reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<false>), reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<true>)};
+                    int lds_bytes = BR_LDS_BYTES;
+#ifdef DF3D_BT_TIMING
+                    if (const char* e = getenv("BR_LDS")) lds_bytes = atoi(e);   // development: force one workgroup per CU (> 80 KB)
+#endif
                     if (first_use_on_this_device(attr_done[which]))
-                        DF3D_HIP(hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, BR_LDS_BYTES));
+                        DF3D_HIP(hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
                     switch (which) {
-                        case 0: hipLaunchKernelGGL((bottleneck_ring_kernel<false>), dim3(blocks), dim3(256), BR_LDS_BYTES, s, r); break;
-                        case 1: hipLaunchKernelGGL((bottleneck_ring_kernel<true>), dim3(blocks), dim3(256), BR_LDS_BYTES, s, r); break;
-                        case 2: hipLaunchKernelGGL((bottleneck_ring_f32_kernel<false>), dim3(blocks), dim3(256), BR_LDS_BYTES, s, r); break;
-                        default: hipLaunchKernelGGL((bottleneck_ring_f32_kernel<true>), dim3(blocks), dim3(256), BR_LDS_BYTES, s, r); break;
+                        case 0: hipLaunchKernelGGL((bottleneck_ring_kernel<false>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
+                        case 1: hipLaunchKernelGGL((bottleneck_ring_kernel<true>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
+                        case 2: hipLaunchKernelGGL((bottleneck_ring_f32_kernel<false>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
+                        default: hipLaunchKernelGGL((bottleneck_ring_f32_kernel<true>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
                     }
                     DF3D_LAUNCH_CHECK();
                     break;

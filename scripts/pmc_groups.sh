@@ -5,12 +5,14 @@ set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$1
 DT=${2:-bf16}
+ONLY=${3:-}   # optional: space-separated group numbers to run
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
 while read -r grp; do
   [ -z "$grp" ] && continue
   i=$((i+1))
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $i "; then continue; fi
   timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/g$i" -o pmc -- python "$R/bench.py" --dtype $DT --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-bf16-leg > "$OUT/g$i.log" 2>&1
   find "$OUT/g$i" -name "*kernel_trace.csv" -delete
 done <<GROUPS

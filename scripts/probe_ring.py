@@ -8,14 +8,17 @@ from deepfly3d_amd.hourglass import HourglassEngine
 from deepfly3d_amd.synthetic import synthetic_state_dict
 
 views = int(sys.argv[1]) if len(sys.argv) > 1 else 896
+dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 dev = torch.device("cuda:0")
-eng = HourglassEngine(synthetic_state_dict(0), dtype="bf16", device=dev)
+eng = HourglassEngine(synthetic_state_dict(0), dtype=dtype, device=dev)
 lib = _native.load()
 img = torch.rand((views, 256, 512, 3), device=dev)
 steps = eng.steps()
 names = [n for n, _ in steps]
 buf = (ctypes.c_ulonglong * 8)()
 labels = ["prologue", "phase1 K loop", "t1 epilogue", "phase2", "phase3a K", "epilogue a", "phase3b K", "epilogue b"]
+if dtype == "f32":  # both t1 halves are summed into the phase-1 / phase-2 slots ("phase2" = second-half entry barrier + both phase 2)
+    labels = ["prologue", "phase1 K loops (2)", "t1 epilogues (2)", "phase2 (2) + entry", "phase3a K", "epilogue a", "phase3b K", "epilogue b"]
 eng.forward(img); torch.cuda.synchronize()
 lib.df3d_dbg_ring_cycles.argtypes = [ctypes.c_void_p]
 lib.df3d_dbg_ring_cycles(buf)
