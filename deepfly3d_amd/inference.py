@@ -161,16 +161,27 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
     chunks = [items[lo:hi] for lo, hi in zip(starts, starts[1:] + [len(items)]) if hi > lo]
     if not chunks:
         raise FileNotFoundError(f"no images to process in {folder}")
-    paths = [[image_path_for(folder, c, t_first + t) for c, t in chunk] for chunk in chunks]
-    width, height = _image_size(paths[0][0])
-    reader = JpegFolderReader(width, height, dev, pinned=not disable_pin_memory)
+    class _Batches:
+        """Paths of batch k, resolved when the reader asks for them (two batches ahead of the GPU): the per-file existence
+        checks of a long recording then run under the previous batches' device work instead of in front of the first one."""
+
+        def __len__(self):
+            return len(chunks)
+
+        def __getitem__(self, k):
+            return [image_path_for(folder, c, t_first + t) for c, t in chunks[k]]
+
+    paths = _Batches()
+    width, height = _image_size(image_path_for(folder, chunks[0][0][0], t_first + chunks[0][0][1]))
+    reader = JpegFolderReader(width, height, dev, pinned=not disable_pin_memory, batch_capacity=max(len(c) for c in chunks))
     try:  # the reader's threads and pinned buffers are released on every path (df3d-cli -r/-f continues after a failed folder)
         with torch.cuda.device(dev):
-            reader.prefetch(paths[0])
-            for k, chunk in enumerate(chunks):
-                luma = reader.decode_next(paths[k + 1] if k + 1 < len(chunks) else None)
-                flip = torch.from_numpy(np.fromiter((1 if c in flip_set else 0 for c, _ in chunk), dtype=np.uint8, count=len(chunk))).to(dev, non_blocking=True)
-                x = preprocess_u8(luma, flip, tuple(config["input_shape"]))
+            flips = [torch.from_numpy(np.fromiter((1 if c in flip_set else 0 for c, _ in chunk), dtype=np.uint8, count=len(chunk))).to(dev, non_blocking=True)
+                     for chunk in chunks]
+            # file reads two batches ahead, H2D + JPEG decode one batch ahead on a second stream, under this batch's hourglass
+            for k, luma in enumerate(reader.stream(paths)):
+                chunk = chunks[k]
+                x = preprocess_u8(luma, flips[k], tuple(config["input_shape"]))
                 res = inference_views(x, engine, return_heatmap=return_heatmap)
                 # items are (camera, frame) in camera-major order = the flat order of points[ncam, T]: contiguous copies
                 lo = starts[k]

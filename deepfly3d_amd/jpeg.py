@@ -71,21 +71,26 @@ def decode_luma(blobs, width, height, device=None, check=True, return_status=Fal
     return (out, path.cpu().numpy()) if return_path else out
 
 
+# pinned staging buffers outlive a reader: page-locking ~80 MB takes longer than decoding a whole batch, and df3d-cli
+# (-r / -f) runs one reader per folder
+_PINNED_POOL = []
+
+
 class JpegFolderReader:
     """Streams JPEG files into the device decoder: a thread pool reads the files of batch k+1 straight into pinned
     staging memory (os.readinto releases the GIL) while the GPU decodes batch k.  Statuses are collected on the
     device and checked once, in `finish()`, so that no batch forces a host synchronisation.
 
         reader = JpegFolderReader(width, height, device)
-        reader.prefetch(paths_0)
-        for k in ...:
-            luma = reader.decode_next(paths_k_plus_1_or_None)   # uint8 [n, H, W] on the device
+        for luma in reader.stream(list_of_path_batches):        # uint8 [n, H, W] on the device, decoded on a second stream
+            ...                                                 # one batch ahead of the caller's work
         reader.finish()
+    (`prefetch` / `decode_next` are the same steps one at a time, on the caller's stream.)
     """
 
     SLOTS = 3
 
-    def __init__(self, width, height, device=None, workers=None, pinned=True):
+    def __init__(self, width, height, device=None, workers=None, pinned=True, batch_capacity=None):
         import os
         from concurrent.futures import ThreadPoolExecutor
 
@@ -97,8 +102,11 @@ class JpegFolderReader:
         self.pool = ThreadPoolExecutor(max_workers=workers or max(2, min(16, (os.cpu_count() or 4) - 1)))
         self.slots = [dict(buf=None, event=None) for _ in range(self.SLOTS)]
         self.turn = 0
-        self.pending = None
+        self.queue = []     # batches being read, oldest first (at most SLOTS - 1: one staging buffer may still feed a copy)
         self.work = None
+        self.batch_capacity = batch_capacity  # largest batch `stream()` will see (None: the first batch is the largest)
+        self.side = None    # second HIP stream of `stream()`: H2D copies + decode kernels under the caller's compute
+        self._keep = None
         self.statuses = []  # (status tensor, paths)
 
     @staticmethod
@@ -108,13 +116,20 @@ class JpegFolderReader:
         if got != len(view):
             raise IOError(f"{path}: short read ({got} of {len(view)} bytes)")
 
-    def prefetch(self, paths):
-        """Start reading `paths` into the next staging slot."""
+    @classmethod
+    def _read_many(cls, jobs):
+        for path, view in jobs:
+            cls._read_into(path, view)
+
+    def prefetch(self, paths, sizes=None):
+        """Start reading `paths` into the next staging slot (`sizes`: their byte sizes when the caller already knows them)."""
         import os
 
-        if self.pending is not None:
-            raise RuntimeError("a batch is already being read")
-        sizes = np.array([os.path.getsize(p) for p in paths], dtype=np.int64)
+        if len(self.queue) >= self.SLOTS - 1:
+            raise RuntimeError("too many batches are being read")
+        if sizes is None:
+            sizes = np.fromiter((os.stat(p).st_size for p in paths), dtype=np.int64, count=len(paths))
+        sizes = np.asarray(sizes, dtype=np.int64)
         padded = (sizes + 15) // 16 * 16
         ends = np.cumsum(padded)
         starts = ends - padded
@@ -126,41 +141,95 @@ class JpegFolderReader:
         if slot["event"] is not None:
             slot["event"].synchronize()  # the copy that last used this staging buffer has finished
         if slot["buf"] is None or slot["buf"].numel() < total + 16:
+            if slot["buf"] is None and self.pinned:
+                fit = [b for b in _PINNED_POOL if b.numel() >= total + 16]
+                if fit:
+                    slot["buf"] = min(fit, key=lambda b: b.numel())
+                    _PINNED_POOL[:] = [b for b in _PINNED_POOL if b is not slot["buf"]]
+        if slot["buf"] is None or slot["buf"].numel() < total + 16:
             slot["buf"] = torch.empty(int((total + 16) * 1.25), dtype=torch.uint8)
             if self.pinned:
                 slot["buf"] = slot["buf"].pin_memory()
         view = memoryview(slot["buf"].numpy())
-        futs = [self.pool.submit(self._read_into, p, view[s : s + n]) for p, s, n in zip(paths, starts, sizes)]
-        self.pending = (slot, futs, starts.astype(np.uint32), sizes.astype(np.uint32), total, list(paths))
+        # a few dozen files per task: one future per file costs more host time than the read itself
+        jobs = [(p, view[s : s + n]) for p, s, n in zip(paths, starts.tolist(), sizes.tolist())]
+        per = max(1, -(-len(jobs) // (4 * self.pool._max_workers)))
+        futs = [self.pool.submit(self._read_many, jobs[i : i + per]) for i in range(0, len(jobs), per)]
+        self.queue.append((slot, futs, starts.astype(np.uint32), sizes.astype(np.uint32), total, list(paths)))
 
-    def decode_next(self, next_paths=None):
-        """Wait for the batch being read, launch its decode, start reading `next_paths`; returns luma [n, H, W]."""
-        slot, futs, starts, sizes, total, paths = self.pending
-        self.pending = None
+    def _launch_decode(self, out, stream):
+        """Wait for the batch being read and enqueue its H2D copy + decode on `stream` into `out[:n]`."""
+        slot, futs, starts, sizes, total, paths = self.queue.pop(0)
         for f in futs:
             f.result()
         n = len(paths)
-        out = torch.empty((n, self.height, self.width), dtype=torch.uint8, device=self.dev)
         if n:
-            files_dev = slot["buf"][: total + 16].to(self.dev, non_blocking=True)
-            tab = torch.from_numpy(np.stack([starts, sizes]).view(np.int32)).to(self.dev, non_blocking=True)
-            slot["event"] = torch.cuda.Event()
-            slot["event"].record(torch.cuda.current_stream(self.dev))
-            status = torch.empty((n,), dtype=torch.int32, device=self.dev)
-            need = self.lib.df3d_jpeg_work_bytes(n, self.width, self.height, total)
-            if self.work is None or self.work.numel() < need:
-                self.work = torch.empty((need,), dtype=torch.uint8, device=self.dev)
-            with torch.cuda.device(self.dev):
+            with torch.cuda.device(self.dev), torch.cuda.stream(stream):
+                files_dev = slot["buf"][: total + 16].to(self.dev, non_blocking=True)
+                tab = torch.from_numpy(np.stack([starts, sizes]).view(np.int32)).to(self.dev, non_blocking=True)
+                slot["event"] = torch.cuda.Event()
+                slot["event"].record(stream)
+                status = torch.empty((n,), dtype=torch.int32, device=self.dev)
+                need = self.lib.df3d_jpeg_work_bytes(n, self.width, self.height, total)
+                if self.work is None or self.work.numel() < need:
+                    self.work = torch.empty((need,), dtype=torch.uint8, device=self.dev)
                 _native.check(
                     self.lib.df3d_jpeg_decode_luma(files_dev.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), n, total, int(sizes.max()), self.width,
                                                    self.height, out.data_ptr(), status.data_ptr(), None, self.work.data_ptr(), self.work.numel(), 0,
-                                                   torch.cuda.current_stream(self.dev).cuda_stream),
+                                                   stream.cuda_stream),
                     "df3d_jpeg_decode_luma",
                 )
+                self._keep = (files_dev, tab)  # alive until the next launch on this stream has been enqueued behind them
             self.statuses.append((status, paths))
+        return n
+
+    def decode_next(self, next_paths=None):
+        """Wait for the batch being read, launch its decode, start reading `next_paths`; returns luma [n, H, W]."""
+        n = len(self.queue[0][5])
+        out = torch.empty((n, self.height, self.width), dtype=torch.uint8, device=self.dev)
+        self._launch_decode(out, torch.cuda.current_stream(self.dev))
         if next_paths is not None:
             self.prefetch(next_paths)
         return out
+
+    def stream(self, batches, sizes=None):
+        """Generator over the decoded batches of `batches` (a list of path lists), pipelined three deep: while the caller's
+        stream works on batch k (everything it enqueues between two `next()` calls), batch k + 1 is copied and decoded on a
+        second HIP stream and the files of batch k + 2 are read by the thread pool.  Each yielded tensor (uint8 [n, H, W],
+        one of two alternating device buffers) is valid on the caller's current stream until the next item is requested.  `sizes[k]`: byte sizes of batch k's files."""
+        if not len(batches):
+            return
+        main = torch.cuda.current_stream(self.dev)
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=self.dev)
+        side = self.side
+        first = batches[0]
+        cap = max(len(first), self.batch_capacity or 0)
+        luma = [torch.empty((cap, self.height, self.width), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        side.wait_stream(main)  # the buffers exist for the side stream
+        decoded, consumed = [None, None], [None, None]
+        size_of = (lambda k: None) if sizes is None else (lambda k: sizes[k])
+        self.prefetch(first, size_of(0))
+        if len(batches) > 1:
+            self.prefetch(batches[1], size_of(1))   # both reads are under way before the first one is waited for
+        n_cur = self._launch_decode(luma[0], side)
+        decoded[0] = torch.cuda.Event()
+        decoded[0].record(side)
+        for k in range(len(batches)):
+            main.wait_event(decoded[k & 1])
+            yield luma[k & 1][:n_cur]
+            consumed[k & 1] = torch.cuda.Event()
+            consumed[k & 1].record(main)  # everything the caller enqueued on batch k
+            if k + 1 < len(batches):
+                nb = (k + 1) & 1
+                if k + 2 < len(batches):
+                    self.prefetch(batches[k + 2], size_of(k + 2))   # before waiting for batch k + 1's reads
+                if consumed[nb] is not None:
+                    side.wait_event(consumed[nb])  # batch k - 1 no longer reads this buffer
+                n_cur = self._launch_decode(luma[nb], side)
+                decoded[nb] = torch.cuda.Event()
+                decoded[nb].record(side)
+        main.wait_stream(side)
 
     def finish(self):
         """Check every decode status (one host synchronisation) and release the reader threads."""
@@ -173,3 +242,17 @@ class JpegFolderReader:
         finally:
             self.statuses = []
             self.pool.shutdown(wait=False)
+            for item in self.queue:  # an error path: file reads may still be writing into a staging buffer
+                for f in item[1]:
+                    try:
+                        f.result()
+                    except Exception:
+                        pass
+            self.queue = []
+            if self.pinned:
+                for slot in self.slots:
+                    if slot["event"] is not None:
+                        slot["event"].synchronize()  # the last copy out of this buffer has finished
+                    if slot["buf"] is not None and len(_PINNED_POOL) < 8:
+                        _PINNED_POOL.append(slot["buf"])
+                    slot["buf"] = None

@@ -104,6 +104,22 @@ def main():
             pts, conf = inference.inference_folder(folder=folder, camera_ids_to_flip=[4, 5, 6], max_img_id=a.frames - 1, dtype=dt_name)
             dt = time.perf_counter() - t0
             res[f"inference_folder_{dt_name}_frames_per_s"] = round(a.frames / dt, 1)
+            # the same work with the luma planes already resident on the device (no files, no PCIe, no JPEG decode): the rate the
+            # file path is compared with
+            eng = inference.get_engine(dtype=dt_name)
+            nb = 896
+            luma = torch.randint(0, 256, (nb, 480, 960), dtype=torch.uint8, device="cuda")
+            flip = torch.zeros((nb,), dtype=torch.uint8, device="cuda")
+            reps = max(1, (a.frames * 7) // nb)
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    inference.inference_views(inference.preprocess_u8(luma, flip, (256, 512)), eng)
+                torch.cuda.synchronize()
+                dtr = time.perf_counter() - t0
+            res[f"resident_{dt_name}_frames_per_s"] = round(reps * nb / 7 / dtr, 1)
+            res[f"file_path_fraction_of_resident_{dt_name}"] = round(res[f"inference_folder_{dt_name}_frames_per_s"] / res[f"resident_{dt_name}_frames_per_s"], 3)
         print(json.dumps(res))
         if a.out:
             with open(a.out, "w") as f:
