@@ -333,11 +333,27 @@ def reprojection_error(points2d_px, points3d, R, tvec, intr, device="cuda:0"):
         return dv._res.value / prob.nobs
 
 
+_side_streams = {}
+
+
 def bundle_adjust(points2d_px, R, tvec, intr, device="cuda:0", return_info=False):
-    """See _bundle_adjust; runs with `device` as the current HIP device (kernels launch on the current device)."""
+    """See _bundle_adjust; runs with `device` as the current HIP device (kernels launch on the current device).  When the
+    caller's current stream is the legacy default stream the solve runs on a private stream ordered behind it: the LSMR
+    chunks are replayed from a HIP graph, and a graph cannot be recorded on the default stream."""
     _native.require_gpu()
-    with torch.cuda.device(torch.device(device)):
-        return _bundle_adjust(points2d_px, R, tvec, intr, device, return_info)
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        cur = torch.cuda.current_stream(dev)
+        if cur.cuda_stream != 0:
+            return _bundle_adjust(points2d_px, R, tvec, intr, device, return_info)
+        side = _side_streams.get(str(dev))
+        if side is None:
+            side = _side_streams[str(dev)] = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out = _bundle_adjust(points2d_px, R, tvec, intr, device, return_info)
+        cur.wait_stream(side)
+        return out
 
 
 def _bundle_adjust(points2d_px, R, tvec, intr, device, return_info):

@@ -656,24 +656,67 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
 
     constexpr int CHUNK = 16;
     df3d_lsmr::State now = init;
+    auto enqueue_iteration = [&]() -> int {
+        // u = A v - alpha u ; beta = |u| ; u /= beta
+        if (int rc = launch_matvec(p, Jc, Jp, d_dev, v, tmp_m, s)) return rc;
+        hipLaunchKernelGGL(lsmr_bidiag_kernel<0>, dim3(gm), dim3(256), 0, s, st, tmp_m, u, m, red);
+        df3d_lsmr::launch_step_a(st, red, gm, s);
+        hipLaunchKernelGGL(lsmr_scale_kernel<0>, dim3(gm), dim3(256), 0, s, st, u, m);
+        // v = A^T u - beta v ; alpha = |v| ; rotations ; v /= alpha
+        if (int rc = launch_rmatvec(p, Jc, Jp, d_dev, u, tmp_n, scratch, s)) return rc;
+        hipLaunchKernelGGL(lsmr_bidiag_kernel<1>, dim3(gn), dim3(256), 0, s, st, tmp_n, v, n, red);
+        df3d_lsmr::launch_step_b(st, red, gn, s);
+        hipLaunchKernelGGL(lsmr_scale_kernel<1>, dim3(gn), dim3(256), 0, s, st, v, n);
+        // hbar, x, h ; |x| ; stopping tests
+        hipLaunchKernelGGL(lsmr_update_dev_kernel, dim3(gn), dim3(256), 0, s, st, hbar, h, x_dev, v, n, red);
+        df3d_lsmr::launch_step_c(st, red, gn, s);
+        return DF3D_OK;
+    };
+    // One chunk of CHUNK iterations = 12 x CHUNK small dependent kernels: launch-bound when enqueued one by one.  On a
+    // capturable stream (not the legacy default stream) the chunk is recorded once into a HIP graph and replayed -- every
+    // scalar the kernels need lives in `st`, so the recording is valid for every chunk of every LSMR run on the same problem
+    // and buffers (the three or four runs of one trust-region solve); otherwise the kernels are enqueued directly.
+    struct ChunkGraph {
+        hipGraphExec_t exec = nullptr;
+        const void* key[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        long long dims[2] = {0, 0};
+    };
+    static thread_local ChunkGraph cache;
+    const void* key[8] = {p->obs_xy, Jc, Jp, d_dev, x_dev, work_dev, p->cam_idx, p->pt_idx};
+    bool use_graph = s != nullptr && maxiter >= CHUNK;
+    if (use_graph) {
+        bool same = cache.exec != nullptr && cache.dims[0] == (long long)m && cache.dims[1] == (long long)n;
+        for (int k = 0; k < 8 && same; ++k) same = cache.key[k] == key[k];
+        if (!same) {
+            if (cache.exec) (void)hipGraphExecDestroy(cache.exec);
+            cache.exec = nullptr;
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                int rc = DF3D_OK;
+                for (int it = 0; it < CHUNK && rc == DF3D_OK; ++it) rc = enqueue_iteration();
+                const hipError_t e = hipStreamEndCapture(s, &graph);
+                if (rc == DF3D_OK && e == hipSuccess && graph && hipGraphInstantiate(&cache.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    for (int k = 0; k < 8; ++k) cache.key[k] = key[k];
+                    cache.dims[0] = (long long)m;
+                    cache.dims[1] = (long long)n;
+                } else {
+                    cache.exec = nullptr;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            (void)hipGetLastError();   // a refused capture is not an error of this call: the direct path below takes over
+            if (!cache.exec) use_graph = false;
+        }
+    }
     for (int done = 0; done < maxiter && now.istop == 0; done += CHUNK) {
         const int todo = maxiter - done < CHUNK ? maxiter - done : CHUNK;
-        for (int it = 0; it < todo; ++it) {
-            // u = A v - alpha u ; beta = |u| ; u /= beta
-            if (int rc = launch_matvec(p, Jc, Jp, d_dev, v, tmp_m, s)) return rc;
-            hipLaunchKernelGGL(lsmr_bidiag_kernel<0>, dim3(gm), dim3(256), 0, s, st, tmp_m, u, m, red);
-            df3d_lsmr::launch_step_a(st, red, gm, s);
-            hipLaunchKernelGGL(lsmr_scale_kernel<0>, dim3(gm), dim3(256), 0, s, st, u, m);
-            // v = A^T u - beta v ; alpha = |v| ; rotations ; v /= alpha
-            if (int rc = launch_rmatvec(p, Jc, Jp, d_dev, u, tmp_n, scratch, s)) return rc;
-            hipLaunchKernelGGL(lsmr_bidiag_kernel<1>, dim3(gn), dim3(256), 0, s, st, tmp_n, v, n, red);
-            df3d_lsmr::launch_step_b(st, red, gn, s);
-            hipLaunchKernelGGL(lsmr_scale_kernel<1>, dim3(gn), dim3(256), 0, s, st, v, n);
-            // hbar, x, h ; |x| ; stopping tests
-            hipLaunchKernelGGL(lsmr_update_dev_kernel, dim3(gn), dim3(256), 0, s, st, hbar, h, x_dev, v, n, red);
-            df3d_lsmr::launch_step_c(st, red, gn, s);
+        if (use_graph && todo == CHUNK) {
+            DF3D_HIP(hipGraphLaunch(cache.exec, s));
+        } else {
+            for (int it = 0; it < todo; ++it)
+                if (int rc = enqueue_iteration()) return rc;
+            DF3D_LAUNCH_CHECK();
         }
-        DF3D_LAUNCH_CHECK();
         DF3D_HIP(hipMemcpyAsync(&now, st, sizeof(now), hipMemcpyDeviceToHost, s));
         DF3D_HIP(hipStreamSynchronize(s));
     }
