@@ -3,7 +3,8 @@
 # --pmc pass per counter group, no other trace domain next to --pmc; summarised by scripts/summarize_counters.py.
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/r01_counters
+TAG=${1:-r02}
+OUT=$R/gpurun_out/${TAG}_counters
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for dt in f32 bf16; do
@@ -13,7 +14,7 @@ for dt in f32 bf16; do
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY" \
              "MfmaUtil"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/${dt}_g$i" -o pmc -- python "$R/bench.py" --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > "$OUT/${dt}_g$i.log" 2>&1
+    rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/${dt}_g$i" -o pmc -- python "$R/bench.py" --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-bf16-leg > "$OUT/${dt}_g$i.log" 2>&1
     find "$OUT/${dt}_g$i" -name "*kernel_trace.csv" -delete
   done
 done
