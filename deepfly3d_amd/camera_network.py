@@ -47,6 +47,30 @@ class Camera:
             path = self.image_path.format(cam_id=self.cam_id, img_id=f"{img_id:06d}")
         return np.asarray(Image.open(path))
 
+    def plot_2d(self, img_id, points2d=None, bones=None, colors=None, image=None, radius=6, width=3):
+        """The camera's image with the 2-D pose drawn on it, as an RGB ndarray (visualisation only, host side; call site
+        reference df3d/core.py:317-319).  points2d: (J, 2) pixels (row, col), default this camera's detections of the
+        image; joints at 0 are unseen and skipped.  bones: [[a, b], ...]; colors: one RGB triple per limb."""
+        from PIL import Image, ImageDraw
+
+        from .config import LIMB_COLORS, limb_of_joint, skeleton_bones
+
+        pts = np.asarray(self.points2d[img_id] if points2d is None else points2d, dtype=np.float64)
+        bones = skeleton_bones() if bones is None else bones
+        colors = LIMB_COLORS if colors is None else colors
+        img = self.get_image(img_id) if image is None else np.asarray(image)
+        canvas = Image.fromarray(img).convert("RGB")
+        draw = ImageDraw.Draw(canvas)
+        seen = lambda j: j < len(pts) and pts[j, 0] != 0 and pts[j, 1] != 0  # noqa: E731
+        colour = lambda j: tuple(int(v) for v in colors[limb_of_joint(j) % len(colors)])  # noqa: E731
+        for a, b in bones:
+            if seen(a) and seen(b):
+                draw.line([(pts[a, 1], pts[a, 0]), (pts[b, 1], pts[b, 0])], fill=colour(a), width=width)
+        for j in range(len(pts)):
+            if seen(j):
+                draw.ellipse([pts[j, 1] - radius, pts[j, 0] - radius, pts[j, 1] + radius, pts[j, 0] + radius], fill=colour(j))
+        return np.asarray(canvas)
+
     def summarize(self):
         # key order as in the reference's golden pickles (SURVEY.md App. A.5)
         return {"R": self.R, "tvec": self.tvec, "distort": self.distort, "intr": self.intr}

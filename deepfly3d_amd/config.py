@@ -39,3 +39,27 @@ def load_calibration():
 
 def load_procrustes_template():
     return np.load(config["procrustes_template"])["points3d"]
+
+
+# ---- drawing tables of the 38-joint skeleton (what pyba.config.df3d_bones / df3d_colors hold for the reference's
+# Core.plot_2d, reference df3d/core.py:311-319).  Joints of one side: three legs of five joints, antenna, three stripes.
+def skeleton_bones():
+    """[[joint_a, joint_b], ...]: consecutive joints of every leg and of the stripe chain, both sides."""
+    bones = []
+    for side in (0, 19):
+        for leg in range(3):
+            bones += [[side + 5 * leg + k, side + 5 * leg + k + 1] for k in range(4)]
+        bones += [[side + 16, side + 17], [side + 17, side + 18]]
+    return bones
+
+
+def limb_of_joint(joint):
+    """Limb id 0..9: right-side view legs 0-2, antenna 3, stripes 4; the other side 5-9."""
+    side, j = divmod(joint, 19)
+    return 5 * side + (j // 5 if j < 15 else 3 if j == 15 else 4)
+
+
+_REDS = [(186, 30, 49), (201, 86, 79), (213, 133, 121)]
+_BLUES = [(15, 115, 153), (26, 141, 175), (117, 190, 203)]
+_GREY = (210, 210, 210)
+LIMB_COLORS = _REDS + [_GREY, _GREY] + _BLUES + [_GREY, _GREY]

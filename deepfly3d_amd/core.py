@@ -264,6 +264,19 @@ class Core:
         order = find_default_camera_ordering(self.input_folder) if camera_ordering is None else camera_ordering
         return np.array(order)
 
+    def plot_2d(self, cam_id, img_id, with_corrections=False, smooth=False, joints=[]):
+        """Image `img_id` of camera `cam_id` with its 2-D pose drawn on it, as an ndarray (reference df3d/core.py:298-319).
+        Host-side drawing; `smooth` (temporal smoothing for videos) is accepted and ignored, `joints` restricts the drawing
+        to the listed joint ids."""
+        from .config import skeleton_bones
+
+        pts = self.corrected_points2d(cam_id, img_id) if with_corrections else np.array(self.camNet.cam_list[cam_id][img_id], dtype=np.float64)
+        if len(joints):
+            keep = np.zeros(len(pts), dtype=bool)
+            keep[list(joints)] = True
+            pts = np.where(keep[:, None], pts, 0.0)
+        return self.camNet[cam_id].plot_2d(img_id, points2d=pts, bones=skeleton_bones())
+
     def get_image(self, cam_id, img_id):
         return self.camNet.cam_list[cam_id].get_image(img_id)
 

@@ -288,3 +288,30 @@ for n in 0 1; do cp {src}/camera_${{cam}}_img_$n.jpg "$(printf "$last" $n)"; don
     (folder / "camera_0_img_0.jpg").write_bytes(open(os.path.join(src, "camera_0_img_0.jpg"), "rb").read())
     assert Core(str(folder), None, 0, [0, 1, 2, 3, 4, 5, 6]).fps is None
     config.pop("image_shape", None)
+
+
+def test_plot_2d_draws_the_pose(golden_dir):
+    """Camera.plot_2d / the drawing tables (reference df3d/core.py:298-319): an RGB image of the frame's size, coloured only
+    around the seen joints and along their bones; unseen joints (0, .) are skipped."""
+    from deepfly3d_amd.camera_network import CameraNetwork
+    from deepfly3d_amd.config import LIMB_COLORS, limb_of_joint, skeleton_bones
+
+    bones = skeleton_bones()
+    assert len(bones) == 28 and [15, 34] not in bones and all(limb_of_joint(a) == limb_of_joint(b) for a, b in bones)
+    assert [limb_of_joint(j) for j in (0, 4, 5, 14, 15, 16, 18, 19, 33, 34, 37)] == [0, 0, 1, 2, 3, 4, 4, 5, 7, 8, 9] and len(LIMB_COLORS) == 10
+    g2 = np.load(f"{golden_dir}/golden_2d.npz")
+    px = g2["points2d"][:, :2] * np.array([480.0, 960.0])
+    net = CameraNetwork(px, image_path=os.path.join(golden_dir, "images", "camera_{cam_id}_img_{img_id}.jpg"))
+    img = net[0].plot_2d(1)
+    raw = net[0].get_image(1)
+    assert img.shape == (480, 960, 3) and img.dtype == np.uint8
+    changed = np.any(img != np.stack([raw] * 3, axis=-1) if raw.ndim == 2 else img != raw[..., :3], axis=-1)
+    seen = (px[0, 1, :, 0] != 0) & (px[0, 1, :, 1] != 0)
+    assert seen.sum() >= 15 and changed.sum() > 30 * seen.sum()
+    for j in np.flatnonzero(seen):
+        r, c = np.round(px[0, 1, j]).astype(int)
+        assert changed[min(r, 479), min(c, 959)] and tuple(img[min(r, 479), min(c, 959)]) == LIMB_COLORS[limb_of_joint(j)]
+    # nothing is drawn far from every seen joint / bone: the left-side joints of camera 0 are unseen
+    assert not changed[:, :5].any()
+    only = net[0].plot_2d(1, points2d=np.where((np.arange(38) == 2)[:, None], px[0, 1], 0.0))
+    assert 50 < np.any(only != img * 0 + np.asarray(net[0].plot_2d(1, points2d=np.zeros((38, 2)))), axis=-1).sum() < 400
