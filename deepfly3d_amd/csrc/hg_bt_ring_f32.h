@@ -49,11 +49,11 @@ __global__ __launch_bounds__(256) void bt_ring_pack_f32_kernel(const float* __re
     *reinterpret_cast<u32x4*>(stream + (size_t)s * BR_STAGE_BYTES + dst) = *reinterpret_cast<const u32x4*>(src);
 }
 
-// max(x, 0) without the NaN-canonicalising v_max hipcc puts in front of fmaxf on MFMA results
+// max(x, 0) without the NaN-canonicalising v_max hipcc puts in front of fmaxf on MFMA results: as a signed integer a negative
+// float is negative, so v_max_i32(bits, 0) is the ReLU (-0 -> +0).  A builtin, not inline assembly -- see br_relu_pk.
 __device__ __forceinline__ float br_relu(float x) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
 template <bool UP>
