@@ -103,7 +103,10 @@ __device__ __forceinline__ void br_wait_vm(int n) {
         BR_W(27) BR_W(28) BR_W(29) BR_W(30) BR_W(31) BR_W(32) BR_W(33) BR_W(34) BR_W(35) BR_W(36) BR_W(37) BR_W(38) BR_W(39) BR_W(40)
         BR_W(41) BR_W(42) BR_W(43) BR_W(44) BR_W(45) BR_W(46) BR_W(47) BR_W(48) BR_W(49) BR_W(50) BR_W(51) BR_W(52) BR_W(53) BR_W(54)
         BR_W(55) BR_W(56) BR_W(57) BR_W(58) BR_W(59) BR_W(60) BR_W(61) BR_W(62) BR_W(63)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (the counter has six bits; a smaller count is always safe)
+        default:   // (the counter has six bits; a smaller count is always safe)
+            if (n > 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            break;
     }
 #undef BR_W
 }
@@ -113,7 +116,7 @@ __device__ __forceinline__ void br_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // max(x, 0) on two packed bf16: as signed 16-bit integers a negative float is a negative integer, so one v_pk_max_i16 does
 // both halves (and needs no NaN-canonicalising v_max before it, which hipcc puts in front of every fmaxf on an MFMA result).
 // NOT inline assembly: hipcc's hazard recognizer does not look inside an asm statement, and a VALU result that the very next
-// instruction, an MFMA, reads as SrcA / SrcB needs a wait state in between on gfx950 (scratch/ubench/mfma_war.hip shows the
+// instruction, an MFMA, reads as SrcA / SrcB needs a wait state in between on gfx950 (tests/perf/ubench/mfma_war.hip shows the
 // stale read) -- with the builtin the compiler sees the producer and keeps its distance.
 typedef short br_i16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned br_relu_pk(unsigned packed) {
@@ -147,38 +150,16 @@ __device__ unsigned long long br_dbg[8];
 #define BR_STAMP(k) do { } while (0)
 #endif
 
-// Tile geometry by P = pixel tiles (of 32) per wave:  P = 1: 8 x 16 output tile, two workgroups per CU (the round-2 kernel);
-// P = 2: 16 x 16 tile, 64 pixels per wave, ONE workgroup per CU whose four waves may use up to 512 registers each.  P = 2 reads
-// six LDS fragments per eight MFMAs in phase 2 (P = 1: five per four), pulls the weight stream once per 256 pixels instead of
-// once per 128 and recomputes 1.27 x instead of 1.41 x the halo -- the CU-level LDS / issue budget is what bounds this kernel.
-template <int P>
-struct BrGeo {
-    static constexpr int TH = 8 * P;                         // output tile height (width is always 16)
-    static constexpr int HALO = (TH + 2) * BT_HW;            // 180 / 324 halo pixels
-    static constexpr int RT = (HALO + 31) / 32;              // 6 / 11 MFMA row tiles in phase 1
-    static constexpr int HROWS = RT * 32;                    // 192 / 352
-    static constexpr int XP = (HROWS * 4 + 255) / 256;       // 16-byte chunks per thread and x step: 3 / 6 (the last pass is partial for P = 2)
-    static constexpr int T1_BYTES = HALO * BR_T1_PITCH;      // 46 080 / 82 944
-    static constexpr int XSTAGE = HROWS * BR_XPITCH;         // 15 360 / 28 160
-    static constexpr int XSLOTS = 3 * XSTAGE <= T1_BYTES ? 3 : 2;
-    static constexpr int MASK_WORDS = (HROWS + 63) / 64;     // 3 / 6
-    static constexpr int LDS_BYTES = BR_RING_BYTES + T1_BYTES + BR_COEF_BYTES + 64;
-    static_assert(XSLOTS * XSTAGE <= T1_BYTES, "the x ring lives inside the t1 region");
-    static_assert(4 * 32 * P * (128 * 2 + 16) <= T1_BYTES, "the epilogue slices live inside the t1 region");
-};
-
-template <bool UP, int P>
-__global__ __launch_bounds__(256, P == 1 ? 2 : 1) void bottleneck_ring_kernel(BtRingArgs p) {
+template <bool UP>
+__global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     using T = __hip_bfloat16;
-    using G = BrGeo<P>;
     constexpr int CIN = 256, CO = 256, NT = 4;
-    constexpr int RT = G::RT, XP = G::XP;
-    constexpr int LX = UP ? 2 * XP : XP;   // vector-memory loads per thread and x step
+    constexpr int LX = UP ? 6 : 3;   // vector-memory loads per thread and x step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;
     unsigned char* const t1_lds = smem + BR_RING_BYTES;
-    float* const coef_lds = reinterpret_cast<float*>(smem + BR_RING_BYTES + G::T1_BYTES);
-    unsigned long long* const valid_lds = reinterpret_cast<unsigned long long*>(smem + BR_RING_BYTES + G::T1_BYTES + BR_COEF_BYTES);
+    float* const coef_lds = reinterpret_cast<float*>(smem + BR_RING_BYTES + BR_T1_BYTES);
+    unsigned long long* const valid_lds = reinterpret_cast<unsigned long long*>(smem + BR_RING_BYTES + BR_T1_BYTES + BR_COEF_BYTES);
     const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -187,9 +168,9 @@ __global__ __launch_bounds__(256, P == 1 ? 2 : 1) void bottleneck_ring_kernel(Bt
 #endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int tiles_x = p.W / BT_TW, tiles_y = p.H / G::TH;
+    const int tiles_x = p.W / BT_TW, tiles_y = p.H / BT_TH;
     // XCD-aware tile order (speed only): workgroup b runs on XCD b % 8, so XCD x takes the x-th contiguous eighth of the tiles and
-    // the workgroups resident on it work on neighbouring tiles, whose halos then meet in that XCD's L2 (bijective for any grid)
+    // the 64 workgroups resident on it work on neighbouring tiles, whose halos then meet in that XCD's L2 (bijective for any grid)
     int b;
     {
         const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
@@ -197,7 +178,7 @@ __global__ __launch_bounds__(256, P == 1 ? 2 : 1) void bottleneck_ring_kernel(Bt
     }
     const int tx0 = (b % tiles_x) * BT_TW;
     b /= tiles_x;
-    const int ty0 = (b % tiles_y) * G::TH;
+    const int ty0 = (b % tiles_y) * BT_TH;
     const int view = b / tiles_y;
     const unsigned char* const xin = reinterpret_cast<const unsigned char*>(p.in) + (size_t)view * p.H * p.W * CIN * 2;
     const unsigned char* const xin2 = UP ? reinterpret_cast<const unsigned char*>(p.in2) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN * 2 : nullptr;
@@ -222,281 +203,141 @@ __global__ __launch_bounds__(256, P == 1 ? 2 : 1) void bottleneck_ring_kernel(Bt
     const float* const b1_lds = coef_lds + 512;
     const float* const b2_lds = coef_lds;
     const float* const b3_lds = coef_lds + 128;
-#pragma unroll
-    for (int k = 0; k < (G::HROWS + 255) / 256; ++k) {
-        const int hp = tid + 256 * k;
-        if (hp < G::HROWS) {
-            const int hy = hp / BT_HW, hx = hp % BT_HW;
-            const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-            const bool ok = hp < G::HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            const unsigned long long m = __ballot(ok);
-            if (lane == 0) valid_lds[hp >> 6] = m;
-        }
+    if (tid < BT_HROWS) {
+        const int hy = tid / BT_HW, hx = tid % BT_HW;
+        const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+        const bool ok = tid < BT_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) valid_lds[wave] = m;
     }
     ring_issue(0);
     ring_issue(1);
     ring_issue(2);
 
     // ---- phase 1: t1^T = relu(W1' relu(bn1 x)^T + b1') on the halo --------------------------------------------
-    // this wave's 32 P pixels (phases 2, 3): pixel tile pt covers tile rows 2 (P wave + pt), + 1; lane -> (row l31 >> 4, column l31 & 15)
-    const int px = l31 & 15;
-    if constexpr (P == 1) {
-        // ---- phase 1: t1^T = relu(W1' relu(bn1 x)^T + b1') on the halo --------------------------------------------
-        // x staging: thread -> (row = (tid + 256 i) >> 2, 16-byte chunk = tid & 3) of a 32-channel K step
-        const int xchunk = tid & 3;
-        const unsigned char* xp[XP];
-        const unsigned char* xq[UP ? XP : 1];
-        unsigned xkeep[XP];
+    // x staging: thread -> (row = (tid + 256 i) >> 2, 16-byte chunk = tid & 3) of a 32-channel K step
+    constexpr int XP = 3;
+    const int xchunk = tid & 3;
+    const unsigned char* xp[XP];
+    const unsigned char* xq[UP ? XP : 1];
+    unsigned xkeep[XP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const int hp = (tid >> 2) + 64 * i;
+        const int hy = hp / BT_HW, hx = hp % BT_HW;
+        const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+        const bool ok = hp < BT_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        xkeep[i] = ok ? 0xffffffffu : 0u;
+        xp[i] = xin + (((size_t)(ok ? y : 0) * p.W + (ok ? x : 0)) * CIN + xchunk * 8) * 2;
+        if constexpr (UP) xq[i] = xin2 + (((size_t)(ok ? (y >> 1) : 0) * (p.W / 2) + (ok ? (x >> 1) : 0)) * CIN + xchunk * 8) * 2;
+    }
+    constexpr int DX = UP ? 2 : 3;   // K steps of x requested ahead (registers); the LDS x ring has three slots either way
+    u32x4 rx[DX][XP];
+    u32x4 rb[UP ? DX : 1][XP];
+    auto loadx = [&](int s, int slot) {   // out-of-image halo rows read pixel (0, 0) (a valid address) and are masked in storex
+#pragma unroll
+#if defined(BR_ABL) && BR_ABL == 5   // ablation: no x loads (registers only)
+        for (int i = 0; i < XP; ++i) rx[slot][i] = u32x4{(unsigned)s, (unsigned)tid, 0u, 0u};
+#else
+        for (int i = 0; i < XP; ++i) rx[slot][i] = *reinterpret_cast<const u32x4*>(xp[i] + s * 64);
+#endif
+        if constexpr (UP) {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) rb[slot][i] = *reinterpret_cast<const u32x4*>(xq[i] + s * 64);
+        }
+    };
+    auto storex = [&](int s, int slot) {
+        PreactCoef<T> coef;
+        const int c0 = s * 32 + xchunk * 8;
+        coef.s[0] = *reinterpret_cast<const f32x4*>(coef_lds + c0);
+        coef.s[1] = *reinterpret_cast<const f32x4*>(coef_lds + c0 + 4);
+        coef.t[0] = *reinterpret_cast<const f32x4*>(coef_lds + 256 + c0);
+        coef.t[1] = *reinterpret_cast<const f32x4*>(coef_lds + 256 + c0 + 4);
+        unsigned char* const sx = t1_lds + (s % 3) * BR_XSTAGE;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            const int hp = (tid >> 2) + 64 * i;
-            const int hy = hp / BT_HW, hx = hp % BT_HW;
-            const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-            const bool ok = hp < G::HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            xkeep[i] = ok ? 0xffffffffu : 0u;
-            xp[i] = xin + (((size_t)(ok ? y : 0) * p.W + (ok ? x : 0)) * CIN + xchunk * 8) * 2;
-            if constexpr (UP) xq[i] = xin2 + (((size_t)(ok ? (y >> 1) : 0) * (p.W / 2) + (ok ? (x >> 1) : 0)) * CIN + xchunk * 8) * 2;
-        }
-        constexpr int DX = UP ? 2 : 3;   // K steps of x requested ahead (registers); the LDS x ring has G::XSLOTS slots
-        u32x4 rx[DX][XP];
-        u32x4 rb[UP ? DX : 1][XP];
-        // (a halo row beyond HROWS exists only in the last, partial pass of P = 2: those threads stage nothing)
-        auto xrow_ok = [&](int i) { return XP * 64 == G::HROWS || i + 1 < XP || (tid >> 2) + 64 * i < G::HROWS; };
-        auto loadx = [&](int s, int slot) {   // out-of-image halo rows read pixel (0, 0) (a valid address) and are masked in storex
-#pragma unroll
-            for (int i = 0; i < XP; ++i) rx[slot][i] = *reinterpret_cast<const u32x4*>(xp[i] + s * 64);
-            if constexpr (UP) {
-#pragma unroll
-                for (int i = 0; i < XP; ++i) rb[slot][i] = *reinterpret_cast<const u32x4*>(xq[i] + s * 64);
-            }
-        };
-        auto storex = [&](int s, int slot) {
-            PreactCoef<T> coef;
-            const int c0 = s * 32 + xchunk * 8;
-            coef.s[0] = *reinterpret_cast<const f32x4*>(coef_lds + c0);
-            coef.s[1] = *reinterpret_cast<const f32x4*>(coef_lds + c0 + 4);
-            coef.t[0] = *reinterpret_cast<const f32x4*>(coef_lds + 256 + c0);
-            coef.t[1] = *reinterpret_cast<const f32x4*>(coef_lds + 256 + c0 + 4);
-            unsigned char* const sx = t1_lds + (s % G::XSLOTS) * G::XSTAGE;
-#pragma unroll
-            for (int i = 0; i < XP; ++i) {
-                u32x4 v = rx[slot][i];
-                if constexpr (UP) v = add_chunk<T>(v, rb[slot][i]);   // x = in + upsample(in2), rounded like upadd_kernel's output
+            u32x4 v = rx[slot][i];
+            if constexpr (UP) v = add_chunk<T>(v, rb[slot][i]);   // x = in + upsample(in2), rounded like upadd_kernel's output
 #if !defined(BR_ABL) || BR_ABL != 6   // ablation 6: no bn1 + ReLU arithmetic
-                v = br_preact(v, coef);
+            v = br_preact(v, coef);
 #endif
-                v &= xkeep[i];
-                if (xrow_ok(i)) *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * BR_XPITCH + xchunk * 16) = v;
-            }
-        };
+            v &= xkeep[i];
+            *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * BR_XPITCH + xchunk * 16) = v;
+        }
+    };
 #pragma unroll
-        for (int k = 0; k < DX; ++k) loadx(k, k);
+    for (int k = 0; k < DX; ++k) loadx(k, k);
 
-        {
-            // wave w owns t1 channels 32 w .. 32 w + 31 for all halo row tiles.  The product is formed TRANSPOSED (A = W1
-            // rows, B = x rows: D[channel][halo pixel]) so that a lane ends up with four consecutive channels of ONE pixel per
-            // register group -> 8-byte LDS stores into the t1 tile, no cross-lane traffic.  Same products, same K order.
-            const int ct = wave;
-            f32x16 acc[RT];
-            br_barrier();   // coefficients, b1 and masks visible
-            BR_STAMP(0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {   // register 4 t + e <-> channel 32 ct + 8 t + 4 half + e
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(b1_lds + ct * 32 + 8 * t + 4 * half);
-#pragma unroll
-                for (int i = 0; i < RT; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][4 * t + e] = bb[e];
-            }
-#pragma unroll
-            for (int s = 0; s < BR_W1_STAGES; ++s) {
-                storex(s, s % DX);
-                // operations issued after stage s's DMA pieces (see the file header): the next two stages' pieces (4) and the x
-                // loads requested since -- the prologue's DX steps for s < 3, then one step's worth per K step while any remain
-                auto cx = [](int k) { return k < BR_W1_STAGES ? LX : 0; };
-                br_wait_vm(s == 0 ? 4 + DX * LX : s == 1 ? 4 + DX * LX + cx(DX) : s == 2 ? 4 + DX * LX + cx(DX) + cx(DX + 1)
-                                                                                   : 4 + cx(s - 3 + DX) + cx(s - 2 + DX) + cx(s - 1 + DX));
-                br_barrier();
-                ring_issue(s + 3);
-                if (s + DX < BR_W1_STAGES) loadx(s + DX, s % DX);
-                const unsigned char* const sx = t1_lds + (s % G::XSLOTS) * G::XSTAGE;
-                // all fragments of the K step are requested before its MFMAs (hipcc would serialise read -> wait -> MFMA)
-                u32x4 wfr[2], xfr[2][RT];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    wfr[j] = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + ct * 2048);
-#pragma unroll
-                    for (int i = 0; i < RT; ++i) xfr[j][i] = *reinterpret_cast<const u32x4*>(sx + (i * 32 + l31) * BR_XPITCH + j * 32 + half * 16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i = 0; i < RT; ++i) mfma_chunk<T>(wfr[j], xfr[j][i], acc[i]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            br_barrier();   // every wave is done with the x ring: the t1 tile may overwrite it
-            BR_STAMP(1);
-            // epilogue: ReLU (the bias was the start value), zero outside the image, 8-byte stores into the swizzled t1 tile
-#pragma unroll
-            for (int i = 0; i < RT; ++i) {
-                const int hp = i * 32 + l31;
-                const unsigned keep = 0u - (unsigned)((valid_lds[i >> 1] >> ((i & 1) * 32 + l31)) & 1ull);
-                unsigned char* const trow = t1_lds + hp * BR_T1_PITCH + half * 8;
-                const int sw = br_t1_swz(hp);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    uint2 w;
-                    w.x = br_relu_pk(pack_bf16x2(acc[i][4 * t + 0], acc[i][4 * t + 1])) & keep;
-                    w.y = br_relu_pk(pack_bf16x2(acc[i][4 * t + 2], acc[i][4 * t + 3])) & keep;
-                    if (i + 1 < RT || hp < G::HALO) *reinterpret_cast<uint2*>(trow + (((ct * 4 + t) ^ sw) << 4)) = w;
-                }
-            }
-            // the bn1 coefficients are dead: b2 / b3 take their place (read after the next barrier)
-            if (tid < 128) coef_lds[tid] = late_b2;
-            coef_lds[128 + tid] = late_b3;
-        }
-    } else {
-        // ---- phase 1, 16 x 16 tiles: every wave owns whole halo ROW tiles (w, w + 4, w + 8) and all 128 t1 channels of them --
-        // The x operand never passes through LDS: lane (l31, half) of row tile k loads the 16 bytes the MFMA wants from it
-        // (channels 32 s + 16 j + 8 half .. + 7 of halo pixel 32 rt + l31) straight into registers, applies bn1 + ReLU there
-        // and feeds the MFMA.  bn1 + ReLU of K step s + 1 is issued between the MFMAs of step s (same wave, independent
-        // registers), the only workgroup synchronisation left is the weight ring's.  Out-of-image halo pixels read pixel
-        // (0, 0) and are zeroed in the t1 epilogue (the twelfth row tile, past the halo, is all padding).
-        constexpr int KT = 3;
-        static_assert(4 * KT >= RT, "three row tiles per wave cover the halo");
-        const unsigned char* xp[KT];
-        const unsigned char* xq[UP ? KT : 1];
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            const int hp = (wave + 4 * k) * 32 + l31;
-            const int hy = hp / BT_HW, hx = hp % BT_HW;
-            const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-            const bool ok = hp < G::HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            xp[k] = xin + (((size_t)(ok ? y : 0) * p.W + (ok ? x : 0)) * CIN + half * 8) * 2;
-            if constexpr (UP) xq[k] = xin2 + (((size_t)(ok ? (y >> 1) : 0) * (p.W / 2) + (ok ? (x >> 1) : 0)) * CIN + half * 8) * 2;
-        }
-#ifndef BR_P2_DXU
-#define BR_P2_DXU 2
-#define BR_P2_DXN 3
-#endif
-        constexpr int DX = UP ? BR_P2_DXU : BR_P2_DXN;   // K steps of x in flight (registers)
-        constexpr int LX1 = (UP ? 2 : 1) * 2 * KT;   // vector-memory loads per K step
-        u32x4 rx[DX][KT][2];
-        u32x4 rb[UP ? DX : 1][KT][2];
-        auto loadx = [&](int s, int slot) {
-#pragma unroll
-            for (int k = 0; k < KT; ++k)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) rx[slot][k][j] = *reinterpret_cast<const u32x4*>(xp[k] + s * 64 + j * 32);
-            if constexpr (UP) {
-#pragma unroll
-                for (int k = 0; k < KT; ++k)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) rb[slot][k][j] = *reinterpret_cast<const u32x4*>(xq[k] + s * 64 + j * 32);
-            }
-        };
-        u32x4 xa[2][KT][2];   // activated operands of K steps s, s + 1
-        auto act = [&](int s, int slot, int buf) {
-#ifdef BR_DBG_A
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                PreactCoef<T> coef;
-                const int c0 = s * 32 + j * 16 + half * 8;
-                coef.s[0] = *reinterpret_cast<const f32x4*>(coef_lds + c0);
-                coef.s[1] = *reinterpret_cast<const f32x4*>(coef_lds + c0 + 4);
-                coef.t[0] = *reinterpret_cast<const f32x4*>(coef_lds + 256 + c0);
-                coef.t[1] = *reinterpret_cast<const f32x4*>(coef_lds + 256 + c0 + 4);
-#pragma unroll
-                for (int k = 0; k < KT; ++k) {
-                    u32x4 v = rx[slot][k][j];
-                    if constexpr (UP) v = add_chunk<T>(v, rb[slot][k][j]);   // x = in + upsample(in2), rounded like upadd_kernel's output
-                    xa[buf][k][j] = br_preact(v, coef);
-                }
-            }
-        };
-#pragma unroll
-        for (int k = 0; k < DX; ++k) loadx(k, k);
-        f32x16 acc[KT][4];
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;   // this wave's 32 pixels (phases 2, 3)
+    {
+        // wave w owns t1 channels 32 w .. 32 w + 31 for all six halo row tiles.  The product is formed TRANSPOSED (A = W1
+        // rows, B = x rows: D[channel][halo pixel]) so that a lane ends up with four consecutive channels of ONE pixel per
+        // register group -> 8-byte LDS stores into the t1 tile, no cross-lane traffic.  Same products, same K order.
+        const int ct = wave;
+        f32x16 acc[6];
         br_barrier();   // coefficients, b1 and masks visible
         BR_STAMP(0);
-        act(0, 0, 0);
-        if (DX < BR_W1_STAGES) loadx(DX, 0);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int t = 0; t < 4; ++t) {   // register 4 t + e <-> channel 32 ct + 8 t + 4 half + e
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b1_lds + ct * 32 + 8 * t + 4 * half);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {   // register 4 t + e of channel tile ct <-> channel 32 ct + 8 t + 4 half + e
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(b1_lds + ct * 32 + 8 * t + 4 * half);
+            for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int k = 0; k < KT; ++k)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[k][ct][4 * t + e] = bb[e];
-            }
+                for (int e = 0; e < 4; ++e) acc[i][4 * t + e] = bb[e];
+        }
 #pragma unroll
         for (int s = 0; s < BR_W1_STAGES; ++s) {
-            // operations issued after stage s's DMA pieces: the next two stages' pieces (4) and the x loads requested since
-            // (K step k + DX is requested right after bn1 + ReLU of step k, which runs one step ahead of the MFMAs)
-            auto cx = [](int k) { return k < BR_W1_STAGES ? LX1 : 0; };
-            br_wait_vm(s == 0 ? 4 + DX * LX1 + cx(DX) : s == 1 ? 4 + DX * LX1 + cx(DX) + cx(DX + 1)
-                       : s == 2 ? 4 + DX * LX1 + cx(DX) + cx(DX + 1) + cx(DX + 2) : 4 + cx(s - 2 + DX) + cx(s - 1 + DX) + cx(s + DX));
+            storex(s, s % DX);
+            // operations issued after stage s's DMA pieces (see the file header): the next two stages' pieces (4) and the x
+            // loads requested since -- the prologue's DX steps for s < 3, then one step's worth per K step while any remain
+            auto cx = [](int k) { return k < BR_W1_STAGES ? LX : 0; };
+            br_wait_vm(s == 0 ? 4 + DX * LX : s == 1 ? 4 + DX * LX + cx(DX) : s == 2 ? 4 + DX * LX + cx(DX) + cx(DX + 1)
+                                                                               : 4 + cx(s - 3 + DX) + cx(s - 2 + DX) + cx(s - 1 + DX));
             br_barrier();
             ring_issue(s + 3);
-            u32x4 wfr[2][4];
+            if (s + DX < BR_W1_STAGES) loadx(s + DX, s % DX);
+            const unsigned char* const sx = t1_lds + (s % 3) * BR_XSTAGE;
+            // both K halves' fragments are requested before the first MFMA (see phase 2: hipcc would serialise read -> MFMA)
+            u32x4 wfr[2], xfr[2][6];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                wfr[j] = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + ct * 2048);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    wfr[j][ct] = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + ct * 2048);
-            if (s + 1 < BR_W1_STAGES) {
-                act(s + 1, (s + 1) % DX, (s + 1) & 1);
-                if (s + 1 + DX < BR_W1_STAGES) loadx(s + 1 + DX, (s + 1) % DX);
+                for (int i = 0; i < 6; ++i) xfr[j][i] = *reinterpret_cast<const u32x4*>(sx + (i * 32 + l31) * BR_XPITCH + j * 32 + half * 16);
             }
-#ifdef BR_DBG_C
             __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int k = 0; k < KT; ++k)
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) mfma_chunk<T>(wfr[j][ct], xa[s & 1][k][j], acc[k][ct]);
+                for (int i = 0; i < 6; ++i) mfma_chunk<T>(wfr[j], xfr[j][i], acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        br_barrier();   // every wave is done with the x ring: the t1 tile may overwrite it
         BR_STAMP(1);
-#ifdef BR_DBG_B
-        br_barrier();
-#endif
-        // epilogue: ReLU (the bias was the start value), zero outside the image, 8-byte stores into the swizzled t1 tile (the
-        // t1 region has no other user in this phase: no barrier before it)
+        // epilogue: ReLU (the bias was the start value), zero outside the image, 8-byte stores into the swizzled t1 tile
 #pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            const int rt = wave + 4 * k;
-            const int hp = rt * 32 + l31;
-            const unsigned keep = 0u - (unsigned)((valid_lds[rt >> 1] >> ((rt & 1) * 32 + l31)) & 1ull);
+        for (int i = 0; i < 6; ++i) {
+            const int hp = i * 32 + l31;
+            const unsigned keep = 0u - (unsigned)((valid_lds[i >> 1] >> ((i & 1) * 32 + l31)) & 1ull);
             unsigned char* const trow = t1_lds + hp * BR_T1_PITCH + half * 8;
             const int sw = br_t1_swz(hp);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    uint2 w;
-                    w.x = br_relu_pk(pack_bf16x2(acc[k][ct][4 * t + 0], acc[k][ct][4 * t + 1])) & keep;
-                    w.y = br_relu_pk(pack_bf16x2(acc[k][ct][4 * t + 2], acc[k][ct][4 * t + 3])) & keep;
-                    if (hp < G::HALO) *reinterpret_cast<uint2*>(trow + (((ct * 4 + t) ^ sw) << 4)) = w;
-                }
+            for (int t = 0; t < 4; ++t) {
+                uint2 w;
+                w.x = br_relu_pk(pack_bf16x2(acc[i][4 * t + 0], acc[i][4 * t + 1])) & keep;
+                w.y = br_relu_pk(pack_bf16x2(acc[i][4 * t + 2], acc[i][4 * t + 3])) & keep;
+                if (i < 5 || hp < BT_HALO) *reinterpret_cast<uint2*>(trow + (((ct * 4 + t) ^ sw) << 4)) = w;
+            }
         }
-        // every wave read its last bn1 coefficients before the last K step's barrier: b2 / b3 take their place
+        // the bn1 coefficients are dead: b2 / b3 take their place (read after the next barrier)
         if (tid < 128) coef_lds[tid] = late_b2;
         coef_lds[128 + tid] = late_b3;
     }
 
     BR_STAMP(2);
     // ---- phase 2: t2^T = W2' (*) t1 (fully unrolled: every LDS address is one register + an immediate) -----------
-    f32x16 t2[NT][P];
-    const unsigned char* t1_lane[P];
-#pragma unroll
-    for (int pt = 0; pt < P; ++pt) t1_lane[pt] = t1_lds + ((2 * (P * wave + pt) + (l31 >> 4)) * BT_HW + px) * BR_T1_PITCH;
+    f32x16 t2[NT];
+    const unsigned char* const t1_lane = t1_lds + (py * BT_HW + px) * BR_T1_PITCH;
     unsigned tsw[3];   // ((tile column + kx) & 15 ^ half) << 4: the swizzle term of this lane's t1 fragment, per kx
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) tsw[kx] = (unsigned)((((px + kx) & 15) ^ half) << 4);
@@ -522,23 +363,19 @@ __global__ __launch_bounds__(256, P == 1 ? 2 : 1) void bottleneck_ring_kernel(Bt
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(b2_lds + 32 * m + 8 * q + 4 * half);
 #pragma unroll
-                    for (int pt = 0; pt < P; ++pt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) t2[m][pt][4 * q + e] = bb[e];
+                    for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
                 }
         }
-        // The four (stage, K half) groups of the double-step, software-pipelined by hand: the fragments of group g + 1 are
-        // requested BEFORE the MFMAs of group g (hipcc otherwise re-uses one register quad for every weight fragment and
+        // The four (stage, K half) groups of the double-step, software-pipelined by hand: the five fragments of group g + 1 are
+        // requested BEFORE the four MFMAs of group g (hipcc otherwise re-uses one register quad for every weight fragment and
         // serialises ds_read -> wait -> MFMA, which leaves the LDS latency exposed in front of every MFMA).
-        u32x4 tfr[2][P], wfr[2][NT];
+        u32x4 tfr[2], wfr[2][NT];
         auto load_group = [&](int g, int buf) {
             const int s = s0 + (g >> 1), j = g & 1;
             const int q = s - BR_W1_STAGES, tap = q >> 2, kc = q & 3;
             const int ky = tap / 3, kx = tap - 3 * ky;
             // chunk (4 kc + 2 j + half) ^ swizzle = ((4 kc + 2 j) << 4) ^ tsw[kx]   (4 kc + 2 j is even)
-#pragma unroll
-            for (int pt = 0; pt < P; ++pt)
-                tfr[buf][pt] = *reinterpret_cast<const u32x4*>(t1_lane[pt] + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
+            tfr[buf] = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
 #pragma unroll
             for (int m = 0; m < NT; ++m)
                 wfr[buf][m] = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + m * 2048);
@@ -552,15 +389,13 @@ __global__ __launch_bounds__(256, P == 1 ? 2 : 1) void bottleneck_ring_kernel(Bt
             __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-            for (int m = 0; m < NT; ++m)
-#pragma unroll
-                for (int pt = 0; pt < P; ++pt) {
+            for (int m = 0; m < NT; ++m) {
 #if defined(BR_ABL) && BR_ABL == 1   // ablation: no MFMAs (the fragments stay live)
-                    asm volatile("" ::"v"(wfr[g & 1][m]), "v"(tfr[g & 1][pt]));
+                asm volatile("" ::"v"(wfr[g & 1][m]), "v"(tfr[g & 1]));
 #else
-                    mfma_chunk<T>(wfr[g & 1][m], tfr[g & 1][pt], t2[m][pt]);
+                mfma_chunk<T>(wfr[g & 1][m], tfr[g & 1], t2[m]);
 #endif
-                }
+            }
 #ifdef BR_SETPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -568,62 +403,55 @@ __global__ __launch_bounds__(256, P == 1 ? 2 : 1) void bottleneck_ring_kernel(Bt
         }
     }
     // ReLU + rounding to bf16 once: the B operands of phase 3 (tile kc, registers 8 q2 .. 8 q2 + 7 -> four dwords)
-    u32x4 t2f[NT][2][P];
+    u32x4 t2f[NT][2];
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
         for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-            for (int pt = 0; pt < P; ++pt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    t2f[m][q2][pt][e] = br_relu_pk(pack_bf16x2(t2[m][pt][8 * q2 + 2 * e], t2[m][pt][8 * q2 + 2 * e + 1]));
+            for (int e = 0; e < 4; ++e) t2f[m][q2][e] = br_relu_pk(pack_bf16x2(t2[m][8 * q2 + 2 * e], t2[m][8 * q2 + 2 * e + 1]));
 
     BR_STAMP(3);
     // ---- phase 3: out^T = W3 t2^T + b3 (+ x) -------------------------------------------------------------------
     // transposed like phase 1 (A = W3 rows, B = the t2 registers): accumulator register 4 t + e of channel tile i holds, for
-    // pixel l31 of pixel tile pt, output channel 128 nh + 32 i + 8 t + 4 half + e -> 8-byte stores into the wave's LDS slice
+    // pixel l31 of the wave, output channel 128 nh + 32 i + 8 t + 4 half + e -> 8-byte stores into the wave's LDS slice
     unsigned char* const outp = reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * CO * 2;
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh) {
-        f32x16 acc[4][P];
-        unsigned xres[P][32];
+        f32x16 acc[4];
+        unsigned xres[32];
 #pragma unroll
         for (int dd = 0; dd < 2; ++dd) {
             const int s0 = BR_W1_STAGES + BR_W2_STAGES + 4 * nh + 2 * dd;
-            // operations issued after the pair's DMA pieces: the 8 P residual loads of this half (requested in its first
-            // double-step, after the DMA), or the first half's epilogue (8 P stores, UP: 4 P loads; the optional 4 P pool stores
+            // operations issued after the pair's DMA pieces: the 8 residual loads of this half (requested in its first
+            // double-step, after the DMA), or the first half's epilogue (8 stores, UP: 4 loads; the optional 4 pool stores
             // are left out, which only makes the wait conservative)
-            constexpr int E0 = (8 + (UP ? 4 : 0)) * P;
-            br_wait_vm(dd == 1 ? 8 * P : nh == 0 ? 0 : E0);
+            constexpr int E0 = 8 + (UP ? 4 : 0);
+            br_wait_vm(dd == 1 ? 8 : nh == 0 ? 0 : E0);
             br_barrier();
             if (s0 + 3 < BR_NSTAGE) {
                 ring_issue(s0 + 2);
                 ring_issue(s0 + 3);
             }
             if (dd == 0) {
-                // residual values requested now: lane owns, for c = 0..7, chunk (lane & 15) of the pixel tile's pixel 4 c + (lane >> 4)
+                // residual values requested now: lane owns, for c = 0..7, chunk (lane & 15) of wave pixel 4 c + (lane >> 4)
 #pragma unroll
-                for (int pt = 0; pt < P; ++pt)
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const int pw = 4 * c + (lane >> 4);
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin) +
-                            ((size_t)(ty0 + 2 * (P * wave + pt) + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CIN + nh * 128 + (lane & 15) * 8);
-                        xres[pt][4 * c + 0] = v[0];
-                        xres[pt][4 * c + 1] = v[1];
-                        xres[pt][4 * c + 2] = v[2];
-                        xres[pt][4 * c + 3] = v[3];
-                    }
+                for (int c = 0; c < 8; ++c) {
+                    const int pw = 4 * c + (lane >> 4);
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin) +
+                        ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CIN + nh * 128 + (lane & 15) * 8);
+                    xres[4 * c + 0] = v[0];
+                    xres[4 * c + 1] = v[1];
+                    xres[4 * c + 2] = v[2];
+                    xres[4 * c + 3] = v[3];
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const f32x4 bb = *reinterpret_cast<const f32x4*>(b3_lds + nh * 128 + i * 32 + 8 * t + 4 * half);
 #pragma unroll
-                        for (int pt = 0; pt < P; ++pt)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[i][pt][4 * t + e] = bb[e];
+                        for (int e = 0; e < 4; ++e) acc[i][4 * t + e] = bb[e];
                     }
             }
             // four (stage, K half) groups, the weight fragments of group g + 1 requested before the MFMAs of group g
@@ -640,67 +468,59 @@ __global__ __launch_bounds__(256, P == 1 ? 2 : 1) void bottleneck_ring_kernel(Bt
             for (int g = 0; g < 4; ++g) {
                 if (g < 3) load_w3(g + 1, (g + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 tf = __builtin_bit_cast(bf16x8, t2f[2 * dd + (g >> 1)][g & 1]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int pt = 0; pt < P; ++pt) {
-                        const bf16x8 tf = __builtin_bit_cast(bf16x8, t2f[2 * dd + (g >> 1)][g & 1][pt]);
-                        acc[i][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3r[g & 1][i], tf, acc[i][pt], 0, 0, 0);
-                    }
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3r[g & 1][i], tf, acc[i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         BR_STAMP(4 + 2 * nh);
-        // epilogue through LDS (the t1 region is dead): every wave parks its 32 P px x 128 ch tile in its own slice (8-byte
-        // stores: a lane owns four consecutive channels of its pixel per register group) and streams it out as 16-byte chunks
-        // with the residual added; rows fully coalesced.  Only this wave touches its slice.
+        // epilogue through LDS (the t1 region is dead): every wave parks its 32 px x 128 ch tile in its own slice (8-byte stores:
+        // a lane owns four consecutive channels of its pixel per register group) and streams it out as 16-byte chunks with the
+        // residual added; rows fully coalesced.  Only this wave touches its slice.
         constexpr int OP = 128 * 2 + 16;
-        unsigned short* const outs = reinterpret_cast<unsigned short*>(outp);
+        unsigned char* const slice = t1_lds + wave * (32 * OP);
+        u32x4 x2[UP ? 4 : 1];
+        if constexpr (UP) {
 #pragma unroll
-        for (int pt = 0; pt < P; ++pt) {
-            unsigned char* const slice = t1_lds + (wave * P + pt) * (32 * OP);
-            const int trow = P * wave + pt;   // this pixel tile = output tile rows 2 trow, 2 trow + 1
-            u32x4 x2[UP ? 4 : 1];
-            if constexpr (UP) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int pw = 4 * c + (lane >> 4);
-                    x2[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin2) +
-                        ((size_t)(ty0 / 2 + trow) * (p.W / 2) + ((tx0 + (pw & 15)) >> 1)) * CIN + nh * 128 + (lane & 15) * 8);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    uint2 w;
-                    w.x = pack_bf16x2(acc[i][pt][4 * t + 0], acc[i][pt][4 * t + 1]);
-                    w.y = pack_bf16x2(acc[i][pt][4 * t + 2], acc[i][pt][4 * t + 3]);
-                    *reinterpret_cast<uint2*>(slice + l31 * OP + (i * 32 + 8 * t + 4 * half) * 2) = w;
-                }
-            u32x4 fin[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < 4; ++c) {
                 const int pw = 4 * c + (lane >> 4);
-                u32x4 v = *reinterpret_cast<const u32x4*>(slice + pw * OP + (lane & 15) * 16);
-                u32x4 x4 = {xres[pt][4 * c], xres[pt][4 * c + 1], xres[pt][4 * c + 2], xres[pt][4 * c + 3]};
-                if constexpr (UP) x4 = add_chunk<T>(x4, x2[c & 3]);
-                v = add_chunk<T>(v, x4);
-                fin[c] = v;
-                *reinterpret_cast<u32x4*>(outs + ((size_t)(ty0 + 2 * trow + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CO + nh * 128 + (lane & 15) * 8) = v;
+                x2[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin2) +
+                    ((size_t)(ty0 / 2 + wave) * (p.W / 2) + ((tx0 + (pw & 15)) >> 1)) * CIN + nh * 128 + (lane & 15) * 8);
             }
-            if (p.pool) {
-                unsigned short* const pp = reinterpret_cast<unsigned short*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;
+        }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    u32x4 m = max_chunk<T>(fin[c], fin[c + 4]);
-                    u32x4 o;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(m[e], 16, 64);
-                    m = max_chunk<T>(m, o);
-                    if (((lane >> 4) & 1) == 0)
-                        *reinterpret_cast<u32x4*>(pp + ((size_t)(ty0 / 2 + trow) * (p.W / 2) + (tx0 / 2 + 2 * c + (lane >> 5))) * CO + nh * 128 + (lane & 15) * 8) = m;
-                }
+            for (int t = 0; t < 4; ++t) {
+                uint2 w;
+                w.x = pack_bf16x2(acc[i][4 * t + 0], acc[i][4 * t + 1]);
+                w.y = pack_bf16x2(acc[i][4 * t + 2], acc[i][4 * t + 3]);
+                *reinterpret_cast<uint2*>(slice + l31 * OP + (i * 32 + 8 * t + 4 * half) * 2) = w;
+            }
+        unsigned short* const outs = reinterpret_cast<unsigned short*>(outp);
+        u32x4 fin[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int pw = 4 * c + (lane >> 4);
+            u32x4 v = *reinterpret_cast<const u32x4*>(slice + pw * OP + (lane & 15) * 16);
+            u32x4 x4 = {xres[4 * c], xres[4 * c + 1], xres[4 * c + 2], xres[4 * c + 3]};
+            if constexpr (UP) x4 = add_chunk<T>(x4, x2[c & 3]);
+            v = add_chunk<T>(v, x4);
+            fin[c] = v;
+            *reinterpret_cast<u32x4*>(outs + ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CO + nh * 128 + (lane & 15) * 8) = v;
+        }
+        if (p.pool) {
+            unsigned short* const pp = reinterpret_cast<unsigned short*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                u32x4 m = max_chunk<T>(fin[c], fin[c + 4]);
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(m[e], 16, 64);
+                m = max_chunk<T>(m, o);
+                if (((lane >> 4) & 1) == 0)
+                    *reinterpret_cast<u32x4*>(pp + ((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + 2 * c + (lane >> 5))) * CO + nh * 128 + (lane & 15) * 8) = m;
             }
         }
         BR_STAMP(5 + 2 * nh);

@@ -95,7 +95,6 @@ struct df3d_hg {
     int fuse = 1;         // 1 = 256->128->128->256 bottlenecks at >= 16x32 run as ONE fused kernel
     int fuse_upadd = 0;   // 1 = the hourglass' upsample + add is folded into the consuming bottleneck's input load (default: on)
     int ring = 1;         // 1 = the 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring*.h)
-    int ring_tile = 2;    // bf16 ring bottleneck: 2 = 16 x 16 output tiles (64 pixels per wave) where the level's height allows, 1 = 8 x 16 only
     size_t stream_bytes = 0;  // weight streams of all ring bottlenecks (behind the bf16 copy of the blob)
     std::vector<TensorDesc> tensors;
     std::vector<int> pooled_of;   // tensor id -> id of its max-pooled copy written by the producing fused bottleneck (-1: none)
@@ -573,30 +572,24 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                     r.wstream = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream;
                     r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.s1 = a.s1; r.t1 = a.t1;
                     r.V = n; r.H = ti.h; r.W = ti.w;
-                    ScopedTimer tm(h, s, std::string(eb == 2 ? "bottleneck_ring_kernel<" : "bottleneck_ring_f32_kernel<") + (a.in2 ? "true" : "false") +
-                                             (eb == 2 ? (h->ring_tile >= 2 && ti.h % 16 == 0 ? ", 2>" : ", 1>") : ">"),
+                    ScopedTimer tm(h, s, std::string(eb == 2 ? "bottleneck_ring_kernel<" : "bottleneck_ring_f32_kernel<") + (a.in2 ? "true" : "false") + ">",
                                    2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl));
-                    // bf16: 16 x 16 tiles (64 pixels per wave, one workgroup per CU) on the levels whose height is a multiple of 16
-                    const bool tall = eb == 2 && h->ring_tile >= 2 && ti.h % 16 == 0;
-                    const int blocks = n * (ti.h / (tall ? 2 * BT_TH : BT_TH)) * (ti.w / BT_TW);
-                    static unsigned attr_done[6] = {0, 0, 0, 0, 0, 0};
-                    const int which = (eb == 2 ? (tall ? 4 : 0) : 2) + (a.in2 ? 1 : 0);
-                    const void* fns[6] = {reinterpret_cast<const void*>(bottleneck_ring_kernel<false, 1>), reinterpret_cast<const void*>(bottleneck_ring_kernel<true, 1>),
-                                          reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<false>), reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<true>),
-                                          reinterpret_cast<const void*>(bottleneck_ring_kernel<false, 2>), reinterpret_cast<const void*>(bottleneck_ring_kernel<true, 2>)};
-                    int lds_bytes = tall ? BrGeo<2>::LDS_BYTES : BR_LDS_BYTES;
+                    const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
+                    static unsigned attr_done[4] = {0, 0, 0, 0};
+                    const int which = (eb == 2 ? 0 : 2) + (a.in2 ? 1 : 0);
+                    const void* fns[4] = {reinterpret_cast<const void*>(bottleneck_ring_kernel<false>), reinterpret_cast<const void*>(bottleneck_ring_kernel<true>),
+                                          reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<false>), reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<true>)};
+                    int lds_bytes = BR_LDS_BYTES;
 #ifdef DF3D_BT_TIMING
                     if (const char* e = getenv("BR_LDS")) lds_bytes = atoi(e);   // development: force one workgroup per CU (> 80 KB)
 #endif
                     if (first_use_on_this_device(attr_done[which]))
                         DF3D_HIP(hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
                     switch (which) {
-                        case 0: hipLaunchKernelGGL((bottleneck_ring_kernel<false, 1>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
-                        case 1: hipLaunchKernelGGL((bottleneck_ring_kernel<true, 1>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
+                        case 0: hipLaunchKernelGGL((bottleneck_ring_kernel<false>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
+                        case 1: hipLaunchKernelGGL((bottleneck_ring_kernel<true>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
                         case 2: hipLaunchKernelGGL((bottleneck_ring_f32_kernel<false>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
-                        case 3: hipLaunchKernelGGL((bottleneck_ring_f32_kernel<true>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
-                        case 4: hipLaunchKernelGGL((bottleneck_ring_kernel<false, 2>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
-                        default: hipLaunchKernelGGL((bottleneck_ring_kernel<true, 2>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
+                        default: hipLaunchKernelGGL((bottleneck_ring_f32_kernel<true>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
                     }
                     DF3D_LAUNCH_CHECK();
                     break;
@@ -743,11 +736,6 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
         DF3D_CHECK_ARG(h->blob == nullptr, "set 'fuse_upadd' before df3d_hg_set_weights (it changes the plan)");
         h->fuse_upadd = value;
         h->build();
-        return DF3D_OK;
-    }
-    if (!strcmp(key, "ring_tile")) {
-        DF3D_CHECK_ARG(value == 1 || value == 2, "ring_tile must be 1 or 2");
-        h->ring_tile = value;
         return DF3D_OK;
     }
     if (!strcmp(key, "ring")) {

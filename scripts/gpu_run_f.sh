@@ -1,13 +1,22 @@
 #!/bin/bash
+# full -m gpu suite + smoke + both bench legs
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/r02f
 mkdir -p "$OUT"
 cd "$R"
-timeout 300 python scripts/dbg_ring_tile.py 3 > "$OUT/dbg.log" 2>&1; grep -v "^  dim\|amdgpu.ids" "$OUT/dbg.log" | tail -8
-timeout 300 python scripts/ab_ring_tile.py 896 > "$OUT/ab.log" 2>&1; cat "$OUT/ab.log" | tail -5
-for rt in ${RTS:-2}; do
-DF3D_LIB=scratch/timing/libdf3d_hip_timing.so timeout 300 python scripts/probe_ring.py 896 bf16 $rt > "$OUT/probe_$rt.log" 2>&1; tail -30 "$OUT/probe_$rt.log"
+timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest.log"
+tail -4 "$OUT/pytest.log"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log"
+for dt in f32 bf16; do
+timeout 400 python bench.py --dtype $dt --no-cpu-baseline --no-bf16-leg > "$OUT/bench_$dt.log" 2>&1
+python - <<PY
+import json
+l=[x for x in open("$OUT/bench_$dt.log") if x.startswith("{")]
+if l:
+    d=json.loads(l[-1]); print("$dt frames/s", round(d["value"],1), "ms/step", round(d["ms_per_step"],2))
+    for k in d["roofline"]["kernels"][:6]: print("  ", k["kernel"], k["launches"], round(k["avg_us"],1), round(k["tflops"],1))
+else:
+    print(open("$OUT/bench_$dt.log").read()[-2000:])
+PY
 done
-timeout 900 python -m pytest tests/test_gpu_hourglass.py -m gpu -x -q > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest.log"
-tail -5 "$OUT/pytest.log"

@@ -10,8 +10,7 @@ from deepfly3d_amd.synthetic import synthetic_state_dict
 views = int(sys.argv[1]) if len(sys.argv) > 1 else 896
 dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 dev = torch.device("cuda:0")
-ring_tile = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-eng = HourglassEngine(synthetic_state_dict(0), dtype=dtype, device=dev, ring_tile=ring_tile)
+eng = HourglassEngine(synthetic_state_dict(0), dtype=dtype, device=dev)
 lib = _native.load()
 img = torch.rand((views, 256, 512, 3), device=dev)
 steps = eng.steps()
@@ -35,9 +34,8 @@ for target in ("hg.0.hg.3.0.0.conv3", "hg.0.hg.2.0.0.conv3", "res.1.0.conv3"):
     before, after = cycles_upto(k - 1), cycles_upto(k)
     own = [a - b for a, b in zip(after, before)]
     hwc = steps[k - 1][1]
-    th = 16 if dtype == "bf16" and ring_tile == 2 and hwc[0] % 16 == 0 else 8
-    tiles = views * (hwc[0] // th) * (hwc[1] // 16)
+    tiles = views * (hwc[0] // 8) * (hwc[1] // 16)
     tot = sum(own)
-    print(f"{target} {hwc}: {tiles} tiles of {th} x 16, wave-0 cycles per tile {tot / tiles:.0f}")
+    print(f"{target} {hwc}: {tiles} tiles, wave-0 cycles per tile {tot / tiles:.0f}")
     for l, v in zip(labels, own):
         print(f"   {l:14s} {v / tiles:9.0f} cycles  {100.0 * v / tot:5.1f} %")
