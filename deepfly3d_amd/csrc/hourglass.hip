@@ -15,6 +15,7 @@
 #include "common.h"
 #include "hg_kernels.h"
 #include "hg_bt_ring.h"
+#include "hg_bt_l1.h"
 #include "hg_bt_ring_f32.h"
 
 using namespace hgk;
@@ -27,6 +28,8 @@ struct TensorDesc {
     size_t off;  // elements per view, from the start of the activation area
     int h, w, c, pitch;
 };
+
+constexpr size_t VIRTUAL_OFF = ~size_t(0);
 
 struct ConvPlan {
     int taps, cin, cout, cin_pad, cout_pad;
@@ -44,6 +47,8 @@ struct Step {
     int pool_out = -1;                // ST_BOTTLENECK: tensor receiving the fused 2x2 max-pool of `out`
     int in2 = -1;                     // ST_BOTTLENECK: low-resolution addend of the input (fused upsample + add)
     long long wstream = -1;           // ST_BOTTLENECK, bf16 256 -> 128 -> 128 -> 256: byte offset of its weight stream behind the bf16 blob
+    bool l1 = false;                  // ST_BOTTLENECK, bf16 64 -> 64 -> 64 -> 128: hg_bt_l1.h (wstream = its LDS weight image)
+    bool pool_only = false;           // ... whose full-resolution output nobody reads: `out` IS the pooled tensor
 };
 
 struct Allocator {
@@ -94,6 +99,7 @@ struct df3d_hg {
     int rb_override = 0;  // 0 = auto, 64 or 128: staged row bytes per K-step (tuning knob)
     int fuse = 1;         // 1 = 256->128->128->256 bottlenecks at >= 16x32 run as ONE fused kernel
     int fuse_upadd = 0;   // 1 = the hourglass' upsample + add is folded into the consuming bottleneck's input load (default: on)
+    int l1 = 1;           // 1 = bf16 layer1 (64 -> 64 -> 64 -> 128) runs as the LDS-resident-weights kernel of hg_bt_l1.h
     int ring = 1;         // 1 = the 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring*.h)
     size_t stream_bytes = 0;  // weight streams of all ring bottlenecks (behind the bf16 copy of the blob)
     std::vector<TensorDesc> tensors;
@@ -133,9 +139,15 @@ struct df3d_hg {
         pooled_of.push_back(-1);
         return (int)tensors.size() - 1;
     }
+    // a tensor that is never materialised (shape only): the full-resolution output of a pooled-output-only bottleneck
+    int new_virtual_tensor(int h, int w, int c) {
+        tensors.push_back(TensorDesc{VIRTUAL_OFF, h, w, c, c});
+        pooled_of.push_back(-1);
+        return (int)tensors.size() - 1;
+    }
     void free_tensor(int id) {
         const TensorDesc& t = tensors[id];
-        alloc.release(t.off, (size_t)t.h * t.w * t.pitch);
+        if (t.off != VIRTUAL_OFF) alloc.release(t.off, (size_t)t.h * t.w * t.pitch);
     }
     size_t add_param(const std::string& name, int kind, int taps, int cin, int cout, int cin_pad, int cout_pad, size_t count,
                      int kperm = 0) {
@@ -187,7 +199,8 @@ struct df3d_hg {
         return st.out;
     }
     // x2 >= 0: the block's input is x + nearest-upsample(x2) (the sum an ST_UPADD step would have written into x)
-    int bottleneck(const std::string& name, int x, int planes, bool want_pool = false, int x2 = -1) {
+    // only_pool: the caller reads nothing but the max-pooled copy of the output
+    int bottleneck(const std::string& name, int x, int planes, bool want_pool = false, int x2 = -1, bool only_pool = false) {
         const int cin = tensors[x].c, cout = 2 * planes;
         const TensorDesc tx = tensors[x];
         const bool shape_ok = (cin == 256 && planes == 128) || (cin == 128 && planes == 128) || (cin == 64 && planes == 64);
@@ -214,6 +227,25 @@ struct df3d_hg {
             if (ring && cin == 256 && planes == 128) {   // weights through the LDS-DMA ring (hg_bt_ring.h, hg_bt_ring_f32.h)
                 st.wstream = (long long)stream_bytes;
                 stream_bytes += (size_t)(dtype == DF3D_DTYPE_BF16 ? BR_NSTAGE : BRF_NSTAGE) * BR_STAGE_BYTES;
+            }
+            if (l1 && dtype == DF3D_DTYPE_BF16 && cin == 64 && planes == 64 && tx.h % 16 == 0 && tx.w % 16 == 0) {
+                st.l1 = true;   // all weights resident in LDS (hg_bt_l1.h)
+                st.wstream = (long long)stream_bytes;
+                stream_bytes += L1_W_BYTES;
+                if (want_pool && only_pool) {   // the full-resolution tensor is never written
+                    st.pool_only = true;
+                    st.out = new_tensor(tx.h / 2, tx.w / 2, cout);
+                    const int virt = new_virtual_tensor(tx.h, tx.w, cout);
+                    pooled_of[virt] = st.out;
+                    elems_per_view += (double)tx.h * tx.w * cout * 1.25;  // model M1 still counts the pooling pass
+                    steps.push_back(st);
+                    const double px = (double)tx.h * tx.w;
+                    account_conv(px, 1, cin, planes, false);
+                    account_conv(px, 9, planes, planes, false);
+                    account_conv(px, 1, cin, cout, false);
+                    account_conv(px, 1, planes, cout, true);
+                    return virt;
+                }
             }
             st.out = new_tensor(tx.h, tx.w, cout);
             if (want_pool) {  // the consumer max-pools this tensor: the epilogue writes the pooled copy too (no pool step)
@@ -315,7 +347,7 @@ struct df3d_hg {
         flops_per_view += 2.0 * (H / 2) * (W / 2) * 147 * 64;
         elems_per_view += (double)H * W * 3 + (double)(H / 2) * (W / 2) * 64;
         int x = st.out;
-        int l1 = bottleneck("layer1.0", x, 64, true);
+        int l1 = bottleneck("layer1.0", x, 64, true, -1, true);
         free_tensor(x);
         int p1 = pool("maxpool", l1);
         free_tensor(l1);
@@ -385,6 +417,18 @@ struct df3d_hg {
 namespace {
 
 // hipFuncSetAttribute acts on the CURRENT device: remember per device (bit i of `mask`) where it has been applied
+// compute units of the current device (persistent kernels launch one workgroup per CU)
+inline int cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
+    }
+    return cached[dev];
+}
+
 inline bool first_use_on_this_device(unsigned& mask) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) return true;
@@ -566,6 +610,24 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.W = ti.w;
                 const int cin = st.conv.cin, pl = st.conv.cout;
                 const double px = (double)n * ti.h * ti.w;
+                if (st.l1) {
+                    BtL1Args r;
+                    r.in = a.in;
+                    r.out = st.pool_only ? nullptr : a.out;
+                    r.pool = st.pool_only ? a.out : a.pool;
+                    r.wimage = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream;
+                    r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd; r.s1 = a.s1; r.t1 = a.t1;
+                    r.V = n; r.H = ti.h; r.W = ti.w;
+                    ScopedTimer tm(h, s, "bottleneck_l1_kernel", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl),
+                                   px * eb * (cin + (st.pool_only ? 0.5 * pl : 2.0 * pl)));
+                    const int tiles = n * (ti.h / L1_TH) * (ti.w / BT_TW);
+                    static unsigned attr_done = 0;
+                    if (first_use_on_this_device(attr_done))
+                        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_l1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
+                    hipLaunchKernelGGL(bottleneck_l1_kernel, dim3(std::min(tiles, cu_count())), dim3(L1_WAVES * 64), L1_LDS_BYTES, s, r);
+                    DF3D_LAUNCH_CHECK();
+                    break;
+                }
                 if (st.wstream >= 0) {
                     BtRingArgs r;
                     r.in = a.in; r.in2 = a.in2; r.out = a.out; r.pool = a.pool;
@@ -738,6 +800,13 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
         h->build();
         return DF3D_OK;
     }
+    if (!strcmp(key, "l1")) {
+        DF3D_CHECK_ARG(value == 0 || value == 1, "l1 must be 0 or 1");
+        DF3D_CHECK_ARG(h->blob == nullptr, "set 'l1' before df3d_hg_set_weights (it changes the plan and the low-precision buffer)");
+        h->l1 = value;
+        h->build();
+        return DF3D_OK;
+    }
     if (!strcmp(key, "ring")) {
         DF3D_CHECK_ARG(value == 0 || value == 1, "ring must be 0 or 1");
         DF3D_CHECK_ARG(h->blob == nullptr, "set 'ring' before df3d_hg_set_weights (it changes the low-precision buffer)");
@@ -786,6 +855,12 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
         for (const Step& st : h->steps) {
             if (st.kind != ST_BOTTLENECK || st.wstream < 0) continue;
             const unsigned short* lp = reinterpret_cast<const unsigned short*>(lowp_dev);
+            if (st.l1) {
+                hipLaunchKernelGGL(bt_l1_pack_kernel, dim3((L1_W_BYTES / 16 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
+                                   lp + st.conv.w_off, lp + st.conv2b.w_off, lp + st.conv3b.w_off, lp + st.conv4b.w_off,
+                                   reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
+                continue;
+            }
             hipLaunchKernelGGL(bt_ring_pack_kernel, dim3((BR_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
                                lp + st.conv.w_off, lp + st.conv2b.w_off, lp + st.conv3b.w_off,
                                reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);

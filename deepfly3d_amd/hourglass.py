@@ -95,7 +95,7 @@ def pack_state_dict(engine_handle, state_dict):
 class HourglassEngine:
     """The device engine: `forward(images_nhwc) -> heat-maps (n, 19, H/4, W/4)` on the current torch stream."""
 
-    def __init__(self, state_dict, dtype="f32", num_stacks=2, device=None, height=256, width=512, row_bytes=0, fuse=True, fuse_upadd=None, ring=None):
+    def __init__(self, state_dict, dtype="f32", num_stacks=2, device=None, height=256, width=512, row_bytes=0, fuse=True, fuse_upadd=None, ring=None, l1=None):
         _native.require_gpu()
         self.lib = _native.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -112,6 +112,8 @@ class HourglassEngine:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"fuse_upadd", 1 if fuse_upadd else 0), "df3d_hg_set_option")
         if ring is not None:  # default: the library's choice (LDS-DMA weight ring in the 256 -> 128 -> 128 -> 256 bottlenecks)
             _native.check(self.lib.df3d_hg_set_option(self.h, b"ring", 1 if ring else 0), "df3d_hg_set_option")
+        if l1 is not None:  # default: on (bf16): layer1 with LDS-resident weights, writing only the pooled tensor its consumer reads
+            _native.check(self.lib.df3d_hg_set_option(self.h, b"l1", 1 if l1 else 0), "df3d_hg_set_option")
         if row_bytes:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"row_bytes", row_bytes), "df3d_hg_set_option")
         blob = pack_state_dict(self.h, state_dict)

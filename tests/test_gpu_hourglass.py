@@ -260,3 +260,33 @@ def test_weight_ring_bottleneck_is_bit_identical(native_lib, cuda, oracle_net, h
     first = on.forward(img).clone()
     for _ in range(3):
         assert torch.equal(on.forward(img), first)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("height,width,n", [(256, 512, 3), (128, 256, 2), (64, 192, 1)])
+def test_resident_weight_layer1_is_bit_identical(native_lib, cuda, oracle_net, height, width, n):
+    """bf16 layer1 with all weights resident in LDS and only the pooled tensor written (csrc/hg_bt_l1.h: persistent workgroups,
+    16 x 16 tiles, x operand straight from global memory one tile ahead) against the generic fused bottleneck + its fused pool:
+    same MFMA K order, so the pooled tensor, every later plan step and the heat-maps must be BIT-identical (image borders,
+    tile counts below and above the workgroup count, a single tile row)."""
+    import torch.nn.functional as F
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
+    img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(5 * height + width), dtype=torch.float32).to(cuda)
+    on = HourglassEngine(sd, dtype="bf16", device=cuda, height=height, width=width, l1=True)
+    off = HourglassEngine(sd, dtype="bf16", device=cuda, height=height, width=width, l1=False)
+    names_on, names_off = [s[0] for s in on.steps()], [s[0] for s in off.steps()]
+    assert names_on == names_off
+    k1 = names_on.index("layer1.0.conv3") + 1
+    assert on.steps()[k1 - 1][1][:2] == tuple(d // 2 for d in off.steps()[k1 - 1][1][:2]), "the layer1 step yields the pooled tensor"
+    full = off.forward_upto(img, k1)                                          # (n, h, w, 128)
+    pooled = F.max_pool2d(full.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert torch.equal(on.forward_upto(img, k1), pooled)
+    for k in range(k1 + 1, len(names_on) + 1):
+        a, b = on.forward_upto(img, k), off.forward_upto(img, k)
+        assert torch.equal(a, b), f"step {k} {names_on[k - 1]} differs: max |diff| {(a - b).abs().max().item():.3e}"
+    first = on.forward(img).clone()
+    assert torch.equal(first, off.forward(img))
+    for _ in range(3):
+        assert torch.equal(on.forward(img), first)
