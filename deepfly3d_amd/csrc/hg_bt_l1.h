@@ -365,11 +365,12 @@ __global__ __launch_bounds__(512, 1) void bottleneck_l1_kernel(BtL1Args p) {
                 if (pp) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {   // pixels 8 c + (lane >> 3) of tile row 0 and the one below; the column partner sits 8 lanes away
-                        u32x4 m = max_chunk<T>(fin[c], fin[c + 2]);
+                        // in the ordered-integer domain (hg_kernels.h: bf16x2_key); lane ^ 8 = a rotation by 8 inside the row of 16: one DPP move
+                        u32x4 m = bf16_key_max_chunk(bf16_key_chunk(fin[c]), bf16_key_chunk(fin[c + 2]));
                         u32x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(m[e], 8, 64);
-                        m = max_chunk<T>(m, o);
+                        for (int e = 0; e < 4; ++e) o[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m[e], 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+                        m = bf16_key_chunk(bf16_key_max_chunk(m, o));
                         if (((lanev >> 3) & 1) == 0)
                             *reinterpret_cast<u32x4*>(pp + ((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + 4 * c + (lanev >> 4))) * CO + 64 * hc + (lanev & 7) * 8) = m;
                     }

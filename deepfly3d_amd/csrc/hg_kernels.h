@@ -505,6 +505,32 @@ __global__ __launch_bounds__(256) void stem_relayout_kernel(const float* __restr
 // -----------------------------------------------------------------------------------------------------
 // 2x2 max-pool and nearest-upsample + add: one thread per 16-byte channel chunk
 // -----------------------------------------------------------------------------------------------------
+// bf16 as an ORDERED 16-bit integer and back (the map is its own inverse): a negative float's magnitude bits are flipped, so
+// that signed integer comparison orders the keys like the floats (-0 just below +0).  Lets max() of packed bf16 run as one
+// v_pk_max_i16 per two values instead of unpack + three v_max_f32 (the NaN-quieting hipcc adds) + repack.
+typedef short hg_i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16x2_key(unsigned v) {
+    const hg_i16x2 x = __builtin_bit_cast(hg_i16x2, v);
+    const hg_i16x2 m = (x >> 15) & (short)0x7fff;
+    return __builtin_bit_cast(unsigned, x ^ m);
+}
+__device__ __forceinline__ unsigned bf16x2_key_max(unsigned ka, unsigned kb) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(hg_i16x2, ka), __builtin_bit_cast(hg_i16x2, kb)));
+}
+__device__ __forceinline__ u32x4 bf16_key_chunk(u32x4 v) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = bf16x2_key(v[i]);
+    return o;
+}
+__device__ __forceinline__ u32x4 bf16_key_max_chunk(u32x4 a, u32x4 b) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = bf16x2_key_max(a[i], b[i]);
+    return o;
+}
+
+// element-wise maximum of one 16-byte chunk (finite values; of +0 and -0 the bf16 form returns +0)
 template <typename T>
 __device__ __forceinline__ u32x4 max_chunk(u32x4 a, u32x4 b) {
     if constexpr (sizeof(T) == 4) {
@@ -513,14 +539,7 @@ __device__ __forceinline__ u32x4 max_chunk(u32x4 a, u32x4 b) {
         for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], y[i]);
         return __builtin_bit_cast(u32x4, x);
     } else {
-        u32x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float al = bf16_bits_to_f32((unsigned short)(a[i] & 0xffffu)), ah = bf16_bits_to_f32((unsigned short)(a[i] >> 16));
-            const float bl = bf16_bits_to_f32((unsigned short)(b[i] & 0xffffu)), bh = bf16_bits_to_f32((unsigned short)(b[i] >> 16));
-            o[i] = pack_bf16x2(fmaxf(al, bl), fmaxf(ah, bh));
-        }
-        return o;
+        return bf16_key_chunk(bf16_key_max_chunk(bf16_key_chunk(a), bf16_key_chunk(b)));
     }
 }
 template <typename T>
@@ -1360,6 +1379,21 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+            // bf16: the skip values of this pass are requested NOW as coalesced 16-byte chunks (lane owns chunk (lane & 7) of the
+            // wave's pixel 8 c + (lane >> 3), per 64-channel half hc): their latency hides behind the K loop, and the epilogue
+            // turns them into the accumulators' layout through a wave-private LDS slice
+            u32x4 xch[EB == 2 ? 2 : 1][4];
+            if constexpr (EB == 2) {
+#pragma unroll
+                for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const long long m = m0 + wave * 32 + 8 * c + (lane >> 3);
+                        u32x4 v = {0u, 0u, 0u, 0u};
+                        if (m < p.M) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.x) + (size_t)m * 256 + nh * CH + 64 * hc + (lane & 7) * 8);
+                        xch[hc][c] = v;
+                    }
+            }
             loadC(nh, 0);
             storeC(0);
             __syncthreads();
@@ -1422,24 +1456,31 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                 }
             } else {
                 // bf16 epilogue on the TRANSPOSED product: lane = pixel m0 + 32 wave + l31, registers 4q..4q+3 of tile i =
-                // channels nh*128 + 32 i + 8 q + 4 half + {0..3}: four consecutive channels = one 8-byte access
-                const long long m = m0 + wave * 32 + l31;
-                if (m < p.M) {
-                    const unsigned short* const xrow = reinterpret_cast<const unsigned short*>(p.x) + (size_t)m * 256;
-                    unsigned short* const orow = reinterpret_cast<unsigned short*>(p.out) + (size_t)m * 256;
-                    uint2 xv[16];
+                // channels nh*128 + 32 i + 8 q + 4 half + {0..3}.  Global memory is touched in whole 128-byte pixel-half rows only
+                // (16-byte chunks, eight lanes per row): x arrives as chunks, is parked in the wave's LDS slice and read back as the
+                // 8-byte pieces the accumulator layout wants; x_new takes the same road in the other direction.  Same fp32
+                // arithmetic and the same single rounding as the direct 8-byte accesses it replaces.
+                constexpr int SP = 64 * 2 + 16;   // slice pitch: 64 channels + pad
+                unsigned char* const slice = stage + 2 * C::STAGE_C + wave * (32 * SP);
+                static_assert(2 * C::STAGE_C + 4 * 32 * SP <= C::STAGE_BYTES, "the epilogue slices sit behind the phase-C stages");
 #pragma unroll
-                    for (int i = 0; i < NI; ++i)
+                for (int hc = 0; hc < 2; ++hc) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) xv[4 * i + q] = *reinterpret_cast<const uint2*>(xrow + nh * CH + 32 * i + 8 * q + 4 * half);
+                    for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(slice + (8 * c + (lane >> 3)) * SP + (lane & 7) * 16) = xch[hc][c];
+                    uint2 xv[8];
 #pragma unroll
-                    for (int i = 0; i < NI; ++i)
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xv[4 * ii + q] = *reinterpret_cast<const uint2*>(slice + l31 * SP + (32 * ii + 8 * q + 4 * half) * 2);
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
+                            const int i = 2 * hc + ii;
                             const int n = nh * CH + 32 * i + 8 * q + 4 * half;
                             const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bfc_ + n);
                             const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bsc_ + n);
-                            const uint2 xx = xv[4 * i + q];
+                            const uint2 xx = xv[4 * ii + q];
                             const float x0 = bf16_bits_to_f32((unsigned short)(xx.x & 0xffffu)), x1 = bf16_bits_to_f32((unsigned short)(xx.x >> 16));
                             const float x2 = bf16_bits_to_f32((unsigned short)(xx.y & 0xffffu)), x3 = bf16_bits_to_f32((unsigned short)(xx.y >> 16));
                             const float v0 = acc[i][4 * q + 0] + (b1[0] + b2[0]) + x0, v1 = acc[i][4 * q + 1] + (b1[1] + b2[1]) + x1;
@@ -1447,8 +1488,14 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                             uint2 o;
                             o.x = (unsigned)f32_to_bf16_bits(v0) | ((unsigned)f32_to_bf16_bits(v1) << 16);
                             o.y = (unsigned)f32_to_bf16_bits(v2) | ((unsigned)f32_to_bf16_bits(v3) << 16);
-                            *reinterpret_cast<uint2*>(orow + n) = o;
+                            *reinterpret_cast<uint2*>(slice + l31 * SP + (32 * ii + 8 * q + 4 * half) * 2) = o;
                         }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const long long m = m0 + wave * 32 + 8 * c + (lane >> 3);
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(slice + (8 * c + (lane >> 3)) * SP + (lane & 7) * 16);
+                        if (m < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)m * 256 + nh * CH + 64 * hc + (lane & 7) * 8) = v;
+                    }
                 }
             }
         }
