@@ -220,21 +220,19 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     const int xchunk = tid & 3;
     const unsigned char* xp[XP];
     const unsigned char* xq[UP ? XP : 1];
-    unsigned xkeep[XP];
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
         const int hp = (tid >> 2) + 64 * i;
         const int hy = hp / BT_HW, hx = hp % BT_HW;
         const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
         const bool ok = hp < BT_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-        xkeep[i] = ok ? 0xffffffffu : 0u;
         xp[i] = xin + (((size_t)(ok ? y : 0) * p.W + (ok ? x : 0)) * CIN + xchunk * 8) * 2;
         if constexpr (UP) xq[i] = xin2 + (((size_t)(ok ? (y >> 1) : 0) * (p.W / 2) + (ok ? (x >> 1) : 0)) * CIN + xchunk * 8) * 2;
     }
     constexpr int DX = UP ? 2 : 3;   // K steps of x requested ahead (registers); the LDS x ring has three slots either way
     u32x4 rx[DX][XP];
     u32x4 rb[UP ? DX : 1][XP];
-    auto loadx = [&](int s, int slot) {   // out-of-image halo rows read pixel (0, 0) (a valid address) and are masked in storex
+    auto loadx = [&](int s, int slot) {   // out-of-image halo rows read pixel (0, 0) (a valid address); the t1 epilogue zeroes what comes of them
 #pragma unroll
 #if defined(BR_ABL) && BR_ABL == 5   // ablation: no x loads (registers only)
         for (int i = 0; i < XP; ++i) rx[slot][i] = u32x4{(unsigned)s, (unsigned)tid, 0u, 0u};
@@ -261,7 +259,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
 #if !defined(BR_ABL) || BR_ABL != 6   // ablation 6: no bn1 + ReLU arithmetic
             v = br_preact(v, coef);
 #endif
-            v &= xkeep[i];
             *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * BR_XPITCH + xchunk * 16) = v;
         }
     };
