@@ -34,7 +34,9 @@ struct BtRingArgs {
     const void* in;       // NHWC bf16 [V, H, W, 256]
     const void* in2;      // UP: NHWC bf16 [V, H/2, W/2, 256]; the block's input is in + nearest-upsample(in2), rounded to bf16
     void* out;            // NHWC bf16 [V, H, W, 256]
-    void* pool;           // optional NHWC bf16 [V, H/2, W/2, 256]
+    void* pool;           // optional NHWC bf16 [V, H/2, W/2, 256]: 2x2 max-pool of `out`
+    void* pool_in;        // optional NHWC bf16 [V, H/2, W/2, 256]: 2x2 max-pool of the block's INPUT (bf16 kernel only; for the
+                          // hourglass level whose input no fused producer has pooled: its skip values pass through the epilogue anyway)
     const void* wstream;  // BR_NSTAGE x BR_STAGE_BYTES: pre-swizzled stage images (bt_ring_pack_kernel)
     const float* b1;      // [128] (bn2 folded)
     const float* b2;      // [128] (bn3 folded)
@@ -506,6 +508,22 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
             v = add_chunk<T>(v, x4);
             fin[c] = v;
             *reinterpret_cast<u32x4*>(outs + ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CO + nh * 128 + (lane & 15) * 8) = v;
+            xres[4 * c] = x4[0], xres[4 * c + 1] = x4[1], xres[4 * c + 2] = x4[2], xres[4 * c + 3] = x4[3];   // (the block's input, for pool_in)
+        }
+        if (p.pool_in) {   // same lane geometry as the pooling of `out` below
+            unsigned short* const pp = reinterpret_cast<unsigned short*>(p.pool_in) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32x4 xa = {xres[4 * c], xres[4 * c + 1], xres[4 * c + 2], xres[4 * c + 3]};
+                const u32x4 xb = {xres[4 * c + 16], xres[4 * c + 17], xres[4 * c + 18], xres[4 * c + 19]};
+                u32x4 m = max_chunk<T>(xa, xb);
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __shfl_xor(m[e], 16, 64);
+                m = max_chunk<T>(m, o);
+                if (((lane >> 4) & 1) == 0)
+                    *reinterpret_cast<u32x4*>(pp + ((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + 2 * c + (lane >> 5))) * CIN + nh * 128 + (lane & 15) * 8) = m;
+            }
         }
         if (p.pool) {
             unsigned short* const pp = reinterpret_cast<unsigned short*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;

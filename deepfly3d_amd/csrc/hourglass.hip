@@ -47,6 +47,7 @@ struct Step {
     int pool_out = -1;                // ST_BOTTLENECK: tensor receiving the fused 2x2 max-pool of `out`
     int in2 = -1;                     // ST_BOTTLENECK: low-resolution addend of the input (fused upsample + add)
     long long wstream = -1;           // ST_BOTTLENECK, bf16 256 -> 128 -> 128 -> 256: byte offset of its weight stream behind the bf16 blob
+    int pool_in = -1;                 // ST_BOTTLENECK (bf16 ring kernel): tensor receiving the 2x2 max-pool of the block's INPUT
     bool l1 = false;                  // ST_BOTTLENECK, bf16 64 -> 64 -> 64 -> 128: hg_bt_l1.h (wstream = its LDS weight image)
     bool pool_only = false;           // ... whose full-resolution output nobody reads: `out` IS the pooled tensor
 };
@@ -200,7 +201,9 @@ struct df3d_hg {
     }
     // x2 >= 0: the block's input is x + nearest-upsample(x2) (the sum an ST_UPADD step would have written into x)
     // only_pool: the caller reads nothing but the max-pooled copy of the output
-    int bottleneck(const std::string& name, int x, int planes, bool want_pool = false, int x2 = -1, bool only_pool = false) {
+    // pool_input: the caller also needs max-pool(x) and nobody has produced it: the bf16 ring kernel writes it on the side
+    // (pooled_of[x] is set when that happened)
+    int bottleneck(const std::string& name, int x, int planes, bool want_pool = false, int x2 = -1, bool only_pool = false, bool pool_input = false) {
         const int cin = tensors[x].c, cout = 2 * planes;
         const TensorDesc tx = tensors[x];
         const bool shape_ok = (cin == 256 && planes == 128) || (cin == 128 && planes == 128) || (cin == 64 && planes == 64);
@@ -227,6 +230,11 @@ struct df3d_hg {
             if (ring && cin == 256 && planes == 128) {   // weights through the LDS-DMA ring (hg_bt_ring.h, hg_bt_ring_f32.h)
                 st.wstream = (long long)stream_bytes;
                 stream_bytes += (size_t)(dtype == DF3D_DTYPE_BF16 ? BR_NSTAGE : BRF_NSTAGE) * BR_STAGE_BYTES;
+                if (pool_input && dtype == DF3D_DTYPE_BF16 && x2 < 0 && pooled_of[x] < 0) {
+                    st.pool_in = new_tensor(tx.h / 2, tx.w / 2, cin);
+                    pooled_of[x] = st.pool_in;
+                    elems_per_view += (double)tx.h * tx.w * cin * 1.25;  // model M1 still counts the pooling pass
+                }
             }
             if (l1 && dtype == DF3D_DTYPE_BF16 && cin == 64 && planes == 64 && tx.h % 16 == 0 && tx.w % 16 == 0) {
                 st.l1 = true;   // all weights resident in LDS (hg_bt_l1.h)
@@ -301,7 +309,7 @@ struct df3d_hg {
     // (the consumer -- always a bottleneck -- adds it while loading its input), or -1 when the sum was materialised.
     int hourglass(const std::string& name, int n, int x, int planes, int* lazy_lo) {
         const std::string lv = name + "." + std::to_string(n - 1);
-        int up1 = bottleneck(lv + ".0.0", x, planes);
+        int up1 = bottleneck(lv + ".0.0", x, planes, false, -1, false, true);
         int low = pool(lv + ".pool", x);
         int low1 = bottleneck(lv + ".1.0", low, planes, n > 1);
         free_tensor(low);
@@ -631,6 +639,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 if (st.wstream >= 0) {
                     BtRingArgs r;
                     r.in = a.in; r.in2 = a.in2; r.out = a.out; r.pool = a.pool;
+                    r.pool_in = st.pool_in >= 0 ? tptr(st.pool_in) : nullptr;
                     r.wstream = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream;
                     r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.s1 = a.s1; r.t1 = a.t1;
                     r.V = n; r.H = ti.h; r.W = ti.w;

@@ -250,11 +250,14 @@ def test_weight_ring_bottleneck_is_bit_identical(native_lib, cuda, oracle_net, h
     img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(3 * height + width), dtype=torch.float32).to(cuda)
     on = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, ring=True)
     off = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, ring=False)
-    steps = on.steps()
-    assert steps == off.steps()
-    for k in range(1, len(steps) + 1):
-        a, b = on.forward_upto(img, k), off.forward_upto(img, k)
-        assert torch.equal(a, b), f"step {k} {steps[k - 1][0]} differs: max |diff| {(a - b).abs().max().item():.3e}"
+    # same plan, except that the bf16 ring kernel also pools its INPUT where no producer has (one pooling step fewer)
+    steps, steps_off = on.steps(), off.steps()
+    index_off = {name: k for k, (name, _) in enumerate(steps_off, start=1)}
+    assert set(name for name, _ in steps) <= set(index_off) and len(steps_off) - len(steps) in (0, 1)
+    for k, (name, hwc) in enumerate(steps, start=1):
+        assert steps_off[index_off[name] - 1][1] == hwc
+        a, b = on.forward_upto(img, k), off.forward_upto(img, index_off[name])
+        assert torch.equal(a, b), f"step {k} {name} differs: max |diff| {(a - b).abs().max().item():.3e}"
     assert torch.equal(on.forward(img), off.forward(img))
     # repeated launches are deterministic (no dependence on DMA timing)
     first = on.forward(img).clone()
