@@ -1,0 +1,422 @@
+// Fused stack head of the hourglass (fc -> score -> fc_ / score_ + skip), moved out of hg_kernels.h because its bf16 form takes
+// Wfc through the LDS-DMA stage ring of hg_bt_ring.h.
+#pragma once
+#include "hg_bt_ring.h"
+
+namespace hgk {
+
+// bf16 blob -> Wfc stage stream: 8 K steps x 2 row halves, every stage the LDS image of 128 rows x 32 K (br_swz order)
+constexpr int HD_FC_STAGES = 16;
+__global__ __launch_bounds__(256) void bt_fc_pack_kernel(const unsigned short* __restrict__ wfc, unsigned char* __restrict__ stream) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= HD_FC_STAGES * 512) return;
+    const int st = idx >> 9, r = (idx >> 2) & 127, c = idx & 3;
+    const int s = st >> 1, rh = st & 1;
+    const unsigned short* const src = wfc + (size_t)(rh * 128 + r) * 256 + 32 * s + 8 * c;   // Wfc [256][256]
+    *reinterpret_cast<u32x4*>(stream + (size_t)st * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(src);
+}
+
+// =====================================================================================================
+// Fused stack head:   y = relu(Wfc r + bfc)                       (fc, BN folded; 256 -> 256)
+//                     score = Wsc y + bsc                          (256 -> 19, padded to 32)
+//   not LAST:         x_new = x + (Wfc_ y + bfc_) + (Wsc_ score + bsc_)
+//   LAST:             heat-maps (NCHW float32) = score
+// All 1x1: a workgroup owns 128 consecutive pixels, a wave 32 of them.  y is computed TRANSPOSED (rows = channels,
+// columns = the wave's pixels) so that its accumulators serve directly as the B operand of the score GEMM
+// (score^T = Wsc y^T) and as the A operand of the fc_ GEMM; score^T in turn is the A operand of score_.
+// r and x are read once, x_new / the heat-maps written once; y and score never leave the registers.
+// =====================================================================================================
+struct HeadArgs {
+    const void* r;       // [M, 256] output of the stack's residual block
+    const void* x;       // [M, 256] stack input (not LAST)
+    void* out;           // [M, 256] next stack input (not LAST)
+    float* heat;         // [V, 19, HW] (LAST)
+    const void* wfc;     // [256][256]
+    const void* wsc;     // [32][256]   (K permuted for bf16)
+    const void* wfc_;    // [256][256]  (K permuted for bf16)
+    const void* wsc_;    // [256][32]   (K permuted for bf16)
+    const float* bfc;    // [256]
+    const float* bsc;    // [32]
+    const float* bfc_;   // [256]
+    const float* bsc_;   // [256]
+    const void* fcstream;  // bf16 only: Wfc as 16 pre-swizzled 8 KB LDS stage images (hg_bt_ring.h: bt_fc_pack_kernel), or nullptr
+    long long M;
+    int HW;
+};
+
+template <typename T>
+struct HeadCfg {
+    static constexpr int EB = Elem<T>::BYTES;
+    static constexpr int RBA = 64;                                   // phase A staged row bytes
+    static constexpr int STAGE_A = (256 + 128) * (RBA + 16);         // Wfc rows + r rows
+    static constexpr int WSC_PITCH = 256 * EB + 16;
+    static constexpr int WSC_BYTES = 32 * WSC_PITCH;
+    static constexpr int RBC = 128;                                  // phase C staged row bytes
+    static constexpr int STAGE_C = 128 * (RBC + 16);
+    static constexpr int S1 = 2 * STAGE_A > WSC_BYTES ? 2 * STAGE_A : WSC_BYTES;
+    static constexpr int STAGE_BYTES = S1 > 2 * STAGE_C ? S1 : 2 * STAGE_C;
+    static constexpr int MISC = (256 + 32) * 4;
+    static constexpr int LDS_BYTES = STAGE_BYTES + MISC;
+};
+
+template <typename T, bool LAST>
+__global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
+    using C = HeadCfg<T>;
+    constexpr int EB = C::EB;
+    constexpr int PER16 = Elem<T>::PER16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const stage = smem;
+    float* const bfc_lds = reinterpret_cast<float*>(smem + C::STAGE_BYTES);
+    float* const bsc_lds = bfc_lds + 256;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const long long m0 = (long long)blockIdx.x * 128;
+    bfc_lds[tid] = p.bfc[tid];
+    if (tid < 32) bsc_lds[tid] = p.bsc[tid];
+
+    // ================= phase A: y^T = Wfc r^T ==========================================================
+    f32x16 y[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[m][r] = 0.0f;
+    if (EB == 2 && p.fcstream != nullptr) {
+        // bf16: Wfc arrives as pre-swizzled 8 KB stage images (two per 32-channel K step: row halves) through a six-slot LDS-DMA
+        // ring, two K steps ahead, one barrier per step; the r operand never touches LDS: lane (l31, half) loads the 16-byte chunks
+        // the MFMAs want from its own pixel -- ALL of them up front, so that no activation load sits in the in-order vector-memory
+        // queue between two weight stages (hg_bt_ring.h: vmcnt discipline).  Same MFMA K order as the staged form below.
+        constexpr int NSLOT = 6;
+        static_assert(NSLOT * BR_STAGE_BYTES <= C::STAGE_BYTES, "the Wfc ring lives in the stage area");
+        const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)stage;
+        const unsigned wvoff = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 2048u + (unsigned)lane * 16u;
+        auto issue_step = [&](int s) {   // both stages of K step s; this wave copies pieces 2 wave, 2 wave + 1 of each
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                const int st = 2 * s + rh;
+                br_glds_stage(reinterpret_cast<const unsigned char*>(p.fcstream) + (size_t)st * BR_STAGE_BYTES, wvoff,
+                              ring_addr + (unsigned)(st % NSLOT) * BR_STAGE_BYTES + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 2048u);
+            }
+        };
+        u32x4 rf[8][2];
+        {
+            long long m = m0 + wave * 32 + l31;
+            if (m >= p.M) m = p.M - 1;   // rows past the end compute on a valid pixel; nothing of them is stored
+            const unsigned char* const src = reinterpret_cast<const unsigned char*>(p.r) + ((size_t)m * 256 + half * 8) * 2;
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rf[s][j] = *reinterpret_cast<const u32x4*>(src + s * 64 + j * 32);
+        }
+        issue_step(0);
+        issue_step(1);
+        const unsigned char* const wf0 = stage + br_swz(l31, half);
+        const unsigned char* const wf1 = stage + br_swz(l31, 2 + half);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            br_wait_vm(s < 7 ? 4 : 0);   // the pieces of step s + 1 (requested one step ago) may still be in flight
+            br_barrier();                // (first step: also publishes the bias vectors)
+            if (s + 2 < 8) issue_step(s + 2);   // into the slots step s - 1 has released
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u32x4 wfr[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    wfr[m] = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + ((2 * s + (m >> 2)) % NSLOT) * BR_STAGE_BYTES + (m & 3) * 2048);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) mfma_chunk<T>(wfr[m], rf[s][j], y[m]);
+            }
+        }
+        __syncthreads();   // every wave is done with the ring before the stage area is reused
+    } else {
+        constexpr int RB = C::RBA, PITCH = RB + 16, CPR = RB / 16, RPP = 256 / CPR;   // 4 chunks per row, 64 rows per pass
+        constexpr int KE = RB / EB, NSTEPS = 256 / KE;
+        constexpr int WP = 256 / RPP, RP = 128 / RPP;                                  // 4 and 2 passes
+        constexpr int W_BYTES = 256 * PITCH;
+        const int chunk = tid % CPR, srow = tid / CPR;
+        u32x4 rw[WP], rr[RP];
+        auto loadA = [&](int s) {
+            const int c0 = s * KE + chunk * PER16;
+#pragma unroll
+            for (int i = 0; i < WP; ++i)
+                rw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.wfc) + ((size_t)(srow + i * RPP) * 256 + c0) * EB);
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                const long long m = m0 + srow + i * RPP;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (m < p.M) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.r) + ((size_t)m * 256 + c0) * EB);
+                rr[i] = v;
+            }
+        };
+        auto storeA = [&](int buf) {
+            unsigned char* const sw = stage + buf * C::STAGE_A;
+            unsigned char* const sr = sw + W_BYTES;
+#pragma unroll
+            for (int i = 0; i < WP; ++i) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
+#pragma unroll
+            for (int i = 0; i < RP; ++i) *reinterpret_cast<u32x4*>(sr + (srow + i * RPP) * PITCH + chunk * 16) = rr[i];
+        };
+        loadA(0);
+        storeA(0);
+        __syncthreads();
+        for (int s = 0; s < NSTEPS; ++s) {
+            const unsigned char* const sw = stage + (s & 1) * C::STAGE_A;
+            const unsigned char* const sr = sw + W_BYTES;
+            if (s + 1 < NSTEPS) loadA(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < RB / 32; ++j) {
+                const u32x4 rf = *reinterpret_cast<const u32x4*>(sr + (wave * 32 + l31) * PITCH + j * 32 + half * 16);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (m * 32 + l31) * PITCH + j * 32 + half * 16);
+                    mfma_chunk<T>(wf, rf, y[m]);
+                }
+            }
+            if (s + 1 < NSTEPS) storeA((s & 1) ^ 1);
+            __syncthreads();
+        }
+    }
+    // bias + ReLU (channel of register r in tile m: 32m + (r&3) + 8(r>>2) + 4*half)
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(bfc_lds + 32 * m + 8 * q + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[m][4 * q + e] = fmaxf(y[m][4 * q + e] + bb[e], 0.0f);
+        }
+    // bf16: pack y once (slot e of group q2 <-> register 8*q2 + e)
+    bf16x8 ypk[EB == 2 ? 8 : 1][2];
+    if constexpr (EB == 2) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ypk[m][q2][e] = (__bf16)y[m][8 * q2 + e];
+    }
+
+    // ================= phase B: score^T = Wsc y^T  (A = Wsc from LDS, B = y registers) =================
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
+    {
+        // stage the whole padded Wsc [32][256] (the last barrier of phase A has passed: the stage area is free)
+        constexpr int CH = 256 * EB / 16;   // 16-byte chunks per row
+        for (int i = tid; i < 32 * CH; i += 256) {
+            const int row = i / CH, ch = i % CH;
+            *reinterpret_cast<u32x4*>(stage + row * C::WSC_PITCH + ch * 16) =
+                *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.wsc) + ((size_t)row * 256) * EB + ch * 16);
+        }
+        __syncthreads();
+        const unsigned char* const wrow = stage + l31 * C::WSC_PITCH;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if constexpr (EB == 4) {
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const f32x4 wf = *reinterpret_cast<const f32x4*>(wrow + (32 * m) * 4 + (4 * q2 + 2 * jj + half) * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[e], y[m][8 * q2 + 4 * jj + e], sc, 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + (32 * m + (2 * q2 + half) * 8) * 2);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, ypk[m][q2], sc, 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // everyone is done reading Wsc before the stage area is reused
+    }
+    // score^T: lane = pixel, register r = score channel (r&3) + 8(r>>2) + 4*half
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bsc_lds + 8 * q + 4 * half);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc[4 * q + e] += bb[e];
+    }
+    const long long mpix = m0 + wave * 32 + l31;   // this lane's pixel
+    if constexpr (LAST) {
+        if (mpix < p.M) {
+            const long long view = mpix / p.HW;
+            const int pix = (int)(mpix - view * p.HW);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (c < 19) p.heat[((size_t)view * 19 + c) * p.HW + pix] = sc[r];
+            }
+        }
+        return;
+    } else {
+        // ================= phase C: x_new = x + Wfc_ y + Wsc_ score + biases ==============================
+        constexpr int RB = C::RBC, PITCH = RB + 16, CPR = RB / 16, RPP = 256 / CPR;   // 8 chunks per row, 32 rows per pass
+        constexpr int KE = RB / EB;
+        // output channels per pass: fp32 64 (two accumulator tiles: with y's 128 registers the kernel then fits 256 VGPRs and
+        // two workgroups share a CU), bf16 128
+        constexpr int NI = EB == 4 ? 2 : 4;
+        constexpr int CH = NI * 32, NPASS = 256 / CH;
+        constexpr int WPASS = CH / RPP;
+        constexpr int YSTEPS = 256 / KE;          // K-steps over y (8 for f32, 4 for bf16); one more step for score
+        const int chunk = tid % CPR, srow = tid / CPR;
+        u32x4 rw[WPASS];
+        // step s < YSTEPS: rows n of Wfc_ (row stride 256), K offset s*KE; step YSTEPS: rows of Wsc_ (row stride 32), first 32 K
+        auto loadC = [&](int nh, int s) {
+            const bool is_sc = s == YSTEPS;
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(is_sc ? p.wsc_ : p.wfc_);
+            const size_t stride = is_sc ? 32 : 256;
+            const size_t koff = is_sc ? 0 : (size_t)s * KE;
+#pragma unroll
+            for (int i = 0; i < WPASS; ++i) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (!is_sc || chunk * PER16 < 32)
+                    v = *reinterpret_cast<const u32x4*>(base + ((size_t)(nh * CH + srow + i * RPP) * stride + koff + chunk * PER16) * EB);
+                rw[i] = v;
+            }
+        };
+        auto storeC = [&](int buf) {
+            unsigned char* const sw = stage + buf * C::STAGE_C;
+#pragma unroll
+            for (int i = 0; i < WPASS; ++i) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
+        };
+        bf16x8 scpk[2];
+        if constexpr (EB == 2) {
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) scpk[q2][e] = (__bf16)sc[8 * q2 + e];
+        }
+#pragma unroll 1
+        for (int nh = 0; nh < NPASS; ++nh) {
+            f32x16 acc[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+            // bf16: the skip values of this pass are requested NOW as coalesced 16-byte chunks (lane owns chunk (lane & 7) of the
+            // wave's pixel 8 c + (lane >> 3), per 64-channel half hc): their latency hides behind the K loop, and the epilogue
+            // turns them into the accumulators' layout through a wave-private LDS slice
+            u32x4 xch[EB == 2 ? 2 : 1][4];
+            if constexpr (EB == 2) {
+#pragma unroll
+                for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const long long m = m0 + wave * 32 + 8 * c + (lane >> 3);
+                        u32x4 v = {0u, 0u, 0u, 0u};
+                        if (m < p.M) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.x) + (size_t)m * 256 + nh * CH + 64 * hc + (lane & 7) * 8);
+                        xch[hc][c] = v;
+                    }
+            }
+            loadC(nh, 0);
+            storeC(0);
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s <= YSTEPS; ++s) {
+                const unsigned char* const sw = stage + (s & 1) * C::STAGE_C;
+                if (s + 1 <= YSTEPS) loadC(nh, s + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (EB == 4) {
+                    // y steps: KE = 32 channels = tile s; score step: the 32 score channels
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                            for (int i = 0; i < NI; ++i) {
+                                const f32x4 wf = *reinterpret_cast<const f32x4*>(sw + (i * 32 + l31) * PITCH + (4 * q2 + 2 * jj + half) * 16);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float a = s < YSTEPS ? y[s < YSTEPS ? s : 0][8 * q2 + 4 * jj + e] : sc[8 * q2 + 4 * jj + e];
+                                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wf[e], acc[i], 0, 0, 0);
+                                }
+                            }
+                } else {
+                    // y steps: KE channels = tiles s*(KE/32) .. +KE/32-1; score step: one 32-channel group
+#pragma unroll
+                    for (int mm = 0; mm < KE / 32; ++mm) {
+                        if (s == YSTEPS && mm >= 1) break;
+#pragma unroll
+                        for (int q2 = 0; q2 < 2; ++q2) {
+                            const bf16x8 af = s < YSTEPS ? ypk[s < YSTEPS ? s * (KE / 32) + mm : 0][q2] : scpk[q2];
+#pragma unroll
+                            for (int i = 0; i < NI; ++i) {
+                                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sw + (i * 32 + l31) * PITCH + (mm * 32 + (2 * q2 + half) * 8) * 2);
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc[i], 0, 0, 0);  // transposed: rows = channels
+                            }
+                        }
+                    }
+                }
+                if (s + 1 <= YSTEPS) storeC((s & 1) ^ 1);
+                __syncthreads();
+            }
+            if constexpr (EB == 4) {
+                // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4*half of the wave][col = channel nh*128 + 32 i + l31]
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int n = nh * CH + i * 32 + l31;
+                    const float bias = p.bfc_[n] + p.bsc_[n];
+                    float xr[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        xr[r] = m < p.M ? reinterpret_cast<const float*>(p.x)[(size_t)m * 256 + n] : 0.0f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (m < p.M) reinterpret_cast<float*>(p.out)[(size_t)m * 256 + n] = acc[i][r] + bias + xr[r];
+                    }
+                }
+            } else {
+                // bf16 epilogue on the TRANSPOSED product: lane = pixel m0 + 32 wave + l31, registers 4q..4q+3 of tile i =
+                // channels nh*128 + 32 i + 8 q + 4 half + {0..3}.  Global memory is touched in whole 128-byte pixel-half rows only
+                // (16-byte chunks, eight lanes per row): x arrives as chunks, is parked in the wave's LDS slice and read back as the
+                // 8-byte pieces the accumulator layout wants; x_new takes the same road in the other direction.  Same fp32
+                // arithmetic and the same single rounding as the direct 8-byte accesses it replaces.
+                constexpr int SP = 64 * 2 + 16;   // slice pitch: 64 channels + pad
+                unsigned char* const slice = stage + 2 * C::STAGE_C + wave * (32 * SP);
+                static_assert(2 * C::STAGE_C + 4 * 32 * SP <= C::STAGE_BYTES, "the epilogue slices sit behind the phase-C stages");
+#pragma unroll
+                for (int hc = 0; hc < 2; ++hc) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(slice + (8 * c + (lane >> 3)) * SP + (lane & 7) * 16) = xch[hc][c];
+                    uint2 xv[8];
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xv[4 * ii + q] = *reinterpret_cast<const uint2*>(slice + l31 * SP + (32 * ii + 8 * q + 4 * half) * 2);
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int i = 2 * hc + ii;
+                            const int n = nh * CH + 32 * i + 8 * q + 4 * half;
+                            const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bfc_ + n);
+                            const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bsc_ + n);
+                            const uint2 xx = xv[4 * ii + q];
+                            const float x0 = bf16_bits_to_f32((unsigned short)(xx.x & 0xffffu)), x1 = bf16_bits_to_f32((unsigned short)(xx.x >> 16));
+                            const float x2 = bf16_bits_to_f32((unsigned short)(xx.y & 0xffffu)), x3 = bf16_bits_to_f32((unsigned short)(xx.y >> 16));
+                            const float v0 = acc[i][4 * q + 0] + (b1[0] + b2[0]) + x0, v1 = acc[i][4 * q + 1] + (b1[1] + b2[1]) + x1;
+                            const float v2 = acc[i][4 * q + 2] + (b1[2] + b2[2]) + x2, v3 = acc[i][4 * q + 3] + (b1[3] + b2[3]) + x3;
+                            uint2 o;
+                            o.x = (unsigned)f32_to_bf16_bits(v0) | ((unsigned)f32_to_bf16_bits(v1) << 16);
+                            o.y = (unsigned)f32_to_bf16_bits(v2) | ((unsigned)f32_to_bf16_bits(v3) << 16);
+                            *reinterpret_cast<uint2*>(slice + l31 * SP + (32 * ii + 8 * q + 4 * half) * 2) = o;
+                        }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const long long m = m0 + wave * 32 + 8 * c + (lane >> 3);
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(slice + (8 * c + (lane >> 3)) * SP + (lane & 7) * 16);
+                        if (m < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)m * 256 + nh * CH + 64 * hc + (lane & 7) * 8) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace hgk

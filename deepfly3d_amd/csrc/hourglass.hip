@@ -16,6 +16,7 @@
 #include "hg_kernels.h"
 #include "hg_bt_ring.h"
 #include "hg_bt_l1.h"
+#include "hg_head.h"
 #include "hg_bt_ring_f32.h"
 
 using namespace hgk;
@@ -378,6 +379,10 @@ struct df3d_hg {
                 Step st;
                 st.kind = ST_HEAD;
                 st.last = last;
+                if (ring && dtype == DF3D_DTYPE_BF16) {   // Wfc through the LDS-DMA stage ring (hg_head.h)
+                    st.wstream = (long long)stream_bytes;
+                    stream_bytes += (size_t)HD_FC_STAGES * BR_STAGE_BYTES;
+                }
                 st.name = last ? "score." + S : "score_." + S;
                 st.in = r;
                 st.res = last ? -1 : x;
@@ -686,6 +691,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.wsc_ = st.last ? nullptr : wb + st.conv4b.w_off * eb;
                 a.bfc_ = st.last ? nullptr : h->blob + st.conv3b.b_off;
                 a.bsc_ = st.last ? nullptr : h->blob + st.conv4b.b_off;
+                a.fcstream = st.wstream >= 0 ? reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream : nullptr;
                 a.M = (long long)n * ti.h * ti.w;
                 a.HW = ti.h * ti.w;
                 const void* fn = st.last ? reinterpret_cast<const void*>(head_kernel<T, true>) : reinterpret_cast<const void*>(head_kernel<T, false>);
@@ -862,6 +868,12 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
                            blob_dev + h->steps[0].conv.w_off, reinterpret_cast<unsigned short*>(lowp_dev) + h->steps[0].conv.w_off);
         // weight streams of the ring bottlenecks: stage-by-stage LDS images (hg_bt_ring.h), from the bf16 copy
         for (const Step& st : h->steps) {
+            if (st.kind == ST_HEAD && st.wstream >= 0) {
+                hipLaunchKernelGGL(bt_fc_pack_kernel, dim3((HD_FC_STAGES * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
+                                   reinterpret_cast<const unsigned short*>(lowp_dev) + st.conv.w_off,
+                                   reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
+                continue;
+            }
             if (st.kind != ST_BOTTLENECK || st.wstream < 0) continue;
             const unsigned short* lp = reinterpret_cast<const unsigned short*>(lowp_dev);
             if (st.l1) {
