@@ -39,10 +39,25 @@ struct HeadArgs {
     const float* bsc;    // [32]
     const float* bfc_;   // [256]
     const float* bsc_;   // [256]
-    const void* fcstream;  // bf16 only: Wfc as 16 pre-swizzled 8 KB LDS stage images (hg_bt_ring.h: bt_fc_pack_kernel), or nullptr
+    const void* fcstream;  // bf16 only: Wfc as 16 pre-swizzled 8 KB LDS stage images (bt_fc_pack_kernel), or nullptr
+    const void* fc2stream; // bf16 only, not LAST: Wfc_ / Wsc_ as 18 stage images (bt_fc2_pack_kernel), or nullptr; needs M % 128 == 0
     long long M;
     int HW;
 };
+
+// bf16 blob -> phase-C stage stream: per 128-channel output half nh: Wfc_ rows 128 nh .. as 8 K slices of 32 (the host's K order),
+// then the same rows of Wsc_ (K = 32) -> 2 x 9 stages
+constexpr int HD_FC2_STAGES = 18;
+__global__ __launch_bounds__(256) void bt_fc2_pack_kernel(const unsigned short* __restrict__ wfc2, const unsigned short* __restrict__ wsc2,
+                                                          unsigned char* __restrict__ stream) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= HD_FC2_STAGES * 512) return;
+    const int st = idx >> 9, r = (idx >> 2) & 127, c = idx & 3;
+    const int nh = st / 9, k = st % 9;
+    const unsigned short* const src = k < 8 ? wfc2 + (size_t)(nh * 128 + r) * 256 + 32 * k + 8 * c     // Wfc_ [256][256]
+                                            : wsc2 + (size_t)(nh * 128 + r) * 32 + 8 * c;              // Wsc_ [256][32]
+    *reinterpret_cast<u32x4*>(stream + (size_t)st * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(src);
+}
 
 template <typename T>
 struct HeadCfg {
@@ -54,7 +69,11 @@ struct HeadCfg {
     static constexpr int RBC = 128;                                  // phase C staged row bytes
     static constexpr int STAGE_C = 128 * (RBC + 16);
     static constexpr int S1 = 2 * STAGE_A > WSC_BYTES ? 2 * STAGE_A : WSC_BYTES;
-    static constexpr int STAGE_BYTES = S1 > 2 * STAGE_C ? S1 : 2 * STAGE_C;
+    static constexpr int S2 = S1 > 2 * STAGE_C ? S1 : 2 * STAGE_C;
+    static constexpr int RING_SLOTS = 6;                             // bf16: LDS-DMA ring of 8 KB weight stages ...
+    static constexpr int SLICE_PITCH = 64 * 2 + 16;                  // ... and, behind it, one 32 px x 64 ch epilogue slice per wave
+    static constexpr int RING_BYTES = EB == 2 ? RING_SLOTS * 8192 + 4 * 32 * SLICE_PITCH : 0;
+    static constexpr int STAGE_BYTES = S2 > RING_BYTES ? S2 : RING_BYTES;
     static constexpr int MISC = (256 + 32) * 4;
     static constexpr int LDS_BYTES = STAGE_BYTES + MISC;
 };
@@ -288,6 +307,107 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
             for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) scpk[q2][e] = (__bf16)sc[8 * q2 + e];
+        }
+        if constexpr (EB == 2) {
+            if (p.fc2stream != nullptr) {
+                // bf16: the 2 x 9 weight stages of phase C through the same six-slot LDS-DMA ring as phase A (two steps ahead, one
+                // barrier per step); the skip values of BOTH passes are requested before the first stage (no activation load
+                // between two weight stages in the in-order queue).  Operations one wave issues, in order: 16 skip loads |
+                // steps 0, 1 | per step t: wait, barrier, step t + 2 | after step 4: 8 stores | ... | after step 9: 8 stores;
+                // a step is two stages (four pieces per wave), the score steps 4 and 9 one.
+                constexpr int NSLOT = C::RING_SLOTS, SP = C::SLICE_PITCH;
+                const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)stage;
+                const unsigned wpiece = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 2048u;
+                auto issue_step = [&](int t) {
+                    const int base = 9 * (t / 5) + 2 * (t % 5), cnt = (t % 5 == 4) ? 1 : 2;
+#pragma unroll
+                    for (int k = 0; k < cnt; ++k)
+                        br_glds_stage(reinterpret_cast<const unsigned char*>(p.fc2stream) + (size_t)(base + k) * BR_STAGE_BYTES, wpiece + (unsigned)lane * 16u,
+                                      ring_addr + (unsigned)((base + k) % NSLOT) * BR_STAGE_BYTES + wpiece);
+                };
+                u32x4 xch[2][2][4];
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const long long m = m0 + wave * 32 + 8 * c + (lane >> 3);   // (M is a multiple of 128 here)
+                            xch[nh][hc][c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.x) + (size_t)m * 256 + nh * 128 + 64 * hc + (lane & 7) * 8);
+                        }
+                issue_step(0);
+                issue_step(1);
+                const unsigned char* const wf0 = stage + br_swz(l31, half);
+                const unsigned char* const wf1 = stage + br_swz(l31, 2 + half);
+                unsigned char* const slice = stage + NSLOT * BR_STAGE_BYTES + wave * (32 * SP);
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    f32x16 acc[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+                    for (int s5 = 0; s5 < 5; ++s5) {
+                        const int t = 5 * nh + s5;
+                        // operations issued after step t's pieces: step t + 1's (4, or 2 for a score step), and for steps 5 and 6
+                        // also the first pass' 8 stores
+                        br_wait_vm(t == 9 ? 0 : ((t + 1) % 5 == 4 ? 2 : 4) + (t == 5 || t == 6 ? 8 : 0));
+                        br_barrier();
+                        if (t + 2 < 10) issue_step(t + 2);
+                        const int base = 9 * nh + 2 * s5;
+#pragma unroll
+                        for (int mm = 0; mm < 2; ++mm) {
+                            if (s5 == 4 && mm >= 1) break;
+#pragma unroll
+                            for (int q2 = 0; q2 < 2; ++q2) {
+                                const bf16x8 af = s5 < 4 ? ypk[2 * s5 + mm][q2] : scpk[q2];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>((q2 ? wf1 : wf0) + ((base + mm) % NSLOT) * BR_STAGE_BYTES + i * 2048);
+                                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc[i], 0, 0, 0);  // transposed: rows = channels
+                                }
+                            }
+                        }
+                    }
+                    // epilogue (see the staged form below): skip chunks -> slice -> accumulator layout; x_new the other way
+#pragma unroll
+                    for (int hc = 0; hc < 2; ++hc) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(slice + (8 * c + (lane >> 3)) * SP + (lane & 7) * 16) = xch[nh][hc][c];
+                        uint2 xv[8];
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) xv[4 * ii + q] = *reinterpret_cast<const uint2*>(slice + l31 * SP + (32 * ii + 8 * q + 4 * half) * 2);
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int i = 2 * hc + ii;
+                                const int n = nh * 128 + 32 * i + 8 * q + 4 * half;
+                                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bfc_ + n);
+                                const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bsc_ + n);
+                                const uint2 xx = xv[4 * ii + q];
+                                const float x0 = bf16_bits_to_f32((unsigned short)(xx.x & 0xffffu)), x1 = bf16_bits_to_f32((unsigned short)(xx.x >> 16));
+                                const float x2 = bf16_bits_to_f32((unsigned short)(xx.y & 0xffffu)), x3 = bf16_bits_to_f32((unsigned short)(xx.y >> 16));
+                                const float v0 = acc[i][4 * q + 0] + (b1[0] + b2[0]) + x0, v1 = acc[i][4 * q + 1] + (b1[1] + b2[1]) + x1;
+                                const float v2 = acc[i][4 * q + 2] + (b1[2] + b2[2]) + x2, v3 = acc[i][4 * q + 3] + (b1[3] + b2[3]) + x3;
+                                uint2 o;
+                                o.x = (unsigned)f32_to_bf16_bits(v0) | ((unsigned)f32_to_bf16_bits(v1) << 16);
+                                o.y = (unsigned)f32_to_bf16_bits(v2) | ((unsigned)f32_to_bf16_bits(v3) << 16);
+                                *reinterpret_cast<uint2*>(slice + l31 * SP + (32 * ii + 8 * q + 4 * half) * 2) = o;
+                            }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const long long m = m0 + wave * 32 + 8 * c + (lane >> 3);
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(slice + (8 * c + (lane >> 3)) * SP + (lane & 7) * 16);
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)m * 256 + nh * 128 + 64 * hc + (lane & 7) * 8) = v;
+                        }
+                    }
+                }
+                return;
+            }
         }
 #pragma unroll 1
         for (int nh = 0; nh < NPASS; ++nh) {

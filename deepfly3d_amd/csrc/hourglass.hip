@@ -49,6 +49,7 @@ struct Step {
     int in2 = -1;                     // ST_BOTTLENECK: low-resolution addend of the input (fused upsample + add)
     long long wstream = -1;           // ST_BOTTLENECK, bf16 256 -> 128 -> 128 -> 256: byte offset of its weight stream behind the bf16 blob
     int pool_in = -1;                 // ST_BOTTLENECK (bf16 ring kernel): tensor receiving the 2x2 max-pool of the block's INPUT
+    long long wstream2 = -1;          // ST_HEAD (bf16, not last): byte offset of the phase-C weight stream
     bool l1 = false;                  // ST_BOTTLENECK, bf16 64 -> 64 -> 64 -> 128: hg_bt_l1.h (wstream = its LDS weight image)
     bool pool_only = false;           // ... whose full-resolution output nobody reads: `out` IS the pooled tensor
 };
@@ -382,6 +383,10 @@ struct df3d_hg {
                 if (ring && dtype == DF3D_DTYPE_BF16) {   // Wfc through the LDS-DMA stage ring (hg_head.h)
                     st.wstream = (long long)stream_bytes;
                     stream_bytes += (size_t)HD_FC_STAGES * BR_STAGE_BYTES;
+                    if (!last) {
+                        st.wstream2 = (long long)stream_bytes;
+                        stream_bytes += (size_t)HD_FC2_STAGES * BR_STAGE_BYTES;
+                    }
                 }
                 st.name = last ? "score." + S : "score_." + S;
                 st.in = r;
@@ -692,6 +697,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.bfc_ = st.last ? nullptr : h->blob + st.conv3b.b_off;
                 a.bsc_ = st.last ? nullptr : h->blob + st.conv4b.b_off;
                 a.fcstream = st.wstream >= 0 ? reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream : nullptr;
+                a.fc2stream = st.wstream2 >= 0 && ((long long)n * ti.h * ti.w) % 128 == 0 ? reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream2 : nullptr;
                 a.M = (long long)n * ti.h * ti.w;
                 a.HW = ti.h * ti.w;
                 const void* fn = st.last ? reinterpret_cast<const void*>(head_kernel<T, true>) : reinterpret_cast<const void*>(head_kernel<T, false>);
@@ -872,6 +878,11 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
                 hipLaunchKernelGGL(bt_fc_pack_kernel, dim3((HD_FC_STAGES * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
                                    reinterpret_cast<const unsigned short*>(lowp_dev) + st.conv.w_off,
                                    reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
+                if (st.wstream2 >= 0)
+                    hipLaunchKernelGGL(bt_fc2_pack_kernel, dim3((HD_FC2_STAGES * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
+                                       reinterpret_cast<const unsigned short*>(lowp_dev) + st.conv3b.w_off,
+                                       reinterpret_cast<const unsigned short*>(lowp_dev) + st.conv4b.w_off,
+                                       reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream2);
                 continue;
             }
             if (st.kind != ST_BOTTLENECK || st.wstream < 0) continue;
