@@ -46,7 +46,7 @@ def main():
                     continue
                 b = (2 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024
                 w.writerow([k, a["n"], a["FETCH_SIZE"] / a["n"], a["WRITE_SIZE"] / a["n"], b / a["n"]])
-                m = re.match(r"hgk::(\w+<[^(]*>)\(", k)
+                m = re.match(r"hgk::(\w+(?:<[^(]*>)?)\(", k)
                 if m:  # key = kernel instantiation exactly as bench.py's roofline.kernel names it
                     cls[m.group(1)][0] += a["n"]
                     cls[m.group(1)][1] += b
