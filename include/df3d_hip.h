@@ -254,13 +254,17 @@ size_t df3d_hg_blob_floats(const df3d_hg* h);
 /* Engine-private device copies of the weights, made by df3d_hg_set_weights in a caller-owned buffer of
  * df3d_hg_lowp_bytes(h) bytes (256-byte aligned; NULL is accepted when that size is 0): the bf16 copy of the blob (bf16
  * engines) and, for both dtypes, the "weight streams" of the 256 -> 128 -> 128 -> 256 bottlenecks -- their weights repacked
- * as the sequence of 8 KB LDS images the kernel pulls through its LDS-DMA ring (option "ring", default 1). */
+ * as the sequence of 8 KB LDS images the kernel pulls through its LDS-DMA ring (option "ring", default 1); bf16 engines also
+ * keep the heads' fc / fc_ / score_ weights in that form and layer1's whole weight set as one LDS image (option "l1"). */
 size_t df3d_hg_lowp_bytes(const df3d_hg* h);
 int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void* stream);
 /* knobs: "fuse" = 1 (default) | 0: run 256->128->128->256 bottlenecks as one fused kernel -- must be set before
  * the weights (it changes the manifest);  "fuse_upadd" = 1 (default) | 0: the hourglass'
  * nearest-upsample + add is folded into the input load of the bottleneck that consumes the sum (same results bit
- * for bit; set before the weights);  "row_bytes" = 0 (auto) | 64 | 128 bytes staged per operand row per K-step */
+ * for bit; set before the weights);  "row_bytes" = 0 (auto) | 64 | 128 bytes staged per operand row per K-step;
+ * "ring" = 1 (default) | 0: weights through LDS-DMA stage rings (see df3d_hg_lowp_bytes) or register-staged;  "l1" = 1
+ * (default) | 0: bf16 layer1 as the LDS-resident-weights kernel that writes only the pooled tensor -- both set before the
+ * weights, both bit-identical to their 0 form */
 int df3d_hg_set_option(df3d_hg* h, const char* key, int value);
 size_t df3d_hg_workspace_bytes(const df3d_hg* h, int n);
 int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_dev, void* workspace_dev,
