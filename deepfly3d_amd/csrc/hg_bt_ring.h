@@ -37,12 +37,13 @@ struct BtRingArgs {
     void* pool;           // optional NHWC bf16 [V, H/2, W/2, 256]: 2x2 max-pool of `out`
     void* pool_in;        // optional NHWC bf16 [V, H/2, W/2, 256]: 2x2 max-pool of the block's INPUT (bf16 kernel only; for the
                           // hourglass level whose input no fused producer has pooled: its skip values pass through the epilogue anyway)
-    const void* wstream;  // BR_NSTAGE x BR_STAGE_BYTES: pre-swizzled stage images (bt_ring_pack_kernel)
+    const void* wstream;  // br_nstage(CIN, DS) x BR_STAGE_BYTES: pre-swizzled stage images (bt_ring_pack_kernel)
     const float* b1;      // [128] (bn2 folded)
     const float* b2;      // [128] (bn3 folded)
     const float* b3;      // [256]
-    const float* s1;      // [256] bn1 scale
-    const float* t1;      // [256] bn1 shift
+    const float* bd;      // [256] skip-convolution bias (DS kernels only)
+    const float* s1;      // [CIN] bn1 scale
+    const float* t1;      // [CIN] bn1 shift
     int V, H, W;
 };
 
@@ -65,21 +66,29 @@ static_assert(2 * BR_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 
 __host__ __device__ constexpr int br_swz(int r, int c) { return (r >> 2) * 256 + (((((r & 3) << 2) | c) ^ ((r >> 3) & 3)) << 4); }
 
-// bf16 blob -> weight stream of one bottleneck.  One thread per 16-byte chunk: 52 stages x 128 rows x 4 chunks.
+// stages of one bottleneck's stream: W1 (CIN / 32) | W2 (36) | per 128-channel output half: W3 (4) and, with the 1x1 skip
+// convolution (DS: CIN != 256), Wd (CIN / 32)
+__host__ __device__ constexpr int br_nstage(int cin, bool ds) { return cin / 32 + BR_W2_STAGES + 2 * (4 + (ds ? cin / 32 : 0)); }
+
+// bf16 blob -> weight stream of one bottleneck.  One thread per 16-byte chunk: stages x 128 rows x 4 chunks.
 __global__ __launch_bounds__(256) void bt_ring_pack_kernel(const unsigned short* __restrict__ w1, const unsigned short* __restrict__ w2,
-                                                           const unsigned short* __restrict__ w3, unsigned char* __restrict__ stream) {
+                                                           const unsigned short* __restrict__ w3, const unsigned short* __restrict__ wd, int cin,
+                                                           unsigned char* __restrict__ stream) {
+    const bool ds = wd != nullptr;
+    const int ns1 = cin / 32, per_nh = 4 + (ds ? ns1 : 0);
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= BR_NSTAGE * 512) return;
+    if (idx >= br_nstage(cin, ds) * 512) return;
     const int s = idx >> 9, r = (idx >> 2) & 127, c = idx & 3;
     const unsigned short* src;
-    if (s < BR_W1_STAGES) {
-        src = w1 + (size_t)r * 256 + 32 * s + 8 * c;                          // W1 [128][256], K slice s
-    } else if (s < BR_W1_STAGES + BR_W2_STAGES) {
-        const int tap = (s - BR_W1_STAGES) >> 2, kc = (s - BR_W1_STAGES) & 3;
+    if (s < ns1) {
+        src = w1 + (size_t)r * cin + 32 * s + 8 * c;                          // W1 [128][CIN], K slice s
+    } else if (s < ns1 + BR_W2_STAGES) {
+        const int tap = (s - ns1) >> 2, kc = (s - ns1) & 3;
         src = w2 + ((size_t)tap * 128 + r) * 128 + 32 * kc + 8 * c;           // W2 [9][128][128]
     } else {
-        const int nh = (s - BR_W1_STAGES - BR_W2_STAGES) >> 2, kc = (s - BR_W1_STAGES - BR_W2_STAGES) & 3;
-        src = w3 + ((size_t)nh * 128 + r) * 128 + 32 * kc + 8 * c;            // W3 [256][128] (K already permuted by the host packer)
+        const int q = s - ns1 - BR_W2_STAGES, nh = q / per_nh, k = q % per_nh;
+        if (k < 4) src = w3 + ((size_t)nh * 128 + r) * 128 + 32 * k + 8 * c;  // W3 [256][128] (K already permuted by the host packer)
+        else src = wd + ((size_t)nh * 128 + r) * cin + 32 * (k - 4) + 8 * c;  // Wd [256][CIN]
     }
     *reinterpret_cast<u32x4*>(stream + (size_t)s * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(src);
 }
@@ -152,10 +161,17 @@ __device__ unsigned long long br_dbg[8];
 #define BR_STAMP(k) do { } while (0)
 #endif
 
-template <bool UP>
+// CIN = 256: the identity-skip block (out = ... + x); CIN = 128 (DS): the skip is a 1x1 convolution of the raw input, accumulated
+// into the same MFMA accumulators behind W3 (layer2), the x operand of which comes straight from global memory in MFMA layout
+template <bool UP, int CIN = 256>
 __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     using T = __hip_bfloat16;
-    constexpr int CIN = 256, CO = 256, NT = 4;
+    constexpr int CO = 256, NT = 4;
+    constexpr bool DS = CIN != 256;
+    static_assert(!(UP && DS), "the upsample-add input exists for the identity-skip block only");
+    constexpr int NS1 = CIN / 32;                        // W1 stages = K steps of phase 1
+    constexpr int NSD = DS ? CIN / 32 : 0;               // skip-convolution stages per output half
+    constexpr int NSTAGE = br_nstage(CIN, DS);
     constexpr int LX = UP ? 6 : 3;   // vector-memory loads per thread and x step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;
@@ -198,10 +214,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     // bn1 coefficients and b1 -> LDS; b2 / b3 wait in two registers and replace the bn1 coefficients after phase 1
     // (the only plain loads before the ring starts); halo validity masks
     //   coef_lds: phase 1: [0..255] scale, [256..511] shift; afterwards [0..127] b2, [128..383] b3;  [512..639] b1
-    coef_lds[tid] = p.s1[tid];
-    coef_lds[256 + tid] = p.t1[tid];
+    if (tid < CIN) {
+        coef_lds[tid] = p.s1[tid];
+        coef_lds[256 + tid] = p.t1[tid];
+    }
     if (tid < 128) coef_lds[512 + tid] = p.b1[tid];
-    const float late_b2 = p.b2[tid & 127], late_b3 = p.b3[tid];
+    const float late_b2 = p.b2[tid & 127], late_b3 = DS ? p.b3[tid] + p.bd[tid] : p.b3[tid];
     const float* const b1_lds = coef_lds + 512;
     const float* const b2_lds = coef_lds;
     const float* const b3_lds = coef_lds + 128;
@@ -285,16 +303,16 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
                 for (int e = 0; e < 4; ++e) acc[i][4 * t + e] = bb[e];
         }
 #pragma unroll
-        for (int s = 0; s < BR_W1_STAGES; ++s) {
+        for (int s = 0; s < NS1; ++s) {
             storex(s, s % DX);
             // operations issued after stage s's DMA pieces (see the file header): the next two stages' pieces (4) and the x
             // loads requested since -- the prologue's DX steps for s < 3, then one step's worth per K step while any remain
-            auto cx = [](int k) { return k < BR_W1_STAGES ? LX : 0; };
+            auto cx = [](int k) { return k < NS1 ? LX : 0; };
             br_wait_vm(s == 0 ? 4 + DX * LX : s == 1 ? 4 + DX * LX + cx(DX) : s == 2 ? 4 + DX * LX + cx(DX) + cx(DX + 1)
                                                                                : 4 + cx(s - 3 + DX) + cx(s - 2 + DX) + cx(s - 1 + DX));
             br_barrier();
             ring_issue(s + 3);
-            if (s + DX < BR_W1_STAGES) loadx(s + DX, s % DX);
+            if (s + DX < NS1) loadx(s + DX, s % DX);
             const unsigned char* const sx = t1_lds + (s % 3) * BR_XSTAGE;
             // both K halves' fragments are requested before the first MFMA (see phase 2: hipcc would serialise read -> MFMA)
             u32x4 wfr[2], xfr[2][6];
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     // slots the previous double-step has just released
 #pragma unroll
     for (int d = 0; d < BR_W2_STAGES / 2; ++d) {
-        const int s0 = BR_W1_STAGES + 2 * d;
+        const int s0 = NS1 + 2 * d;
 #if !defined(BR_ABL) || BR_ABL != 4
         br_wait_vm(d == 0 ? 2 : 0);   // d = 0: phase 1 has already requested stage 10
         br_barrier();                 // (first iteration: also publishes the t1 tile and b2 / b3)
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
         u32x4 tfr[2], wfr[2][NT];
         auto load_group = [&](int g, int buf) {
             const int s = s0 + (g >> 1), j = g & 1;
-            const int q = s - BR_W1_STAGES, tap = q >> 2, kc = q & 3;
+            const int q = s - NS1, tap = q >> 2, kc = q & 3;
             const int ky = tap / 3, kx = tap - 3 * ky;
             // chunk (4 kc + 2 j + half) ^ swizzle = ((4 kc + 2 j) << 4) ^ tsw[kx]   (4 kc + 2 j is even)
             tfr[buf] = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
@@ -415,34 +433,49 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     // transposed like phase 1 (A = W3 rows, B = the t2 registers): accumulator register 4 t + e of channel tile i holds, for
     // pixel l31 of the wave, output channel 128 nh + 32 i + 8 t + 4 half + e -> 8-byte stores into the wave's LDS slice
     unsigned char* const outp = reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * CO * 2;
+    constexpr int S3 = NS1 + BR_W2_STAGES;   // first W3 stage
+    constexpr int PER_NH = 4 + NSD;          // stages per 128-channel output half: W3 (4), then the skip convolution's (DS)
+    // DS: the raw input of this lane's pixel as MFMA B operands -- K chunk kc = channels 16 kc + 8 half .. (requested once, in the
+    // first double-step, straight from global memory: tile pixel (2 wave + (l31 >> 4), l31 & 15))
+    u32x4 xc[DS ? CIN / 16 : 1];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh) {
         f32x16 acc[4];
-        unsigned xres[32];
+        unsigned xres[DS ? 1 : 32];
 #pragma unroll
-        for (int dd = 0; dd < 2; ++dd) {
-            const int s0 = BR_W1_STAGES + BR_W2_STAGES + 4 * nh + 2 * dd;
-            // operations issued after the pair's DMA pieces: the 8 residual loads of this half (requested in its first
-            // double-step, after the DMA), or the first half's epilogue (8 stores, UP: 4 loads; the optional 4 pool stores
-            // are left out, which only makes the wait conservative)
+        for (int dd = 0; dd < PER_NH / 2; ++dd) {
+            const int s0 = S3 + PER_NH * nh + 2 * dd;
+            // operations issued after the pair's DMA pieces: identity skip: the 8 residual loads of this half (requested in its
+            // first double-step, after the DMA), or the first half's epilogue (8 stores, UP: 4 loads; the optional pool stores are
+            // left out, which only makes the wait conservative); DS: the CIN / 16 input loads of the very first double-step, the
+            // first half's 8 stores in front of the second half
             constexpr int E0 = 8 + (UP ? 4 : 0);
-            br_wait_vm(dd == 1 ? 8 : nh == 0 ? 0 : E0);
+            if constexpr (DS) br_wait_vm(dd == 0 ? (nh == 0 ? 0 : 8) : (dd == 1 && nh == 0) ? CIN / 16 : 0);
+            else br_wait_vm(dd == 1 ? 8 : nh == 0 ? 0 : E0);
             br_barrier();
-            if (s0 + 3 < BR_NSTAGE) {
+            if (s0 + 3 < NSTAGE) {
                 ring_issue(s0 + 2);
                 ring_issue(s0 + 3);
             }
             if (dd == 0) {
-                // residual values requested now: lane owns, for c = 0..7, chunk (lane & 15) of wave pixel 4 c + (lane >> 4)
+                if constexpr (DS) {
+                    if (nh == 0) {
+                        const unsigned char* const src = xin + (((size_t)(ty0 + py) * p.W + (tx0 + px)) * CIN + half * 8) * 2;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int pw = 4 * c + (lane >> 4);
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin) +
-                        ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CIN + nh * 128 + (lane & 15) * 8);
-                    xres[4 * c + 0] = v[0];
-                    xres[4 * c + 1] = v[1];
-                    xres[4 * c + 2] = v[2];
-                    xres[4 * c + 3] = v[3];
+                        for (int kc = 0; kc < CIN / 16; ++kc) xc[kc] = *reinterpret_cast<const u32x4*>(src + kc * 32);
+                    }
+                } else {
+                    // residual values requested now: lane owns, for c = 0..7, chunk (lane & 15) of wave pixel 4 c + (lane >> 4)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int pw = 4 * c + (lane >> 4);
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin) +
+                            ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CIN + nh * 128 + (lane & 15) * 8);
+                        xres[4 * c + 0] = v[0];
+                        xres[4 * c + 1] = v[1];
+                        xres[4 * c + 2] = v[2];
+                        xres[4 * c + 3] = v[3];
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -453,8 +486,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
                         for (int e = 0; e < 4; ++e) acc[i][4 * t + e] = bb[e];
                     }
             }
-            // four (stage, K half) groups, the weight fragments of group g + 1 requested before the MFMAs of group g
-            // t2 tile kc, registers 8 q2 .. 8 q2 + 7 <-> packed W3 K positions 32 kc + 16 q2 + 8 half .. (host K order, kperm)
+            // four (stage, K half) groups, the weight fragments of group g + 1 requested before the MFMAs of group g.  W3 steps
+            // (dd < 2): t2 tile kc, registers 8 q2 .. 8 q2 + 7 <-> packed W3 K positions 32 kc + 16 q2 + 8 half .. (host K order,
+            // kperm); skip-convolution steps (dd >= 2): K chunk 2 (stage) + q2 of the raw input
             bf16x8 w3r[2][4];
             auto load_w3 = [&](int g, int buf) {
                 const int s = s0 + (g >> 1), q2 = g & 1;
@@ -467,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
             for (int g = 0; g < 4; ++g) {
                 if (g < 3) load_w3(g + 1, (g + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 tf = __builtin_bit_cast(bf16x8, t2f[2 * dd + (g >> 1)][g & 1]);
+                const bf16x8 tf = __builtin_bit_cast(bf16x8, dd < 2 ? t2f[2 * dd + (g >> 1)][g & 1] : xc[DS ? 2 * (2 * (dd - 2) + (g >> 1)) + (g & 1) : 0]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3r[g & 1][i], tf, acc[i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -503,19 +537,21 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
         for (int c = 0; c < 8; ++c) {
             const int pw = 4 * c + (lane >> 4);
             u32x4 v = *reinterpret_cast<const u32x4*>(slice + pw * OP + (lane & 15) * 16);
-            u32x4 x4 = {xres[4 * c], xres[4 * c + 1], xres[4 * c + 2], xres[4 * c + 3]};
-            if constexpr (UP) x4 = add_chunk<T>(x4, x2[c & 3]);
-            v = add_chunk<T>(v, x4);
+            if constexpr (!DS) {   // identity skip (DS: the skip convolution is already in the accumulators)
+                u32x4 x4 = {xres[4 * c], xres[4 * c + 1], xres[4 * c + 2], xres[4 * c + 3]};
+                if constexpr (UP) x4 = add_chunk<T>(x4, x2[c & 3]);
+                v = add_chunk<T>(v, x4);
+                xres[4 * c] = x4[0], xres[4 * c + 1] = x4[1], xres[4 * c + 2] = x4[2], xres[4 * c + 3] = x4[3];   // (the block's input, for pool_in)
+            }
             fin[c] = v;
             *reinterpret_cast<u32x4*>(outs + ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CO + nh * 128 + (lane & 15) * 8) = v;
-            xres[4 * c] = x4[0], xres[4 * c + 1] = x4[1], xres[4 * c + 2] = x4[2], xres[4 * c + 3] = x4[3];   // (the block's input, for pool_in)
         }
-        if (p.pool_in) {   // same lane geometry as the pooling of `out` below
+        if (!DS && p.pool_in) {   // same lane geometry as the pooling of `out` below
             unsigned short* const pp = reinterpret_cast<unsigned short*>(p.pool_in) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const u32x4 xa = {xres[4 * c], xres[4 * c + 1], xres[4 * c + 2], xres[4 * c + 3]};
-                const u32x4 xb = {xres[4 * c + 16], xres[4 * c + 17], xres[4 * c + 18], xres[4 * c + 19]};
+                const u32x4 xa = {xres[DS ? 0 : 4 * c], xres[DS ? 0 : 4 * c + 1], xres[DS ? 0 : 4 * c + 2], xres[DS ? 0 : 4 * c + 3]};
+                const u32x4 xb = {xres[DS ? 0 : 4 * c + 16], xres[DS ? 0 : 4 * c + 17], xres[DS ? 0 : 4 * c + 18], xres[DS ? 0 : 4 * c + 19]};
                 u32x4 m = max_chunk<T>(xa, xb);
                 u32x4 o;
 #pragma unroll

@@ -229,6 +229,11 @@ struct df3d_hg {
             st.conv2b = plan_conv(name + ".conv2", 9, planes, planes, planes, false, true, false);
             if (ds) st.conv4b = plan_conv(name + ".downsample.0", 1, cin, cin, cout, false, false, false);
             st.conv3b = plan_conv(name + ".conv3", 1, planes, planes, cout, false, false, false, dtype == DF3D_DTYPE_BF16 ? 1 : 0);
+            if (ring && dtype == DF3D_DTYPE_BF16 && cin == 128 && planes == 128 && x2 < 0 && !want_pool) {
+                // layer2: the same ring kernel with 128 input channels and the skip convolution as eight more stages
+                st.wstream = (long long)stream_bytes;
+                stream_bytes += (size_t)br_nstage(128, true) * BR_STAGE_BYTES;
+            }
             if (ring && cin == 256 && planes == 128) {   // weights through the LDS-DMA ring (hg_bt_ring.h, hg_bt_ring_f32.h)
                 st.wstream = (long long)stream_bytes;
                 stream_bytes += (size_t)(dtype == DF3D_DTYPE_BF16 ? BR_NSTAGE : BRF_NSTAGE) * BR_STAGE_BYTES;
@@ -651,8 +656,17 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                     r.in = a.in; r.in2 = a.in2; r.out = a.out; r.pool = a.pool;
                     r.pool_in = st.pool_in >= 0 ? tptr(st.pool_in) : nullptr;
                     r.wstream = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream;
-                    r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.s1 = a.s1; r.t1 = a.t1;
+                    r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd; r.s1 = a.s1; r.t1 = a.t1;
                     r.V = n; r.H = ti.h; r.W = ti.w;
+                    if (ds) {   // bf16 layer2
+                        ScopedTimer tm(h, s, "bottleneck_ring_kernel<false, 128>", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl), px * eb * (cin + 2.0 * pl));
+                        static unsigned attr_ds = 0;
+                        if (first_use_on_this_device(attr_ds))
+                            DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, BR_LDS_BYTES));
+                        hipLaunchKernelGGL((bottleneck_ring_kernel<false, 128>), dim3(n * (ti.h / BT_TH) * (ti.w / BT_TW)), dim3(256), BR_LDS_BYTES, s, r);
+                        DF3D_LAUNCH_CHECK();
+                        break;
+                    }
                     ScopedTimer tm(h, s, std::string(eb == 2 ? "bottleneck_ring_kernel<" : "bottleneck_ring_f32_kernel<") + (a.in2 ? "true" : "false") + ">",
                                    2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl));
                     const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
@@ -893,8 +907,9 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
                                    reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
                 continue;
             }
-            hipLaunchKernelGGL(bt_ring_pack_kernel, dim3((BR_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
-                               lp + st.conv.w_off, lp + st.conv2b.w_off, lp + st.conv3b.w_off,
+            const bool dsb = st.conv.cin != 2 * st.conv.cout;   // layer2: 128 -> 128 -> 128 -> 256 with the skip convolution
+            hipLaunchKernelGGL(bt_ring_pack_kernel, dim3((br_nstage(st.conv.cin, dsb) * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
+                               lp + st.conv.w_off, lp + st.conv2b.w_off, lp + st.conv3b.w_off, dsb ? lp + st.conv4b.w_off : nullptr, st.conv.cin,
                                reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
         }
         DF3D_LAUNCH_CHECK();
