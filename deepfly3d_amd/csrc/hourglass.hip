@@ -667,7 +667,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                         DF3D_LAUNCH_CHECK();
                         break;
                     }
-                    ScopedTimer tm(h, s, std::string(eb == 2 ? "bottleneck_ring_kernel<" : "bottleneck_ring_f32_kernel<") + (a.in2 ? "true" : "false") + ">",
+                    ScopedTimer tm(h, s, std::string(eb == 2 ? "bottleneck_ring_kernel<" : "bottleneck_ring_f32_kernel<") + (a.in2 ? "true" : "false") + (eb == 2 ? ", 256>" : ">"),   // as rocprofv3 prints them
                                    2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl));
                     const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
                     static unsigned attr_done[4] = {0, 0, 0, 0};
