@@ -35,8 +35,8 @@ struct BtRingArgs {
     const void* in2;      // UP: NHWC bf16 [V, H/2, W/2, 256]; the block's input is in + nearest-upsample(in2), rounded to bf16
     void* out;            // NHWC bf16 [V, H, W, 256]
     void* pool;           // optional NHWC bf16 [V, H/2, W/2, 256]: 2x2 max-pool of `out`
-    void* pool_in;        // optional NHWC bf16 [V, H/2, W/2, 256]: 2x2 max-pool of the block's INPUT (bf16 kernel only; for the
-                          // hourglass level whose input no fused producer has pooled: its skip values pass through the epilogue anyway)
+    void* pool_in;        // optional NHWC [V, H/2, W/2, 256]: 2x2 max-pool of the block's INPUT (for the hourglass level whose
+                          // input no fused producer has pooled: its skip values pass through the epilogue anyway)
     const void* wstream;  // br_nstage(CIN, DS) x BR_STAGE_BYTES: pre-swizzled stage images (bt_ring_pack_kernel)
     const float* b1;      // [128] (bn2 folded)
     const float* b2;      // [128] (bn3 folded)

@@ -343,6 +343,18 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
                 const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n;
                 reinterpret_cast<float*>(outp)[po] = acc[i][r];
             }
+            if constexpr (!UP) if (p.pool_in) {   // 2x2 max-pool of the block's INPUT (the skip values just added), same in-lane geometry as below (the engine asks for it on plain blocks only)
+                float* const pp = reinterpret_cast<float*>(p.pool_in) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN;
+#pragma unroll
+                for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        const int r0 = 2 * a2 + 4 * b2;
+                        const float v = fmaxf(fmaxf(xv[r0], xv[r0 + 1]), fmaxf(xv[r0 + 8], xv[r0 + 9]));
+                        const int ppx = a2 + 4 * b2 + 2 * half;
+                        pp[((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + ppx)) * CIN + n] = v;
+                    }
+            }
             if (p.pool) {
                 // 2x2 max-pool inside the lane: horizontal neighbour = register r^1, vertical neighbour = r^8
                 float* const pp = reinterpret_cast<float*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;

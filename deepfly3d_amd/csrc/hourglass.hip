@@ -48,7 +48,7 @@ struct Step {
     int pool_out = -1;                // ST_BOTTLENECK: tensor receiving the fused 2x2 max-pool of `out`
     int in2 = -1;                     // ST_BOTTLENECK: low-resolution addend of the input (fused upsample + add)
     long long wstream = -1;           // ST_BOTTLENECK, bf16 256 -> 128 -> 128 -> 256: byte offset of its weight stream behind the bf16 blob
-    int pool_in = -1;                 // ST_BOTTLENECK (bf16 ring kernel): tensor receiving the 2x2 max-pool of the block's INPUT
+    int pool_in = -1;                 // ST_BOTTLENECK (ring kernels): tensor receiving the 2x2 max-pool of the block's INPUT
     long long wstream2 = -1;          // ST_HEAD (bf16, not last): byte offset of the phase-C weight stream
     bool l1 = false;                  // ST_BOTTLENECK, bf16 64 -> 64 -> 64 -> 128: hg_bt_l1.h (wstream = its LDS weight image)
     bool pool_only = false;           // ... whose full-resolution output nobody reads: `out` IS the pooled tensor
@@ -237,7 +237,7 @@ struct df3d_hg {
             if (ring && cin == 256 && planes == 128) {   // weights through the LDS-DMA ring (hg_bt_ring.h, hg_bt_ring_f32.h)
                 st.wstream = (long long)stream_bytes;
                 stream_bytes += (size_t)(dtype == DF3D_DTYPE_BF16 ? BR_NSTAGE : BRF_NSTAGE) * BR_STAGE_BYTES;
-                if (pool_input && dtype == DF3D_DTYPE_BF16 && x2 < 0 && pooled_of[x] < 0) {
+                if (pool_input && x2 < 0 && pooled_of[x] < 0) {
                     st.pool_in = new_tensor(tx.h / 2, tx.w / 2, cin);
                     pooled_of[x] = st.pool_in;
                     elems_per_view += (double)tx.h * tx.w * cin * 1.25;  // model M1 still counts the pooling pass

@@ -88,9 +88,9 @@ def test_engine_plan_accounting(native_lib):
         assert abs(fl.value / 1e9 - 35.9934) < 1e-3
         assert abs(by.value / 1e6 - mb) < 0.05
         # 25 fused bottlenecks, 2 fused heads, 8 max-pools folded into bottleneck epilogues, 8 upsample + add passes
-        # folded into the consuming bottlenecks (the M1 byte model above still counts them); bf16: the ninth max-pool (input of
-        # the second stack) is written by the ring bottleneck that reads that tensor
-        assert native_lib.df3d_hg_num_steps(h) == 119 - 2 * 23 - 6 - 4 - 8 - 8 - (1 if dtype == _native.DF3D_DTYPE_BF16 else 0)
+        # folded into the consuming bottlenecks (the M1 byte model above still counts them), the ninth max-pool (input of the
+        # second stack) written by the ring bottleneck that reads that tensor
+        assert native_lib.df3d_hg_num_steps(h) == 119 - 2 * 23 - 6 - 4 - 8 - 8 - 1
         assert native_lib.df3d_hg_set_option(h, b"fuse", 0) == 0 and native_lib.df3d_hg_num_steps(h) == 119
         native_lib.df3d_hg_destroy(h)
 
