@@ -293,3 +293,28 @@ def test_resident_weight_layer1_is_bit_identical(native_lib, cuda, oracle_net, h
     assert torch.equal(first, off.forward(img))
     for _ in range(3):
         assert torch.equal(on.forward(img), first)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_repeated_forwards_are_bit_stable_under_concurrent_load(native_lib, cuda, dtype):
+    """The weight rings rely on COUNTED vector-memory waits (csrc/hg_bt_ring.h, hg_head.h): a wrong count would show up as a
+    rare, timing-dependent difference.  Repeat forwards at several batch sizes while a second engine keeps the memory system
+    busy on another stream: every repeat must reproduce the first heat-maps bit for bit (scripts/stress_determinism.py is
+    the longer form)."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    sd = synthetic_state_dict(0)
+    eng = HourglassEngine(sd, dtype=dtype, device=cuda)
+    other = HourglassEngine(sd, dtype="f32" if dtype == "bf16" else "bf16", device=cuda)
+    side = torch.cuda.Stream()
+    noise = torch.rand((14, 256, 512, 3), device=cuda)
+    for n in (1, 7, 35):
+        img = torch.rand((n, 256, 512, 3), generator=torch.Generator().manual_seed(n), dtype=torch.float32).to(cuda)
+        ref = eng.forward(img).clone()
+        for _ in range(8):
+            with torch.cuda.stream(side):
+                other.forward(noise)
+            assert torch.equal(eng.forward(img), ref)
+    torch.cuda.synchronize()
