@@ -74,7 +74,7 @@ struct HeadCfg {
     static constexpr int SLICE_PITCH = 64 * 2 + 16;                  // ... and, behind it, one 32 px x 64 ch epilogue slice per wave
     static constexpr int RING_BYTES = EB == 2 ? RING_SLOTS * 8192 + 4 * 32 * SLICE_PITCH : 0;
     static constexpr int STAGE_BYTES = S2 > RING_BYTES ? S2 : RING_BYTES;
-    static constexpr int MISC = (256 + 32) * 4;
+    static constexpr int MISC = (256 + 32 + 256) * 4;                // bfc | bsc | bfc_ + bsc_
     static constexpr int LDS_BYTES = STAGE_BYTES + MISC;
 };
 
@@ -91,8 +91,10 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const long long m0 = (long long)blockIdx.x * 128;
+    float* const bout_lds = bsc_lds + 32;   // not LAST: bfc_ + bsc_ (the sum the epilogue adds), staged once instead of 32 global loads per pass
     bfc_lds[tid] = p.bfc[tid];
     if (tid < 32) bsc_lds[tid] = p.bsc[tid];
+    if constexpr (!LAST) bout_lds[tid] = p.bfc_[tid] + p.bsc_[tid];
 
     // ================= phase A: y^T = Wfc r^T ==========================================================
     f32x16 y[8];
@@ -386,13 +388,12 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                             for (int q = 0; q < 4; ++q) {
                                 const int i = 2 * hc + ii;
                                 const int n = nh * 128 + 32 * i + 8 * q + 4 * half;
-                                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bfc_ + n);
-                                const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bsc_ + n);
+                                const f32x4 bb = *reinterpret_cast<const f32x4*>(bout_lds + n);   // bfc_ + bsc_
                                 const uint2 xx = xv[4 * ii + q];
                                 const float x0 = bf16_bits_to_f32((unsigned short)(xx.x & 0xffffu)), x1 = bf16_bits_to_f32((unsigned short)(xx.x >> 16));
                                 const float x2 = bf16_bits_to_f32((unsigned short)(xx.y & 0xffffu)), x3 = bf16_bits_to_f32((unsigned short)(xx.y >> 16));
-                                const float v0 = acc[i][4 * q + 0] + (b1[0] + b2[0]) + x0, v1 = acc[i][4 * q + 1] + (b1[1] + b2[1]) + x1;
-                                const float v2 = acc[i][4 * q + 2] + (b1[2] + b2[2]) + x2, v3 = acc[i][4 * q + 3] + (b1[3] + b2[3]) + x3;
+                                const float v0 = acc[i][4 * q + 0] + bb[0] + x0, v1 = acc[i][4 * q + 1] + bb[1] + x1;
+                                const float v2 = acc[i][4 * q + 2] + bb[2] + x2, v3 = acc[i][4 * q + 3] + bb[3] + x3;
                                 uint2 o;
                                 o.x = (unsigned)f32_to_bf16_bits(v0) | ((unsigned)f32_to_bf16_bits(v1) << 16);
                                 o.y = (unsigned)f32_to_bf16_bits(v2) | ((unsigned)f32_to_bf16_bits(v3) << 16);
@@ -515,13 +516,12 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                         for (int q = 0; q < 4; ++q) {
                             const int i = 2 * hc + ii;
                             const int n = nh * CH + 32 * i + 8 * q + 4 * half;
-                            const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bfc_ + n);
-                            const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bsc_ + n);
+                            const f32x4 bb = *reinterpret_cast<const f32x4*>(bout_lds + n);   // bfc_ + bsc_
                             const uint2 xx = xv[4 * ii + q];
                             const float x0 = bf16_bits_to_f32((unsigned short)(xx.x & 0xffffu)), x1 = bf16_bits_to_f32((unsigned short)(xx.x >> 16));
                             const float x2 = bf16_bits_to_f32((unsigned short)(xx.y & 0xffffu)), x3 = bf16_bits_to_f32((unsigned short)(xx.y >> 16));
-                            const float v0 = acc[i][4 * q + 0] + (b1[0] + b2[0]) + x0, v1 = acc[i][4 * q + 1] + (b1[1] + b2[1]) + x1;
-                            const float v2 = acc[i][4 * q + 2] + (b1[2] + b2[2]) + x2, v3 = acc[i][4 * q + 3] + (b1[3] + b2[3]) + x3;
+                            const float v0 = acc[i][4 * q + 0] + bb[0] + x0, v1 = acc[i][4 * q + 1] + bb[1] + x1;
+                            const float v2 = acc[i][4 * q + 2] + bb[2] + x2, v3 = acc[i][4 * q + 3] + bb[3] + x3;
                             uint2 o;
                             o.x = (unsigned)f32_to_bf16_bits(v0) | ((unsigned)f32_to_bf16_bits(v1) << 16);
                             o.y = (unsigned)f32_to_bf16_bits(v2) | ((unsigned)f32_to_bf16_bits(v3) << 16);
