@@ -432,12 +432,26 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(StemArgs p) {
         reinterpret_cast<u32x4*>(wl)[i] = reinterpret_cast<const u32x4*>(p.w_bf16)[i];
     const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
     const float* img = p.img + (size_t)view * p.H * p.W * 3;
-    for (int i = tid; i < PR * PROW + 64; i += 256) {
-        const int r = i / PROW, cc = i % PROW;
-        const int y = iy0 + r, x = ix0 + cc / 3;
-        float v = 0.0f;
-        if (r < PR && cc < PC * 3 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) v = img[((size_t)y * p.W + x) * 3 + cc % 3];
-        patch[i] = f32_to_bf16_bits(v);
+    // one item = one patch pixel (three contiguous floats): the index arithmetic and the bounds test are per pixel, not per value
+    for (int i = tid; i < PR * PC; i += 256) {
+        const int r = i / PC, pxl = i - r * PC;
+        const int y = iy0 + r, x = ix0 + pxl;
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+            const float* const src = img + ((size_t)y * p.W + x) * 3;
+            v0 = src[0];
+            v1 = src[1];
+            v2 = src[2];
+        }
+        unsigned short* const dst = patch + r * PROW + 3 * pxl;
+        dst[0] = f32_to_bf16_bits(v0);
+        dst[1] = f32_to_bf16_bits(v1);
+        dst[2] = f32_to_bf16_bits(v2);
+    }
+    // the pad cells behind the 111 values of a row and behind the last row (read by the last K slots against zero weights) are zero
+    for (int i = tid; i < PR * (PROW - PC * 3) + 64; i += 256) {
+        const int r = i / (PROW - PC * 3), c = i - r * (PROW - PC * 3);
+        patch[i < PR * (PROW - PC * 3) ? r * PROW + PC * 3 + c : PR * PROW + (i - PR * (PROW - PC * 3))] = 0;
     }
     __syncthreads();
 
