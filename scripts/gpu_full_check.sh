@@ -2,7 +2,7 @@
 # full -m gpu suite + smoke + both bench legs
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/r02f
+OUT=$R/gpurun_out/full_check
 mkdir -p "$OUT"
 cd "$R"
 timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest.log"

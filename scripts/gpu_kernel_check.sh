@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/r02g
+OUT=$R/gpurun_out/kernel_check
 mkdir -p "$OUT"
 cd "$R"
 timeout 600 python -m pytest tests/test_gpu_hourglass.py -m gpu -x -q -k "${K:-layer1}" > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest.log"
