@@ -360,14 +360,23 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
         reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
     const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
     const float* img = p.img + (size_t)view * p.H * p.W * 3;
-    for (int i = tid; i < PR * PROW; i += 256) {
-        const int r = i / PROW, cc = i % PROW;
-        const int y = iy0 + r, x = ix0 + cc / 3;
-        float v = 0.0f;
-        if (cc < PC * 3 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
-            v = img[((size_t)y * p.W + x) * 3 + cc % 3];
-        patch[i] = v;
+    // one item = one patch pixel (three contiguous floats): index arithmetic and bounds test per pixel, not per value
+    for (int i = tid; i < PR * PC; i += 256) {
+        const int r = i / PC, pxl = i - r * PC;
+        const int y = iy0 + r, x = ix0 + pxl;
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+            const float* const src = img + ((size_t)y * p.W + x) * 3;
+            v0 = src[0];
+            v1 = src[1];
+            v2 = src[2];
+        }
+        float* const dst = patch + r * PROW + 3 * pxl;
+        dst[0] = v0;
+        dst[1] = v1;
+        dst[2] = v2;
     }
+    if (tid < PR) patch[tid * PROW + PC * 3] = 0.0f;   // the pad cell behind the 111 values of a row
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6;
