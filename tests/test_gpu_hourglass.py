@@ -319,3 +319,20 @@ def test_repeated_forwards_are_bit_stable_under_concurrent_load(native_lib, cuda
                 other.forward(noise)
             assert torch.equal(eng.forward(img), ref)
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("height,width,n", [(64, 64, 1), (128, 64, 2), (64, 512, 1), (192, 128, 3), (64, 64, 9)])
+def test_default_kernels_match_the_register_staged_kernels_on_small_and_odd_shapes(native_lib, cuda, height, width, n, dtype):
+    """Everything round 2 added to the default plan (weight rings in the bottlenecks and heads, the LDS-resident layer1 kernel,
+    pooled-input side outputs, persistent workgroups with fewer tiles than compute units) against the round-1 kernels
+    (`ring=0, l1=0`): bit-identical heat-maps on the smallest legal images, non-square shapes and tile counts below eight."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    sd = synthetic_state_dict(0)
+    img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(7 * height + width), dtype=torch.float32).to(cuda)
+    new = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width)
+    old = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, ring=False, l1=False)
+    assert torch.equal(new.forward(img), old.forward(img))
