@@ -378,7 +378,7 @@ struct df3d_hg {
             free_tensor(y);
             if (ylo >= 0) free_tensor(ylo);
             if (fuse) {
-                // fc -> score -> (fc_, score_) + x in one kernel (hg_kernels.h: head_kernel)
+                // fc -> score -> (fc_, score_) + x in one kernel (hg_head.h: head_kernel)
                 const bool last = s == num_stacks - 1;
                 const int kp = dtype == DF3D_DTYPE_BF16 ? 1 : 0;
                 const TensorDesc tr = tensors[r];
