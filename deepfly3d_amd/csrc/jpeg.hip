@@ -273,27 +273,38 @@ __global__ __launch_bounds__(PT) void jpeg_parse_kernel(const unsigned char* __r
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned rfl(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
-template <int LB>
+template <int LB, int NTAB = 8>
 struct HuffLds {
-    unsigned short lut[8][1 << LB];  // (len << 8) | symbol, 0 = code longer than LB bits (or invalid)
-    unsigned limit[8][18];           // (maxcode[l] + 1) << (16 - l): left-justified 16-bit compare; [17] = 65536
-    int valoff[8][17];               // valptr[l] - mincode[l]
-    unsigned char vals[8][256];
+    unsigned short lut[NTAB][1 << LB];  // (len << 8) | symbol, 0 = code longer than LB bits (or invalid)
+    unsigned limit[NTAB][18];           // (maxcode[l] + 1) << (16 - l): left-justified 16-bit compare; [17] = 65536
+    int valoff[NTAB][17];               // valptr[l] - mincode[l]
+    unsigned char vals[NTAB][256];
 };
 
-// Build every present table; all NT threads of the workgroup call this.  Returns non-zero for an invalid table or
-// when a table a component refers to is missing.
-template <int LB, int NT>
-__device__ int build_tables(const Meta* M, HuffLds<LB>& T, int tid) {
+// Table slot (tc * 4 + th) -> row of a HuffLds: the identity, or the compact numbering of the tables a scan refers to
+struct SlotMap {
+    int row[8];
+};
+
+// Build every present table that has a row; all NT threads of the workgroup call this.  Returns non-zero for an invalid
+// table or when a table a component refers to is missing.
+template <int LB, int NT, int NTAB>
+__device__ int build_tables(const Meta* M, HuffLds<LB, NTAB>& T, const SlotMap& map, int tid) {
     int bad = 0;
-    for (int t = 0; t < 8; ++t) {
-        if (!rfl(M->dht_present[t])) continue;
+    const int lane = tid & 63;
+    // the descriptor's small fields through one load per wave each (lane l holds entry l), not one dependent load per entry
+    const unsigned present = lane < 8 ? M->dht_present[lane] : 0u;
+    for (int slot = 0; slot < 8; ++slot) {
+        const int t = map.row[slot];
+        if (t < 0 || !__builtin_amdgcn_readlane((int)present, slot)) continue;
+        const unsigned counts = lane < 16 ? M->dht_counts[slot][lane] : 0u;
         for (int i = tid; i < (1 << LB); i += NT) T.lut[t][i] = 0;
-        for (int i = tid; i < 256; i += NT) T.vals[t][i] = M->dht_vals[t][i];
+        for (int i = tid; i < 256; i += NT) T.vals[t][i] = M->dht_vals[slot][i];
         __syncthreads();
         int code = 0, k = 0;
+#pragma unroll
         for (int l = 1; l <= 16; ++l) {
-            const int c = (int)rfl(M->dht_counts[t][l - 1]);
+            const int c = __builtin_amdgcn_readlane((int)counts, l - 1);
             if (tid == 0) T.valoff[t][l] = k - code;
             // an over-subscribed length (untrusted DHT) would index past the 2^LB-entry table: flag it BEFORE the fill
             const bool fits = code + c <= (1 << l) && k + c <= 256;
@@ -301,7 +312,7 @@ __device__ int build_tables(const Meta* M, HuffLds<LB>& T, int tid) {
             if (l <= LB && fits) {  // symbols k .. k+c-1 have the codes code .. code+c-1 of length l
                 const int span = 1 << (LB - l);
                 for (int e = tid; e < c * span; e += NT) {
-                    const int j = e / span;
+                    const int j = e >> (LB - l);
                     T.lut[t][((code + j) << (LB - l)) + (e - j * span)] = (unsigned short)((l << 8) | T.vals[t][(k + j) & 255]);
                 }
             }
@@ -340,149 +351,197 @@ constexpr int PNT = 256;
 constexpr int MAX_PASSES = 32;  // a pass costs ~0.25 ms, the sequential fall-back ~40 ms per 70 KB file
 constexpr unsigned MIN_CHUNK = 2048;
 
+constexpr int PTAB = 4;  // rows of the parallel decoder's tables: the tables one scan refers to (more: sequential kernel)
+using HuffPar = HuffLds<PLB, PTAB>;
+
 struct ParCtx {
     const unsigned* words;    // un-stuffed stream as dwords: global memory (raw byte order) or LDS (already byte-swapped)
     unsigned nwords;
     int nbm;                  // blocks per MCU
-    int td[4], ta[4];
+    int td[4], ta[4];         // table ROW (of HuffPar) per component
     unsigned total_y;
 };
 
-// IN_LDS: the whole stream sits byte-swapped in LDS and the 64-bit window is read afresh for every symbol.
-// Otherwise three dwords are kept in registers and the next one is fetched from global memory on a word crossing.
-template <bool IN_LDS>
-struct LaneBits {
-    unsigned wi, w0, w1, w2;
-    __device__ __forceinline__ static unsigned ld(const ParCtx& cx, unsigned i) { return i < cx.nwords ? __builtin_bswap32(cx.words[i]) : 0u; }
-    __device__ __forceinline__ void seek(const ParCtx& cx, unsigned p) {
-        if (IN_LDS) return;
-        wi = p >> 5;
-        w0 = ld(cx, wi);
-        w1 = ld(cx, wi + 1);
-        w2 = ld(cx, wi + 2);
-    }
-    __device__ __forceinline__ unsigned window(const ParCtx& cx, unsigned p) const {  // the 32 bits starting at bit p
-        unsigned a = w0, b = w1;
-        if (IN_LDS) {
-            a = cx.words[p >> 5];
-            b = cx.words[(p >> 5) + 1];
-        }
-        const unsigned sh = p & 31u;
-        return sh ? __builtin_amdgcn_alignbit(a, b, 32u - sh) : a;
-    }
-    __device__ __forceinline__ void advance(const ParCtx& cx, unsigned p) {  // p moved by < 32 bits
-        if (IN_LDS) return;
-        if ((p >> 5) != wi) {
-            ++wi;
-            w0 = w1;
-            w1 = w2;
-            w2 = ld(cx, wi + 2);
-        }
-    }
-};
+// Stream access without memory latency on the per-symbol dependency chain: the wave walks its lanes' chunks in lockstep,
+// one 64-bit unit (dwords q, q+1 of the lane's own chunk) per outer step.  c0 c1 c2 hold dwords q .. q+2 (big-endian bit
+// order; c2 serves windows that start in q+1), n0 n1 the raw dwords q+3, q+4, loaded one outer step before they are needed.
+// Inside a step every lane decodes symbols until its bit position leaves the unit; the step ends when the slowest lane has.
+__device__ __forceinline__ unsigned stream_dword(const ParCtx& cx, unsigned i) { return cx.words[min(i, cx.nwords - 1u)]; }  // tail: zero padding
 
-// blk[b] (LDS): for block b of the MCU  bits 0-2 = DC table slot, bits 3-5 = AC table slot, bit 7 = luma component
-template <bool WRITE, bool IN_LDS>
-__device__ void decode_chunk(const ParCtx& cx, const HuffLds<PLB>& T, const unsigned char* zz, const unsigned char* blk, unsigned& p,
-                             int& k, int& b, unsigned end, unsigned& ycount, int& err, unsigned ybase, short* __restrict__ cbase) {
-    LaneBits<IN_LDS> lb;
-    lb.seek(cx, p);
-    ycount = 0;
-    err = 0;
-    while (true) {
-        const bool active = p < end;
-        if (!__any(active)) break;
-        if (active) {
-            const unsigned win = lb.window(cx, p);
-            const bool isdc = k == 0;
-            const unsigned sel = blk[b];
-            const int t = (int)(isdc ? (sel & 7u) : ((sel >> 3) & 7u));
-            const bool luma = (sel & 0x80u) != 0;
-            unsigned e = T.lut[t][win >> (32 - PLB)];
-            bool invalid = false;
-            if (e == 0) {  // longer than PLB bits: canonical search over the 5 remaining lengths, loads issued together
-                const unsigned p16 = win >> 16;
-                const unsigned l12 = T.limit[t][12], l13 = T.limit[t][13], l14 = T.limit[t][14], l15 = T.limit[t][15], l16 = T.limit[t][16];
-                const int l = 12 + (p16 >= l12) + (p16 >= l13) + (p16 >= l14) + (p16 >= l15) + (p16 >= l16);
-                if (l <= 16) {
-                    e = ((unsigned)l << 8) | T.vals[t][(T.valoff[t][l] + (int)(p16 >> (16 - l))) & 255];
-                } else {
-                    e = (16u << 8);  // invalid code: keep moving
-                    invalid = true;
-                }
-            }
-            const int len = (int)(e >> 8), sym = (int)(e & 255u);
-            const int size = isdc ? (sym > 15 ? 15 : sym) : (sym & 15);
-            const int run = isdc ? 0 : (sym >> 4);
-            const unsigned rest = win << len;
-            const unsigned bits = size ? rest >> (32 - size) : 0u;
-            const int val = size ? ((int)bits < (1 << (size - 1)) ? (int)bits - (1 << size) + 1 : (int)bits) : 0;
-            const int kk = k + run;  // coefficient this symbol sets (when size > 0)
-            if (WRITE) {
-                const unsigned j = ybase + ycount;  // luma blocks finished before this symbol
-                if (j < cx.total_y) {               // still inside the image (behind it: marker bytes and padding)
-                    if (invalid || (isdc ? sym > 11 : (size > 0 && kk > 63))) err = 1;
-                    if (luma && (isdc || size > 0) && kk <= 63) cbase[(long long)j * 64 + zz[kk]] = (short)val;
-                }
-            }
-            const int knext = isdc ? 1 : (sym == 0 ? 64 : kk + 1);
-            if (knext >= 64) {
-                ycount += luma ? 1u : 0u;
-                b = b + 1 == cx.nbm ? 0 : b + 1;
-                k = 0;
-            } else {
-                k = knext;
-            }
-            p += (unsigned)(len + size);
-            lb.advance(cx, p);
+// DC look-up entries of the parallel decoder: low byte = min(symbol, 15) (the number of difference bits; > 11 is invalid) and,
+// when the component's end-of-block code follows the difference bits inside the look-up window, bit 7 set and bits 4-6 = the
+// length of that code - 1.  A flat block (DC difference + EOB: most blocks of a dark camera frame, and the lanes that walk
+// them set the pace of their wave) then costs one step instead of two.  A DC table shared by components with different AC
+// tables is only normalised.
+__device__ void fuse_dc_eob(HuffPar& T, const ParCtx& cx, int ncomp, int tid, unsigned* s_min) {
+    for (int d = 0; d < 4; ++d) {
+        int a = -1;
+        bool used = false, same = true;
+        for (int c = 0; c < ncomp; ++c) {
+            if (cx.td[c] != d) continue;
+            if (used && cx.ta[c] != a) same = false;
+            a = cx.ta[c];
+            used = true;
         }
+        if (!used) continue;
+        if (tid == 0) *s_min = 0xffffffffu;
+        __syncthreads();
+        if (same) {
+            for (int j = tid; j < (1 << PLB); j += PNT) {
+                const unsigned e = T.lut[a][j];
+                if (e != 0 && (e & 255u) == 0) atomicMin(s_min, (unsigned)j);
+            }
+        }
+        __syncthreads();
+        const unsigned jmin = *s_min;
+        const bool have = jmin != 0xffffffffu;
+        const int eobl = have ? (int)(T.lut[a][jmin] >> 8) : 0;
+        const unsigned code = have ? jmin >> (PLB - eobl) : 0u;
+        for (int i = tid; i < (1 << PLB); i += PNT) {
+            const unsigned e = T.lut[d][i];
+            if (e == 0) continue;
+            const int len = (int)(e >> 8), sym = (int)(e & 255u), sz = sym > 15 ? 15 : sym;
+            unsigned low = (unsigned)sz;
+            if (have && eobl <= 8 && sym <= 11 && len + sz + eobl <= PLB && (((unsigned)i >> (PLB - len - sz - eobl)) & ((1u << eobl) - 1u)) == code)
+                low |= 0x80u | ((unsigned)(eobl - 1) << 4);
+            T.lut[d][i] = (unsigned short)((len << 8) | low);
+        }
+        __syncthreads();
     }
 }
 
-template <bool IN_LDS>
+// blk_lo / blk_hi (wave-uniform): byte b = block b of the MCU: bits 0-2 = DC table slot, bits 3-5 = AC table slot,
+// bit 7 = luma component.  `run` = false: the lane keeps its state untouched (its start state did not change).
+template <bool WRITE>
+__device__ void decode_chunk(const ParCtx& cx, const HuffPar& T, const unsigned char* zz, unsigned long long blk_lo, unsigned long long blk_hi,
+                             bool run, unsigned& p, int& k, int& b, unsigned end, unsigned& ycount, int& err, unsigned ybase, short* __restrict__ cbase) {
+    if (!run) end = 0;
+    if (run) {
+        ycount = 0;
+        err = 0;
+    }
+    unsigned q = p >> 5;
+    unsigned c0 = __builtin_bswap32(stream_dword(cx, q)), c1 = __builtin_bswap32(stream_dword(cx, q + 1)), c2 = __builtin_bswap32(stream_dword(cx, q + 2));
+    unsigned n0 = stream_dword(cx, q + 3), n1 = stream_dword(cx, q + 4);
+    const unsigned short* lut = &T.lut[0][0];
+    while (__any(p < end)) {
+        const unsigned lim = min(end, (q + 2u) << 5);
+        while (true) {
+            const bool active = p < lim;
+            if (!__any(active)) break;
+            if (active) {
+                const bool first = (p >> 5) == q;
+                const unsigned win = __builtin_elementwise_fshl(first ? c0 : c1, first ? c1 : c2, p & 31u);  // the 32 bits starting at bit p
+                const bool isdc = k == 0;
+                const unsigned sel = (unsigned)((b < 8 ? blk_lo : blk_hi) >> ((b & 7) * 8));
+                const unsigned t = isdc ? (sel & 7u) : ((sel >> 3) & 7u);
+                const bool luma = (sel & 0x80u) != 0;
+                unsigned e = lut[(t << PLB) + (win >> (32 - PLB))];
+                bool invalid = false;
+                if (e == 0) {  // longer than PLB bits: canonical search over the 5 remaining lengths, loads issued together
+                    const unsigned p16 = win >> 16;
+                    const unsigned l12 = T.limit[t][12], l13 = T.limit[t][13], l14 = T.limit[t][14], l15 = T.limit[t][15], l16 = T.limit[t][16];
+                    const int l = 12 + (p16 >= l12) + (p16 >= l13) + (p16 >= l14) + (p16 >= l15) + (p16 >= l16);
+                    if (l <= 16) {
+                        const unsigned v = T.vals[t][(T.valoff[t][l] + (int)(p16 >> (16 - l))) & 255];
+                        e = ((unsigned)l << 8) | (isdc ? min(v, 15u) : v);
+                    } else {
+                        e = (16u << 8);  // invalid code: keep moving
+                        invalid = true;
+                    }
+                }
+                const int len = (int)(e >> 8), sym = (int)(e & 255u);
+                const int size = sym & 15;  // DC entries hold min(symbol, 15) there (fuse_dc_eob)
+                const int run_len = isdc ? 0 : (sym >> 4);
+                const bool fused = isdc && (sym & 0x80);  // the block's EOB code sits right behind the DC difference
+                const int eob_len = fused ? ((sym >> 4) & 7) + 1 : 0;
+                const int kk = k + run_len;  // coefficient this symbol sets (when size > 0)
+                if (WRITE) {
+                    const unsigned rest = win << len;
+                    const unsigned bits = size ? rest >> (32 - size) : 0u;
+                    const int val = size ? ((int)bits < (1 << (size - 1)) ? (int)bits - (1 << size) + 1 : (int)bits) : 0;
+                    const unsigned j = ybase + ycount;  // luma blocks finished before this symbol
+                    if (j < cx.total_y) {               // still inside the image (behind it: marker bytes and padding)
+                        if (invalid || (isdc ? size > 11 : (size > 0 && kk > 63))) err = 1;
+                        if (luma && (isdc || size > 0) && kk <= 63) cbase[(long long)j * 64 + zz[kk]] = (short)val;
+                    }
+                }
+                const int knext = isdc ? (fused ? 64 : 1) : (sym == 0 ? 64 : kk + 1);
+                if (knext >= 64) {
+                    ycount += luma ? 1u : 0u;
+                    b = b + 1 == cx.nbm ? 0 : b + 1;
+                    k = 0;
+                } else {
+                    k = knext;
+                }
+                p += (unsigned)(len + size + eob_len);  // < 32 bits: the position ends inside dword q + 2 at most
+            }
+        }
+        q += 2;
+        c0 = c2;
+        c1 = __builtin_bswap32(n0);
+        c2 = __builtin_bswap32(n1);
+        n0 = stream_dword(cx, q + 3);
+        n1 = stream_dword(cx, q + 4);
+    }
+}
+
 __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict__ metas, const unsigned* __restrict__ offsets,
                                                                const unsigned char* __restrict__ clean, short* __restrict__ coef,
-                                                               long long coef_stride, unsigned lds_words) {
-    extern __shared__ unsigned s_stream[];  // IN_LDS: the file's un-stuffed stream, byte-swapped dwords
-    __shared__ HuffLds<PLB> T;
+                                                               long long coef_stride) {
+    __shared__ HuffPar T;
     __shared__ unsigned s_p[PNT + 1];
     __shared__ unsigned s_kb[PNT + 1];
     __shared__ unsigned s_cnt[PNT];
     __shared__ int s_dc[PNT];
     __shared__ unsigned char s_zz[64];
-    __shared__ unsigned char s_blk[16];
     __shared__ int s_flag;
+    __shared__ unsigned s_ep[PNT], s_ekb[PNT];  // end state per chunk
+    __shared__ unsigned short s_list[PNT];
+    __shared__ unsigned s_wcnt[PNT / 64];
     const int img = blockIdx.x, tid = threadIdx.x;
     Meta* M = metas + img;
     if (tid == 0) M->par_done = 0;
     if (rfl((unsigned)M->status) != ST_OK) return;
     if (rfl((unsigned)M->restart_interval) != 0) return;  // restart markers sit inside the stream: sequential kernel
-    if (build_tables<PLB, PNT>(M, T, tid)) return;         // the sequential kernel reports the error
+    ParCtx cx;
+    const int ncomp = (int)rfl((unsigned)M->ncomp);
+    int nb[4] = {0, 0, 0, 0};
+    SlotMap map;
+    for (int i = 0; i < 8; ++i) map.row[i] = -1;
+    int rows = 0;
+    for (int c = 0; c < 4; ++c) {
+        if (c < ncomp) nb[c] = (int)rfl((unsigned)M->comp_h[c]) * (int)rfl((unsigned)M->comp_v[c]);
+        const int sd = (int)rfl((unsigned)M->comp_td[c]) & 3, sa = 4 + ((int)rfl((unsigned)M->comp_ta[c]) & 3);
+        if (c < ncomp) {
+            for (int i = 0; i < 8; ++i) {  // (static indexing keeps the map in scalar registers)
+                if ((i == sd || i == sa) && map.row[i] < 0) map.row[i] = rows++;
+            }
+        }
+        cx.td[c] = cx.ta[c] = 0;
+        for (int i = 0; i < 8; ++i) {
+            if (i == sd) cx.td[c] = map.row[i];
+            if (i == sa) cx.ta[c] = map.row[i];
+        }
+    }
+    if (rows > PTAB) return;                                     // more tables than rows: sequential kernel
+    if (build_tables<PLB, PNT, PTAB>(M, T, map, tid)) return;   // the sequential kernel reports the error
     if (tid < 64) s_zz[tid] = ZIGZAG[tid];
 
-    ParCtx cx;
     const unsigned clean_len = rfl(M->clean_len);
     cx.words = reinterpret_cast<const unsigned*>(clean + rfl(offsets[img]));
     cx.nwords = (clean_len + 3) / 4 + 8;
-    if (IN_LDS) {
-        if (cx.nwords + 2 > lds_words) return;  // does not fit: sequential kernel
-        for (unsigned i = tid; i < cx.nwords + 2; i += PNT) s_stream[i] = i < cx.nwords ? __builtin_bswap32(cx.words[i]) : 0u;
-        cx.words = s_stream;
-    }
-    const int ncomp = (int)rfl((unsigned)M->ncomp);
-    int nb[4] = {0, 0, 0, 0};
-    for (int c = 0; c < 4; ++c) {
-        if (c < ncomp) nb[c] = (int)rfl((unsigned)M->comp_h[c]) * (int)rfl((unsigned)M->comp_v[c]);
-        cx.td[c] = (int)rfl((unsigned)M->comp_td[c]) & 3;
-        cx.ta[c] = 4 + ((int)rfl((unsigned)M->comp_ta[c]) & 3);
-    }
     cx.nbm = nb[0] + nb[1] + nb[2] + nb[3];
     if (cx.nbm > 16) return;  // beyond the standard's 10 blocks per MCU: sequential kernel
-    if (tid < 16) {
-        const int c = (tid >= nb[0]) + (tid >= nb[0] + nb[1]) + (tid >= nb[0] + nb[1] + nb[2]);
+    fuse_dc_eob(T, cx, ncomp, tid, &s_wcnt[0]);
+    unsigned long long blk_lo = 0, blk_hi = 0;  // wave-uniform: one byte per block of the MCU
+    for (int i = 0; i < 16; ++i) {
+        const int c = (i >= nb[0]) + (i >= nb[0] + nb[1]) + (i >= nb[0] + nb[1] + nb[2]);
         const int tdc = c == 0 ? cx.td[0] : (c == 1 ? cx.td[1] : (c == 2 ? cx.td[2] : cx.td[3]));
         const int tac = c == 0 ? cx.ta[0] : (c == 1 ? cx.ta[1] : (c == 2 ? cx.ta[2] : cx.ta[3]));
-        s_blk[tid] = (unsigned char)(tdc | (tac << 3) | (c == 0 ? 0x80 : 0));
+        const unsigned long long v = (unsigned long long)(tdc | (tac << 3) | (c == 0 ? 0x80 : 0));
+        if (i < 8) blk_lo |= v << (8 * i);
+        else blk_hi |= v << (8 * (i - 8));
     }
     const unsigned mcus = rfl((unsigned)M->mcus_x) * rfl((unsigned)M->mcus_y);
     cx.total_y = mcus * (unsigned)nb[0];
@@ -501,28 +560,55 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     s_kb[tid] = 0;
     __syncthreads();
 
-    unsigned p, ycount;
-    int k, b, err;
+    unsigned p = 0, ycount = 0;
+    int k = 0, b = 0, err = 0;
+    unsigned used_p = 0, used_kb = 0;  // the start state chunk tid was last decoded from
     bool converged = false;
     int passes = 0;
+    const int wave = tid >> 6, lane = tid & 63;
     for (int pass = 0; pass < MAX_PASSES; ++pass) {
         passes = pass + 1;
-        p = s_p[tid];
-        k = (int)(s_kb[tid] & 255u);
-        b = (int)(s_kb[tid] >> 8);
-        decode_chunk<false, IN_LDS>(cx, T, s_zz, s_blk, p, k, b, end, ycount, err, 0u, cbase);
+        // a chunk whose start state is the one it was decoded from in the previous pass would only repeat itself: the
+        // chunks that do need decoding are compacted (in order) onto the first lanes, so that late passes, which repair a
+        // handful of chunks, occupy one wave instead of four
+        const unsigned sp = s_p[tid], skb = s_kb[tid];
+        const bool redo = pass == 0 || sp != used_p || skb != used_kb;
+        used_p = sp;
+        used_kb = skb;
+        const unsigned long long m = __ballot(redo);
+        if (lane == 0) s_wcnt[wave] = (unsigned)__popcll(m);
         __syncthreads();
-        // lane tid's end state is lane tid+1's next start state
+        unsigned before = 0, n = 0;
+        for (int w = 0; w < PNT / 64; ++w) {
+            const unsigned c = s_wcnt[w];
+            before += w < wave ? c : 0u;
+            n += c;
+        }
+        if (redo) s_list[before + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+        __syncthreads();
+        const bool work = (unsigned)tid < n;
+        const unsigned c = work ? s_list[tid] : 0u;
+        const unsigned ckb = s_kb[c];
+        p = s_p[c];
+        k = (int)(ckb & 255u);
+        b = (int)(ckb >> 8);
+        decode_chunk<false>(cx, T, s_zz, blk_lo, blk_hi, work, p, k, b, min(c * chunk + chunk, total_bits), ycount, err, 0u, cbase);
+        if (work) {
+            s_ep[c] = p;
+            s_ekb[c] = (unsigned)k | ((unsigned)b << 8);
+            s_cnt[c] = ycount;
+        }
+        __syncthreads();
+        // chunk tid's end state is chunk tid+1's next start state
         int changed = 0;
         if (tid + 1 < PNT) {
-            const unsigned np = p, nkb = (unsigned)k | ((unsigned)b << 8);
-            // lanes whose chunk lies behind the stream decode nothing: their start state is irrelevant (and would
-            // otherwise ripple through the idle lanes one lane per pass)
+            const unsigned np = s_ep[tid], nkb = s_ekb[tid];
+            // chunks that lie behind the stream hold nothing: their start state is irrelevant (and would otherwise
+            // ripple through the idle chunks one per pass)
             changed = (nominal + chunk < total_bits) && ((s_p[tid + 1] != np) || (s_kb[tid + 1] != nkb));
             s_p[tid + 1] = np;
             s_kb[tid + 1] = nkb;
         }
-        s_cnt[tid] = ycount;
         if (!__syncthreads_or(changed)) {
             converged = pass > 0 || PNT == 1;
             if (pass > 0) break;
@@ -544,11 +630,12 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
         if (tid == 0) M->par_done = -2;
         return;
     }  // the stream ends early: sequential kernel (it feeds zeros like libjpeg's callers expect)
+    ycount = s_cnt[tid] - (tid ? s_cnt[tid - 1] : 0u);
     const unsigned ybase = s_cnt[tid] - ycount;
     p = s_p[tid];
     k = (int)(s_kb[tid] & 255u);
     b = (int)(s_kb[tid] >> 8);
-    decode_chunk<true, IN_LDS>(cx, T, s_zz, s_blk, p, k, b, end, ycount, err, ybase, cbase);
+    decode_chunk<true>(cx, T, s_zz, blk_lo, blk_hi, true, p, k, b, end, ycount, err, ybase, cbase);
     if (tid == 0) s_flag = 0;
     __threadfence_block();
     __syncthreads();
@@ -662,7 +749,9 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(Meta* __restrict__ met
     if (rfl((unsigned)M->status) != ST_OK) return;
     if ((int)rfl((unsigned)M->par_done) > 0) return;  // the parallel kernel finished this file
     const int ncomp = (int)rfl((unsigned)M->ncomp);
-    if (build_tables<LUT_BITS, 64>(M, T, lane)) {
+    SlotMap ident;
+    for (int i = 0; i < 8; ++i) ident.row[i] = i;
+    if (build_tables<LUT_BITS, 64, 8>(M, T, ident, lane)) {
         if (lane == 0) M->status = ST_CORRUPT;
         return;
     }
@@ -898,15 +987,7 @@ int df3d_jpeg_decode_luma(const unsigned char* files_dev, const unsigned* offset
     if (!(flags & 1)) {
         // the parallel decoder writes only non-zero coefficients
         DF3D_HIP(hipMemsetAsync(coef, 0, (size_t)n * cs * sizeof(short), s));
-        // stream in LDS when the largest file fits next to the tables (the un-stuffed stream is shorter than the file)
-        const size_t lds_cap = 112 * 1024;
-        const size_t want = ((size_t)max_file_bytes + 3) / 4 * 4 + 64;
-        if (max_file_bytes > 0 && want <= lds_cap) {
-            hipLaunchKernelGGL(jpg::jpeg_huffman_par_kernel<true>, dim3(n), dim3(jpg::PNT), want, s, metas, offsets_dev, clean, coef, cs,
-                               (unsigned)(want / 4));
-        } else {
-            hipLaunchKernelGGL(jpg::jpeg_huffman_par_kernel<false>, dim3(n), dim3(jpg::PNT), 0, s, metas, offsets_dev, clean, coef, cs, 0u);
-        }
+        hipLaunchKernelGGL(jpg::jpeg_huffman_par_kernel, dim3(n), dim3(jpg::PNT), 0, s, metas, offsets_dev, clean, coef, cs);
     }
     hipLaunchKernelGGL(jpg::jpeg_huffman_kernel, dim3(n), dim3(64), 0, s, metas, offsets_dev, clean, coef, cs);
     const int blocks = (int)(cs / 64);
