@@ -355,10 +355,12 @@ constexpr int PTAB = 4;  // rows of the parallel decoder's tables: the tables on
 using HuffPar = HuffLds<PLB, PTAB>;
 
 struct ParCtx {
-    const unsigned* words;    // un-stuffed stream as dwords: global memory (raw byte order) or LDS (already byte-swapped)
+    const unsigned* words;    // un-stuffed stream as dwords (global memory, raw byte order)
     unsigned nwords;
-    int nbm;                  // blocks per MCU
+    int nbm, nb0;             // blocks per MCU, luma blocks per MCU (they come first)
     int td[4], ta[4];         // table ROW (of HuffPar) per component
+    unsigned long long blk;   // 4 bits per block of the MCU: bits 0-1 = DC table row, bits 2-3 = AC table row
+    unsigned eobpack;         // byte r = length of the EOB code fused into DC row r's entries (0: none)
     unsigned total_y;
 };
 
@@ -368,58 +370,94 @@ struct ParCtx {
 // Inside a step every lane decodes symbols until its bit position leaves the unit; the step ends when the slowest lane has.
 __device__ __forceinline__ unsigned stream_dword(const ParCtx& cx, unsigned i) { return cx.words[min(i, cx.nwords - 1u)]; }  // tail: zero padding
 
-// DC look-up entries of the parallel decoder: low byte = min(symbol, 15) (the number of difference bits; > 11 is invalid) and,
-// when the component's end-of-block code follows the difference bits inside the look-up window, bit 7 set and bits 4-6 = the
-// length of that code - 1.  A flat block (DC difference + EOB: most blocks of a dark camera frame, and the lanes that walk
-// them set the pace of their wave) then costs one step instead of two.  A DC table shared by components with different AC
-// tables is only normalised.
-__device__ void fuse_dc_eob(HuffPar& T, const ParCtx& cx, int ncomp, int tid, unsigned* s_min) {
-    for (int d = 0; d < 4; ++d) {
-        int a = -1;
-        bool used = false, same = true;
-        for (int c = 0; c < ncomp; ++c) {
-            if (cx.td[c] != d) continue;
-            if (used && cx.ta[c] != a) same = false;
-            a = cx.ta[c];
-            used = true;
-        }
-        if (!used) continue;
+// Look-up entries of the parallel decoder, re-packed from build_tables' (len << 8 | symbol) into what one decode step needs:
+//   bits 0-4  bits the step consumes (code + value bits [+ a fused EOB code])      1 .. 31
+//   bits 5-8  number of value bits (DC: min(symbol, 15), > 11 is invalid)
+//   bits 9-15 what the step adds to the coefficient index k: run + 1, or 64 = the block ends here (EOB)
+// DC rows: when the component's EOB code follows the difference bits inside the look-up window the entry swallows it
+// (consumes both, ends the block).  A flat block (DC difference + EOB: most blocks of a dark camera frame, and the lanes that
+// walk them set the pace of their wave) then costs one step instead of two.  A DC table shared by components with different
+// AC tables is not fused.
+__device__ __forceinline__ unsigned pack_entry(unsigned adv, unsigned size, unsigned kd) { return adv | (size << 5) | (kd << 9); }
+
+__device__ void pack_entries(HuffPar& T, ParCtx& cx, int ncomp, int rows, unsigned dcrows, int tid, unsigned* s_min) {
+    unsigned eobl[PTAB], eobc[PTAB];
+    for (int a = 0; a < PTAB; ++a) {  // the EOB code of every AC row (symbol 0x00), while the rows are still unpacked
+        eobl[a] = eobc[a] = 0;
+        if (a >= rows || ((dcrows >> a) & 1u)) continue;
         if (tid == 0) *s_min = 0xffffffffu;
         __syncthreads();
-        if (same) {
-            for (int j = tid; j < (1 << PLB); j += PNT) {
-                const unsigned e = T.lut[a][j];
-                if (e != 0 && (e & 255u) == 0) atomicMin(s_min, (unsigned)j);
-            }
+        for (int j = tid; j < (1 << PLB); j += PNT) {
+            const unsigned e = T.lut[a][j];
+            if (e != 0 && (e & 255u) == 0) atomicMin(s_min, (unsigned)j);
         }
         __syncthreads();
         const unsigned jmin = *s_min;
-        const bool have = jmin != 0xffffffffu;
-        const int eobl = have ? (int)(T.lut[a][jmin] >> 8) : 0;
-        const unsigned code = have ? jmin >> (PLB - eobl) : 0u;
-        for (int i = tid; i < (1 << PLB); i += PNT) {
-            const unsigned e = T.lut[d][i];
-            if (e == 0) continue;
-            const int len = (int)(e >> 8), sym = (int)(e & 255u), sz = sym > 15 ? 15 : sym;
-            unsigned low = (unsigned)sz;
-            if (have && eobl <= 8 && sym <= 11 && len + sz + eobl <= PLB && (((unsigned)i >> (PLB - len - sz - eobl)) & ((1u << eobl) - 1u)) == code)
-                low |= 0x80u | ((unsigned)(eobl - 1) << 4);
-            T.lut[d][i] = (unsigned short)((len << 8) | low);
+        if (jmin != 0xffffffffu) {
+            eobl[a] = T.lut[a][jmin] >> 8;
+            eobc[a] = jmin >> (PLB - eobl[a]);
         }
         __syncthreads();
     }
+    cx.eobpack = 0;
+    for (int r = 0; r < PTAB; ++r) {
+        if (r >= rows) continue;
+        const bool dc = (dcrows >> r) & 1u;
+        unsigned el = 0, ec = 0;
+        if (dc) {
+            int a = -1;
+            bool same = true;
+            for (int c = 0; c < ncomp; ++c) {
+                if (cx.td[c] != r) continue;
+                if (a >= 0 && cx.ta[c] != a) same = false;
+                a = cx.ta[c];
+            }
+            for (int i = 0; i < PTAB; ++i) {
+                if (same && i == a) {
+                    el = eobl[i];
+                    ec = eobc[i];
+                }
+            }
+            cx.eobpack |= el << (8 * r);
+        }
+        for (int i = tid; i < (1 << PLB); i += PNT) {
+            const unsigned e = T.lut[r][i];
+            if (e == 0) continue;
+            const unsigned len = e >> 8, sym = e & 255u;
+            unsigned adv, size, kd;
+            if (dc) {
+                size = min(sym, 15u);
+                adv = len + size;
+                kd = 1;
+                if (el && sym <= 11u && adv + el <= (unsigned)PLB && (((unsigned)i >> (PLB - adv - el)) & ((1u << el) - 1u)) == ec) {
+                    adv += el;
+                    kd = 64;
+                }
+            } else {
+                size = sym & 15u;
+                adv = len + size;
+                kd = sym == 0 ? 64u : (sym >> 4) + 1u;
+            }
+            T.lut[r][i] = (unsigned short)pack_entry(adv, size, kd);
+        }
+    }
+    __syncthreads();
 }
 
-// blk_lo / blk_hi (wave-uniform): byte b = block b of the MCU: bits 0-2 = DC table slot, bits 3-5 = AC table slot,
-// bit 7 = luma component.  `run` = false: the lane keeps its state untouched (its start state did not change).
+// One chunk: decode from the state (p, k, b) up to bit `end`.  `run` = false: the lane keeps its state untouched.  Lanes that
+// have left the current unit take part in the steps of the others with a zero entry (no advance), so the step itself is
+// branch-free but for the long codes.
 template <bool WRITE>
-__device__ void decode_chunk(const ParCtx& cx, const HuffPar& T, const unsigned char* zz, unsigned long long blk_lo, unsigned long long blk_hi,
-                             bool run, unsigned& p, int& k, int& b, unsigned end, unsigned& ycount, int& err, unsigned ybase, short* __restrict__ cbase) {
+__device__ void decode_chunk(const ParCtx& cx, const HuffPar& T, const unsigned char* zz, bool run, unsigned& p, int& k, int& b, unsigned end,
+                             unsigned& ycount, int& err, unsigned ybase, short* __restrict__ cbase) {
     if (!run) end = 0;
     if (run) {
         ycount = 0;
         err = 0;
     }
+    unsigned kk = (unsigned)k, b4 = (unsigned)b * 4u;
+    const unsigned nbm4 = (unsigned)cx.nbm * 4u, luma4 = (unsigned)cx.nb0 * 4u;
+    const unsigned long long blk = cx.blk;
     unsigned q = p >> 5;
     unsigned c0 = __builtin_bswap32(stream_dword(cx, q)), c1 = __builtin_bswap32(stream_dword(cx, q + 1)), c2 = __builtin_bswap32(stream_dword(cx, q + 2));
     unsigned n0 = stream_dword(cx, q + 3), n1 = stream_dword(cx, q + 4);
@@ -429,53 +467,50 @@ __device__ void decode_chunk(const ParCtx& cx, const HuffPar& T, const unsigned 
         while (true) {
             const bool active = p < lim;
             if (!__any(active)) break;
-            if (active) {
-                const bool first = (p >> 5) == q;
-                const unsigned win = __builtin_elementwise_fshl(first ? c0 : c1, first ? c1 : c2, p & 31u);  // the 32 bits starting at bit p
-                const bool isdc = k == 0;
-                const unsigned sel = (unsigned)((b < 8 ? blk_lo : blk_hi) >> ((b & 7) * 8));
-                const unsigned t = isdc ? (sel & 7u) : ((sel >> 3) & 7u);
-                const bool luma = (sel & 0x80u) != 0;
-                unsigned e = lut[(t << PLB) + (win >> (32 - PLB))];
-                bool invalid = false;
-                if (e == 0) {  // longer than PLB bits: canonical search over the 5 remaining lengths, loads issued together
-                    const unsigned p16 = win >> 16;
-                    const unsigned l12 = T.limit[t][12], l13 = T.limit[t][13], l14 = T.limit[t][14], l15 = T.limit[t][15], l16 = T.limit[t][16];
-                    const int l = 12 + (p16 >= l12) + (p16 >= l13) + (p16 >= l14) + (p16 >= l15) + (p16 >= l16);
-                    if (l <= 16) {
-                        const unsigned v = T.vals[t][(T.valoff[t][l] + (int)(p16 >> (16 - l))) & 255];
-                        e = ((unsigned)l << 8) | (isdc ? min(v, 15u) : v);
-                    } else {
-                        e = (16u << 8);  // invalid code: keep moving
-                        invalid = true;
-                    }
+            const bool first = (p >> 5) == q;
+            const unsigned long long pair = ((unsigned long long)(first ? c0 : c1) << 32) | (first ? c1 : c2);
+            const unsigned win = (unsigned)((pair << (p & 31u)) >> 32);  // the 32 bits starting at bit p
+            const bool isdc = kk == 0;
+            const unsigned t = ((unsigned)(blk >> b4) >> (isdc ? 0u : 2u)) & 3u;
+            unsigned e = lut[(t << PLB) + (win >> (32 - PLB))];
+            bool invalid = false;
+            if (e == 0 && active) {  // longer than PLB bits: canonical search over the 5 remaining lengths, loads issued together
+                const unsigned p16 = win >> 16;
+                const unsigned l12 = T.limit[t][12], l13 = T.limit[t][13], l14 = T.limit[t][14], l15 = T.limit[t][15], l16 = T.limit[t][16];
+                const int l = 12 + (p16 >= l12) + (p16 >= l13) + (p16 >= l14) + (p16 >= l15) + (p16 >= l16);
+                if (l <= 16) {
+                    const unsigned v = T.vals[t][(T.valoff[t][l] + (int)(p16 >> (16 - l))) & 255];
+                    const unsigned size = isdc ? min(v, 15u) : (v & 15u);
+                    e = pack_entry((unsigned)l + size, size, isdc ? 1u : (v == 0 ? 64u : (v >> 4) + 1u));
+                } else {
+                    e = pack_entry(16u, 0u, isdc ? 1u : 64u);  // invalid code: keep moving
+                    invalid = true;
                 }
-                const int len = (int)(e >> 8), sym = (int)(e & 255u);
-                const int size = sym & 15;  // DC entries hold min(symbol, 15) there (fuse_dc_eob)
-                const int run_len = isdc ? 0 : (sym >> 4);
-                const bool fused = isdc && (sym & 0x80);  // the block's EOB code sits right behind the DC difference
-                const int eob_len = fused ? ((sym >> 4) & 7) + 1 : 0;
-                const int kk = k + run_len;  // coefficient this symbol sets (when size > 0)
-                if (WRITE) {
-                    const unsigned rest = win << len;
-                    const unsigned bits = size ? rest >> (32 - size) : 0u;
+            }
+            if (!active) e = 0;
+            const unsigned adv = e & 31u;
+            const unsigned knext = kk + (e >> 9);
+            if (WRITE) {
+                if (active) {
+                    const unsigned size = (e >> 5) & 15u;
+                    const bool fused = isdc && (e >> 9) == 64u;
+                    const unsigned vend = adv - (fused ? (cx.eobpack >> (8u * t)) & 255u : 0u);  // offset just behind the value bits
+                    const unsigned bits = __builtin_amdgcn_ubfe(win, 32u - vend, size);
                     const int val = size ? ((int)bits < (1 << (size - 1)) ? (int)bits - (1 << size) + 1 : (int)bits) : 0;
                     const unsigned j = ybase + ycount;  // luma blocks finished before this symbol
                     if (j < cx.total_y) {               // still inside the image (behind it: marker bytes and padding)
-                        if (invalid || (isdc ? size > 11 : (size > 0 && kk > 63))) err = 1;
-                        if (luma && (isdc || size > 0) && kk <= 63) cbase[(long long)j * 64 + zz[kk]] = (short)val;
+                        const unsigned ci = isdc ? 0u : knext - 1u;  // the coefficient this symbol sets (DC, or size > 0)
+                        if (invalid || (isdc ? size > 11u : (size > 0u && ci > 63u))) err = 1;
+                        if (b4 < luma4 && (isdc || size > 0u) && ci <= 63u) cbase[(long long)j * 64 + zz[ci]] = (short)val;
                     }
                 }
-                const int knext = isdc ? (fused ? 64 : 1) : (sym == 0 ? 64 : kk + 1);
-                if (knext >= 64) {
-                    ycount += luma ? 1u : 0u;
-                    b = b + 1 == cx.nbm ? 0 : b + 1;
-                    k = 0;
-                } else {
-                    k = knext;
-                }
-                p += (unsigned)(len + size + eob_len);  // < 32 bits: the position ends inside dword q + 2 at most
             }
+            const bool done = knext >= 64u;
+            ycount += (done && b4 < luma4) ? 1u : 0u;
+            const unsigned bn = b4 + 4u == nbm4 ? 0u : b4 + 4u;
+            b4 = done ? bn : b4;
+            kk = done ? 0u : knext;
+            p += adv;  // < 32 bits: the position ends inside dword q + 2 at most
         }
         q += 2;
         c0 = c2;
@@ -484,6 +519,8 @@ __device__ void decode_chunk(const ParCtx& cx, const HuffPar& T, const unsigned 
         n0 = stream_dword(cx, q + 3);
         n1 = stream_dword(cx, q + 4);
     }
+    k = (int)kk;
+    b = (int)(b4 >> 2);
 }
 
 __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict__ metas, const unsigned* __restrict__ offsets,
@@ -510,12 +547,16 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     SlotMap map;
     for (int i = 0; i < 8; ++i) map.row[i] = -1;
     int rows = 0;
+    unsigned dcrows = 0;  // bit r: row r holds a DC table
     for (int c = 0; c < 4; ++c) {
         if (c < ncomp) nb[c] = (int)rfl((unsigned)M->comp_h[c]) * (int)rfl((unsigned)M->comp_v[c]);
         const int sd = (int)rfl((unsigned)M->comp_td[c]) & 3, sa = 4 + ((int)rfl((unsigned)M->comp_ta[c]) & 3);
         if (c < ncomp) {
             for (int i = 0; i < 8; ++i) {  // (static indexing keeps the map in scalar registers)
-                if ((i == sd || i == sa) && map.row[i] < 0) map.row[i] = rows++;
+                if ((i == sd || i == sa) && map.row[i] < 0) {
+                    if (i < 4 && rows < 32) dcrows |= 1u << rows;
+                    map.row[i] = rows++;
+                }
             }
         }
         cx.td[c] = cx.ta[c] = 0;
@@ -533,15 +574,14 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     cx.nwords = (clean_len + 3) / 4 + 8;
     cx.nbm = nb[0] + nb[1] + nb[2] + nb[3];
     if (cx.nbm > 16) return;  // beyond the standard's 10 blocks per MCU: sequential kernel
-    fuse_dc_eob(T, cx, ncomp, tid, &s_wcnt[0]);
-    unsigned long long blk_lo = 0, blk_hi = 0;  // wave-uniform: one byte per block of the MCU
+    cx.nb0 = nb[0];
+    pack_entries(T, cx, ncomp, rows, dcrows, tid, &s_wcnt[0]);
+    cx.blk = 0;
     for (int i = 0; i < 16; ++i) {
         const int c = (i >= nb[0]) + (i >= nb[0] + nb[1]) + (i >= nb[0] + nb[1] + nb[2]);
         const int tdc = c == 0 ? cx.td[0] : (c == 1 ? cx.td[1] : (c == 2 ? cx.td[2] : cx.td[3]));
         const int tac = c == 0 ? cx.ta[0] : (c == 1 ? cx.ta[1] : (c == 2 ? cx.ta[2] : cx.ta[3]));
-        const unsigned long long v = (unsigned long long)(tdc | (tac << 3) | (c == 0 ? 0x80 : 0));
-        if (i < 8) blk_lo |= v << (8 * i);
-        else blk_hi |= v << (8 * (i - 8));
+        cx.blk |= (unsigned long long)((tdc & 3) | ((tac & 3) << 2)) << (4 * i);
     }
     const unsigned mcus = rfl((unsigned)M->mcus_x) * rfl((unsigned)M->mcus_y);
     cx.total_y = mcus * (unsigned)nb[0];
@@ -592,7 +632,7 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
         p = s_p[c];
         k = (int)(ckb & 255u);
         b = (int)(ckb >> 8);
-        decode_chunk<false>(cx, T, s_zz, blk_lo, blk_hi, work, p, k, b, min(c * chunk + chunk, total_bits), ycount, err, 0u, cbase);
+        decode_chunk<false>(cx, T, s_zz, work, p, k, b, min(c * chunk + chunk, total_bits), ycount, err, 0u, cbase);
         if (work) {
             s_ep[c] = p;
             s_ekb[c] = (unsigned)k | ((unsigned)b << 8);
@@ -635,7 +675,7 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     p = s_p[tid];
     k = (int)(s_kb[tid] & 255u);
     b = (int)(s_kb[tid] >> 8);
-    decode_chunk<true>(cx, T, s_zz, blk_lo, blk_hi, true, p, k, b, end, ycount, err, ybase, cbase);
+    decode_chunk<true>(cx, T, s_zz, true, p, k, b, end, ycount, err, ybase, cbase);
     if (tid == 0) s_flag = 0;
     __threadfence_block();
     __syncthreads();
