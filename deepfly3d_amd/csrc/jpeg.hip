@@ -40,6 +40,10 @@ struct Meta {
     unsigned char dht_present[8];  // [tc*4 + th]
     unsigned char dht_counts[8][16];
     unsigned char dht_vals[8][256];
+    // parallel Huffman kernel (par_done > 0): its lane l decoded the DCs of luma blocks [dc_cnt[l-1], dc_cnt[l]) and stored them
+    // as running sums that start at zero; dc_sum[l-1] (inclusive scan of the lanes' sums) is what the IDCT adds back
+    unsigned dc_cnt[256];
+    int dc_sum[256];
 };
 
 __constant__ unsigned char ZIGZAG[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
@@ -348,6 +352,7 @@ __device__ int build_tables(const Meta* M, HuffLds<LB, NTAB>& T, const SlotMap& 
 // ---------------------------------------------------------------------------------------------------------
 constexpr int PLB = 11;  // look-up bits of the parallel decoder
 constexpr int PNT = 256;
+static_assert(PNT == 256, "Meta::dc_cnt / dc_sum hold one entry per lane");
 constexpr int MAX_PASSES = 32;  // a pass costs ~0.25 ms, the sequential fall-back ~40 ms per 70 KB file
 constexpr unsigned MIN_CHUNK = 2048;
 
@@ -448,8 +453,8 @@ __device__ void pack_entries(HuffPar& T, ParCtx& cx, int ncomp, int rows, unsign
 // have left the current unit take part in the steps of the others with a zero entry (no advance), so the step itself is
 // branch-free but for the long codes.
 template <bool WRITE>
-__device__ void decode_chunk(const ParCtx& cx, const HuffPar& T, const unsigned char* zz, bool run, unsigned& p, int& k, int& b, unsigned end,
-                             unsigned& ycount, int& err, unsigned ybase, short* __restrict__ cbase) {
+__device__ void decode_chunk(const ParCtx& cx, const HuffPar& T, bool run, unsigned& p, int& k, int& b, unsigned end,
+                             unsigned& ycount, int& err, unsigned ybase, short* __restrict__ cbase, int& dcsum, unsigned& ndc) {
     if (!run) end = 0;
     if (run) {
         ycount = 0;
@@ -501,7 +506,12 @@ __device__ void decode_chunk(const ParCtx& cx, const HuffPar& T, const unsigned 
                     if (j < cx.total_y) {               // still inside the image (behind it: marker bytes and padding)
                         const unsigned ci = isdc ? 0u : knext - 1u;  // the coefficient this symbol sets (DC, or size > 0)
                         if (invalid || (isdc ? size > 11u : (size > 0u && ci > 63u))) err = 1;
-                        if (b4 < luma4 && (isdc || size > 0u) && ci <= 63u) cbase[(long long)j * 64 + zz[ci]] = (short)val;
+                        // WRITE: a luma DC leaves as the lane's running sum of differences (the kernel adds the sum of the lanes
+                        // before it afterwards); ndc counts them
+                        const bool ydc = isdc && b4 < luma4;
+                        dcsum += ydc ? val : 0;
+                        ndc += ydc ? 1u : 0u;
+                        if (b4 < luma4 && (isdc || size > 0u) && ci <= 63u) cbase[(long long)j * 64 + ci] = (short)(isdc ? dcsum : val);
                     }
                 }
             }
@@ -531,7 +541,6 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     __shared__ unsigned s_kb[PNT + 1];
     __shared__ unsigned s_cnt[PNT];
     __shared__ int s_dc[PNT];
-    __shared__ unsigned char s_zz[64];
     __shared__ int s_flag;
     __shared__ unsigned s_ep[PNT], s_ekb[PNT];  // end state per chunk
     __shared__ unsigned short s_list[PNT];
@@ -567,7 +576,6 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     }
     if (rows > PTAB) return;                                     // more tables than rows: sequential kernel
     if (build_tables<PLB, PNT, PTAB>(M, T, map, tid)) return;   // the sequential kernel reports the error
-    if (tid < 64) s_zz[tid] = ZIGZAG[tid];
 
     const unsigned clean_len = rfl(M->clean_len);
     cx.words = reinterpret_cast<const unsigned*>(clean + rfl(offsets[img]));
@@ -576,6 +584,9 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     if (cx.nbm > 16) return;  // beyond the standard's 10 blocks per MCU: sequential kernel
     cx.nb0 = nb[0];
     pack_entries(T, cx, ncomp, rows, dcrows, tid, &s_wcnt[0]);
+#if JPG_ABL == 1
+    return;
+#endif
     cx.blk = 0;
     for (int i = 0; i < 16; ++i) {
         const int c = (i >= nb[0]) + (i >= nb[0] + nb[1]) + (i >= nb[0] + nb[1] + nb[2]);
@@ -632,7 +643,9 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
         p = s_p[c];
         k = (int)(ckb & 255u);
         b = (int)(ckb >> 8);
-        decode_chunk<false>(cx, T, s_zz, work, p, k, b, min(c * chunk + chunk, total_bits), ycount, err, 0u, cbase);
+        int dc_unused = 0;
+        unsigned ndc_unused = 0;
+        decode_chunk<false>(cx, T, work, p, k, b, min(c * chunk + chunk, total_bits), ycount, err, 0u, cbase, dc_unused, ndc_unused);
         if (work) {
             s_ep[c] = p;
             s_ekb[c] = (unsigned)k | ((unsigned)b << 8);
@@ -658,6 +671,9 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
         if (tid == 0) M->par_done = -1;
         return;
     }
+#if JPG_ABL == 2
+    return;
+#endif
     // the counts of the last pass belong to the converged start states: exclusive scan -> first block per lane
     for (int o = 1; o < PNT; o <<= 1) {
         const unsigned a = tid >= o ? s_cnt[tid - o] : 0;
@@ -675,7 +691,9 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     p = s_p[tid];
     k = (int)(s_kb[tid] & 255u);
     b = (int)(s_kb[tid] >> 8);
-    decode_chunk<true>(cx, T, s_zz, true, p, k, b, end, ycount, err, ybase, cbase);
+    int dcsum = 0;
+    unsigned ndc = 0;
+    decode_chunk<true>(cx, T, true, p, k, b, end, ycount, err, ybase, cbase, dcsum, ndc);
     if (tid == 0) s_flag = 0;
     __threadfence_block();
     __syncthreads();
@@ -685,24 +703,26 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
         if (tid == 0) M->par_done = -3;
         return;
     }  // invalid symbols: let the sequential kernel classify the file
-    // integrate the DC differences over the luma blocks in decode order
-    const unsigned per = (cx.total_y + PNT - 1) / PNT;
-    const unsigned j0 = min((unsigned)tid * per, cx.total_y), j1 = min(j0 + per, cx.total_y);
-    int sum = 0;
-    for (unsigned j = j0; j < j1; ++j) sum += cbase[(long long)j * 64];
-    s_dc[tid] = sum;
+#if JPG_ABL == 3
+    return;
+#endif
+    // integrating the DC differences over the luma blocks in decode order: every lane wrote running sums that start at zero;
+    // what is missing is the sum of the lanes before it.  Lane l decoded the DCs of blocks [cnt(l-1), cnt(l)) (inclusive
+    // scans of the DC counts), so the IDCT kernel, which reads every block anyway, finds a block's lane by bisection and adds
+    // that lane's offset (a separate pass over the DC terms costs as much memory time as the whole IDCT).
+    s_cnt[tid] = ndc;
+    s_dc[tid] = dcsum;
     __syncthreads();
     for (int o = 1; o < PNT; o <<= 1) {
-        const int a = tid >= o ? s_dc[tid - o] : 0;
+        const unsigned a = tid >= o ? s_cnt[tid - o] : 0u;
+        const int d = tid >= o ? s_dc[tid - o] : 0;
         __syncthreads();
-        s_dc[tid] += a;
+        s_cnt[tid] += a;
+        s_dc[tid] += d;
         __syncthreads();
     }
-    int run = s_dc[tid] - sum;
-    for (unsigned j = j0; j < j1; ++j) {
-        run += cbase[(long long)j * 64];
-        cbase[(long long)j * 64] = (short)run;
-    }
+    M->dc_cnt[tid] = s_cnt[tid];
+    M->dc_sum[tid] = s_dc[tid];
     if (tid == 0) M->par_done = passes;  // > 0: done here (the value is the number of synchronisation passes)
 }
 
@@ -808,9 +828,8 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(Meta* __restrict__ met
         td[c] = (int)rfl((unsigned)M->comp_td[c]) & 3;
         ta[c] = 4 + ((int)rfl((unsigned)M->comp_ta[c]) & 3);
     }
-    // lane i keeps natural-order coefficient i of the current block; kz = its position in the zig-zag sequence
-    int kz = 0;
-    for (int k = 0; k < 64; ++k) kz = ZIGZAG[k] == lane ? k : kz;
+    // lane i keeps coefficient i of the current block in zig-zag order (the order of the coefficient buffer)
+    const int kz = lane;
     short* cbase = coef + (long long)img * coef_stride;
     int restart_left = ri, next_rst = 0, status = ST_OK;
     long long yblock = 0;  // luma blocks in decode order
@@ -931,6 +950,14 @@ __device__ __forceinline__ void idct_1d(const int (&in)[8], int (&out)[8]) {
     out[4] = (t13 - t0 + rnd) >> SHIFT;
 }
 
+// position of natural-order coefficient n in the zig-zag sequence
+__device__ __forceinline__ constexpr int zigzag_index(int n) {
+    constexpr unsigned char inv[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
+                                       41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
+                                       46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+    return inv[n];
+}
+
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(const Meta* __restrict__ metas, const short* __restrict__ coef,
                                                         long long coef_stride, int n, int width, int height,
                                                         unsigned char* __restrict__ luma) {
@@ -946,17 +973,40 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const Meta* __restrict__
     const int j = ((by / v0) * M->mcus_x + bx / h0) * (h0 * v0) + (by % v0) * h0 + bx % h0;  // decode order: MCU by MCU
     const short* c = coef + (long long)img * coef_stride + (long long)j * 64;
     const unsigned short* q = M->q[M->comp_tq[0]];
+    int dc_offset = 0;
+    if (M->par_done > 0) {
+        int lo = 0, hi = 255;  // smallest l with dc_cnt[l] > j
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const bool right = M->dc_cnt[mid] <= (unsigned)j;
+            lo = right ? mid + 1 : lo;
+            hi = right ? hi : mid;
+        }
+        dc_offset = lo ? M->dc_sum[lo - 1] : 0;
+    }
+    // the coefficient buffer is in zig-zag order (where the non-zero terms of a block cluster: the Huffman kernels' sparse
+    // stores touch one or two 32-byte sectors per block instead of four); un-zig-zag = static register picks
+    unsigned w[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(c + i * 8);
+        w[4 * i] = raw.x;
+        w[4 * i + 1] = raw.y;
+        w[4 * i + 2] = raw.z;
+        w[4 * i + 3] = raw.w;
+    }
     int ws[8][8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(c + r * 8);
-        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ws[r][2 * j] = (int)(short)(w[j] & 0xffff) * (int)q[r * 8 + 2 * j];
-            ws[r][2 * j + 1] = (int)(short)(w[j] >> 16) * (int)q[r * 8 + 2 * j + 1];
+        for (int cc = 0; cc < 8; ++cc) {
+            const int z = zigzag_index(r * 8 + cc);
+            const unsigned half = (z & 1) ? w[z >> 1] >> 16 : w[z >> 1] & 0xffffu;
+            ws[r][cc] = (int)(short)half * (int)q[r * 8 + cc];
         }
     }
+    ws[0][0] = (int)(short)((w[0] & 0xffffu) + (unsigned)dc_offset) * (int)q[0];
 #pragma unroll
     for (int col = 0; col < 8; ++col) {
         int in[8], out[8];
