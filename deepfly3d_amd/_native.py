@@ -9,6 +9,8 @@ from ctypes import POINTER, Structure, c_char, c_char_p, c_double, c_float, c_in
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DF3D_LIB") or os.path.join(_HERE, "libdf3d_hip.so")  # DF3D_LIB: developer override (kernel A/B builds)
 
+DF3D_ENOSPC = -5  # include/df3d_hip.h
+DF3D_EIO = -6
 DF3D_DTYPE_F32 = 0
 DF3D_DTYPE_BF16 = 1
 
@@ -55,6 +57,7 @@ PROTOTYPES = {
     "df3d_device_count": (c_int, []),
     "df3d_device_name": (c_int, [c_int, c_char_p, c_int]),
     "df3d_preprocess_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
+    "df3d_read_files": (c_int, [POINTER(c_char_p), c_int, c_void_p, c_size_t, c_void_p, c_void_p, POINTER(c_size_t), c_int]),
     "df3d_jpeg_work_bytes": (c_size_t, [c_int, c_int, c_int, c_size_t]),
     "df3d_jpeg_decode_luma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_uint, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "df3d_heatmap_argmax": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -960,9 +960,14 @@ __device__ __forceinline__ constexpr int zigzag_index(int n) {
 
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(const Meta* __restrict__ metas, const short* __restrict__ coef,
                                                         long long coef_stride, int n, int width, int height,
-                                                        unsigned char* __restrict__ luma) {
+                                                        unsigned char* __restrict__ luma, int* __restrict__ status_out,
+                                                        int* __restrict__ path_out) {
     const int img = blockIdx.y;
     const Meta* M = metas + img;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the file's verdict leaves with the last kernel of the chain
+        status_out[img] = M->status;
+        if (path_out) path_out[img] = M->par_done;
+    }
     if (M->status != ST_OK) return;
     const int ybw = M->ybw, ybh = M->ybh;
     const int blk = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1065,6 +1070,7 @@ int df3d_jpeg_decode_luma(const unsigned char* files_dev, const unsigned* offset
     DF3D_CHECK_ARG(files_dev && offsets_dev && sizes_dev && luma_dev && status_dev && work_dev, "null pointer");
     DF3D_CHECK_ARG(((uintptr_t)files_dev & 15) == 0, "files_dev must be 16-byte aligned (and every file offset a multiple of 16)");
     DF3D_CHECK_ARG(work_bytes >= df3d_jpeg_work_bytes(n, width, height, total_file_bytes), "work buffer too small (df3d_jpeg_work_bytes)");
+    (void)max_file_bytes;  // (see the header: a hint no decoder needs any more)
     hipStream_t s = df3d::as_stream(stream);
     char* w = static_cast<char*>(work_dev);
     jpg::Meta* metas = reinterpret_cast<jpg::Meta*>(w);
@@ -1081,11 +1087,8 @@ int df3d_jpeg_decode_luma(const unsigned char* files_dev, const unsigned* offset
     }
     hipLaunchKernelGGL(jpg::jpeg_huffman_kernel, dim3(n), dim3(64), 0, s, metas, offsets_dev, clean, coef, cs);
     const int blocks = (int)(cs / 64);
-    hipLaunchKernelGGL(jpg::jpeg_idct_kernel, dim3((blocks + 255) / 256, n), dim3(256), 0, s, metas, coef, cs, n, width, height, luma_dev);
-    // status: first int of every descriptor
-    DF3D_HIP(hipMemcpy2DAsync(status_dev, sizeof(int), metas, sizeof(jpg::Meta), sizeof(int), n, hipMemcpyDeviceToDevice, s));
-    if (path_dev)
-        DF3D_HIP(hipMemcpy2DAsync(path_dev, sizeof(int), &metas->par_done, sizeof(jpg::Meta), sizeof(int), n, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(jpg::jpeg_idct_kernel, dim3((blocks + 255) / 256, n), dim3(256), 0, s, metas, coef, cs, n, width, height, luma_dev, status_dev,
+                       path_dev);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }

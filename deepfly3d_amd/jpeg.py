@@ -77,9 +77,10 @@ _PINNED_POOL = []
 
 
 class JpegFolderReader:
-    """Streams JPEG files into the device decoder: a thread pool reads the files of batch k+1 straight into pinned
-    staging memory (os.readinto releases the GIL) while the GPU decodes batch k.  Statuses are collected on the
-    device and checked once, in `finish()`, so that no batch forces a host synchronisation.
+    """Streams JPEG files into the device decoder: the library's native reader threads (df3d_read_files, one call per
+    batch, issued from a pool thread) put the files of batch k+1 straight into pinned staging memory while the GPU
+    decodes batch k.  Statuses are collected on the device and checked once, in `finish()`, so that no batch forces a
+    host synchronisation.
 
         reader = JpegFolderReader(width, height, device)
         for luma in reader.stream(list_of_path_batches):        # uint8 [n, H, W] on the device, decoded on a second stream
@@ -99,7 +100,7 @@ class JpegFolderReader:
         self.dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.width, self.height = int(width), int(height)
         self.pinned = bool(pinned)
-        self.pool = ThreadPoolExecutor(max_workers=workers or max(2, min(16, (os.cpu_count() or 4) - 1)))
+        self.pool = ThreadPoolExecutor(max_workers=workers or self.SLOTS)  # one task per batch being read; the reading itself is native
         self.slots = [dict(buf=None, event=None) for _ in range(self.SLOTS)]
         self.turn = 0
         self.queue = []     # batches being read, oldest first (at most SLOTS - 1: one staging buffer may still feed a copy)
@@ -109,60 +110,69 @@ class JpegFolderReader:
         self._keep = None
         self.statuses = []  # (status tensor, paths)
 
-    @staticmethod
-    def _read_into(path, view):
-        with open(path, "rb", buffering=0) as f:
-            got = f.readinto(view)
-        if got != len(view):
-            raise IOError(f"{path}: short read ({got} of {len(view)} bytes)")
+    READ_THREADS = 8  # native reader threads per batch (two batches may be in flight)
 
-    @classmethod
-    def _read_many(cls, jobs):
-        for path, view in jobs:
-            cls._read_into(path, view)
+    def _pinned(self, nbytes):
+        return torch.empty(int(nbytes), dtype=torch.uint8, pin_memory=self.pinned)
+
+    def _read_batch(self, slot, paths):
+        """The files of one batch -> the slot's staging buffer through df3d_read_files (native threads open, size and read
+        them; run from a pool thread, the interpreter lock is free meanwhile).  Returns (rc, starts, sizes, total bytes);
+        rc = DF3D_ENOSPC: nothing was read, the buffer must hold total + 16 bytes (the caller, on the main thread, makes
+        one: pinned allocations from a fresh thread cost hundreds of milliseconds)."""
+        import ctypes
+        import os
+
+        n = len(paths)
+        arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        starts, sizes = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        total = ctypes.c_size_t(0)
+        buf = slot["buf"]
+        rc = self.lib.df3d_read_files(arr, n, buf.data_ptr() if buf is not None else None, buf.numel() if buf is not None else 0, starts.ctypes.data,
+                                      sizes.ctypes.data, ctypes.byref(total), self.READ_THREADS)
+        if rc == _native.DF3D_EIO:
+            msg = self.lib.df3d_last_error().decode()
+            raise (FileNotFoundError if "No such file" in msg else IOError)(msg)
+        if rc != _native.DF3D_ENOSPC:
+            _native.check(rc, "df3d_read_files")
+        return rc, starts, sizes, int(total.value)
 
     def prefetch(self, paths, sizes=None):
-        """Start reading `paths` into the next staging slot (`sizes`: their byte sizes when the caller already knows them)."""
+        """Start reading `paths` into the next staging slot (`sizes` is accepted for callers of round 1 and ignored: the native
+        reader sizes the files as it opens them)."""
         import os
 
         if len(self.queue) >= self.SLOTS - 1:
             raise RuntimeError("too many batches are being read")
-        if sizes is None:
-            sizes = np.fromiter((os.stat(p).st_size for p in paths), dtype=np.int64, count=len(paths))
-        sizes = np.asarray(sizes, dtype=np.int64)
-        padded = (sizes + 15) // 16 * 16
-        ends = np.cumsum(padded)
-        starts = ends - padded
-        total = int(ends[-1]) if len(paths) else 0
-        if total >= 2**32 - 64:
-            raise ValueError("more than 4 GiB of JPEG data in one batch")
         slot = self.slots[self.turn]
         self.turn = (self.turn + 1) % self.SLOTS
         if slot["event"] is not None:
             slot["event"].synchronize()  # the copy that last used this staging buffer has finished
-        if slot["buf"] is None or slot["buf"].numel() < total + 16:
+        paths = list(paths)
+        if paths:
+            # room for the batch if its files are like the first one (camera frames are); a wrong guess costs one re-read
+            guess = int(max(len(paths), self.batch_capacity or 0) * (os.stat(paths[0]).st_size + 16) * 1.25) + 4096
             if slot["buf"] is None and self.pinned:
-                fit = [b for b in _PINNED_POOL if b.numel() >= total + 16]
+                fit = [b for b in _PINNED_POOL if b.numel() >= guess]
                 if fit:
                     slot["buf"] = min(fit, key=lambda b: b.numel())
                     _PINNED_POOL[:] = [b for b in _PINNED_POOL if b is not slot["buf"]]
-        if slot["buf"] is None or slot["buf"].numel() < total + 16:
-            slot["buf"] = torch.empty(int((total + 16) * 1.25), dtype=torch.uint8)
-            if self.pinned:
-                slot["buf"] = slot["buf"].pin_memory()
-        view = memoryview(slot["buf"].numpy())
-        # a few dozen files per task: one future per file costs more host time than the read itself
-        jobs = [(p, view[s : s + n]) for p, s, n in zip(paths, starts.tolist(), sizes.tolist())]
-        per = max(1, -(-len(jobs) // (4 * self.pool._max_workers)))
-        futs = [self.pool.submit(self._read_many, jobs[i : i + per]) for i in range(0, len(jobs), per)]
-        self.queue.append((slot, futs, starts.astype(np.uint32), sizes.astype(np.uint32), total, list(paths)))
+            if slot["buf"] is None or slot["buf"].numel() < guess:
+                slot["buf"] = self._pinned(guess)
+        self.queue.append((slot, self.pool.submit(self._read_batch, slot, paths) if paths else None, paths))
 
     def _launch_decode(self, out, stream):
         """Wait for the batch being read and enqueue its H2D copy + decode on `stream` into `out[:n]`."""
-        slot, futs, starts, sizes, total, paths = self.queue.pop(0)
-        for f in futs:
-            f.result()
+        slot, fut, paths = self.queue.pop(0)
         n = len(paths)
+        if n:
+            rc, starts, sizes, total = fut.result()
+            if rc == _native.DF3D_ENOSPC:  # the size guess was too small
+                slot["buf"] = self._pinned((total + 16) * 1.25)
+                rc, starts, sizes, total = self._read_batch(slot, paths)
+                _native.check(rc, "df3d_read_files")
+            if total >= 2**32 - 64:
+                raise ValueError("more than 4 GiB of JPEG data in one batch")
         if n:
             with torch.cuda.device(self.dev), torch.cuda.stream(stream):
                 files_dev = slot["buf"][: total + 16].to(self.dev, non_blocking=True)
@@ -185,7 +195,7 @@ class JpegFolderReader:
 
     def decode_next(self, next_paths=None):
         """Wait for the batch being read, launch its decode, start reading `next_paths`; returns luma [n, H, W]."""
-        n = len(self.queue[0][5])
+        n = len(self.queue[0][2])
         out = torch.empty((n, self.height, self.width), dtype=torch.uint8, device=self.dev)
         self._launch_decode(out, torch.cuda.current_stream(self.dev))
         if next_paths is not None:
@@ -243,11 +253,11 @@ class JpegFolderReader:
             self.statuses = []
             self.pool.shutdown(wait=False)
             for item in self.queue:  # an error path: file reads may still be writing into a staging buffer
-                for f in item[1]:
-                    try:
-                        f.result()
-                    except Exception:
-                        pass
+                try:
+                    if item[1] is not None:
+                        item[1].result()
+                except Exception:
+                    pass
             self.queue = []
             if self.pinned:
                 for slot in self.slots:

@@ -28,6 +28,8 @@ extern "C" {
 #define DF3D_EHIP (-2)    /* a HIP runtime call failed          */
 #define DF3D_ESTATE (-3)  /* handle not ready (weights missing) */
 #define DF3D_ENOGPU (-4)  /* no gfx950 device visible           */
+#define DF3D_ENOSPC (-5)  /* the caller's buffer is too small (the size needed was reported) */
+#define DF3D_EIO (-6)     /* a file could not be opened or read */
 
 #define DF3D_DTYPE_F32 0
 #define DF3D_DTYPE_BF16 1
@@ -56,8 +58,9 @@ int df3d_preprocess_u8(const unsigned char* img_dev, const unsigned char* flip_d
  * files_dev   the files' bytes in one 16-byte aligned buffer of total_file_bytes (+ 16 readable bytes behind it);
  *             file i = [offsets[i], offsets[i] + sizes[i]), every offset a multiple of 16, files in
  *             ascending, non-overlapping order
- * offsets_dev, sizes_dev  [n] uint32 (device);  max_file_bytes = the largest size (host value; 0 = unknown: the
- *             parallel decoder then reads the stream from global memory instead of staging it in LDS)
+ * offsets_dev, sizes_dev  [n] uint32 (device);  max_file_bytes = the largest size (host value, 0 = unknown; a hint kept
+ *             for callers of round 1, whose parallel decoder staged small streams in LDS: the decoder now keeps each lane's
+ *             next stream dwords in registers and ignores it)
  * luma_dev    [n, height, width] uint8;   every file must be width x height
  * status_dev  [n] int32: 0 ok, 1 truncated, 2 not a JPEG, 3 unsupported (progressive / arithmetic / 12 bit /
  *             multi-scan), 4 corrupt, 5 size differs.  Planes of failed files are left untouched.
@@ -74,6 +77,15 @@ size_t df3d_jpeg_work_bytes(int n, int width, int height, size_t total_file_byte
 int df3d_jpeg_decode_luma(const unsigned char* files_dev, const unsigned* offsets_dev, const unsigned* sizes_dev, int n,
                           size_t total_file_bytes, unsigned max_file_bytes, int width, int height, unsigned char* luma_dev, int* status_dev,
                           int* path_dev, void* work_dev, size_t work_bytes, int flags, void* stream);
+
+/* Host helper of the JPEG front-end (no device work): read n files with `threads` native threads into one staging buffer
+ * (pinned host memory, typically) in the layout df3d_jpeg_decode_luma takes: file i at starts[i] (a multiple of 16, path
+ * order, padding zeroed), sizes[i] bytes; *total_bytes = the bytes the layout needs (16 readable bytes follow it).  Returns
+ * DF3D_ENOSPC, with *total_bytes set and nothing read, when dst is NULL or dst_bytes < *total_bytes + 16; DF3D_EIO (and the
+ * path in df3d_last_error()) when a file cannot be opened or read.  The reference reads its frames one per DataLoader
+ * worker call (df2d, behind reference df3d/core.py:177-185). */
+int df3d_read_files(const char* const* paths, int n, unsigned char* dst, size_t dst_bytes, unsigned* starts, unsigned* sizes,
+                    size_t* total_bytes, int threads);
 
 /* ------------------------------------------------------------------------------------------------
  * a3  heat-map -> point + confidence.   Replaces df2d's heatmap2points / confidence extraction behind

@@ -98,7 +98,7 @@ def main():
         # ---- end to end ---------------------------------------------------------------------------------------
         os.environ["DF3D_SYNTHETIC_WEIGHTS"] = "0"
         for dt_name in ("f32", "bf16"):
-            inference.inference_folder(folder=folder, camera_ids_to_flip=[4, 5, 6], max_img_id=31, dtype=dt_name)  # warm-up: engine, buffers
+            inference.inference_folder(folder=folder, camera_ids_to_flip=[4, 5, 6], max_img_id=min(a.frames, 256) - 1, dtype=dt_name)  # warm-up: engine, full-size batch buffers
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             pts, conf = inference.inference_folder(folder=folder, camera_ids_to_flip=[4, 5, 6], max_img_id=a.frames - 1, dtype=dt_name)

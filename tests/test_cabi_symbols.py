@@ -76,6 +76,39 @@ def test_argument_validation_without_gpu(native_lib):
     assert native_lib.df3d_oneeuro_filter(None, 0, 114, 100.0, 0.1, 2.0, 1.0, 1, 0.1, None, None) == 0  # no frames
 
 
+def test_native_file_reader(native_lib, tmp_path):
+    """df3d_read_files (host helper of the JPEG front-end): layout, padding, size query, error reporting."""
+    import numpy as np
+
+    from deepfly3d_amd import _native
+
+    rng = np.random.default_rng(3)
+    blobs = [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in (1, 15, 16, 17, 70001, 0, 4096)]
+    paths = []
+    for i, b in enumerate(blobs):
+        paths.append(str(tmp_path / f"f{i}.bin"))
+        open(paths[-1], "wb").write(b)
+    n = len(paths)
+    arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    starts, sizes, total = np.empty(n, np.uint32), np.empty(n, np.uint32), ctypes.c_size_t()
+    assert native_lib.df3d_read_files(arr, n, None, 0, starts.ctypes.data, sizes.ctypes.data, ctypes.byref(total), 3) == _native.DF3D_ENOSPC
+    assert total.value == sum((len(b) + 15) // 16 * 16 for b in blobs)
+    buf = np.full(total.value + 16, 0xAB, np.uint8)
+    assert native_lib.df3d_read_files(arr, n, buf.ctypes.data, buf.size - 1, starts.ctypes.data, sizes.ctypes.data, ctypes.byref(total), 3) == _native.DF3D_ENOSPC
+    assert native_lib.df3d_read_files(arr, n, buf.ctypes.data, buf.size, starts.ctypes.data, sizes.ctypes.data, ctypes.byref(total), 3) == 0
+    off = 0
+    for b, s, z in zip(blobs, starts, sizes):
+        assert s == off and s % 16 == 0 and z == len(b) and bytes(buf[s : s + z]) == b
+        pad = (len(b) + 15) // 16 * 16
+        assert not buf[s + z : s + pad].any()  # padding zeroed
+        off += pad
+    assert not buf[total.value :].any()
+    arr2 = (ctypes.c_char_p * 2)(os.fsencode(paths[0]), os.fsencode(str(tmp_path / "missing.jpg")))
+    assert native_lib.df3d_read_files(arr2, 2, buf.ctypes.data, buf.size, starts.ctypes.data, sizes.ctypes.data, ctypes.byref(total), 8) == _native.DF3D_EIO
+    assert b"missing.jpg" in native_lib.df3d_last_error()
+    assert native_lib.df3d_read_files(None, 0, None, 0, None, None, ctypes.byref(total), 1) == 0 and total.value == 0
+
+
 def test_engine_plan_accounting(native_lib):
     """FLOPs / bytes of the engine's own plan equal the SURVEY.md 8d figures (35.993 GFLOP, 647.3 MB per view fp32)."""
     from deepfly3d_amd import _native
