@@ -6,15 +6,18 @@
 //   jpeg_parse_kernel    one workgroup per file: marker walk out of an LDS window, tables into a per-file
 //                        descriptor, then the entropy-coded segment is un-stuffed (FF00 -> FF) cooperatively
 //                        into a clean byte stream (tile-wise flag / scan / compact)
-//   jpeg_huffman_kernel  one 64-lane wave per file, wave-uniform control flow: the bit buffer lives in scalar
+//   jpeg_huffman_par_kernel  256 lanes per file, self-synchronising chunks: the fast path
+//   jpeg_huffman_kernel  the exact fall-back (restart intervals, invalid or truncated streams, no convergence): one
+//                        64-lane wave per file, wave-uniform control flow: the bit buffer lives in scalar
 //                        registers, the next 256 stream bytes in one VGPR (v_readlane), 9-bit code look-up
 //                        tables in LDS; lane i keeps coefficient i of the current block, so a decoded value is a
 //                        compare + select and a finished luma block leaves as one coalesced 128-byte store
-//   jpeg_idct_kernel     one thread per 8x8 luma block: de-quantise, 2 x 8 one-dimensional LL&M passes, clamp
+//   jpeg_idct_kernel     one thread per 8x8 luma block: de-quantise, 2 x 8 one-dimensional LL&M passes, clamp;
+//                        adds the parallel decoder's per-lane DC offsets, writes the per-file status
 //
 // Only the luma component is reconstructed (the rig's cameras are monochrome; chroma blocks are entropy-decoded
-// and dropped).  Integer work: results are bit-exact.  Per file the Huffman stage is sequential (latency-bound,
-// ~140 k symbols); throughput comes from one wave per file across the 1 024 SIMDs.
+// and dropped).  Integer work: results are bit-exact.  The coefficient buffer between the Huffman kernels and the
+// IDCT holds 64 shorts per luma block in zig-zag order.
 #include <cstdint>
 
 #include "common.h"
