@@ -204,3 +204,99 @@ def test_large_files_exceed_the_lds_stage(native_lib, cuda):
     out, path = jpeg.decode_luma(blobs, 1600, 1200, return_path=True)
     for i, b in enumerate(blobs):
         assert np.array_equal(out[i].cpu().numpy(), pil_luma(b)), f"file {i} (path {path[i]})"
+
+
+def _segments(blob):
+    """[(marker, start, end)] of the marker segments in front of the entropy-coded data; end of the SOS header."""
+    out, pos = [], 2
+    while True:
+        assert blob[pos] == 0xFF
+        marker = blob[pos + 1]
+        length = int.from_bytes(blob[pos + 2 : pos + 4], "big")
+        out.append((marker, pos, pos + 2 + length))
+        pos += 2 + length
+        if marker == 0xDA:
+            return out
+
+
+def _relabel_tables(blob, dc_ids, ac_ids, extra):
+    """Same entropy-coded data, other table numbering: `extra` = [(class, new id, copy of id)] tables are added as copies and
+    scan component i is pointed at DC table dc_ids[i] / AC table ac_ids[i]."""
+    segs = _segments(blob)
+    tables = {}
+    for m, a, b in segs:
+        if m == 0xC4:
+            p = a + 4
+            while p < b:
+                tc_th = blob[p]
+                n = sum(blob[p + 1 : p + 17])
+                tables[tc_th] = blob[p + 1 : p + 17 + n]
+                p += 17 + n
+    add = b""
+    for tc, new, src in extra:
+        body = bytes([(tc << 4) | new]) + tables[(tc << 4) | src]
+        add += b"\xff\xc4" + (len(body) + 2).to_bytes(2, "big") + body
+    m, a, b = segs[-1]
+    sos = bytearray(blob[a:b])
+    ns = sos[4]
+    for i in range(ns):
+        sos[5 + 2 * i + 1] = (dc_ids[i] << 4) | ac_ids[i]
+    return blob[:a] + add + bytes(sos) + blob[b:]
+
+
+def test_table_numbering_variants(native_lib, cuda):
+    """The parallel decoder keeps the (at most four) tables a scan refers to in compact rows: scans that use other table ids,
+    or more than four tables (copies under new ids: every component its own pair -> sequential kernel), decode the same."""
+    from deepfly3d_amd import jpeg
+
+    rng = np.random.default_rng(21)
+    col = _smooth(rng, 96, 160, 3)
+    for sub in (0, 2):
+        b = _encode(col, quality=88, subsampling=sub)
+        ref = pil_luma(b)
+        variants = {
+            "as encoded": (b, True),
+            # chroma tables moved to ids 3 / 2 (still four tables)
+            "other ids": (_relabel_tables(b, [0, 3, 3], [0, 2, 2], [(0, 3, 1), (1, 2, 1)]), True),
+            # Cr gets its own copies: six tables in the scan
+            "six tables": (_relabel_tables(b, [0, 1, 2], [0, 1, 2], [(0, 2, 1), (1, 2, 1)]), False),
+            # Cb and Cr share a DC table but use different AC tables (five tables)
+            "shared DC, own AC": (_relabel_tables(b, [0, 1, 1], [0, 1, 2], [(1, 2, 1)]), False),
+        }
+        for name, (v, parallel) in variants.items():
+            assert np.array_equal(pil_luma(v), ref), name  # libjpeg agrees that the relabelled file is the same picture
+            out, path = jpeg.decode_luma([v], 160, 96, return_path=True)
+            assert np.array_equal(out.cpu().numpy()[0], ref), (sub, name)
+            if not parallel:
+                assert path[0] == 0, (sub, name, path)   # too many tables for the parallel kernel's rows
+            assert np.array_equal(jpeg.decode_luma([v], 160, 96, sequential=True).cpu().numpy()[0], ref), (sub, name)
+
+
+def test_folder_reader_grows_its_staging_buffer(native_lib, cuda, tmp_path):
+    """The reader sizes its pinned staging buffer from the first file of a batch; a batch whose other files are much larger
+    makes the native reader report the size (nothing read), the buffer is replaced and the batch read again."""
+    from deepfly3d_amd import jpeg
+
+    rng = np.random.default_rng(22)
+    flat = _encode(np.full((96, 160), 128, np.uint8), quality=50)                       # a few hundred bytes
+    busy = [_encode(rng.integers(0, 256, size=(96, 160), dtype=np.uint8), quality=95) for _ in range(6)]
+    assert min(len(b) for b in busy) > 20 * len(flat)
+    blobs = [flat] + busy + [flat]
+    paths = []
+    for i, b in enumerate(blobs):
+        paths.append(str(tmp_path / f"camera_0_img_{i}.jpg"))
+        open(paths[-1], "wb").write(b)
+    rd = jpeg.JpegFolderReader(160, 96, cuda, pinned=True)
+    try:
+        got = [luma.cpu().numpy().copy() for luma in rd.stream([paths[:5], paths[5:]])]
+    finally:
+        rd.finish()
+    out = np.concatenate(got)
+    for i, b in enumerate(blobs):
+        assert np.array_equal(out[i], pil_luma(b)), i
+    rd = jpeg.JpegFolderReader(160, 96, cuda)
+    with pytest.raises(FileNotFoundError):
+        try:
+            list(rd.stream([paths[:2] + [str(tmp_path / "camera_0_img_99.jpg")]]))
+        finally:
+            rd.finish()
