@@ -498,25 +498,25 @@ __device__ void decode_chunk(const ParCtx& cx, const HuffPar& T, bool run, unsig
             if (!active) e = 0;
             const unsigned adv = e & 31u;
             const unsigned knext = kk + (e >> 9);
-            if (WRITE) {
-                if (active) {
-                    const unsigned size = (e >> 5) & 15u;
-                    const bool fused = isdc && (e >> 9) == 64u;
-                    const unsigned vend = adv - (fused ? (cx.eobpack >> (8u * t)) & 255u : 0u);  // offset just behind the value bits
-                    const unsigned bits = __builtin_amdgcn_ubfe(win, 32u - vend, size);
-                    const int val = size ? ((int)bits < (1 << (size - 1)) ? (int)bits - (1 << size) + 1 : (int)bits) : 0;
-                    const unsigned j = ybase + ycount;  // luma blocks finished before this symbol
-                    if (j < cx.total_y) {               // still inside the image (behind it: marker bytes and padding)
-                        const unsigned ci = isdc ? 0u : knext - 1u;  // the coefficient this symbol sets (DC, or size > 0)
-                        if (invalid || (isdc ? size > 11u : (size > 0u && ci > 63u))) err = 1;
-                        // WRITE: a luma DC leaves as the lane's running sum of differences (the kernel adds the sum of the lanes
-                        // before it afterwards); ndc counts them
-                        const bool ydc = isdc && b4 < luma4;
-                        dcsum += ydc ? val : 0;
-                        ndc += ydc ? 1u : 0u;
-                        if (b4 < luma4 && (isdc || size > 0u) && ci <= 63u) cbase[(long long)j * 64 + ci] = (short)(isdc ? dcsum : val);
-                    }
-                }
+            if (WRITE) {  // (an inactive lane carries e = 0: no value bits, and `inside` below is false)
+                const unsigned size = (e >> 5) & 15u;
+                const bool fused = isdc && (e >> 9) == 64u;
+                const unsigned vend = adv - (fused ? (cx.eobpack >> (8u * t)) & 255u : 0u);  // offset just behind the value bits
+                const unsigned bits = __builtin_amdgcn_ubfe(win, 32u - vend, size);
+                // JPEG's EXTEND without a branch: values below 2^(size-1) stand for bits - (2^size - 1)
+                const unsigned half = (1u << size) >> 1;
+                const int val = (int)bits - (((int)(bits - half) >> 31) & (int)((1u << size) - 1u));
+                const unsigned j = ybase + ycount;            // luma blocks finished before this symbol
+                const bool inside = active && j < cx.total_y;  // (behind the image: marker bytes and padding)
+                const bool luma = b4 < luma4;
+                const unsigned ci = isdc ? 0u : knext - 1u;  // the coefficient this symbol sets (DC, or size > 0)
+                if (inside && (invalid || (isdc ? size > 11u : (size > 0u && ci > 63u)))) err = 1;
+                // a luma DC leaves as the lane's running sum of differences (the IDCT adds the sum of the lanes before it);
+                // ndc counts them
+                const bool ydc = inside && isdc && luma;
+                dcsum += ydc ? val : 0;
+                ndc += ydc ? 1u : 0u;
+                if (inside && luma && (isdc || size > 0u) && ci <= 63u) cbase[(long long)j * 64 + ci] = (short)(isdc ? dcsum : val);
             }
             const bool done = knext >= 64u;
             ycount += (done && b4 < luma4) ? 1u : 0u;
@@ -587,9 +587,6 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     if (cx.nbm > 16) return;  // beyond the standard's 10 blocks per MCU: sequential kernel
     cx.nb0 = nb[0];
     pack_entries(T, cx, ncomp, rows, dcrows, tid, &s_wcnt[0]);
-#if JPG_ABL == 1
-    return;
-#endif
     cx.blk = 0;
     for (int i = 0; i < 16; ++i) {
         const int c = (i >= nb[0]) + (i >= nb[0] + nb[1]) + (i >= nb[0] + nb[1] + nb[2]);
@@ -608,9 +605,11 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
     const unsigned end = min(nominal + chunk, total_bits);
     short* cbase = coef + (long long)img * coef_stride;
 
-    // start states of pass 0: speculative (a block starts there), one chunk AHEAD of the lane's own chunk so that the
-    // decode has a whole extra chunk to synchronise before the end state that matters (lanes 0 and 1 are exact)
-    s_p[tid] = min(tid > 0 ? nominal - chunk : 0u, total_bits);
+    // start states of pass 0: speculative (a block starts at the chunk's first bit; chunk 0 is exact).  Pass 1 then runs every
+    // chunk from its predecessor's speculative end -- a state that had a whole chunk to synchronise -- and from pass 2 on only
+    // the chunks whose predecessor still moved are decoded again (a run-in chunk inside pass 0 would reach the same states one
+    // pass earlier, but by decoding every chunk three times instead of twice)
+    s_p[tid] = min(nominal, total_bits);
     s_kb[tid] = 0;
     __syncthreads();
 
@@ -674,9 +673,6 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
         if (tid == 0) M->par_done = -1;
         return;
     }
-#if JPG_ABL == 2
-    return;
-#endif
     // the counts of the last pass belong to the converged start states: exclusive scan -> first block per lane
     for (int o = 1; o < PNT; o <<= 1) {
         const unsigned a = tid >= o ? s_cnt[tid - o] : 0;
@@ -706,9 +702,6 @@ __global__ __launch_bounds__(PNT) void jpeg_huffman_par_kernel(Meta* __restrict_
         if (tid == 0) M->par_done = -3;
         return;
     }  // invalid symbols: let the sequential kernel classify the file
-#if JPG_ABL == 3
-    return;
-#endif
     // integrating the DC differences over the luma blocks in decode order: every lane wrote running sums that start at zero;
     // what is missing is the sum of the lanes before it.  Lane l decoded the DCs of blocks [cnt(l-1), cnt(l)) (inclusive
     // scans of the DC counts), so the IDCT kernel, which reads every block anyway, finds a block's lane by bisection and adds
