@@ -20,7 +20,6 @@ namespace {
 struct ReadJob {
     const char* const* paths;
     int n;
-    std::vector<int> fd;
     std::vector<long long> size;
     std::atomic<int> next{0};
     std::atomic<int> failed{-1};  // index of the first file that failed
@@ -53,32 +52,23 @@ extern "C" int df3d_read_files(const char* const* paths, int n, unsigned char* d
     ReadJob job;
     job.paths = paths;
     job.n = n;
-    job.fd.assign(n, -1);
     job.size.assign(n, 0);
-    auto close_all = [&]() {
-        for (int i = 0; i < n; ++i)
-            if (job.fd[i] >= 0) close(job.fd[i]);
-    };
-    // 1. open + size
+    // 1. sizes (stat, not open: two batches of ~900 files in flight must not need ~1 800 descriptors)
     run_threads(threads, [&]() {
         for (int i; (i = job.next.fetch_add(1)) < n;) {
-            const int fd = open(paths[i], O_RDONLY | O_CLOEXEC);
-            if (fd < 0) {
-                fail(job, i, errno);
-                continue;
-            }
             struct stat st;
-            if (fstat(fd, &st) != 0) {
+            if (stat(paths[i], &st) != 0) {
                 fail(job, i, errno);
-                close(fd);
                 continue;
             }
-            job.fd[i] = fd;
+            if (!S_ISREG(st.st_mode)) {
+                fail(job, i, EINVAL);
+                continue;
+            }
             job.size[i] = (long long)st.st_size;
         }
     });
     if (job.failed.load() >= 0) {
-        close_all();
         df3d::set_error("df3d_read_files: %s: %s", paths[job.failed.load()], strerror(job.err));
         return DF3D_EIO;
     }
@@ -86,7 +76,6 @@ extern "C" int df3d_read_files(const char* const* paths, int n, unsigned char* d
     unsigned long long off = 0;
     for (int i = 0; i < n; ++i) {
         if (off + (unsigned long long)job.size[i] + 64 >= (1ull << 32)) {
-            close_all();
             df3d::set_error("df3d_read_files: more than 4 GiB of file data in one batch");
             return DF3D_EINVAL;
         }
@@ -95,18 +84,20 @@ extern "C" int df3d_read_files(const char* const* paths, int n, unsigned char* d
         off += ((unsigned long long)job.size[i] + 15ull) / 16ull * 16ull;
     }
     *total_bytes = (size_t)off;
-    if (!dst || off + 16 > dst_bytes) {  // the caller learns the size and comes back with a larger buffer
-        close_all();
-        return DF3D_ENOSPC;
-    }
-    // 3. read
+    if (!dst || off + 16 > dst_bytes) return DF3D_ENOSPC;  // the caller learns the size and comes back with a larger buffer
+    // 3. read (one descriptor per thread at a time); a file that changed size since step 1 is an error
     job.next.store(0);
     run_threads(threads, [&]() {
         for (int i; (i = job.next.fetch_add(1)) < n;) {
+            const int fd = open(paths[i], O_RDONLY | O_CLOEXEC);
+            if (fd < 0) {
+                fail(job, i, errno);
+                continue;
+            }
             unsigned char* p = dst + starts[i];
             long long left = job.size[i];
             while (left > 0) {
-                const ssize_t got = read(job.fd[i], p, (size_t)left);
+                const ssize_t got = read(fd, p, (size_t)left);
                 if (got < 0 && errno == EINTR) continue;
                 if (got <= 0) {  // error, or the file shrank under us
                     fail(job, i, got < 0 ? errno : EIO);
@@ -115,15 +106,13 @@ extern "C" int df3d_read_files(const char* const* paths, int n, unsigned char* d
                 p += got;
                 left -= got;
             }
+            close(fd);
             const unsigned long long pad = ((unsigned long long)job.size[i] + 15ull) / 16ull * 16ull - (unsigned long long)job.size[i];
             if (left == 0 && pad) memset(p, 0, (size_t)pad);
-            close(job.fd[i]);
-            job.fd[i] = -1;
         }
     });
     memset(dst + off, 0, 16);
     if (job.failed.load() >= 0) {
-        close_all();
         df3d::set_error("df3d_read_files: %s: %s", paths[job.failed.load()], strerror(job.err));
         return DF3D_EIO;
     }

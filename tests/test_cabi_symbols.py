@@ -106,6 +106,8 @@ def test_native_file_reader(native_lib, tmp_path):
     arr2 = (ctypes.c_char_p * 2)(os.fsencode(paths[0]), os.fsencode(str(tmp_path / "missing.jpg")))
     assert native_lib.df3d_read_files(arr2, 2, buf.ctypes.data, buf.size, starts.ctypes.data, sizes.ctypes.data, ctypes.byref(total), 8) == _native.DF3D_EIO
     assert b"missing.jpg" in native_lib.df3d_last_error()
+    arr3 = (ctypes.c_char_p * 1)(os.fsencode(str(tmp_path)))  # a directory is not a frame
+    assert native_lib.df3d_read_files(arr3, 1, buf.ctypes.data, buf.size, starts.ctypes.data, sizes.ctypes.data, ctypes.byref(total), 2) == _native.DF3D_EIO
     assert native_lib.df3d_read_files(None, 0, None, 0, None, None, ctypes.byref(total), 1) == 0 and total.value == 0
 
 
