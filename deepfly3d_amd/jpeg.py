@@ -37,7 +37,7 @@ def pack_files(blobs, pinned=True):
     return buf, starts.astype(np.uint32), sizes.astype(np.uint32), total
 
 
-def decode_luma(blobs, width, height, device=None, check=True, return_status=False, sequential=False, return_path=False, stream_in_lds=True):
+def decode_luma(blobs, width, height, device=None, check=True, return_status=False, sequential=False, return_path=False):
     """[bytes, ...] of width x height baseline JPEGs -> uint8 CUDA tensor [n, height, width] (luma planes)."""
     _native.require_gpu()
     lib = _native.load()
@@ -57,7 +57,7 @@ def decode_luma(blobs, width, height, device=None, check=True, return_status=Fal
     with torch.cuda.device(dev):  # kernels launch on the current HIP device
         stream = torch.cuda.current_stream(dev).cuda_stream
         _native.check(
-            lib.df3d_jpeg_decode_luma(files_dev.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), n, total, int(sizes.max()) if stream_in_lds else 0, width, height, out.data_ptr(),
+            lib.df3d_jpeg_decode_luma(files_dev.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), n, total, int(sizes.max()), width, height, out.data_ptr(),
                                       status.data_ptr(), path.data_ptr() if return_path else None, work.data_ptr(), need, 1 if sequential else 0, stream),
             "df3d_jpeg_decode_luma",
         )

@@ -168,16 +168,14 @@ def test_many_files_one_call(native_lib, cuda, golden_dir):
 
 
 def test_parallel_decoder_paths(native_lib, cuda, golden_dir):
-    """The reference's JPEGs take the parallel (self-synchronising) Huffman kernel, with the stream staged in LDS or
-    read from global memory; restart-interval files fall back to the sequential kernel; all bit-identical."""
+    """The reference's JPEGs take the parallel (self-synchronising) Huffman kernel; restart-interval files fall back to the
+    sequential kernel; all bit-identical."""
     from deepfly3d_amd import jpeg
 
     blobs = [open(p, "rb").read() for p in sorted(glob.glob(f"{golden_dir}/images/*.jpg"))]
     ref = np.stack([pil_luma(b) for b in blobs])
     out, path = jpeg.decode_luma(blobs, 960, 480, return_path=True)
     assert np.array_equal(out.cpu().numpy(), ref) and (path > 0).all() and path.max() <= 12  # value = synchronisation passes
-    out, path = jpeg.decode_luma(blobs, 960, 480, return_path=True, stream_in_lds=False)
-    assert np.array_equal(out.cpu().numpy(), ref) and (path > 0).all()
     out, path = jpeg.decode_luma(blobs, 960, 480, return_path=True, sequential=True)
     assert np.array_equal(out.cpu().numpy(), ref) and (path == 0).all()
     rng = np.random.default_rng(8)
@@ -192,9 +190,9 @@ def test_parallel_decoder_paths(native_lib, cuda, golden_dir):
         assert np.array_equal(out.cpu().numpy()[i], pil_luma(b))
 
 
-def test_large_files_exceed_the_lds_stage(native_lib, cuda):
-    """Noise at quality 97, 1600x1200: files of several hundred KB, far beyond the 112 KB LDS stage -> the
-    global-memory variant of the parallel kernel; also a larger block grid than the camera frames."""
+def test_large_files_with_long_chunks(native_lib, cuda):
+    """Noise at quality 97, 1600x1200: files of several hundred KB (chunks of ~10 000 bits per lane), and a larger block grid
+    than the camera frames."""
     from deepfly3d_amd import jpeg
 
     rng = np.random.default_rng(9)
