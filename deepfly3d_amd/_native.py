@@ -96,6 +96,7 @@ PROTOTYPES = {
     "df3d_hg_set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "df3d_hg_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "df3d_hg_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "df3d_hg_forward_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p, c_size_t, c_void_p]),
     "df3d_hg_work": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_double)]),
     "df3d_hg_profile": (c_int, [c_void_p, c_int]),
     "df3d_hg_profile_count": (c_int, [c_void_p]),

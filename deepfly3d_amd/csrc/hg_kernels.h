@@ -20,6 +20,8 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_runtime.h>
 
+#include "preprocess_math.h"
+
 namespace hgk {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -332,6 +334,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 // Workgroup = 8 x 16 output pixels x 64 channels; input patch 21 x 37 x 3 and the whole 147 x 64 weight
 // matrix live in LDS.  K index k = ky*21 + kx*3 + c, so a patch row is contiguous in k.
 // -----------------------------------------------------------------------------------------------------
+// camera frames as the stem's input (df3d_hg_forward_u8): the patch values are sampled from the uint8 frames with the front-end's
+// arithmetic (preprocess_math.h) instead of being read from a float image
+struct StemU8 {
+    const unsigned char* frames;   // [V][FH][FW][FC] uint8, or nullptr: read StemArgs::img
+    const unsigned char* flip;     // [V] or nullptr
+    int FH, FW, FC;
+    df3d_pre::Norm nm;
+};
+
 struct StemArgs {
     const float* img;
     void* out;           // NHWC [V, H/2, W/2, 64] (T)
@@ -339,6 +350,7 @@ struct StemArgs {
     const void* w_bf16;  // bf16 engine: [64][184] bf16, k' = ky*24 + kx*3 + c (stem_relayout_kernel)
     const float* bias;   // [64]
     int V, H, W;         // input size
+    StemU8 u8;
 };
 
 template <typename T>
@@ -366,10 +378,19 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
         const int y = iy0 + r, x = ix0 + pxl;
         float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
         if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
-            const float* const src = img + ((size_t)y * p.W + x) * 3;
-            v0 = src[0];
-            v1 = src[1];
-            v2 = src[2];
+            if (p.u8.frames) {
+                float res[3];
+                df3d_pre::pixel(p.u8.frames + (size_t)view * p.u8.FH * p.u8.FW * p.u8.FC, p.u8.FH, p.u8.FW, p.u8.FC, p.u8.flip && p.u8.flip[view], p.H, p.W, y, x,
+                                p.u8.nm, res);
+                v0 = res[0];
+                v1 = res[1];
+                v2 = res[2];
+            } else {
+                const float* const src = img + ((size_t)y * p.W + x) * 3;
+                v0 = src[0];
+                v1 = src[1];
+                v2 = src[2];
+            }
         }
         float* const dst = patch + r * PROW + 3 * pxl;
         dst[0] = v0;
@@ -447,10 +468,19 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(StemArgs p) {
         const int y = iy0 + r, x = ix0 + pxl;
         float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
         if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
-            const float* const src = img + ((size_t)y * p.W + x) * 3;
-            v0 = src[0];
-            v1 = src[1];
-            v2 = src[2];
+            if (p.u8.frames) {
+                float res[3];
+                df3d_pre::pixel(p.u8.frames + (size_t)view * p.u8.FH * p.u8.FW * p.u8.FC, p.u8.FH, p.u8.FW, p.u8.FC, p.u8.flip && p.u8.flip[view], p.H, p.W, y, x,
+                                p.u8.nm, res);
+                v0 = res[0];
+                v1 = res[1];
+                v2 = res[2];
+            } else {
+                const float* const src = img + ((size_t)y * p.W + x) * 3;
+                v0 = src[0];
+                v1 = src[1];
+                v2 = src[2];
+            }
         }
         unsigned short* const dst = patch + r * PROW + 3 * pxl;
         dst[0] = f32_to_bf16_bits(v0);

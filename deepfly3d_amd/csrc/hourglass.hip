@@ -105,6 +105,7 @@ struct df3d_hg {
     int l1 = 1;           // 1 = bf16 layer1 (64 -> 64 -> 64 -> 128) runs as the LDS-resident-weights kernel of hg_bt_l1.h
     int ring = 1;         // 1 = the 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring*.h)
     size_t stream_bytes = 0;  // weight streams of all ring bottlenecks (behind the bf16 copy of the blob)
+    hgk::StemU8 u8in{nullptr, nullptr, 0, 0, 0, {{0, 0, 0}, {1, 1, 1}}};   // df3d_hg_forward_u8: the stem's input for the duration of that call
     std::vector<TensorDesc> tensors;
     std::vector<int> pooled_of;   // tensor id -> id of its max-pooled copy written by the producing fused bottleneck (-1: none)
     std::vector<Step> steps;
@@ -568,6 +569,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.V = n;
                 a.H = h->H;
                 a.W = h->W;
+                a.u8 = h->u8in;
                 const int blocks = n * (h->H / 2 / 8) * (h->W / 2 / 16);
                 const double opx = (double)n * (h->H / 2) * (h->W / 2);
                 ScopedTimer tm(h, s, eb == 2 ? std::string("stem_bf16_kernel") : std::string("stem_kernel<") + tname + ">", 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb));
@@ -757,7 +759,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
     return DF3D_OK;
 }
 
-int check_forward_args(df3d_hg* h, const float* images, int n, void* ws, size_t ws_bytes) {
+int check_forward_args(df3d_hg* h, const void* images, int n, void* ws, size_t ws_bytes) {
     DF3D_CHECK_ARG(h != nullptr, "null handle");
     if (!h->blob) {
         df3d::set_error("df3d_hg_forward: weights not set (call df3d_hg_set_weights first)");
@@ -943,6 +945,31 @@ int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_
     if (h->dtype == DF3D_DTYPE_F32)
         return run_steps<float>(h, images_dev, n, (int)h->steps.size(), heatmaps_dev, act, df3d::as_stream(stream));
     return run_steps<__hip_bfloat16>(h, images_dev, n, (int)h->steps.size(), heatmaps_dev, act, df3d::as_stream(stream));
+}
+
+int df3d_hg_forward_u8(df3d_hg* h, const unsigned char* frames_dev, const unsigned char* flip_dev, int n, int frame_h, int frame_w, int frame_c,
+                       const float* mean3_host, const float* std3_host, float* heatmaps_dev, void* workspace_dev, size_t workspace_bytes,
+                       void* stream) {
+    if (int rc = check_forward_args(h, frames_dev, n, workspace_dev, workspace_bytes)) return rc;
+    DF3D_CHECK_ARG(heatmaps_dev != nullptr && mean3_host && std3_host, "null pointer");
+    DF3D_CHECK_ARG(frame_h > 0 && frame_w > 0 && (frame_c == 1 || frame_c == 3), "bad frame shape (C must be 1 or 3)");
+    hgk::StemU8 u;
+    u.frames = frames_dev;
+    u.flip = flip_dev;
+    u.FH = frame_h;
+    u.FW = frame_w;
+    u.FC = frame_c;
+    for (int c = 0; c < 3; ++c) {
+        DF3D_CHECK_ARG(std3_host[c] != 0.0f, "std must be non-zero");
+        u.nm.mean[c] = mean3_host[c];
+        u.nm.inv_std[c] = 1.0f / std3_host[c];
+    }
+    h->u8in = u;
+    unsigned char* act = reinterpret_cast<unsigned char*>(workspace_dev);
+    const int rc = h->dtype == DF3D_DTYPE_F32 ? run_steps<float>(h, nullptr, n, (int)h->steps.size(), heatmaps_dev, act, df3d::as_stream(stream))
+                                              : run_steps<__hip_bfloat16>(h, nullptr, n, (int)h->steps.size(), heatmaps_dev, act, df3d::as_stream(stream));
+    h->u8in.frames = nullptr;
+    return rc;
 }
 
 int df3d_hg_work(const df3d_hg* h, int n, double* flops, double* bytes) {

@@ -3,13 +3,11 @@
 // bilinear down-scale with half-pixel centres, grey -> 3 channels, (v/255 - mean) / std.  HBM-bound.
 // df2d's exact resize/normalisation is not in the reference checkout ("parity unpinned"), so mean/std are data.
 #include "common.h"
+#include "preprocess_math.h"
 
 namespace {
 
-struct Norm {
-    float mean[3];
-    float inv_std[3];
-};
+using df3d_pre::Norm;
 
 __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __restrict__ img, const unsigned char* __restrict__ flip,
                                                          int n, int H, int W, int C, float* __restrict__ out, int OH, int OW, Norm nm) {
@@ -19,25 +17,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __
     const int ox = (int)(idx % OW);
     const int oy = (int)((idx / OW) % OH);
     const int v = (int)(idx / ((long long)OW * OH));
-    const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
-    float fy = (oy + 0.5f) * sy - 0.5f, fx = (ox + 0.5f) * sx - 0.5f;
-    fy = fminf(fmaxf(fy, 0.0f), (float)(H - 1));
-    fx = fminf(fmaxf(fx, 0.0f), (float)(W - 1));
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-    const float wy = fy - (float)y0, wx = fx - (float)x0;
-    const bool fl = flip && flip[v];
-    const int xa = fl ? W - 1 - x0 : x0, xb = fl ? W - 1 - x1 : x1;
-    const unsigned char* base = img + (size_t)v * H * W * C;
     float res[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int cc = C == 1 ? 0 : c;
-        const float p00 = base[((size_t)y0 * W + xa) * C + cc], p01 = base[((size_t)y0 * W + xb) * C + cc];
-        const float p10 = base[((size_t)y1 * W + xa) * C + cc], p11 = base[((size_t)y1 * W + xb) * C + cc];
-        const float top = p00 + (p01 - p00) * wx, bot = p10 + (p11 - p10) * wx;
-        res[c] = ((top + (bot - top) * wy) * (1.0f / 255.0f) - nm.mean[c]) * nm.inv_std[c];
-    }
+    df3d_pre::pixel(img + (size_t)v * H * W * C, H, W, C, flip && flip[v], OH, OW, oy, ox, nm, res);
     float* o = out + idx * 3;
     o[0] = res[0];
     o[1] = res[1];

@@ -177,6 +177,36 @@ class HourglassEngine:
             )
         return out
 
+    def forward_u8(self, frames_u8, flip=None, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), out=None):
+        """Heat-maps straight from camera frames: frames_u8 [n, H, W] or [n, H, W, C] uint8 cuda, flip [n] uint8 or None.  The stem
+        samples the frames with df3d_preprocess_u8's arithmetic: bit for bit forward(preprocess(frames)), one kernel and one
+        float image per batch fewer."""
+        import ctypes
+
+        if frames_u8.dim() == 3:
+            frames_u8 = frames_u8.unsqueeze(-1)
+        if not (frames_u8.is_cuda and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.dim() == 4):
+            raise ValueError("frames must be a contiguous uint8 CUDA tensor [n, H, W(, C)]")
+        if frames_u8.device != self.device:
+            raise ValueError(f"frames live on {frames_u8.device}, the engine on {self.device}")
+        n, fh, fw, fc = frames_u8.shape
+        if fc not in (1, 3) or n < 1:
+            raise ValueError("frames must have 1 or 3 channels and at least one view")
+        if out is None:
+            out = torch.empty((n, self.num_classes, self.height // 4, self.width // 4), dtype=torch.float32, device=self.device)
+        fl = None
+        if flip is not None:
+            fl = flip.to(device=self.device, dtype=torch.uint8).contiguous()
+        ws = self._workspace(n)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _native.check(
+                self.lib.df3d_hg_forward_u8(self.h, frames_u8.data_ptr(), fl.data_ptr() if fl is not None else None, n, fh, fw, fc,
+                                            (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std), out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                "df3d_hg_forward_u8",
+            )
+        return out
+
     def forward_upto(self, images, upto):
         """Layer-wise parity helper: output of plan step `upto - 1` as float32 NHWC (or NCHW for the final score)."""
         self._check_images(images)

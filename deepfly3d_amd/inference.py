@@ -106,6 +106,16 @@ def inference_views(images, engine, return_heatmap=False):
     return (pts, conf, hm) if return_heatmap else (pts, conf)
 
 
+def inference_frames(frames_u8, flip, engine, return_heatmap=False):
+    """frames_u8: uint8 [n, H, W(, C)] cuda camera frames, flip [n] uint8 or None -> (points [n, 19, 2], conf [n, 19]) (+ heat-maps):
+    `inference_views(preprocess_u8(frames, flip), engine)` with the resize / normalisation done inside the network's first kernel."""
+    if tuple(config["input_shape"]) != (engine.height, engine.width):
+        raise ValueError("engine input size differs from config['input_shape']")
+    hm = engine.forward_u8(frames_u8, flip, PREPROCESS["mean"], PREPROCESS["std"])
+    pts, conf = ops.heatmap_argmax(hm)
+    return (pts, conf, hm) if return_heatmap else (pts, conf)
+
+
 def _image_size(path):
     """(width, height) from the JPEG header (host IO only; pixels are decoded on the device)."""
     from PIL import Image
@@ -181,8 +191,7 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
             # file reads two batches ahead, H2D + JPEG decode one batch ahead on a second stream, under this batch's hourglass
             for k, luma in enumerate(reader.stream(paths)):
                 chunk = chunks[k]
-                x = preprocess_u8(luma, flips[k], tuple(config["input_shape"]))
-                res = inference_views(x, engine, return_heatmap=return_heatmap)
+                res = inference_frames(luma, flips[k], engine, return_heatmap=return_heatmap)
                 # items are (camera, frame) in camera-major order = the flat order of points[ncam, T]: contiguous copies
                 lo = starts[k]
                 points_flat[lo : lo + len(chunk)] = res[0]

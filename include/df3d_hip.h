@@ -281,6 +281,14 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value);
 size_t df3d_hg_workspace_bytes(const df3d_hg* h, int n);
 int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_dev, void* workspace_dev,
                     size_t workspace_bytes, void* stream);
+/* The same forward pass fed with the camera frames themselves: frames_dev [n][frame_h][frame_w][frame_c] uint8 (frame_c = 1 or
+ * 3), flip_dev [n] uint8 or NULL (non-zero: mirror the frame left-right).  The stem samples its input patches from the frames
+ * with the arithmetic of df3d_preprocess_u8 (bilinear to the engine's input size, (v/255 - mean) / std), so the result is bit
+ * for bit df3d_hg_forward(df3d_preprocess_u8(frames)) without the float image in between (the call df2d's dataset +
+ * network make per batch, behind reference df3d/core.py:177-185). */
+int df3d_hg_forward_u8(df3d_hg* h, const unsigned char* frames_dev, const unsigned char* flip_dev, int n, int frame_h, int frame_w,
+                       int frame_c, const float* mean3_host, const float* std3_host, float* heatmaps_dev, void* workspace_dev,
+                       size_t workspace_bytes, void* stream);
 /* algorithmic work of one forward over n views: FLOPs and activation bytes (fusion model M1 of
  * SURVEY.md 8d evaluated on this engine's own plan) */
 int df3d_hg_work(const df3d_hg* h, int n, double* flops, double* bytes);

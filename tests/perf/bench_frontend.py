@@ -115,7 +115,7 @@ def main():
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(reps):
-                    inference.inference_views(inference.preprocess_u8(luma, flip, (256, 512)), eng)
+                    inference.inference_frames(luma, flip, eng)
                 torch.cuda.synchronize()
                 dtr = time.perf_counter() - t0
             res[f"resident_{dt_name}_frames_per_s"] = round(reps * nb / 7 / dtr, 1)

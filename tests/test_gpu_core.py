@@ -307,3 +307,33 @@ def test_full_size_workload_properties(native_lib, cuda, golden_dir, dtype):
         assert np.array_equal(p2[:, t].cpu().numpy(), p38[:, 0]) and np.array_equal(conf[:, t].cpu().numpy(), cf)
         X = og.triangulate_dlt(og.pixels_from_normalised(p38, [960, 480]), og.projection_matrices(c["R"], c["tvec"], c["intr"]))
         assert np.abs(p3[t].cpu().numpy() - X[0]).max() < 1e-6 * max(1.0, np.abs(X).max())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_forward_from_camera_frames_equals_preprocess_then_forward(native_lib, cuda, dtype):
+    """df3d_hg_forward_u8 (the stem samples the uint8 frames itself) is bit for bit df3d_hg_forward(df3d_preprocess_u8(frames)):
+    grey and 3-channel frames, flipped and not, a frame size that is not a multiple of the network input, non-trivial mean / std."""
+    from deepfly3d_amd import inference
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    eng = HourglassEngine(synthetic_state_dict(3), dtype=dtype, device=cuda)
+    g = torch.Generator().manual_seed(11)
+    mean, std = (0.22, 0.31, 0.18), (0.9, 1.1, 1.3)
+    saved = dict(inference.PREPROCESS)
+    inference.PREPROCESS.update(mean=mean, std=std)
+    try:
+        for shape in ((3, 480, 960), (2, 301, 517, 3)):
+            frames = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g).to(cuda)
+            flip = torch.tensor([0, 1, 1][: shape[0]], dtype=torch.uint8, device=cuda)
+            ref = eng.forward(inference.preprocess_u8(frames, flip, (256, 512)))
+            got = eng.forward_u8(frames, flip, mean, std)
+            assert torch.equal(ref, got), shape
+            assert torch.equal(eng.forward(inference.preprocess_u8(frames, None, (256, 512))), eng.forward_u8(frames, None, mean, std))
+            p, c = inference.inference_frames(frames, flip, eng)
+            assert p.shape == (shape[0], 19, 2) and c.shape[0] == shape[0]
+    finally:
+        inference.PREPROCESS.clear()
+        inference.PREPROCESS.update(saved)
+    with pytest.raises(ValueError):
+        eng.forward_u8(torch.zeros((1, 8, 8, 2), dtype=torch.uint8, device=cuda))
