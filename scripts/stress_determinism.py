@@ -30,4 +30,30 @@ for dtype in ("bf16", "f32"):
         print(f"{dtype} n={n}: {diffs} of {reps} repeats differ")
         bad += diffs
         del other
-print("STRESS", "FAILED" if bad else "OK")
+print("network:", "FAILED" if bad else "OK")
+
+# the JPEG front-end under the same kind of load: one batch of camera frames decoded again and again on a side stream while
+# the network runs (the parallel Huffman kernel exchanges chunk states through LDS and hands DC offsets to the IDCT through
+# the per-file descriptor; the pipeline of inference_folder runs exactly this overlap)
+import glob
+from deepfly3d_amd import jpeg
+here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+base = [open(p, "rb").read() for p in sorted(glob.glob(os.path.join(here, "tests/golden/images/*.jpg")))]
+blobs = [base[i % len(base)] for i in range(448)]
+ref = jpeg.decode_luma(blobs, 960, 480).clone()
+eng = HourglassEngine(sd, dtype="bf16", device=dev)
+noise = torch.rand((224, 256, 512, 3), device=dev)
+side = torch.cuda.Stream()
+diffs = 0
+for r in range(reps):
+    eng.forward(noise)
+    with torch.cuda.stream(side):
+        out = jpeg.decode_luma(blobs, 960, 480, check=False)
+    side.synchronize()
+    if not torch.equal(out, ref):
+        diffs += 1
+torch.cuda.synchronize()
+print(f"jpeg decode of 448 frames beside the network: {diffs} of {reps} repeats differ")
+bad += diffs
+print("OK" if bad == 0 else f"FAILED: {bad} differing repeats")
+sys.exit(1 if bad else 0)
