@@ -243,16 +243,30 @@ def main():
         ba_pool = ThreadPoolExecutor(max_workers=1)
         ba_stream = torch.cuda.Stream(device=dev)
 
+    ba_ms = []
+
     def recalibrate(window_px):
+        t_ba = time.perf_counter()
         with torch.cuda.device(dev), torch.cuda.stream(ba_stream):
             Rn, tn, info = bundle_adjust(window_px, calib["R"], calib["tvec"], calib["intr"], device=dev, return_info=True)
+        ba_ms.append(round(1e3 * (time.perf_counter() - t_ba), 1))   # wall time of the solve (beside the pipeline when threaded)
+        if timeline is not None:
+            timeline["ba"].append((t_ba, time.perf_counter()))
         return np.concatenate([Rn.reshape(7, 9), tn.reshape(7, 3)], axis=1), info["nfev"]
 
+    timeline = {"enq": [], "ev": [], "ba": []} if os.environ.get("DF3D_BENCH_TIMELINE") else None
+
     def step(i, pipeline=pipe, record=True):
+        if timeline is not None and record:
+            timeline["enq"].append(time.perf_counter())
         f0 = i * fps_step
         n = min(fps_step, total_frames - f0)
         lo = f0 % pool
         pipeline.run_batch(frames[lo : lo + n], *outs, f0)
+        if timeline is not None and record:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            timeline["ev"].append(ev)
         # a window closes with this batch (the last window of the share may be shorter)
         if ba_px is not None and ((f0 + n) // a.ba_window > f0 // a.ba_window or (f0 + n == total_frames and total_frames % a.ba_window)):
             closed = (f0 + n) // a.ba_window - 1 if (f0 + n) // a.ba_window > f0 // a.ba_window else len(ba_px) - 1
@@ -282,18 +296,46 @@ def main():
 
     for w in range(a.warmup):
         step(w % a.steps, record=False)
+    if ba_px is not None:
+        # the re-calibration has one-time costs of its own (allocator growth on its stream, the LSMR chunk's graph: ~0.7 s per
+        # call until buffers and graph settle) and no window closes inside the W warm-up steps: warm it on its worker thread,
+        # where its graph cache lives
+        for _ in range(2):
+            ba_pool.submit(recalibrate, ba_px[0]).result()
+        del ba_ms[:]
+    if collective and world == 1:
+        # a multi-rank run creates its RCCL communicator in the barrier below; the 1-rank group of --force-collective would
+        # create it inside the first gather, i.e. inside the timed region (0.9 s when nothing else hides it)
+        torch.distributed.all_reduce(torch.zeros(1, device=dev))
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     t_start = time.perf_counter()
+    if timeline is not None:
+        timeline["ev0"] = torch.cuda.Event(enable_timing=True)
+        timeline["ev0"].record()
     for i in range(a.steps):
         step(i)
+    t_marks = [time.perf_counter()]
     join_recalibrations()
+    t_marks.append(time.perf_counter())
     gathered = gather()
+    t_marks.append(time.perf_counter())
     torch.cuda.synchronize()
+    t_marks.append(time.perf_counter())
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t_start
+    if timeline is not None:   # development aid: host enqueue time, GPU completion time of every step, the solves' intervals
+        ev0 = timeline["ev"][0]
+        done = [ev0.elapsed_time(e) for e in timeline["ev"]]
+        enq = [1e3 * (x - t_start) for x in timeline["enq"]]
+        print("TIMELINE step: enqueue_ms gpu_done_ms(from step 0's end)", file=sys.stderr)
+        for i in range(0, len(enq), max(1, len(enq) // 24)):
+            print(f"  step {i:3d}: {enq[i]:8.1f} {done[i]:8.1f}", file=sys.stderr)
+        print("  step 0 gpu done", round(timeline["ev0"].elapsed_time(ev0), 1), "ms after the start; last step", round(done[-1], 1), "ms after step 0; elapsed", round(1e3 * elapsed, 1), file=sys.stderr)
+        print("  host marks (ms): loop end, joined, gather returned, synchronised:", [round(1e3 * (m - t_start), 1) for m in t_marks], file=sys.stderr)
+        print("  BA [start, end] ms:", [(round(1e3 * (a0 - t_start)), round(1e3 * (a1 - t_start))) for a0, a1 in timeline["ba"][-len(ba_runs):]], file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -375,6 +417,7 @@ def main():
                 "bundle_adjust_every_frames": a.ba_window or None,
                 "bundle_adjust_runs_rank0": len(ba_runs) or None,
                 "bundle_adjust_nfev": ba_runs or None,
+                "bundle_adjust_wall_ms": ba_ms[-len(ba_runs):] if ba_runs else None,
                 "hourglass_tflops_end_to_end": per_step * fl / (ms_step * 1e-3) / 1e12,
                 "hourglass_gbs_algorithmic_end_to_end": per_step * by / (ms_step * 1e-3) / 1e9,
                 "hbm_frac": per_step * by / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
