@@ -435,6 +435,8 @@ def main():
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
+        if world > 1:
+            torch.distributed.barrier()   # rank 0 is still measuring the per-kernel table while the others are done: tear down together
         torch.distributed.destroy_process_group()
 
 
