@@ -92,6 +92,111 @@ __global__ __launch_bounds__(256) void median_kernel(const double* __restrict__ 
     }
 }
 
+// ---- long columns: the same radix select spread over many workgroups -------------------------------------------------------
+// One workgroup per column walks all n values eight times: fine for the 60 columns of 1e5 segment lengths, 44 ms for the three
+// columns of 3.8e6 coordinates of a 100 000-frame recording (two workgroups' worth of loads on a 256-CU device).  With a little
+// scratch memory a pass becomes a histogram kernel over all the values (LDS histograms, one global atomic per bin and
+// workgroup) and a one-wave kernel that picks the bin -- the same counts, the same medians.
+constexpr int MED_SCRATCH_DOUBLES = 272;   // per column: hist [2][256] u32 (256 doubles) + prefix [2] + rank [2] (+ pad)
+constexpr long long MED_LONG = 1 << 16;    // columns at least this long take the multi-workgroup route when scratch is there
+struct MedCol {
+    unsigned int hist[2][256];
+    unsigned long long prefix[2];
+    long long rank[2];
+};
+static_assert(sizeof(MedCol) <= MED_SCRATCH_DOUBLES * 8, "scratch per column");
+
+__global__ __launch_bounds__(256) void median_hist_kernel(const double* __restrict__ data, long long n, long long inner_n, long long inner_stride,
+                                                          long long outer_stride, long long col_stride_x, long long col_stride_y, int shift,
+                                                          unsigned long long mask, MedCol* __restrict__ cols) {
+    __shared__ unsigned int hist[2][256];
+    const int c = blockIdx.z * gridDim.y + blockIdx.y;
+    const double* col = data + blockIdx.y * col_stride_x + blockIdx.z * col_stride_y;
+    MedCol* const mc = cols + c;
+    const int tid = threadIdx.x;
+    hist[0][tid] = 0;
+    hist[1][tid] = 0;
+    __syncthreads();
+    const unsigned long long p0 = mc->prefix[0], p1 = mc->prefix[1];
+    const bool same = p0 == p1;
+    const bool dense = inner_n >= n;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < n; i += (long long)gridDim.x * 256) {
+        long long o = 0, r = i;
+        if (!dense) {
+            const unsigned q = (unsigned)i / (unsigned)inner_n;
+            o = q;
+            r = (long long)((unsigned)i - q * (unsigned)inner_n);
+        }
+        const unsigned long long k = order_key(col[o * outer_stride + r * inner_stride]);
+        const unsigned int bin = (unsigned int)(k >> shift) & 255u;
+        if ((k & mask) == p0) atomicAdd(&hist[0][bin], 1u);
+        if (!same && (k & mask) == p1) atomicAdd(&hist[1][bin], 1u);
+    }
+    __syncthreads();
+    if (hist[0][tid]) atomicAdd(&mc->hist[0][tid], hist[0][tid]);
+    if (hist[1][tid]) atomicAdd(&mc->hist[1][tid], hist[1][tid]);
+}
+
+// shift = 64: initialise the column's state; otherwise pick the bin of this pass, clear the histograms; shift = 0: write the median
+__global__ __launch_bounds__(256) void median_select_kernel(MedCol* __restrict__ cols, long long n, int shift, double* __restrict__ out) {
+    MedCol* const mc = cols + blockIdx.x;
+    const int tid = threadIdx.x;
+    if (shift == 64) {
+        mc->hist[0][tid] = 0;
+        mc->hist[1][tid] = 0;
+        if (tid == 0) {
+            mc->prefix[0] = mc->prefix[1] = 0;
+            mc->rank[0] = (n - 1) / 2;
+            mc->rank[1] = n / 2;
+        }
+        return;
+    }
+    __shared__ unsigned int hist[2][256];
+    hist[0][tid] = mc->hist[0][tid];
+    hist[1][tid] = mc->hist[1][tid];
+    const bool same = mc->prefix[0] == mc->prefix[1];
+    __syncthreads();
+    mc->hist[0][tid] = 0;
+    mc->hist[1][tid] = 0;
+    if (tid < 2) {
+        const int w = (same && tid == 1) ? 0 : tid;
+        long long rank = mc->rank[tid];
+        int b = 0;
+        for (; b < 255; ++b) {
+            const long long c = hist[w][b];
+            if (rank < c) break;
+            rank -= c;
+        }
+        mc->rank[tid] = rank;
+        mc->prefix[tid] |= (unsigned long long)b << shift;
+    }
+    if (shift == 0) {
+        __syncthreads();
+        if (tid == 0) {
+#pragma clang fp contract(off)
+            const double a = key_value(mc->prefix[0]), b = key_value(mc->prefix[1]);
+            out[blockIdx.x] = (n & 1) ? a : (a + b) / 2.0;
+        }
+    }
+}
+
+// medians of gx x gy columns (column (x, y) -> out[y * gx + x]) through the multi-workgroup route; scratch: gx * gy MedCol
+void launch_long_median(const double* data, long long n, long long inner_n, long long inner_stride, long long outer_stride, long long col_stride_x,
+                        long long col_stride_y, int gx, int gy, double* out, double* scratch, hipStream_t s) {
+    MedCol* const cols = reinterpret_cast<MedCol*>(scratch);
+    const int ncols = gx * gy;
+    const int nb = (int)((n + 256 * 16 - 1) / (256 * 16) < 1024 ? (n + 256 * 16 - 1) / (256 * 16) : 1024);
+    hipLaunchKernelGGL(median_select_kernel, dim3(ncols), dim3(256), 0, s, cols, n, 64, out);
+    unsigned long long mask = 0;
+    for (int pass = 7; pass >= 0; --pass) {
+        const int shift = 8 * pass;
+        hipLaunchKernelGGL(median_hist_kernel, dim3(nb, gx, gy), dim3(256), 0, s, data, n, inner_n, inner_stride, outer_stride, col_stride_x, col_stride_y, shift,
+                           mask, cols);
+        hipLaunchKernelGGL(median_select_kernel, dim3(ncols), dim3(256), 0, s, cols, n, shift, out);
+        mask |= 255ull << shift;
+    }
+}
+
 // work-buffer layout (doubles), T = frames:
 //   seg   [2][12][T]      segment lengths per side
 //   fit   [2][18][T]      scaled, centred fit-joint coordinates per side
@@ -99,7 +204,7 @@ __global__ __launch_bounds__(256) void median_kernel(const double* __restrict__ 
 struct Work {
     double *seg, *fit, *med_seg, *med_all, *scale, *med_fit, *xf;
 };
-__host__ __device__ inline long long work_doubles(long long T) { return 2 * (NSEG + 3 * NFIT) * T + 128; }
+__host__ __device__ inline long long work_doubles(long long T) { return 2 * (NSEG + 3 * NFIT) * T + 128 + 6 * MED_SCRATCH_DOUBLES; }
 inline Work carve(double* w, long long T) {
     Work k;
     k.seg = w;
@@ -344,8 +449,12 @@ int df3d_procrustes(const double* pts, long long T, const double* tmpl_seg_med, 
     hipLaunchKernelGGL(seglen_kernel, dim3(grid_for(T, 256)), dim3(256), 0, s, pts, T, w.seg);
     // medians: 24 segment-length columns over T; per side and axis all T*19 points (strided in place)
     hipLaunchKernelGGL(median_kernel, dim3(2 * NSEG, 1), dim3(256), 0, s, w.seg, T, T, 1LL, 0LL, T, 0LL, w.med_seg);
-    hipLaunchKernelGGL(median_kernel, dim3(3, 2), dim3(256), 0, s, pts, T * SIDE_JOINTS, (long long)SIDE_JOINTS, 3LL, 114LL, 1LL,
-                       (long long)SIDE_JOINTS * 3, w.med_all);
+    if (T * SIDE_JOINTS >= MED_LONG)
+        launch_long_median(pts, T * SIDE_JOINTS, (long long)SIDE_JOINTS, 3LL, 114LL, 1LL, (long long)SIDE_JOINTS * 3, 3, 2, w.med_all,
+                           work + work_doubles(T) - 6 * MED_SCRATCH_DOUBLES, s);
+    else
+        hipLaunchKernelGGL(median_kernel, dim3(3, 2), dim3(256), 0, s, pts, T * SIDE_JOINTS, (long long)SIDE_JOINTS, 3LL, 114LL, 1LL,
+                           (long long)SIDE_JOINTS * 3, w.med_all);
     hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(64), 0, s, tm, w.med_seg, w.scale);
     hipLaunchKernelGGL(fit_cols_kernel, dim3(grid_for(T, 256)), dim3(256), 0, s, pts, T, w.med_all, w.scale, w.fit);
     hipLaunchKernelGGL(median_kernel, dim3(2 * 3 * NFIT, 1), dim3(256), 0, s, w.fit, T, T, 1LL, 0LL, T, 0LL, w.med_fit);
@@ -362,7 +471,10 @@ int df3d_pose_normalize(const double* in, long long T, int njoints, int rotate, 
     DF3D_CHECK_ARG(work_len >= 3, "work buffer needs 3 doubles");
     hipStream_t s = df3d::as_stream(stream);
     const long long TJ = T * njoints;
-    hipLaunchKernelGGL(median_kernel, dim3(3, 1), dim3(256), 0, s, in, TJ, TJ, 3LL, 0LL, 1LL, 0LL, work);
+    if (TJ >= MED_LONG && work_len >= 8 + 3 * MED_SCRATCH_DOUBLES)   // (a caller of round 1 passes 3 doubles: one workgroup per column)
+        launch_long_median(in, TJ, TJ, 3LL, 0LL, 1LL, 0LL, 3, 1, work, work + 8, s);
+    else
+        hipLaunchKernelGGL(median_kernel, dim3(3, 1), dim3(256), 0, s, in, TJ, TJ, 3LL, 0LL, 1LL, 0LL, work);
     hipLaunchKernelGGL(normalize_kernel, dim3(grid_for(TJ, 256)), dim3(256), 0, s, in, TJ, work, rotate, out);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;

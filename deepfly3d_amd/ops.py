@@ -129,9 +129,9 @@ def pose_normalize(points3d, rotate=True):
     T, J, three = points3d.shape
     if three != 3:
         raise ValueError("points3d must be [T, J, 3]")
-    work = torch.empty((3,), dtype=torch.float64, device=points3d.device)
+    work = torch.empty((1024,), dtype=torch.float64, device=points3d.device)   # medians + scratch of the long-column median
     out = torch.empty_like(points3d)
-    _native.check(lib.df3d_pose_normalize(points3d.data_ptr(), T, J, 1 if rotate else 0, out.data_ptr(), work.data_ptr(), 3, _stream(points3d)),
+    _native.check(lib.df3d_pose_normalize(points3d.data_ptr(), T, J, 1 if rotate else 0, out.data_ptr(), work.data_ptr(), work.numel(), _stream(points3d)),
                   "df3d_pose_normalize")
     return out
 

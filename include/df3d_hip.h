@@ -135,7 +135,8 @@ int df3d_triangulate_scaled(const double* P, const double* pts_norm_dev, double 
  *                      the template's 6 fit joints (side joints 0,1,5,6,10,11).  work_dev >=
  *                      df3d_procrustes_work_doubles(T) doubles.
  * df3d_pose_normalize: out = in - median over all T*njoints points (per axis); rotate != 0 additionally maps
- *                      (x, y, z) -> (x, -z, -y).  work_dev >= 3 doubles.  in == out allowed.
+ *                      (x, y, z) -> (x, -z, -y).  work_dev >= 3 doubles; with >= 1024 doubles the medians of sequences of
+ *                      more than 65 536 values per axis are taken by many workgroups (same values).  in == out allowed.
  * df3d_oneeuro_filter: in/out [T, nch]; one independent One-Euro filter per channel; sample i carries the time
  *                      stamp (i + first_stamp) * stamp_step and, like the reference, the filter re-derives its
  *                      sampling frequency from consecutive stamps.  The reference's `filter_batch` is

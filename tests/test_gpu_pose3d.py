@@ -83,6 +83,29 @@ def test_pose_normalize_bit_exact(native_lib, cuda, golden_dir):
         assert np.array_equal(plain, pp.normalize_pose_3d(d["procrustes"], rotate=False))
 
 
+def test_pose_normalize_long_sequences_take_the_multi_workgroup_median(native_lib, cuda):
+    """More than 65 536 values per axis: the medians come from the histogram / select kernel pairs (many workgroups per
+    column) -- same exact order statistics: odd and even counts, ties, against numpy; and against the 3-double work buffer of
+    round 1's callers, which keeps the one-workgroup kernel."""
+    import ctypes
+
+    from deepfly3d_amd import _native, ops
+
+    lib = _native.load()
+    rng = np.random.default_rng(17)
+    for T in (20001, 20000):
+        X = rng.normal(0, 1, size=(T, 38, 3))
+        X[::7] = np.round(X[::7], 1)   # plenty of exact ties
+        X[:, :, 2] = -np.abs(X[:, :, 2]) * 1e-3   # one axis with all keys in one top-level bin
+        got = ops.pose_normalize(_dev(X), rotate=False).cpu().numpy()
+        assert np.array_equal(got, X - np.median(X.reshape(-1, 3), axis=0))
+        x = _dev(X)
+        out, work = torch.empty_like(x), torch.empty(3, dtype=torch.float64, device=x.device)
+        _native.check(lib.df3d_pose_normalize(x.data_ptr(), T, 38, 0, out.data_ptr(), work.data_ptr(), 3, None), "df3d_pose_normalize")
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), got)
+
+
 def test_oneeuro_bit_exact(native_lib, cuda, golden_dir):
     from deepfly3d_amd import ops
 
