@@ -676,17 +676,23 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
     // capturable stream (not the legacy default stream) the chunk is recorded once into a HIP graph and replayed -- every
     // scalar the kernels need lives in `st`, so the recording is valid for every chunk of every LSMR run on the same problem
     // and buffers (the three or four runs of one trust-region solve); otherwise the kernels are enqueued directly.
+    // The recorded kernels take *p BY VALUE, so the key is every field of the problem (all index tables and the ncam / nobs /
+    // npts split, not only their sum) plus every buffer the chunk touches: a recording is replayed only against exactly the
+    // arguments it was made with.
+    constexpr int NKEY = 12;
     struct ChunkGraph {
         hipGraphExec_t exec = nullptr;
-        const void* key[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        long long dims[2] = {0, 0};
+        const void* key[NKEY] = {};
+        long long dims[5] = {0, 0, 0, 0, 0};
     };
     static thread_local ChunkGraph cache;
-    const void* key[8] = {p->obs_xy, Jc, Jp, d_dev, x_dev, work_dev, p->cam_idx, p->pt_idx};
+    const void* key[NKEY] = {p->obs_xy, Jc, Jp, d_dev, x_dev, work_dev, p->cam_idx, p->pt_idx, p->intr4, p->pt_start, p->cam_perm, p->cam_start};
+    const long long dims[5] = {(long long)m, (long long)n, p->ncam, p->nobs, p->npts};
     bool use_graph = s != nullptr && maxiter >= CHUNK;
     if (use_graph) {
-        bool same = cache.exec != nullptr && cache.dims[0] == (long long)m && cache.dims[1] == (long long)n;
-        for (int k = 0; k < 8 && same; ++k) same = cache.key[k] == key[k];
+        bool same = cache.exec != nullptr;
+        for (int k = 0; k < 5 && same; ++k) same = cache.dims[k] == dims[k];
+        for (int k = 0; k < NKEY && same; ++k) same = cache.key[k] == key[k];
         if (!same) {
             if (cache.exec) (void)hipGraphExecDestroy(cache.exec);
             cache.exec = nullptr;
@@ -696,9 +702,8 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
                 for (int it = 0; it < CHUNK && rc == DF3D_OK; ++it) rc = enqueue_iteration();
                 const hipError_t e = hipStreamEndCapture(s, &graph);
                 if (rc == DF3D_OK && e == hipSuccess && graph && hipGraphInstantiate(&cache.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                    for (int k = 0; k < 8; ++k) cache.key[k] = key[k];
-                    cache.dims[0] = (long long)m;
-                    cache.dims[1] = (long long)n;
+                    for (int k = 0; k < NKEY; ++k) cache.key[k] = key[k];
+                    for (int k = 0; k < 5; ++k) cache.dims[k] = dims[k];
                 } else {
                     cache.exec = nullptr;
                 }

@@ -163,18 +163,29 @@ def gather_results(points2d, conf, points3d, num_frames, rank, world_size, align
     if cameras is not None:
         # windows per rank follow from the frame ranges (a window never straddles two ranks: `align`)
         wcounts = [(c + align - 1) // align for c in counts]
-        if cameras.shape[0] != wcounts[rank]:
-            raise ValueError(f"rank {rank}: {cameras.shape[0]} camera windows for {counts[rank]} frames (align {align})")
-        cam_tab, cam_layout = _pack_rows([cameras], cameras.shape[0])
+        # A rank whose window count is wrong must NOT raise in front of the collective (its peers would wait in the gather
+        # until the back-end's timeout): it enters the gather like everybody else, its record says how many windows it
+        # holds, and the mismatch is raised behind the collective -- on that rank and on rank 0.
+        have = int(cameras.shape[0])
+        keep = min(have, wcounts[rank])
+        cam_tab, cam_layout = _pack_rows([cameras[:keep]], keep)
         cw = cam_tab.shape[1]
-        # one flat byte record per rank: [longest frames x fw | longest windows x cw]
+        # one flat byte record per rank: [window count (8 B) | longest frames x fw | longest windows x cw]
         lf, lw = max(counts), max(wcounts)
-        flat = torch.zeros((1, lf * fw + lw * cw), dtype=torch.uint8, device=frame_tab.device)
-        flat[0, : Tr * fw] = frame_tab.reshape(-1)
-        flat[0, lf * fw : lf * fw + cam_tab.numel()] = cam_tab.reshape(-1)
+        flat = torch.zeros((1, 8 + lf * fw + lw * cw), dtype=torch.uint8, device=frame_tab.device)
+        flat[0, :8] = torch.tensor([have], dtype=torch.int64).view(torch.uint8).to(flat.device)
+        flat[0, 8 : 8 + Tr * fw] = frame_tab.reshape(-1)
+        flat[0, 8 + lf * fw : 8 + lf * fw + cam_tab.numel()] = cam_tab.reshape(-1)
         rows = _gather_rows(flat, [1] * world_size, rank, world_size, group, force_collective)
+        if have != wcounts[rank]:
+            raise ValueError(f"rank {rank}: {have} camera windows for {counts[rank]} frames (align {align})")
         if rows is None:
             return None, None, None, None
+        sent = rows[:, :8].contiguous().cpu().view(torch.int64).reshape(-1).tolist()
+        bad = [(r, sent[r], wcounts[r]) for r in range(world_size) if sent[r] != wcounts[r]]
+        if bad:
+            raise ValueError("camera window counts do not match the frame ranges: " + ", ".join(f"rank {r} sent {n}, expected {e}" for r, n, e in bad))
+        rows = rows[:, 8:]
         ftabs = torch.cat([rows[r, : counts[r] * fw].reshape(counts[r], fw) for r in range(world_size)], dim=0)
         ctabs = torch.cat([rows[r, lf * fw : lf * fw + wcounts[r] * cw].reshape(wcounts[r], cw) for r in range(world_size)], dim=0)
         cams = _unpack_rows(ctabs, cam_layout)[0].to(cameras.device)

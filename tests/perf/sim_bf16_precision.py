@@ -1,0 +1,126 @@
+"""CPU emulation of where the bf16 engine rounds (torch fp32 convolutions on operands rounded to bf16): which roundings put
+the heat-map peak values outside the reference's confidence tolerance (reference tests/test_df3d.py:173-178: atol 2e-3 on
+peaks ~1), and what a float32 residual trunk buys.  Measurement helper (imports the oracle): not part of the product.
+
+    python tests/perf/sim_bf16_precision.py [fixture.npz]
+
+variants:  all_bf16   every activation tensor stored as bf16 (the plain bf16 engine)
+           trunk_f32  the 256-channel residual trunk (block inputs / outputs, upsample sums, pooled copies, head skip) stays
+                      float32; every MFMA operand (weights, bn1+ReLU output, t1, t2, fc output) is bf16
+           trunk_f32+heads_f32ops   as trunk_f32, the two stack heads multiply float32 operands
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import geometry as og  # noqa: E402
+from oracle import hourglass_torch as oh  # noqa: E402
+
+EPS = 1e-5
+
+
+def bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def ident(t):
+    return t
+
+
+def bn_affine(bn):
+    s = (bn.weight.double() / torch.sqrt(bn.running_var.double() + EPS))
+    return s, bn.bias.double() - bn.running_mean.double() * s
+
+
+def fold(conv, bn):
+    """conv followed by bn -> (weight, bias) in float64"""
+    w, b = conv.weight.double(), conv.bias.double()
+    if bn is not None:
+        s, t = bn_affine(bn)
+        w = w * s[:, None, None, None]
+        b = b * s + t
+    return w, b
+
+
+class Sim:
+    def __init__(self, net, trunk, op=bf, head_op=None, small=bf):
+        self.net, self.trunk, self.op, self.small = net, trunk, op, small
+        self.head_op = head_op or op
+
+    def conv(self, x, conv, bn, op, **kw):
+        w, b = fold(conv, bn)
+        return F.conv2d(op(x), op(w.float()), b.float(), **kw)
+
+    def block(self, seq, x, store):
+        b = seq[0]
+        op = self.op
+        s, t = bn_affine(b.bn1)
+        a = F.relu(x * s.float()[None, :, None, None] + t.float()[None, :, None, None])
+        t1 = F.relu(self.conv(a, b.conv1, b.bn2, op))
+        t2 = F.relu(self.conv(t1, b.conv2, b.bn3, op, padding=1))
+        y = self.conv(t2, b.conv3, None, op)
+        if b.downsample is None:
+            # plain bf16 engine: the fp32 accumulator is rounded, then added to x in bf16 arithmetic (rounded again)
+            return store(store(y) + x)
+        return store(y + self.conv(x, b.downsample[0], None, op))
+
+    def level(self, hg, n, x):
+        T = self.trunk
+        blocks = hg.hg[n - 1]
+        up1 = self.block(blocks[0], x, T)
+        low = self.block(blocks[1], F.max_pool2d(x, 2, stride=2), T)
+        low = self.level(hg, n - 1, low) if n > 1 else self.block(blocks[3], low, T)
+        low = self.block(blocks[2], low, T)
+        return T(up1 + F.interpolate(low, scale_factor=2, mode="nearest"))
+
+    @torch.no_grad()
+    def forward(self, images_nhwc):
+        net, T, S = self.net, self.trunk, self.small
+        x = images_nhwc.permute(0, 3, 1, 2).contiguous()
+        x = S(F.relu(self.conv(x, net.conv1, net.bn1, self.op, stride=2, padding=3)))
+        x = F.max_pool2d(self.block(net.layer1, x, S), 2, stride=2)
+        x = self.block(net.layer2, x, T)
+        x = self.block(net.layer3, x, T)
+        for s in range(net.num_stacks):
+            y = self.block(net.res[s], self.level(net.hg[s], net.hg[s].depth, x), T)
+            hop = self.head_op
+            y = F.relu(self.conv(y, net.fc[s][0], net.fc[s][1], hop))
+            score = self.conv(y, net.score[s], None, hop)
+            if s < net.num_stacks - 1:
+                x = T(x + self.conv(y, net.fc_[s], None, hop) + self.conv(score, net.score_[s], None, hop))
+        return score
+
+
+def main():
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "peaked_input.npz")
+    torch.set_num_threads(os.cpu_count() or 1)
+    net = oh.build(seed=0)
+    d = np.load(path)
+    u8 = d["images_u8"][: int(os.environ.get("SIM_N", "4"))]
+    x = torch.from_numpy(u8.astype(np.float32) / 255.0)[..., None].expand(-1, -1, -1, 3).contiguous()
+    ref = oh.forward_nhwc(net, x)
+    rp, rc = og.heatmap_argmax(ref.numpy())
+    scale = float(ref.abs().max())
+    print(f"{len(u8)} images, peaks {rc.min():.2f}..{rc.max():.2f}, max |heat-map| {scale:.2f}")
+    variants = {
+        "fp32 emulation (sanity)": Sim(net, ident, ident, ident, ident),
+        "all_bf16": Sim(net, bf),
+        "trunk_f32": Sim(net, ident),
+        "trunk_f32 + heads_f32ops": Sim(net, ident, head_op=ident),
+        "trunk_f32 + small tensors f32": Sim(net, ident, small=ident),
+    }
+    for name, sim in variants.items():
+        hm = sim.forward(x)
+        p, c = og.heatmap_argmax(hm.numpy())
+        same = np.all(p == rp, axis=-1).mean()
+        print(f"{name:34s} heat-map rel err {float((hm - ref).abs().max()) / scale:.2e}   conf: max |diff| / peak {np.abs((c - rc) / rc).max():.2e}, "
+              f"/ max|hm| {np.abs(c - rc).max() / scale:.2e}   identical cells {same:.4f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

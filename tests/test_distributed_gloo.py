@@ -78,6 +78,63 @@ def test_two_rank_gather_with_window_cameras(tmp_path, T, align):
         assert g.dtype == r.dtype and torch.equal(g, r)
 
 
+@pytest.mark.parametrize("T,align,with_cameras", [(100, 10, False), (100, 10, True), (7, 1, False), (7, 1, True), (100000, 1000, True)])
+def test_eight_rank_gather_with_uneven_and_empty_shards(tmp_path, T, align, with_cameras):
+    """The node-level run is 8 ranks: uneven window counts ((100, 10): 2,2,1,1,1,1,1,1 windows; configs[3]/[4]'s
+    (100 000, 1 000): 13 000 x 4 + 12 000 x 4 frames), a rank with NO frames ((7, 1): rank 7's shard is empty) -- padded
+    shards, empty records and the window cameras all through the one collective, bit-identical to one process."""
+    from deepfly3d_amd import distributed as dd
+
+    ranges = dd.all_ranges(T, 8, align)
+    assert ranges[0][0] == 0 and ranges[-1][1] == T and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    if (T, align) == (100, 10):
+        assert [b - a for a, b in ranges] == [20, 20, 10, 10, 10, 10, 10, 10]
+    if (T, align) == (7, 1):
+        assert ranges[7] == (7, 7)
+    if T == 100000:
+        assert [b - a for a, b in ranges] == [13000] * 4 + [12000] * 4
+    port = _free_port()
+    mp.spawn(_worker, args=(8, port, T, align, str(tmp_path), with_cameras), nprocs=8, join=True)
+    got = torch.load(os.path.join(tmp_path, "gathered.pt"))
+    ref = (*_full_sequence(T), _window_cameras(T, align)) if with_cameras else _full_sequence(T)
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert g.dtype == r.dtype and torch.equal(g, r)
+
+
+def _bad_worker(rank, world, port, T, align, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from deepfly3d_amd import distributed as dd
+
+    dd.init_from_env(backend="gloo")
+    p2, cf, p3 = _full_sequence(T)
+    a, b = dd.shard_range(T, world, rank, align)
+    cams = _window_cameras(T, align)[a // align : (b + align - 1) // align].contiguous()
+    if rank == 1:
+        cams = cams[:-1]   # one window short
+    try:
+        dd.gather_results(p2[:, a:b].contiguous(), cf[:, a:b].contiguous(), p3[a:b].contiguous(), T, rank, world, align, cameras=cams)
+        outcome = "returned"
+    except ValueError as e:
+        outcome = "ValueError: " + str(e)
+    with open(os.path.join(outdir, f"outcome{rank}.txt"), "w") as f:
+        f.write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_wrong_window_count_fails_behind_the_collective_not_in_front_of_it(tmp_path):
+    """A rank with the wrong number of camera windows still enters the gather (its peers would otherwise hang in the
+    collective until the back-end's timeout); the error is raised afterwards on that rank and on rank 0."""
+    port = _free_port()
+    mp.spawn(_bad_worker, args=(3, port, 60, 10, str(tmp_path)), nprocs=3, join=True)
+    out = [open(os.path.join(tmp_path, f"outcome{r}.txt")).read() for r in range(3)]
+    assert out[0].startswith("ValueError") and "rank 1 sent 1, expected 2" in out[0]
+    assert out[1].startswith("ValueError") and "rank 1: 1 camera windows" in out[1]
+    assert out[2] == "returned"
+
+
 def test_one_rank_group_executes_the_collective():
     """A 1-rank process group with force_collective runs the real `dist.gather` (what the GPU box does on RCCL with
     its single GPU) and returns the same tensors."""
