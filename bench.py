@@ -35,11 +35,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}  # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 PEAK_HBM_GBS = 8000.0
 # which roof binds the hourglass per dtype (fp32: AI 55.6 FLOP/B > 19.7 balance -> FLOP-bound;
 # bf16 on MFMA: 323.7 MB/view of activation traffic in the fusion model M1 -> HBM-bound)
-BOUND = {"f32": "mfma", "bf16": "hbm"}
+BOUND = {"f32": "mfma", "bf16": "hbm", "f16": "hbm"}
 
 
 def parse():
@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-step", type=int, default=128)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f16"], default="f32")
     ap.add_argument("--pool-frames", type=int, default=0, help="distinct frames resident in HBM (0 = steps*frames_per_step, capped at 1024)")
     ap.add_argument("--ba-window", type=int, default=0,
                     help="BASELINE configs[4]: run one bundle adjustment (HIP kernels + TRF/LSMR driver) per this many frames on "

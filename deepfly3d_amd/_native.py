@@ -13,6 +13,9 @@ DF3D_ENOSPC = -5  # include/df3d_hip.h
 DF3D_EIO = -6
 DF3D_DTYPE_F32 = 0
 DF3D_DTYPE_BF16 = 1
+DF3D_DTYPE_F16 = 2
+# df3d_preprocess_u8 / df3d_hg_forward_u8: the resize rule (DF3D_RESIZE_* of include/df3d_hip.h)
+RESIZE_MODES = {"bilinear": 0, "bilinear_align_corners": 1, "area": 2}
 
 
 class NativeLibraryError(RuntimeError):
@@ -56,7 +59,7 @@ PROTOTYPES = {
     "df3d_version": (c_int, []),
     "df3d_device_count": (c_int, []),
     "df3d_device_name": (c_int, [c_int, c_char_p, c_int]),
-    "df3d_preprocess_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
+    "df3d_preprocess_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), c_int, c_void_p]),
     "df3d_read_files": (c_int, [POINTER(c_char_p), c_int, c_void_p, c_size_t, c_void_p, c_void_p, POINTER(c_size_t), c_int]),
     "df3d_jpeg_work_bytes": (c_size_t, [c_int, c_int, c_int, c_size_t]),
     "df3d_jpeg_decode_luma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_uint, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
@@ -96,7 +99,7 @@ PROTOTYPES = {
     "df3d_hg_set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "df3d_hg_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "df3d_hg_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "df3d_hg_forward_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p, c_size_t, c_void_p]),
+    "df3d_hg_forward_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "df3d_hg_work": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_double)]),
     "df3d_hg_profile": (c_int, [c_void_p, c_int]),
     "df3d_hg_profile_count": (c_int, [c_void_p]),

@@ -55,6 +55,12 @@ def _matrix_from_rotvec(r):
     return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
 
 
+def _visible_pairs(points2d_px):
+    """(T, J) mask of the joints seen by at least two cameras (a camera sees a joint iff neither coordinate is 0)."""
+    p = np.asarray(points2d_px, np.float64)
+    return ((p[..., 0] != 0) & (p[..., 1] != 0)).sum(axis=0) >= 2
+
+
 class BAProblemDevice:
     """Observation tables on the device (built once per calibration window) + work buffers."""
 
@@ -319,6 +325,12 @@ def reprojection_error(points2d_px, points3d, R, tvec, intr, device="cuda:0"):
     fixed-order device reduction (df3d_vec_pairnorm_sum)."""
     _native.require_gpu()
     dev = torch.device(device)
+    if not np.any(_visible_pairs(points2d_px)):
+        # a recording without a single joint seen by two cameras: the reference only prints this number (core.py:250)
+        from . import logger
+
+        logger.warning("reprojection error: no joint is seen by two cameras, nothing to average")
+        return float("nan")
     with torch.cuda.device(dev):
         prob = BAProblemDevice(points2d_px, intr, dev)
         dv = _Dev(prob)

@@ -134,15 +134,32 @@ class CameraNetwork:
         # reference checkout, SURVEY.md App. A.3 "unpinned: frame sub-sampling"); recordings up to that length -- every
         # golden vector, every 1 000-frame window -- use all frames.  Longer ones are cut to an evenly strided,
         # deterministic subset, which also bounds the Jacobian (12 * nobs doubles) instead of growing with T.
-        T = self._points2d.shape[1]
-        cap = int(config.get("ba_max_images") or 0)
-        pts = self._points2d if cap <= 0 or T <= cap else np.ascontiguousarray(self._points2d[:, :: -(-T // cap)])
+        pts = self._ba_subset()
         R_new, t_new, info = _ba.bundle_adjust(pts, R, t, K, device=self._device(), return_info=True)
         for c, cam in enumerate(self.cam_list):
             cam.R, cam.tvec = R_new[c], t_new[c]
         self.ba_info = {k: v for k, v in info.items() if k != "x"}
         self.triangulate()
         return self.ba_info
+
+    def _ba_subset(self, points3d=None):
+        """The frames the bundle adjustment (and its reported error) look at: all of them up to config["ba_max_images"],
+        an evenly strided subset beyond.  Returns points2d[, points3d] of that subset."""
+        T = self._points2d.shape[1]
+        cap = int(config.get("ba_max_images") or 0)
+        if cap <= 0 or T <= cap:
+            return self._points2d if points3d is None else (self._points2d, points3d)
+        stride = -(-T // cap)
+        if not getattr(self, "_warned_subset", False):
+            self._warned_subset = True
+            from . import logger
+
+            logger.warning(
+                f"bundle adjustment: {T} frames > ba_max_images = {cap}: using every {stride}th frame ({len(range(0, T, stride))} frames). "
+                "pyba draws a RANDOM subset here (not in the reference checkout, unpinned): calibrations of recordings longer than "
+                f"{cap} frames are not comparable number for number with the reference's.")
+        p2 = np.ascontiguousarray(self._points2d[:, ::stride])
+        return p2 if points3d is None else (p2, np.ascontiguousarray(points3d[::stride]))
 
     def reprojection_error(self):
         """Mean pixel distance between observations and re-projected triangulated joints (device residual kernel of
@@ -152,7 +169,10 @@ class CameraNetwork:
         if self.points3d is None:
             self.triangulate()
         R, t, K = self._stack()
-        return _ba.reprojection_error(self._points2d, self.points3d, R, t, K, device=self._device())
+        # on the frames the bundle adjustment itself used (a 100 000-frame recording would otherwise upload tens of millions of
+        # observation rows to print one number)
+        p2, p3 = self._ba_subset(self.points3d)
+        return _ba.reprojection_error(p2, p3, R, t, K, device=self._device())
 
     def summarize(self):
         out = {c.cam_id: c.summarize() for c in self.cam_list}

@@ -1,4 +1,4 @@
-// bf16 fused pre-activation bottleneck 64 -> 64 -> 64 -> 128 with the 1x1 skip convolution (layer1 of the hourglass stem),
+// 16-bit (T = __hip_bfloat16 or _Float16; "bf16" below stands for either) fused pre-activation bottleneck 64 -> 64 -> 64 -> 128 with the 1x1 skip convolution (layer1 of the hourglass stem),
 // ALL WEIGHTS RESIDENT IN LDS, persistent workgroups, 16 x 16 output tiles, optional "pooled output only".
 //
 // layer1 runs at half the image resolution (128 x 256 for the reference's 256 x 512 views): 29 M pixels per 896 views, only
@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void bt_l1_pack_kernel(const unsigned short* _
     *reinterpret_cast<u32x4*>(image + off + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(src);
 }
 
+template <typename T>
 __global__ __launch_bounds__(512, 1) void bottleneck_l1_kernel(BtL1Args p) {
-    using T = __hip_bfloat16;
+    static_assert(sizeof(T) == 2, "16-bit storage formats only");
     constexpr int CIN = 64, CO = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const w_lds = smem;
@@ -215,12 +216,12 @@ __global__ __launch_bounds__(512, 1) void bottleneck_l1_kernel(BtL1Args p) {
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) wfr[ct] = *reinterpret_cast<const u32x4*>(wfrag(L1_W1_OFF, 4096, kc, ct));
                 {
-                    const u32x4 xa = br_preact(rx[0][kc], coef);
+                    const u32x4 xa = br_preact<T>(rx[0][kc], coef);
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) mfma_chunk<T>(wfr[ct], xa, acc[0][ct]);
                 }
                 if (two) {
-                    const u32x4 xa = br_preact(rx[1][kc], coef);
+                    const u32x4 xa = br_preact<T>(rx[1][kc], coef);
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) mfma_chunk<T>(wfr[ct], xa, acc[1][ct]);
                 }
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(512, 1) void bottleneck_l1_kernel(BtL1Args p) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         uint2 w;
-                        w.x = br_relu_pk(pack_bf16x2(acc[k][ct][4 * t + 0], acc[k][ct][4 * t + 1])) & keep;
-                        w.y = br_relu_pk(pack_bf16x2(acc[k][ct][4 * t + 2], acc[k][ct][4 * t + 3])) & keep;
+                        w.x = br_relu_pk(Lp<T>::pack2(acc[k][ct][4 * t + 0], acc[k][ct][4 * t + 1])) & keep;
+                        w.y = br_relu_pk(Lp<T>::pack2(acc[k][ct][4 * t + 2], acc[k][ct][4 * t + 3])) & keep;
                         if (hp < L1_HALO) *reinterpret_cast<uint2*>(trow + (((ct * 4 + t) ^ sw) << 4)) = w;
                     }
             }
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck_l1_kernel(BtL1Args p) {
                 for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        t2f[m][q2][e] = br_relu_pk(pack_bf16x2(t2[m][8 * q2 + 2 * e], t2[m][8 * q2 + 2 * e + 1]));
+                        t2f[m][q2][e] = br_relu_pk(Lp<T>::pack2(t2[m][8 * q2 + 2 * e], t2[m][8 * q2 + 2 * e + 1]));
         }
         BR_STAMP(4);
         br_barrier();   // B2: every wave is done with the t1 tile -> the epilogue slices may overwrite it
@@ -321,12 +322,12 @@ __global__ __launch_bounds__(512, 1) void bottleneck_l1_kernel(BtL1Args p) {
             // W3: t2 tile m, registers 8 q2 .. 8 q2 + 7 <-> packed W3 K positions 32 m + 16 q2 + 8 half .. (host K order): K chunk 2 m + q2
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
-                bf16x8 wf[4];
+                u32x4 wf[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wfrag(L1_W3_OFF, 8192, kc, i));
-                const bf16x8 tf = __builtin_bit_cast(bf16x8, t2f[kc >> 1][kc & 1]);
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const u32x4*>(wfrag(L1_W3_OFF, 8192, kc, i));
+                const u32x4 tf = t2f[kc >> 1][kc & 1];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], tf, acc[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i] = Lp<T>::mfma(wf[i], tf, acc[i]);
             }
             // skip convolution on the raw input
 #pragma unroll
@@ -350,8 +351,8 @@ __global__ __launch_bounds__(512, 1) void bottleneck_l1_kernel(BtL1Args p) {
                     for (int t = 0; t < 4; ++t) {
                         const int i = 2 * hc + ii;
                         uint2 w;
-                        w.x = pack_bf16x2(acc[i][4 * t + 0], acc[i][4 * t + 1]);
-                        w.y = pack_bf16x2(acc[i][4 * t + 2], acc[i][4 * t + 3]);
+                        w.x = Lp<T>::pack2(acc[i][4 * t + 0], acc[i][4 * t + 1]);
+                        w.y = Lp<T>::pack2(acc[i][4 * t + 2], acc[i][4 * t + 3]);
                         *reinterpret_cast<uint2*>(slice + l31v * L1_OP + (ii * 32 + 8 * t + 4 * halfv) * 2) = w;
                     }
                 u32x4 fin[4];

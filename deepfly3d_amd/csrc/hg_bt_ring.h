@@ -1,4 +1,5 @@
-// bf16 fused pre-activation bottleneck 256 -> 128 -> 128 -> 256 (identity skip) with the WEIGHTS streamed by LDS-DMA.
+// 16-bit (T = __hip_bfloat16 or _Float16: hg_kernels.h Lp<T>; "bf16" below stands for either) fused pre-activation bottleneck
+// 256 -> 128 -> 128 -> 256 (identity skip) with the WEIGHTS streamed by LDS-DMA.
 //
 // Same tile (8 x 16 output pixels, 10 x 18 halo), same wave -> tile mapping, same MFMA K order as
 // hg_kernels.h:bottleneck_kernel<bf16, 256, 128, false, UP> -- the results are bit-identical -- but the 416 KB of
@@ -124,7 +125,7 @@ __device__ __forceinline__ void br_wait_vm(int n) {
 // workgroup barrier that does NOT drain the vector-memory queue (a __syncthreads() beside pending LDS-DMA waits vmcnt(0))
 __device__ __forceinline__ void br_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// max(x, 0) on two packed bf16: as signed 16-bit integers a negative float is a negative integer, so one v_pk_max_i16 does
+// max(x, 0) on two packed 16-bit floats (bf16 or half: both are sign-magnitude): as signed 16-bit integers a negative float is a negative integer, so one v_pk_max_i16 does
 // both halves (and needs no NaN-canonicalising v_max before it, which hipcc puts in front of every fmaxf on an MFMA result).
 // NOT inline assembly: hipcc's hazard recognizer does not look inside an asm statement, and a VALU result that the very next
 // instruction, an MFMA, reads as SrcA / SrcB needs a wait state in between on gfx950 (tests/perf/ubench/mfma_war.hip shows the
@@ -134,16 +135,17 @@ __device__ __forceinline__ unsigned br_relu_pk(unsigned packed) {
     const br_i16x2 zero = {0, 0};
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(br_i16x2, packed), zero));
 }
-// bn1 + ReLU on one 16-byte chunk of 8 bf16: y = max(x * s + t, 0), rounded to bf16 (rounding and max(., 0) commute)
-__device__ __forceinline__ u32x4 br_preact(u32x4 raw, const PreactCoef<__hip_bfloat16>& k) {
+// bn1 + ReLU on one 16-byte chunk of 8 values: y = max(x * s + t, 0), rounded to T (rounding and max(., 0) commute)
+template <typename T>
+__device__ __forceinline__ u32x4 br_preact(u32x4 raw, const PreactCoef<T>& k) {
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float lo = bf16_bits_to_f32((unsigned short)(raw[i] & 0xffffu));
-        const float hi = bf16_bits_to_f32((unsigned short)(raw[i] >> 16));
+        const float lo = Lp<T>::to_f32((unsigned short)(raw[i] & 0xffffu));
+        const float hi = Lp<T>::to_f32((unsigned short)(raw[i] >> 16));
         const float a = fmaf(lo, k.s[i >> 1][(2 * i) & 3], k.t[i >> 1][(2 * i) & 3]);
         const float b = fmaf(hi, k.s[i >> 1][(2 * i + 1) & 3], k.t[i >> 1][(2 * i + 1) & 3]);
-        o[i] = br_relu_pk(pack_bf16x2(a, b));
+        o[i] = br_relu_pk(Lp<T>::pack2(a, b));
     }
     return o;
 }
@@ -163,9 +165,9 @@ __device__ unsigned long long br_dbg[8];
 
 // CIN = 256: the identity-skip block (out = ... + x); CIN = 128 (DS): the skip is a 1x1 convolution of the raw input, accumulated
 // into the same MFMA accumulators behind W3 (layer2), the x operand of which comes straight from global memory in MFMA layout
-template <bool UP, int CIN = 256>
+template <typename T, bool UP, int CIN = 256>
 __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
-    using T = __hip_bfloat16;
+    static_assert(sizeof(T) == 2, "16-bit storage formats only (the fp32 form is hg_bt_ring_f32.h)");
     constexpr int CO = 256, NT = 4;
     constexpr bool DS = CIN != 256;
     static_assert(!(UP && DS), "the upsample-add input exists for the identity-skip block only");
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
             u32x4 v = rx[slot][i];
             if constexpr (UP) v = add_chunk<T>(v, rb[slot][i]);   // x = in + upsample(in2), rounded like upadd_kernel's output
 #if !defined(BR_ABL) || BR_ABL != 6   // ablation 6: no bn1 + ReLU arithmetic
-            v = br_preact(v, coef);
+            v = br_preact<T>(v, coef);
 #endif
             *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * BR_XPITCH + xchunk * 16) = v;
         }
@@ -341,8 +343,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 uint2 w;
-                w.x = br_relu_pk(pack_bf16x2(acc[i][4 * t + 0], acc[i][4 * t + 1])) & keep;
-                w.y = br_relu_pk(pack_bf16x2(acc[i][4 * t + 2], acc[i][4 * t + 3])) & keep;
+                w.x = br_relu_pk(Lp<T>::pack2(acc[i][4 * t + 0], acc[i][4 * t + 1])) & keep;
+                w.y = br_relu_pk(Lp<T>::pack2(acc[i][4 * t + 2], acc[i][4 * t + 3])) & keep;
                 if (i < 5 || hp < BT_HALO) *reinterpret_cast<uint2*>(trow + (((ct * 4 + t) ^ sw) << 4)) = w;
             }
         }
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
 #pragma unroll
         for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t2f[m][q2][e] = br_relu_pk(pack_bf16x2(t2[m][8 * q2 + 2 * e], t2[m][8 * q2 + 2 * e + 1]));
+            for (int e = 0; e < 4; ++e) t2f[m][q2][e] = br_relu_pk(Lp<T>::pack2(t2[m][8 * q2 + 2 * e], t2[m][8 * q2 + 2 * e + 1]));
 
     BR_STAMP(3);
     // ---- phase 3: out^T = W3 t2^T + b3 (+ x) -------------------------------------------------------------------
@@ -489,21 +491,21 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
             // four (stage, K half) groups, the weight fragments of group g + 1 requested before the MFMAs of group g.  W3 steps
             // (dd < 2): t2 tile kc, registers 8 q2 .. 8 q2 + 7 <-> packed W3 K positions 32 kc + 16 q2 + 8 half .. (host K order,
             // kperm); skip-convolution steps (dd >= 2): K chunk 2 (stage) + q2 of the raw input
-            bf16x8 w3r[2][4];
+            u32x4 w3r[2][4];
             auto load_w3 = [&](int g, int buf) {
                 const int s = s0 + (g >> 1), q2 = g & 1;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    w3r[buf][i] = *reinterpret_cast<const bf16x8*>((q2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
+                    w3r[buf][i] = *reinterpret_cast<const u32x4*>((q2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
             };
             load_w3(0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (g < 3) load_w3(g + 1, (g + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 tf = __builtin_bit_cast(bf16x8, dd < 2 ? t2f[2 * dd + (g >> 1)][g & 1] : xc[DS ? 2 * (2 * (dd - 2) + (g >> 1)) + (g & 1) : 0]);
+                const u32x4 tf = dd < 2 ? t2f[2 * dd + (g >> 1)][g & 1] : xc[DS ? 2 * (2 * (dd - 2) + (g >> 1)) + (g & 1) : 0];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3r[g & 1][i], tf, acc[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i] = Lp<T>::mfma(w3r[g & 1][i], tf, acc[i]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -527,8 +529,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 uint2 w;
-                w.x = pack_bf16x2(acc[i][4 * t + 0], acc[i][4 * t + 1]);
-                w.y = pack_bf16x2(acc[i][4 * t + 2], acc[i][4 * t + 3]);
+                w.x = Lp<T>::pack2(acc[i][4 * t + 0], acc[i][4 * t + 1]);
+                w.y = Lp<T>::pack2(acc[i][4 * t + 2], acc[i][4 * t + 3]);
                 *reinterpret_cast<uint2*>(slice + l31 * OP + (i * 32 + 8 * t + 4 * half) * 2) = w;
             }
         unsigned short* const outs = reinterpret_cast<unsigned short*>(outp);

@@ -207,15 +207,15 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[m][4 * q + e] = fmaxf(y[m][4 * q + e] + bb[e], 0.0f);
         }
-    // bf16: pack y once (slot e of group q2 <-> register 8*q2 + e)
-    bf16x8 ypk[EB == 2 ? 8 : 1][2];
+    // 16-bit engines: pack y once (slot e of group q2 <-> register 8*q2 + e)
+    u32x4 ypk[EB == 2 ? 8 : 1][2];
     if constexpr (EB == 2) {
 #pragma unroll
         for (int m = 0; m < 8; ++m)
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ypk[m][q2][e] = (__bf16)y[m][8 * q2 + e];
+                ypk[m][q2] = lp_pack8<T>(y[m][8 * q2], y[m][8 * q2 + 1], y[m][8 * q2 + 2], y[m][8 * q2 + 3], y[m][8 * q2 + 4], y[m][8 * q2 + 5], y[m][8 * q2 + 6],
+                                         y[m][8 * q2 + 7]);
     }
 
     // ================= phase B: score^T = Wsc y^T  (A = Wsc from LDS, B = y registers) =================
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
             } else {
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2) {
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + (32 * m + (2 * q2 + half) * 8) * 2);
-                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, ypk[m][q2], sc, 0, 0, 0);
+                    const u32x4 wf = *reinterpret_cast<const u32x4*>(wrow + (32 * m + (2 * q2 + half) * 8) * 2);
+                    sc = Lp<T>::mfma(wf, ypk[m][q2], sc);
                 }
             }
         }
@@ -303,12 +303,11 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
 #pragma unroll
             for (int i = 0; i < WPASS; ++i) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
         };
-        bf16x8 scpk[2];
+        u32x4 scpk[2];
         if constexpr (EB == 2) {
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) scpk[q2][e] = (__bf16)sc[8 * q2 + e];
+                scpk[q2] = lp_pack8<T>(sc[8 * q2], sc[8 * q2 + 1], sc[8 * q2 + 2], sc[8 * q2 + 3], sc[8 * q2 + 4], sc[8 * q2 + 5], sc[8 * q2 + 6], sc[8 * q2 + 7]);
         }
         if constexpr (EB == 2) {
             if (p.fc2stream != nullptr) {
@@ -363,11 +362,11 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                             if (s5 == 4 && mm >= 1) break;
 #pragma unroll
                             for (int q2 = 0; q2 < 2; ++q2) {
-                                const bf16x8 af = s5 < 4 ? ypk[2 * s5 + mm][q2] : scpk[q2];
+                                const u32x4 af = s5 < 4 ? ypk[2 * s5 + mm][q2] : scpk[q2];
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
-                                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>((q2 ? wf1 : wf0) + ((base + mm) % NSLOT) * BR_STAGE_BYTES + i * 2048);
-                                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc[i], 0, 0, 0);  // transposed: rows = channels
+                                    const u32x4 wf = *reinterpret_cast<const u32x4*>((q2 ? wf1 : wf0) + ((base + mm) % NSLOT) * BR_STAGE_BYTES + i * 2048);
+                                    acc[i] = Lp<T>::mfma(wf, af, acc[i]);  // transposed: rows = channels
                                 }
                             }
                         }
@@ -390,13 +389,13 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                                 const int n = nh * 128 + 32 * i + 8 * q + 4 * half;
                                 const f32x4 bb = *reinterpret_cast<const f32x4*>(bout_lds + n);   // bfc_ + bsc_
                                 const uint2 xx = xv[4 * ii + q];
-                                const float x0 = bf16_bits_to_f32((unsigned short)(xx.x & 0xffffu)), x1 = bf16_bits_to_f32((unsigned short)(xx.x >> 16));
-                                const float x2 = bf16_bits_to_f32((unsigned short)(xx.y & 0xffffu)), x3 = bf16_bits_to_f32((unsigned short)(xx.y >> 16));
+                                const float x0 = Lp<T>::to_f32((unsigned short)(xx.x & 0xffffu)), x1 = Lp<T>::to_f32((unsigned short)(xx.x >> 16));
+                                const float x2 = Lp<T>::to_f32((unsigned short)(xx.y & 0xffffu)), x3 = Lp<T>::to_f32((unsigned short)(xx.y >> 16));
                                 const float v0 = acc[i][4 * q + 0] + bb[0] + x0, v1 = acc[i][4 * q + 1] + bb[1] + x1;
                                 const float v2 = acc[i][4 * q + 2] + bb[2] + x2, v3 = acc[i][4 * q + 3] + bb[3] + x3;
                                 uint2 o;
-                                o.x = (unsigned)f32_to_bf16_bits(v0) | ((unsigned)f32_to_bf16_bits(v1) << 16);
-                                o.y = (unsigned)f32_to_bf16_bits(v2) | ((unsigned)f32_to_bf16_bits(v3) << 16);
+                                o.x = (unsigned)Lp<T>::from_f32(v0) | ((unsigned)Lp<T>::from_f32(v1) << 16);
+                                o.y = (unsigned)Lp<T>::from_f32(v2) | ((unsigned)Lp<T>::from_f32(v3) << 16);
                                 *reinterpret_cast<uint2*>(slice + l31 * SP + (32 * ii + 8 * q + 4 * half) * 2) = o;
                             }
 #pragma unroll
@@ -462,11 +461,11 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                         if (s == YSTEPS && mm >= 1) break;
 #pragma unroll
                         for (int q2 = 0; q2 < 2; ++q2) {
-                            const bf16x8 af = s < YSTEPS ? ypk[s < YSTEPS ? s * (KE / 32) + mm : 0][q2] : scpk[q2];
+                            const u32x4 af = s < YSTEPS ? ypk[s < YSTEPS ? s * (KE / 32) + mm : 0][q2] : scpk[q2];
 #pragma unroll
                             for (int i = 0; i < NI; ++i) {
-                                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sw + (i * 32 + l31) * PITCH + (mm * 32 + (2 * q2 + half) * 8) * 2);
-                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc[i], 0, 0, 0);  // transposed: rows = channels
+                                const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (i * 32 + l31) * PITCH + (mm * 32 + (2 * q2 + half) * 8) * 2);
+                                acc[i] = Lp<T>::mfma(wf, af, acc[i]);  // transposed: rows = channels
                             }
                         }
                     }
@@ -518,13 +517,13 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                             const int n = nh * CH + 32 * i + 8 * q + 4 * half;
                             const f32x4 bb = *reinterpret_cast<const f32x4*>(bout_lds + n);   // bfc_ + bsc_
                             const uint2 xx = xv[4 * ii + q];
-                            const float x0 = bf16_bits_to_f32((unsigned short)(xx.x & 0xffffu)), x1 = bf16_bits_to_f32((unsigned short)(xx.x >> 16));
-                            const float x2 = bf16_bits_to_f32((unsigned short)(xx.y & 0xffffu)), x3 = bf16_bits_to_f32((unsigned short)(xx.y >> 16));
+                            const float x0 = Lp<T>::to_f32((unsigned short)(xx.x & 0xffffu)), x1 = Lp<T>::to_f32((unsigned short)(xx.x >> 16));
+                            const float x2 = Lp<T>::to_f32((unsigned short)(xx.y & 0xffffu)), x3 = Lp<T>::to_f32((unsigned short)(xx.y >> 16));
                             const float v0 = acc[i][4 * q + 0] + bb[0] + x0, v1 = acc[i][4 * q + 1] + bb[1] + x1;
                             const float v2 = acc[i][4 * q + 2] + bb[2] + x2, v3 = acc[i][4 * q + 3] + bb[3] + x3;
                             uint2 o;
-                            o.x = (unsigned)f32_to_bf16_bits(v0) | ((unsigned)f32_to_bf16_bits(v1) << 16);
-                            o.y = (unsigned)f32_to_bf16_bits(v2) | ((unsigned)f32_to_bf16_bits(v3) << 16);
+                            o.x = (unsigned)Lp<T>::from_f32(v0) | ((unsigned)Lp<T>::from_f32(v1) << 16);
+                            o.y = (unsigned)Lp<T>::from_f32(v2) | ((unsigned)Lp<T>::from_f32(v3) << 16);
                             *reinterpret_cast<uint2*>(slice + l31 * SP + (32 * ii + 8 * q + 4 * half) * 2) = o;
                         }
 #pragma unroll

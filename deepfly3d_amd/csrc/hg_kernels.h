@@ -5,7 +5,7 @@
 //           out[m, n] = sum_{tap, c} act(in[pixel(m) + tap, c]) * W[tap][n][c]  (+ bias, + residual, ReLU)
 //       with m = (view, y, x) flattened.  Workgroup tile 128 pixels x BN channels, 4 wavefronts, each owning
 //       32x32 MFMA tiles (v_mfma_f32_32x32x2_f32 for T=float: exact f32 FMA chains at the 157 TF rate;
-//       v_mfma_f32_32x32x16_bf16 for T=bf16).  Per K-step both operands are staged global -> registers -> LDS
+//       v_mfma_f32_32x32x16_bf16 / _f16 for the 16-bit engines, T = __hip_bfloat16 / _Float16: see Lp<T>).  Per K-step both operands are staged global -> registers -> LDS
 //       as RB-byte row segments (16-byte chunks), double-buffered with one barrier per step; the global loads
 //       for step s+1 are issued before the MFMAs of step s.  Rows are padded by 16 bytes in LDS, which makes
 //       the 16-byte ds_read of a 32-row fragment conflict-free (row pitch 80 B / 144 B: see DESIGN.md).
@@ -46,14 +46,48 @@ struct ConvArgs {
     int cout_real;
 };
 
-__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
-// round-to-nearest-even conversions through the hardware converter (v_cvt_pk_bf16_f32 on gfx950)
-__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+
+// The 16-bit storage formats of the low-precision engines.  Both carry a sign, so one bit pattern trick serves both (ReLU and
+// max as signed 16-bit integers: br_relu_pk, bf16x2_key); both multiply on the matrix cores at the same rate with fp32
+// accumulation.  What differs is where the 16 bits go:
+//   __hip_bfloat16  8 exponent bits (fp32's range), 8 significant bits: every stored value carries 2^-9 relative rounding
+//   _Float16        IEEE half: 11 significant bits (2^-12 relative, eight times finer), range 6.1e-5 .. 65 504 -- ample for
+//                   this network's batch-normalised activations and O(1) weights
+// Conversions round to nearest even through the hardware converters (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 on gfx950).
+template <typename T>
+struct Lp;
+template <>
+struct Lp<__hip_bfloat16> {
+    static __device__ __forceinline__ float to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+    static __device__ __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+        const f32x2 v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    }
+    static __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& acc) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+template <>
+struct Lp<_Float16> {
+    static __device__ __forceinline__ float to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+    static __device__ __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+        const f32x2 v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+    }
+    static __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& acc) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    }
+};
+// eight consecutive floats -> one 16-byte MFMA operand chunk
+template <typename T>
+__device__ __forceinline__ u32x4 lp_pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    return u32x4{Lp<T>::pack2(a0, a1), Lp<T>::pack2(a2, a3), Lp<T>::pack2(a4, a5), Lp<T>::pack2(a6, a7)};
 }
 
 template <typename T>
@@ -65,6 +99,11 @@ struct Elem<float> {
 };
 template <>
 struct Elem<__hip_bfloat16> {
+    static constexpr int BYTES = 2;
+    static constexpr int PER16 = 8;
+};
+template <>
+struct Elem<_Float16> {
     static constexpr int BYTES = 2;
     static constexpr int PER16 = 8;
 };
@@ -96,11 +135,11 @@ __device__ __forceinline__ u32x4 preact_apply(u32x4 raw, const PreactCoef<T>& k)
         u32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float lo = bf16_bits_to_f32((unsigned short)(raw[i] & 0xffffu));
-            const float hi = bf16_bits_to_f32((unsigned short)(raw[i] >> 16));
+            const float lo = Lp<T>::to_f32((unsigned short)(raw[i] & 0xffffu));
+            const float hi = Lp<T>::to_f32((unsigned short)(raw[i] >> 16));
             const float a = fmaxf(fmaf(lo, k.s[i >> 1][(2 * i) & 3], k.t[i >> 1][(2 * i) & 3]), 0.0f);
             const float b = fmaxf(fmaf(hi, k.s[i >> 1][(2 * i + 1) & 3], k.t[i >> 1][(2 * i + 1) & 3]), 0.0f);
-            o[i] = pack_bf16x2(a, b);
+            o[i] = Lp<T>::pack2(a, b);
         }
         return o;
     }
@@ -115,8 +154,7 @@ __device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x1
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
     } else {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                      acc, 0, 0, 0);
+        acc = Lp<T>::mfma(a, b, acc);
     }
 }
 
@@ -293,7 +331,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                     if constexpr (sizeof(T) == 4)
                         resv[r] = reinterpret_cast<const float*>(p.res)[(size_t)m * p.res_pitch + n];
                     else
-                        resv[r] = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.res)[(size_t)m * p.res_pitch + n]);
+                        resv[r] = Lp<T>::to_f32(reinterpret_cast<const unsigned short*>(p.res)[(size_t)m * p.res_pitch + n]);
                 }
             }
 #pragma unroll
@@ -307,7 +345,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                         if constexpr (sizeof(T) == 4)
                             reinterpret_cast<float*>(p.out)[(size_t)m * p.out_pitch + n] = v;
                         else
-                            reinterpret_cast<unsigned short*>(p.out)[(size_t)m * p.out_pitch + n] = f32_to_bf16_bits(v);
+                            reinterpret_cast<unsigned short*>(p.out)[(size_t)m * p.out_pitch + n] = Lp<T>::from_f32(v);
                     }
                 }
                 acc[i][j][r] = v;
@@ -430,20 +468,21 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
             reinterpret_cast<float*>(p.out)[o + n] = v0;
             reinterpret_cast<float*>(p.out)[o + 32 + n] = v1;
         } else {
-            reinterpret_cast<unsigned short*>(p.out)[o + n] = f32_to_bf16_bits(v0);
-            reinterpret_cast<unsigned short*>(p.out)[o + 32 + n] = f32_to_bf16_bits(v1);
+            reinterpret_cast<unsigned short*>(p.out)[o + n] = Lp<T>::from_f32(v0);
+            reinterpret_cast<unsigned short*>(p.out)[o + 32 + n] = Lp<T>::from_f32(v1);
         }
     }
 }
 
 // -----------------------------------------------------------------------------------------------------
-// stem for the bf16 engine: the same 7x7/2 convolution on v_mfma_f32_32x32x16_bf16.  K is laid out ky-major
+// stem for the 16-bit engines (T = __hip_bfloat16 / _Float16): the same 7x7/2 convolution on v_mfma_f32_32x32x16_bf16 / _f16.  K is laid out ky-major
 // with every ky row padded from 21 to 24 taps (k' = ky*24 + kx*3 + c; 7*24 = 168, padded to 176 = 11 MFMA steps),
 // so the 8 K-slots a lane feeds to one MFMA are 8 CONSECUTIVE bf16 values of one patch row (4 ds_read_b32).
 // The f32 image patch is converted to bf16 while it is staged; weights are re-laid [64][176] bf16 in LDS from the
 // same f32 blob the f32 stem uses.  22 MFMAs per wave instead of 148: the kernel becomes load/store-bound.
 // -----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stem_bf16_kernel(StemArgs p) {
+template <typename T>
+__global__ __launch_bounds__(256) void stem_lp_kernel(StemArgs p) {
     constexpr int PR = 21, PC = 37, PROW = 120;   // patch row pitch in bf16 elements (111 used; 240 B, a multiple of 16)
     constexpr int KP = 176, WPITCH = KP + 8;      // weight row: 176 k' + 8 pad (368 B: conflict-free 16-byte reads)
     __shared__ __attribute__((aligned(16))) unsigned short patch[PR * PROW + 64];
@@ -483,9 +522,9 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(StemArgs p) {
             }
         }
         unsigned short* const dst = patch + r * PROW + 3 * pxl;
-        dst[0] = f32_to_bf16_bits(v0);
-        dst[1] = f32_to_bf16_bits(v1);
-        dst[2] = f32_to_bf16_bits(v2);
+        dst[0] = Lp<T>::from_f32(v0);
+        dst[1] = Lp<T>::from_f32(v1);
+        dst[2] = Lp<T>::from_f32(v2);
     }
     // the pad cells behind the 111 values of a row and behind the last row (read by the last K slots against zero weights) are zero
     for (int i = tid; i < PR * (PROW - PC * 3) + 64; i += 256) {
@@ -515,11 +554,10 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(StemArgs p) {
             av[2] = ap[2];
             av[3] = ap[3];   // taps 21..23 of the row multiply zero weights
         }
-        const bf16x8 a = __builtin_bit_cast(bf16x8, av);
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wrow0 + kp);
-        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wrow1 + kp);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
+        const u32x4 b0 = *reinterpret_cast<const u32x4*>(wrow0 + kp);
+        const u32x4 b1 = *reinterpret_cast<const u32x4*>(wrow1 + kp);
+        acc0 = Lp<T>::mfma(av, b0, acc0);
+        acc1 = Lp<T>::mfma(av, b1, acc1);
     }
     // epilogue: adjacent lanes hold adjacent channels of the same pixel; exchanging one register between lane pairs
     // lets every lane store TWO channels (4 bytes) of one pixel: even lanes take pixel-register r, odd lanes r + 1
@@ -536,14 +574,15 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(StemArgs p) {
         const int mm = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
         const int oy = ty0 + wave * 2 + (mm >> 4), ox = tx0 + (mm & 15);
         const size_t o = (((size_t)view * OH + oy) * OW + ox) * 64 + (n & ~1);
-        const unsigned w0 = odd ? pack_bf16x2(g0, v0b) : pack_bf16x2(v0a, g0);
-        const unsigned w1 = odd ? pack_bf16x2(g1, v1b) : pack_bf16x2(v1a, g1);
+        const unsigned w0 = odd ? Lp<T>::pack2(g0, v0b) : Lp<T>::pack2(v0a, g0);
+        const unsigned w1 = odd ? Lp<T>::pack2(g1, v1b) : Lp<T>::pack2(v1a, g1);
         *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.out) + o) = w0;
         *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.out) + o + 32) = w1;
     }
 }
 
-// one-time re-layout of the stem weights for stem_bf16_kernel: f32 [148][64] (k = ky*21 + kk) -> bf16 [64][184]
+// one-time re-layout of the stem weights for stem_lp_kernel: f32 [148][64] (k = ky*21 + kk) -> 16-bit [64][184]
+template <typename T>
 __global__ __launch_bounds__(256) void stem_relayout_kernel(const float* __restrict__ w, unsigned short* __restrict__ out) {
     constexpr int WPITCH = 184;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -552,7 +591,7 @@ __global__ __launch_bounds__(256) void stem_relayout_kernel(const float* __restr
     const int ky = kp / 24, kk = kp % 24;
     float v = 0.0f;
     if (kp < 168 && kk < 21) v = w[(ky * 21 + kk) * 64 + n];
-    out[i] = f32_to_bf16_bits(v);
+    out[i] = Lp<T>::from_f32(v);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -605,9 +644,9 @@ __device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b) {
         u32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float al = bf16_bits_to_f32((unsigned short)(a[i] & 0xffffu)), ah = bf16_bits_to_f32((unsigned short)(a[i] >> 16));
-            const float bl = bf16_bits_to_f32((unsigned short)(b[i] & 0xffffu)), bh = bf16_bits_to_f32((unsigned short)(b[i] >> 16));
-            o[i] = pack_bf16x2(al + bl, ah + bh);
+            const float al = Lp<T>::to_f32((unsigned short)(a[i] & 0xffffu)), ah = Lp<T>::to_f32((unsigned short)(a[i] >> 16));
+            const float bl = Lp<T>::to_f32((unsigned short)(b[i] & 0xffffu)), bh = Lp<T>::to_f32((unsigned short)(b[i] >> 16));
+            o[i] = Lp<T>::pack2(al + bl, ah + bh);
         }
         return o;
     }
@@ -658,12 +697,13 @@ __global__ __launch_bounds__(256) void export_kernel(const void* __restrict__ in
     if constexpr (sizeof(T) == 4)
         out[idx] = reinterpret_cast<const float*>(in)[(size_t)pix * pitch + ch];
     else
-        out[idx] = bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(in)[(size_t)pix * pitch + ch]);
+        out[idx] = Lp<T>::to_f32(reinterpret_cast<const unsigned short*>(in)[(size_t)pix * pitch + ch]);
 }
 
-// weights f32 -> bf16 bits (round to nearest even)
-__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = f32_to_bf16_bits(in[i]);
+// weights f32 -> 16-bit storage format (round to nearest even)
+template <typename T>
+__global__ __launch_bounds__(256) void f32_to_lp_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = Lp<T>::from_f32(in[i]);
 }
 
 
@@ -899,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
                 if constexpr (EB == 4)
                     *reinterpret_cast<float*>(trow + ro * C::T1_PITCH) = v;
                 else
-                    *reinterpret_cast<unsigned short*>(trow + ro * C::T1_PITCH) = f32_to_bf16_bits(v);
+                    *reinterpret_cast<unsigned short*>(trow + ro * C::T1_PITCH) = Lp<T>::from_f32(v);
             }
         }
     };
@@ -1032,13 +1072,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
                 for (int mm = 0; mm < KE / 32; ++mm)
 #pragma unroll
                     for (int q2 = 0; q2 < 2; ++q2) {
-                        bf16x8 af;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) af[e] = (__bf16)t2[s * (KE / 32) + mm][8 * q2 + e];
+                        const f32x16& tt = t2[s * (KE / 32) + mm];
+                        const u32x4 af = lp_pack8<T>(tt[8 * q2], tt[8 * q2 + 1], tt[8 * q2 + 2], tt[8 * q2 + 3], tt[8 * q2 + 4], tt[8 * q2 + 5], tt[8 * q2 + 6], tt[8 * q2 + 7]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sw + (i * 32 + l31) * PITCH + (mm * 32 + (2 * q2 + half) * 8) * 2);
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf, acc[i], 0, 0, 0);
+                            const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (i * 32 + l31) * PITCH + (mm * 32 + (2 * q2 + half) * 8) * 2);
+                            acc[i] = Lp<T>::mfma(af, wf, acc[i]);
                         }
                     }
             }
@@ -1166,7 +1205,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
                     const int pl = (rr & 3) + 8 * (rr >> 2) + 4 * half;
                     const float va = acc[i][2 * q], vb = acc[i][2 * q + 1];
                     const float g = __shfl_xor(odd ? va : vb, 1, 64);
-                    *reinterpret_cast<unsigned*>(slice + pl * OP + (i * 32 + (l31 & ~1)) * 2) = pack_bf16x2(odd ? g : va, odd ? vb : g);
+                    *reinterpret_cast<unsigned*>(slice + pl * OP + (i * 32 + (l31 & ~1)) * 2) = Lp<T>::pack2(odd ? g : va, odd ? vb : g);
                 }
             unsigned short* const outs = reinterpret_cast<unsigned short*>(outp);
             u32x4 fin[8];

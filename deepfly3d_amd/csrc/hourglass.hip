@@ -105,7 +105,7 @@ struct df3d_hg {
     int l1 = 1;           // 1 = bf16 layer1 (64 -> 64 -> 64 -> 128) runs as the LDS-resident-weights kernel of hg_bt_l1.h
     int ring = 1;         // 1 = the 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring*.h)
     size_t stream_bytes = 0;  // weight streams of all ring bottlenecks (behind the bf16 copy of the blob)
-    hgk::StemU8 u8in{nullptr, nullptr, 0, 0, 0, {{0, 0, 0}, {1, 1, 1}}};   // df3d_hg_forward_u8: the stem's input for the duration of that call
+    hgk::StemU8 u8in{nullptr, nullptr, 0, 0, 0, {{0, 0, 0}, {1, 1, 1}, 0}};   // df3d_hg_forward_u8: the stem's input for the duration of that call
     std::vector<TensorDesc> tensors;
     std::vector<int> pooled_of;   // tensor id -> id of its max-pooled copy written by the producing fused bottleneck (-1: none)
     std::vector<Step> steps;
@@ -132,9 +132,10 @@ struct df3d_hg {
     std::vector<Timed> timed;
     std::vector<hipEvent_t> event_pool;
 
-    int elem_bytes() const { return dtype == DF3D_DTYPE_BF16 ? 2 : 4; }
-    // byte offset of the weight streams in the caller's "lowp" buffer: behind the bf16 copy of the blob (bf16), at its start (f32)
-    size_t stream_base() const { return dtype == DF3D_DTYPE_BF16 ? (blob_floats * 2 + 255) & ~size_t(255) : 0; }
+    bool lp() const { return dtype != DF3D_DTYPE_F32; }   // a 16-bit engine (bf16 or f16: same plan, same kernels, other element type)
+    int elem_bytes() const { return lp() ? 2 : 4; }
+    // byte offset of the weight streams in the caller's "lowp" buffer: behind the 16-bit copy of the blob (bf16 / f16), at its start (f32)
+    size_t stream_base() const { return lp() ? (blob_floats * 2 + 255) & ~size_t(255) : 0; }
 
     int new_tensor(int h, int w, int c, int pitch = 0) {
         if (!pitch) pitch = c;
@@ -229,22 +230,22 @@ struct df3d_hg {
             st.conv = plan_conv(name + ".conv1", 1, cin, cin, planes, true, true, false);
             st.conv2b = plan_conv(name + ".conv2", 9, planes, planes, planes, false, true, false);
             if (ds) st.conv4b = plan_conv(name + ".downsample.0", 1, cin, cin, cout, false, false, false);
-            st.conv3b = plan_conv(name + ".conv3", 1, planes, planes, cout, false, false, false, dtype == DF3D_DTYPE_BF16 ? 1 : 0);
-            if (ring && dtype == DF3D_DTYPE_BF16 && cin == 128 && planes == 128 && x2 < 0 && !want_pool) {
+            st.conv3b = plan_conv(name + ".conv3", 1, planes, planes, cout, false, false, false, lp() ? 1 : 0);
+            if (ring && lp() && cin == 128 && planes == 128 && x2 < 0 && !want_pool) {
                 // layer2: the same ring kernel with 128 input channels and the skip convolution as eight more stages
                 st.wstream = (long long)stream_bytes;
                 stream_bytes += (size_t)br_nstage(128, true) * BR_STAGE_BYTES;
             }
             if (ring && cin == 256 && planes == 128) {   // weights through the LDS-DMA ring (hg_bt_ring.h, hg_bt_ring_f32.h)
                 st.wstream = (long long)stream_bytes;
-                stream_bytes += (size_t)(dtype == DF3D_DTYPE_BF16 ? BR_NSTAGE : BRF_NSTAGE) * BR_STAGE_BYTES;
+                stream_bytes += (size_t)(lp() ? BR_NSTAGE : BRF_NSTAGE) * BR_STAGE_BYTES;
                 if (pool_input && x2 < 0 && pooled_of[x] < 0) {
                     st.pool_in = new_tensor(tx.h / 2, tx.w / 2, cin);
                     pooled_of[x] = st.pool_in;
                     elems_per_view += (double)tx.h * tx.w * cin * 1.25;  // model M1 still counts the pooling pass
                 }
             }
-            if (l1 && dtype == DF3D_DTYPE_BF16 && cin == 64 && planes == 64 && tx.h % 16 == 0 && tx.w % 16 == 0) {
+            if (l1 && lp() && cin == 64 && planes == 64 && tx.h % 16 == 0 && tx.w % 16 == 0) {
                 st.l1 = true;   // all weights resident in LDS (hg_bt_l1.h)
                 st.wstream = (long long)stream_bytes;
                 stream_bytes += L1_W_BYTES;
@@ -381,12 +382,12 @@ struct df3d_hg {
             if (fuse) {
                 // fc -> score -> (fc_, score_) + x in one kernel (hg_head.h: head_kernel)
                 const bool last = s == num_stacks - 1;
-                const int kp = dtype == DF3D_DTYPE_BF16 ? 1 : 0;
+                const int kp = lp() ? 1 : 0;
                 const TensorDesc tr = tensors[r];
                 Step st;
                 st.kind = ST_HEAD;
                 st.last = last;
-                if (ring && dtype == DF3D_DTYPE_BF16) {   // Wfc through the LDS-DMA stage ring (hg_head.h)
+                if (ring && lp()) {   // Wfc through the LDS-DMA stage ring (hg_head.h)
                     st.wstream = (long long)stream_bytes;
                     stream_bytes += (size_t)HD_FC_STAGES * BR_STAGE_BYTES;
                     if (!last) {
@@ -550,10 +551,35 @@ int launch_bottleneck(const BottleneckArgs& a, int cin, int pl, int blocks, hipS
     return DF3D_EINVAL;
 }
 
+template <typename T> struct TypeName;
+template <> struct TypeName<float> { static constexpr const char* value = "float"; };
+template <> struct TypeName<__hip_bfloat16> { static constexpr const char* value = "__hip_bfloat16"; };
+template <> struct TypeName<_Float16> { static constexpr const char* value = "_Float16"; };
+
+// one launcher per 16-bit element type (hipFuncSetAttribute is per instantiation and per device)
+template <typename T, bool UP, int CIN>
+int launch_ring_lp(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
+    static unsigned attr_done = 0;
+    if (first_use_on_this_device(attr_done))
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_kernel<T, UP, CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL((bottleneck_ring_kernel<T, UP, CIN>), dim3(blocks), dim3(256), lds_bytes, s, r);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+template <bool UP>
+int launch_ring_f32(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
+    static unsigned attr_done = 0;
+    if (first_use_on_this_device(attr_done))
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<UP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL((bottleneck_ring_f32_kernel<UP>), dim3(blocks), dim3(256), lds_bytes, s, r);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
 template <typename T>
 int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps, unsigned char* act, hipStream_t s) {
     const int eb = sizeof(T);
-    const char* const tname = eb == 4 ? "float" : "__hip_bfloat16";
+    const char* const tname = TypeName<T>::value;   // as rocprofv3 prints the template argument
     auto tptr = [&](int id) -> unsigned char* { return act + h->tensors[id].off * (size_t)n * eb; };
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(eb == 4 ? (const void*)h->blob : h->lowp);
     for (int i = 0; i < upto; ++i) {
@@ -572,9 +598,9 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.u8 = h->u8in;
                 const int blocks = n * (h->H / 2 / 8) * (h->W / 2 / 16);
                 const double opx = (double)n * (h->H / 2) * (h->W / 2);
-                ScopedTimer tm(h, s, eb == 2 ? std::string("stem_bf16_kernel") : std::string("stem_kernel<") + tname + ">", 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb));
+                ScopedTimer tm(h, s, std::string(eb == 2 ? "stem_lp_kernel<" : "stem_kernel<") + tname + ">", 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb));
                 if constexpr (sizeof(T) == 2)
-                    hipLaunchKernelGGL(stem_bf16_kernel, dim3(blocks), dim3(256), 0, s, a);
+                    hipLaunchKernelGGL((stem_lp_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
                 else
                     hipLaunchKernelGGL((stem_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
                 DF3D_LAUNCH_CHECK();
@@ -643,14 +669,16 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                     r.wimage = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream;
                     r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd; r.s1 = a.s1; r.t1 = a.t1;
                     r.V = n; r.H = ti.h; r.W = ti.w;
-                    ScopedTimer tm(h, s, "bottleneck_l1_kernel", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl),
+                    ScopedTimer tm(h, s, std::string("bottleneck_l1_kernel<") + tname + ">", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl),
                                    px * eb * (cin + (st.pool_only ? 0.5 * pl : 2.0 * pl)));
                     const int tiles = n * (ti.h / L1_TH) * (ti.w / BT_TW);
-                    static unsigned attr_done = 0;
-                    if (first_use_on_this_device(attr_done))
-                        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_l1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
-                    hipLaunchKernelGGL(bottleneck_l1_kernel, dim3(std::min(tiles, cu_count())), dim3(L1_WAVES * 64), L1_LDS_BYTES, s, r);
-                    DF3D_LAUNCH_CHECK();
+                    if constexpr (sizeof(T) == 2) {
+                        static unsigned attr_done = 0;
+                        if (first_use_on_this_device(attr_done))
+                            DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_l1_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS_BYTES));
+                        hipLaunchKernelGGL((bottleneck_l1_kernel<T>), dim3(std::min(tiles, cu_count())), dim3(L1_WAVES * 64), L1_LDS_BYTES, s, r);
+                        DF3D_LAUNCH_CHECK();
+                    }
                     break;
                 }
                 if (st.wstream >= 0) {
@@ -660,35 +688,26 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                     r.wstream = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream;
                     r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd; r.s1 = a.s1; r.t1 = a.t1;
                     r.V = n; r.H = ti.h; r.W = ti.w;
-                    if (ds) {   // bf16 layer2
-                        ScopedTimer tm(h, s, "bottleneck_ring_kernel<false, 128>", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl), px * eb * (cin + 2.0 * pl));
-                        static unsigned attr_ds = 0;
-                        if (first_use_on_this_device(attr_ds))
-                            DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, BR_LDS_BYTES));
-                        hipLaunchKernelGGL((bottleneck_ring_kernel<false, 128>), dim3(n * (ti.h / BT_TH) * (ti.w / BT_TW)), dim3(256), BR_LDS_BYTES, s, r);
-                        DF3D_LAUNCH_CHECK();
+                    if (ds) {   // 16-bit layer2
+                        ScopedTimer tm(h, s, std::string("bottleneck_ring_kernel<") + tname + ", false, 128>", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl), px * eb * (cin + 2.0 * pl));
+                        if constexpr (sizeof(T) == 2)
+                            if (int rc = launch_ring_lp<T, false, 128>(r, n * (ti.h / BT_TH) * (ti.w / BT_TW), BR_LDS_BYTES, s)) return rc;
                         break;
                     }
-                    ScopedTimer tm(h, s, std::string(eb == 2 ? "bottleneck_ring_kernel<" : "bottleneck_ring_f32_kernel<") + (a.in2 ? "true" : "false") + (eb == 2 ? ", 256>" : ">"),   // as rocprofv3 prints them
+                    ScopedTimer tm(h, s, eb == 2 ? std::string("bottleneck_ring_kernel<") + tname + (a.in2 ? ", true, 256>" : ", false, 256>")
+                                                 : std::string("bottleneck_ring_f32_kernel<") + (a.in2 ? "true>" : "false>"),   // as rocprofv3 prints them
                                    2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl));
                     const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
-                    static unsigned attr_done[4] = {0, 0, 0, 0};
-                    const int which = (eb == 2 ? 0 : 2) + (a.in2 ? 1 : 0);
-                    const void* fns[4] = {reinterpret_cast<const void*>(bottleneck_ring_kernel<false>), reinterpret_cast<const void*>(bottleneck_ring_kernel<true>),
-                                          reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<false>), reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<true>)};
                     int lds_bytes = BR_LDS_BYTES;
 #ifdef DF3D_BT_TIMING
                     if (const char* e = getenv("BR_LDS")) lds_bytes = atoi(e);   // development: force one workgroup per CU (> 80 KB)
 #endif
-                    if (first_use_on_this_device(attr_done[which]))
-                        DF3D_HIP(hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-                    switch (which) {
-                        case 0: hipLaunchKernelGGL((bottleneck_ring_kernel<false>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
-                        case 1: hipLaunchKernelGGL((bottleneck_ring_kernel<true>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
-                        case 2: hipLaunchKernelGGL((bottleneck_ring_f32_kernel<false>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
-                        default: hipLaunchKernelGGL((bottleneck_ring_f32_kernel<true>), dim3(blocks), dim3(256), lds_bytes, s, r); break;
-                    }
-                    DF3D_LAUNCH_CHECK();
+                    int rc;
+                    if constexpr (sizeof(T) == 2)
+                        rc = a.in2 ? launch_ring_lp<T, true, 256>(r, blocks, lds_bytes, s) : launch_ring_lp<T, false, 256>(r, blocks, lds_bytes, s);
+                    else
+                        rc = a.in2 ? launch_ring_f32<true>(r, blocks, lds_bytes, s) : launch_ring_f32<false>(r, blocks, lds_bytes, s);
+                    if (rc) return rc;
                     break;
                 }
                 ScopedTimer tm(h, s, std::string("bottleneck_kernel<") + tname + ", " + std::to_string(cin) + ", " + std::to_string(pl) + ", " + (ds ? "true" : "false") + ", " + (a.in2 ? "true" : "false") + ">",
@@ -759,6 +778,14 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
     return DF3D_OK;
 }
 
+int run_steps_dtype(df3d_hg* h, const float* images, int n, int upto, float* heatmaps, unsigned char* act, hipStream_t s) {
+    switch (h->dtype) {
+        case DF3D_DTYPE_F32: return run_steps<float>(h, images, n, upto, heatmaps, act, s);
+        case DF3D_DTYPE_F16: return run_steps<_Float16>(h, images, n, upto, heatmaps, act, s);
+        default: return run_steps<__hip_bfloat16>(h, images, n, upto, heatmaps, act, s);
+    }
+}
+
 int check_forward_args(df3d_hg* h, const void* images, int n, void* ws, size_t ws_bytes) {
     DF3D_CHECK_ARG(h != nullptr, "null handle");
     if (!h->blob) {
@@ -787,7 +814,7 @@ int df3d_dbg_ring_cycles(unsigned long long* out8) {
 
 int df3d_hg_create(int dtype, int num_stacks, df3d_hg** out) {
     DF3D_CHECK_ARG(out != nullptr, "null out");
-    DF3D_CHECK_ARG(dtype == DF3D_DTYPE_F32 || dtype == DF3D_DTYPE_BF16, "dtype must be DF3D_DTYPE_F32 or DF3D_DTYPE_BF16");
+    DF3D_CHECK_ARG(dtype == DF3D_DTYPE_F32 || dtype == DF3D_DTYPE_BF16 || dtype == DF3D_DTYPE_F16, "dtype must be DF3D_DTYPE_F32, DF3D_DTYPE_BF16 or DF3D_DTYPE_F16");
     DF3D_CHECK_ARG(num_stacks >= 1 && num_stacks <= 8, "num_stacks must be in [1, 8]");
     df3d_hg* h = new df3d_hg();
     h->dtype = dtype;
@@ -880,15 +907,23 @@ size_t df3d_hg_lowp_bytes(const df3d_hg* h) {
 int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void* stream) {
     DF3D_CHECK_ARG(h && blob_dev, "null argument");
     DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(blob_dev) & 255) == 0, "blob must be 256-byte aligned");
-    if (h->dtype == DF3D_DTYPE_BF16) {
-        DF3D_CHECK_ARG(lowp_dev != nullptr, "bf16 engine needs a df3d_hg_lowp_bytes() device buffer");
+    if (h->lp()) {
+        DF3D_CHECK_ARG(lowp_dev != nullptr, "a 16-bit engine needs a df3d_hg_lowp_bytes() device buffer");
         DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(lowp_dev) & 255) == 0, "lowp buffer must be 256-byte aligned");
-        hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(1024), dim3(256), 0, df3d::as_stream(stream), blob_dev,
-                           reinterpret_cast<unsigned short*>(lowp_dev), h->blob_floats);
-        // the bf16 stem wants its weights as a [64][184] bf16 tile: overwrite the stem's slot of the low-precision copy
-        hipLaunchKernelGGL(stem_relayout_kernel, dim3((64 * 184 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
-                           blob_dev + h->steps[0].conv.w_off, reinterpret_cast<unsigned short*>(lowp_dev) + h->steps[0].conv.w_off);
-        // weight streams of the ring bottlenecks: stage-by-stage LDS images (hg_bt_ring.h), from the bf16 copy
+        // the 16-bit copy of the blob; the 16-bit stem wants its weights as a [64][184] tile: overwrite the stem's slot of the copy
+        if (h->dtype == DF3D_DTYPE_F16) {
+            hipLaunchKernelGGL((f32_to_lp_kernel<_Float16>), dim3(1024), dim3(256), 0, df3d::as_stream(stream), blob_dev,
+                               reinterpret_cast<unsigned short*>(lowp_dev), h->blob_floats);
+            hipLaunchKernelGGL((stem_relayout_kernel<_Float16>), dim3((64 * 184 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
+                               blob_dev + h->steps[0].conv.w_off, reinterpret_cast<unsigned short*>(lowp_dev) + h->steps[0].conv.w_off);
+        } else {
+            hipLaunchKernelGGL((f32_to_lp_kernel<__hip_bfloat16>), dim3(1024), dim3(256), 0, df3d::as_stream(stream), blob_dev,
+                               reinterpret_cast<unsigned short*>(lowp_dev), h->blob_floats);
+            hipLaunchKernelGGL((stem_relayout_kernel<__hip_bfloat16>), dim3((64 * 184 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
+                               blob_dev + h->steps[0].conv.w_off, reinterpret_cast<unsigned short*>(lowp_dev) + h->steps[0].conv.w_off);
+        }
+        // weight streams of the ring bottlenecks: stage-by-stage LDS images (hg_bt_ring.h), from the 16-bit copy (byte movers:
+        // the same kernels serve both formats)
         for (const Step& st : h->steps) {
             if (st.kind == ST_HEAD && st.wstream >= 0) {
                 hipLaunchKernelGGL(bt_fc_pack_kernel, dim3((HD_FC_STAGES * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
@@ -942,18 +977,18 @@ int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_
     if (int rc = check_forward_args(h, images_dev, n, workspace_dev, workspace_bytes)) return rc;
     DF3D_CHECK_ARG(heatmaps_dev != nullptr, "null heatmaps");
     unsigned char* act = reinterpret_cast<unsigned char*>(workspace_dev);
-    if (h->dtype == DF3D_DTYPE_F32)
-        return run_steps<float>(h, images_dev, n, (int)h->steps.size(), heatmaps_dev, act, df3d::as_stream(stream));
-    return run_steps<__hip_bfloat16>(h, images_dev, n, (int)h->steps.size(), heatmaps_dev, act, df3d::as_stream(stream));
+    return run_steps_dtype(h, images_dev, n, (int)h->steps.size(), heatmaps_dev, act, df3d::as_stream(stream));
 }
 
 int df3d_hg_forward_u8(df3d_hg* h, const unsigned char* frames_dev, const unsigned char* flip_dev, int n, int frame_h, int frame_w, int frame_c,
-                       const float* mean3_host, const float* std3_host, float* heatmaps_dev, void* workspace_dev, size_t workspace_bytes,
+                       const float* mean3_host, const float* std3_host, int resize, float* heatmaps_dev, void* workspace_dev, size_t workspace_bytes,
                        void* stream) {
     if (int rc = check_forward_args(h, frames_dev, n, workspace_dev, workspace_bytes)) return rc;
     DF3D_CHECK_ARG(heatmaps_dev != nullptr && mean3_host && std3_host, "null pointer");
     DF3D_CHECK_ARG(frame_h > 0 && frame_w > 0 && (frame_c == 1 || frame_c == 3), "bad frame shape (C must be 1 or 3)");
+    DF3D_CHECK_ARG(resize >= DF3D_RESIZE_BILINEAR && resize <= DF3D_RESIZE_AREA, "resize must be one of DF3D_RESIZE_*");
     hgk::StemU8 u;
+    u.nm.resize = resize;
     u.frames = frames_dev;
     u.flip = flip_dev;
     u.FH = frame_h;
@@ -966,8 +1001,7 @@ int df3d_hg_forward_u8(df3d_hg* h, const unsigned char* frames_dev, const unsign
     }
     h->u8in = u;
     unsigned char* act = reinterpret_cast<unsigned char*>(workspace_dev);
-    const int rc = h->dtype == DF3D_DTYPE_F32 ? run_steps<float>(h, nullptr, n, (int)h->steps.size(), heatmaps_dev, act, df3d::as_stream(stream))
-                                              : run_steps<__hip_bfloat16>(h, nullptr, n, (int)h->steps.size(), heatmaps_dev, act, df3d::as_stream(stream));
+    const int rc = run_steps_dtype(h, nullptr, n, (int)h->steps.size(), heatmaps_dev, act, df3d::as_stream(stream));
     h->u8in.frames = nullptr;
     return rc;
 }
@@ -1041,12 +1075,7 @@ int df3d_hg_forward_upto(df3d_hg* h, const float* images_dev, int n, int upto, f
     unsigned char* act = reinterpret_cast<unsigned char*>(workspace_dev);
     hipStream_t s = df3d::as_stream(stream);
     // a final NCHW step writes straight into out_dev (as heat-maps)
-    int rc;
-    if (h->dtype == DF3D_DTYPE_F32)
-        rc = run_steps<float>(h, images_dev, n, upto, out_dev, act, s);
-    else
-        rc = run_steps<__hip_bfloat16>(h, images_dev, n, upto, out_dev, act, s);
-    if (rc) return rc;
+    if (int rc = run_steps_dtype(h, images_dev, n, upto, out_dev, act, s)) return rc;
     if (st.out < 0) return DF3D_OK;
     const TensorDesc& t = h->tensors[st.out];
     const long long pixels = (long long)n * t.h * t.w;
@@ -1054,6 +1083,8 @@ int df3d_hg_forward_upto(df3d_hg* h, const float* images_dev, int n, int upto, f
     const void* src = act + t.off * (size_t)n * h->elem_bytes();
     if (h->dtype == DF3D_DTYPE_F32)
         hipLaunchKernelGGL((export_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, out_dev, pixels, t.c, t.pitch);
+    else if (h->dtype == DF3D_DTYPE_F16)
+        hipLaunchKernelGGL((export_kernel<_Float16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, out_dev, pixels, t.c, t.pitch);
     else
         hipLaunchKernelGGL((export_kernel<__hip_bfloat16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, out_dev, pixels, t.c, t.pitch);
     DF3D_LAUNCH_CHECK();

@@ -1,7 +1,7 @@
 // Input front-end of inference_folder: uint8 camera frames -> network input.
 // One thread per output pixel: optional left-right flip (cameras facing left, reference df3d/core.py:179),
-// bilinear down-scale with half-pixel centres, grey -> 3 channels, (v/255 - mean) / std.  HBM-bound.
-// df2d's exact resize/normalisation is not in the reference checkout ("parity unpinned"), so mean/std are data.
+// down-scale (rule = DF3D_RESIZE_*), grey -> 3 channels, (v/255 - mean) / std.  HBM-bound.
+// df2d's exact resize/normalisation is not in the reference checkout ("parity unpinned"), so mean/std and the rule are data.
 #include "common.h"
 #include "preprocess_math.h"
 
@@ -28,12 +28,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __
 }  // namespace
 
 extern "C" int df3d_preprocess_u8(const unsigned char* img_dev, const unsigned char* flip_dev, int n, int H, int W, int C,
-                                  float* out_dev, int OH, int OW, const float* mean3_host, const float* std3_host, void* stream) {
+                                  float* out_dev, int OH, int OW, const float* mean3_host, const float* std3_host, int resize, void* stream) {
+    DF3D_CHECK_ARG(resize >= DF3D_RESIZE_BILINEAR && resize <= DF3D_RESIZE_AREA, "resize must be one of DF3D_RESIZE_*");
     DF3D_CHECK_ARG(n >= 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "bad shape");
     DF3D_CHECK_ARG(C == 1 || C == 3, "C must be 1 or 3");
     if (n == 0) return DF3D_OK;
     DF3D_CHECK_ARG(img_dev && out_dev && mean3_host && std3_host, "null pointer");
     Norm nm;
+    nm.resize = resize;
     for (int c = 0; c < 3; ++c) {
         DF3D_CHECK_ARG(std3_host[c] != 0.0f, "std must be non-zero");
         nm.mean[c] = mean3_host[c];

@@ -100,7 +100,7 @@ class HourglassEngine:
         self.lib = _native.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.dtype = dtype
-        code = {"f32": _native.DF3D_DTYPE_F32, "bf16": _native.DF3D_DTYPE_BF16}[dtype]
+        code = {"f32": _native.DF3D_DTYPE_F32, "bf16": _native.DF3D_DTYPE_BF16, "f16": _native.DF3D_DTYPE_F16}[dtype]
         h = ctypes.c_void_p()
         _native.check(self.lib.df3d_hg_create(code, num_stacks, ctypes.byref(h)), "df3d_hg_create")
         self.h = h
@@ -177,7 +177,7 @@ class HourglassEngine:
             )
         return out
 
-    def forward_u8(self, frames_u8, flip=None, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), out=None):
+    def forward_u8(self, frames_u8, flip=None, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), out=None, resize="bilinear"):
         """Heat-maps straight from camera frames: frames_u8 [n, H, W] or [n, H, W, C] uint8 cuda, flip [n] uint8 or None.  The stem
         samples the frames with df3d_preprocess_u8's arithmetic: bit for bit forward(preprocess(frames)), one kernel and one
         float image per batch fewer."""
@@ -202,7 +202,8 @@ class HourglassEngine:
             stream = torch.cuda.current_stream(self.device).cuda_stream
             _native.check(
                 self.lib.df3d_hg_forward_u8(self.h, frames_u8.data_ptr(), fl.data_ptr() if fl is not None else None, n, fh, fw, fc,
-                                            (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std), out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                                            (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std), _native.RESIZE_MODES[resize], out.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), stream),
                 "df3d_hg_forward_u8",
             )
         return out

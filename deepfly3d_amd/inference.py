@@ -25,23 +25,83 @@ from .hourglass import HourglassEngine
 from .os_util import image_path_for
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# df2d's normalisation constants are not in the reference checkout ("parity unpinned"): kept as data
-# (bearpaw's `color_normalize` subtracts the mean and does not divide; mean 0.22 as recalled -- unverifiable here).
-# DF3D_PREPROCESS='{"mean": [m, m, m], "std": [s, s, s]}' overrides them without a code change; the dormant
-# reference-pin test (tests/test_gpu_reference_pin.py) reads the same variable.
-PREPROCESS = {"mean": (0.22, 0.22, 0.22), "std": (1.0, 1.0, 1.0)}
-if os.environ.get("DF3D_PREPROCESS"):
+# df2d's preprocessing is not in the reference checkout ("parity unpinned"), so all of it is DATA:
+#   mean / std   the reference names the source of the mean: `weights/mean.pth.tar` next to the checkpoint (reference
+#                df3d/config.py:37-39; bearpaw's dataset cache {'mean': tensor[3], 'std': tensor[3]}).  load_state_dict()
+#                reads that file when it finds it; bearpaw's `color_normalize` subtracts the mean and does NOT divide, so the
+#                file's std is only applied with "divide_by_std": true.  Without the file: mean 0.22 as recalled.
+#   resize       "bilinear" (half-pixel centres, no antialias: cv2.INTER_LINEAR) | "bilinear_align_corners" | "area"
+#                (cv2.INTER_AREA); the rule df2d uses for 960x480 -> 512x256 is unknown here.
+# DF3D_PREPROCESS='{"mean": [m, m, m], "std": [s, s, s], "resize": "area", "divide_by_std": false}' overrides any of
+# them without a code change (every key optional); the dormant reference-pin test sweeps the resize rules.
+PREPROCESS = {"mean": (0.22, 0.22, 0.22), "std": (1.0, 1.0, 1.0), "resize": "bilinear"}
+_PREPROCESS_SOURCE = {"mean": "default (recalled)", "resize": "default"}
+_warned_preprocess = []
+
+
+def _three(v):
+    v = [float(x) for x in np.asarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float64).reshape(-1)]
+    if len(v) == 1:
+        v = v * 3
+    if len(v) != 3:
+        raise ValueError(f"expected 1 or 3 values, got {len(v)}")
+    return tuple(v)
+
+
+def _apply_env_preprocess():
+    if not os.environ.get("DF3D_PREPROCESS"):
+        return {}
     import json as _json
 
-    _p = _json.loads(os.environ["DF3D_PREPROCESS"])
-    PREPROCESS = {"mean": tuple(float(v) for v in _p["mean"]), "std": tuple(float(v) for v in _p["std"])}
-_warned_preprocess = []
+    p = _json.loads(os.environ["DF3D_PREPROCESS"])
+    unknown = set(p) - {"mean", "std", "resize", "divide_by_std"}
+    if unknown:
+        raise ValueError(f"DF3D_PREPROCESS: unknown keys {sorted(unknown)}")
+    if "mean" in p:
+        PREPROCESS["mean"] = _three(p["mean"])
+        _PREPROCESS_SOURCE["mean"] = "DF3D_PREPROCESS"
+    if "std" in p:
+        PREPROCESS["std"] = _three(p["std"])
+    if "resize" in p:
+        if p["resize"] not in _native.RESIZE_MODES:
+            raise ValueError(f"DF3D_PREPROCESS: resize must be one of {sorted(_native.RESIZE_MODES)}")
+        PREPROCESS["resize"] = p["resize"]
+        _PREPROCESS_SOURCE["resize"] = "DF3D_PREPROCESS"
+    return p
+
+
+_env_preprocess = _apply_env_preprocess()
 
 _engine_cache = {}
 
 
+def load_mean_file(path):
+    """bearpaw / df2d's `mean.pth.tar` ({'mean': tensor, 'std': tensor}) -> (mean3, std3) as float tuples."""
+    meta = torch.load(path, map_location="cpu", weights_only=False)
+    if not (isinstance(meta, dict) and "mean" in meta):
+        raise ValueError(f"{path}: expected a dict with 'mean' (and 'std')")
+    return _three(meta["mean"]), (_three(meta["std"]) if "std" in meta else (1.0, 1.0, 1.0))
+
+
+def _adopt_mean_file(checkpoint):
+    """The normalisation mean that belongs to `checkpoint`: $DF3D_MEAN, or mean.pth.tar beside it (reference
+    df3d/config.py:37-39).  An explicit DF3D_PREPROCESS mean wins.  Returns the file used, or None."""
+    cands = [os.environ.get("DF3D_MEAN"), os.path.join(os.path.dirname(os.path.abspath(checkpoint)), "mean.pth.tar")]
+    for cand in cands:
+        if cand and os.path.exists(cand):
+            mean, std = load_mean_file(cand)
+            if "mean" not in _env_preprocess:
+                PREPROCESS["mean"] = mean
+                _PREPROCESS_SOURCE["mean"] = cand
+            if _env_preprocess.get("divide_by_std") and "std" not in _env_preprocess:
+                PREPROCESS["std"] = std
+            return cand
+    return None
+
+
 def load_state_dict(path=None):
-    """Locate and load the hourglass parameters ({name: array})."""
+    """Locate and load the hourglass parameters ({name: array}); with a trained checkpoint also its normalisation mean
+    (mean.pth.tar beside it)."""
     if os.environ.get("DF3D_SYNTHETIC_WEIGHTS") is not None:
         from .synthetic import synthetic_state_dict
 
@@ -49,14 +109,17 @@ def load_state_dict(path=None):
     cands = [path, os.environ.get("DF3D_WEIGHTS"), os.path.join(_HERE, "weights", "sh8_deepfly.tar")]
     for cand in cands:
         if cand and os.path.exists(cand):
-            if "DF3D_PREPROCESS" not in os.environ and not _warned_preprocess:
+            mean_file = _adopt_mean_file(cand)
+            if not _warned_preprocess and (mean_file is None and "mean" not in _env_preprocess or _PREPROCESS_SOURCE["resize"] == "default"):
                 _warned_preprocess.append(True)
                 from . import logger
 
                 logger.warning(
-                    f"Trained weights {cand} with UNPINNED input normalisation {PREPROCESS}: df2d's constants are not in "
-                    "the reference checkout.  Verify them against nely-df2d (dataset mean/std, resize) or set "
-                    'DF3D_PREPROCESS=\'{"mean": [..], "std": [..]}\'; a wrong value silently degrades every 2-D pose.')
+                    f"Trained weights {cand}: input preprocessing is only partly pinned -- mean {PREPROCESS['mean']} from "
+                    f"{_PREPROCESS_SOURCE['mean']}, std {PREPROCESS['std']}, resize '{PREPROCESS['resize']}' ({_PREPROCESS_SOURCE['resize']}).  df2d's "
+                    "constants are not in the reference checkout: put mean.pth.tar beside the checkpoint (reference df3d/config.py:37-39) "
+                    'and/or set DF3D_PREPROCESS=\'{"mean": [..], "std": [..], "resize": "bilinear|bilinear_align_corners|area"}\'; '
+                    "tests/test_gpu_reference_pin.py reports which resize rule meets the reference's bars.")
             ckpt = torch.load(cand, map_location="cpu", weights_only=False)
             sd = ckpt.get("state_dict", ckpt) if isinstance(ckpt, dict) else ckpt
             return {k[len("module.") :] if k.startswith("module.") else k: v for k, v in sd.items()}
@@ -93,7 +156,7 @@ def preprocess_u8(frames_u8, flip, out_hw=(256, 512)):
     with torch.cuda.device(frames_u8.device):  # kernels launch on the current HIP device
         _native.check(
             lib.df3d_preprocess_u8(frames_u8.data_ptr(), fl.data_ptr() if fl is not None else None, n, H, W, C, out.data_ptr(), out_hw[0], out_hw[1],
-                                   mean, std, torch.cuda.current_stream(frames_u8.device).cuda_stream),
+                                   mean, std, _native.RESIZE_MODES[PREPROCESS["resize"]], torch.cuda.current_stream(frames_u8.device).cuda_stream),
             "df3d_preprocess_u8",
         )
     return out
@@ -111,7 +174,7 @@ def inference_frames(frames_u8, flip, engine, return_heatmap=False):
     `inference_views(preprocess_u8(frames, flip), engine)` with the resize / normalisation done inside the network's first kernel."""
     if tuple(config["input_shape"]) != (engine.height, engine.width):
         raise ValueError("engine input size differs from config['input_shape']")
-    hm = engine.forward_u8(frames_u8, flip, PREPROCESS["mean"], PREPROCESS["std"])
+    hm = engine.forward_u8(frames_u8, flip, PREPROCESS["mean"], PREPROCESS["std"], resize=PREPROCESS["resize"])
     pts, conf = ops.heatmap_argmax(hm)
     return (pts, conf, hm) if return_heatmap else (pts, conf)
 
@@ -184,6 +247,7 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
     paths = _Batches()
     width, height = _image_size(image_path_for(folder, chunks[0][0][0], t_first + chunks[0][0][1]))
     reader = JpegFolderReader(width, height, dev, pinned=not disable_pin_memory, batch_capacity=max(len(c) for c in chunks))
+    done = False
     try:  # the reader's threads and pinned buffers are released on every path (df3d-cli -r/-f continues after a failed folder)
         with torch.cuda.device(dev):
             flips = [torch.from_numpy(np.fromiter((1 if c in flip_set else 0 for c, _ in chunk), dtype=np.uint8, count=len(chunk))).to(dev, non_blocking=True)
@@ -198,8 +262,9 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
                 conf_flat[lo : lo + len(chunk), :, 0] = res[1]
                 if return_heatmap:
                     heat.append(res[2].cpu())
+        done = True
     finally:
-        reader.finish()
+        reader.finish(check=done)   # a bad frame raises JpegDecodeError from inside the loop, within two batches of it
     host = (lambda t: t) if as_device_tensors else (lambda t: t.cpu().numpy())
     out = [host(points)]
     if return_heatmap:

@@ -72,15 +72,31 @@ def decode_luma(blobs, width, height, device=None, check=True, return_status=Fal
 
 
 # pinned staging buffers outlive a reader: page-locking ~80 MB takes longer than decoding a whole batch, and df3d-cli
-# (-r / -f) runs one reader per folder
+# (-r / -f) runs one reader per folder.  The pool is bounded by bytes: when a returned buffer does not fit, the smallest
+# ones (the least likely to satisfy a later folder's size guess) are dropped first.
 _PINNED_POOL = []
+PINNED_POOL_MAX_BYTES = 384 << 20
+
+
+def _pool_put(buf):
+    _PINNED_POOL.append(buf)
+    _PINNED_POOL.sort(key=lambda b: b.numel())
+    while _PINNED_POOL and sum(b.numel() for b in _PINNED_POOL) > PINNED_POOL_MAX_BYTES:
+        _PINNED_POOL.pop(0)
+
+
+def clear_pinned_pool():
+    """Release the page-locked staging buffers kept for the next reader (long-lived library users)."""
+    del _PINNED_POOL[:]
 
 
 class JpegFolderReader:
     """Streams JPEG files into the device decoder: the library's native reader threads (df3d_read_files, one call per
     batch, issued from a pool thread) put the files of batch k+1 straight into pinned staging memory while the GPU
-    decodes batch k.  Statuses are collected on the device and checked once, in `finish()`, so that no batch forces a
-    host synchronisation.
+    decodes batch k.  Every batch's decode statuses follow it to the host as one asynchronous copy of n int32 on the
+    decode's stream; they are looked at when the NEXT batches are submitted (by then the copy has long finished: no
+    stall), so a corrupt or unsupported file raises `JpegDecodeError` naming the file within two batches -- not after
+    the whole folder has been inferred.  `finish()` checks what is still pending.
 
         reader = JpegFolderReader(width, height, device)
         for luma in reader.stream(list_of_path_batches):        # uint8 [n, H, W] on the device, decoded on a second stream
@@ -108,7 +124,8 @@ class JpegFolderReader:
         self.batch_capacity = batch_capacity  # largest batch `stream()` will see (None: the first batch is the largest)
         self.side = None    # second HIP stream of `stream()`: H2D copies + decode kernels under the caller's compute
         self._keep = None
-        self.statuses = []  # (status tensor, paths)
+        self.pending = []   # (event, pinned host statuses, n, paths) of decoded batches whose statuses have not been looked at
+        self._status_host = []  # pinned int32 buffers, recycled
 
     READ_THREADS = 8  # native reader threads per batch (two batches may be in flight)
 
@@ -163,6 +180,7 @@ class JpegFolderReader:
 
     def _launch_decode(self, out, stream):
         """Wait for the batch being read and enqueue its H2D copy + decode on `stream` into `out[:n]`."""
+        self.check_statuses()   # of the batches decoded before: fail within two batches of a bad file
         slot, fut, paths = self.queue.pop(0)
         n = len(paths)
         if n:
@@ -189,9 +207,31 @@ class JpegFolderReader:
                                                    stream.cuda_stream),
                     "df3d_jpeg_decode_luma",
                 )
-                self._keep = (files_dev, tab)  # alive until the next launch on this stream has been enqueued behind them
-            self.statuses.append((status, paths))
+                self._keep = (files_dev, tab, status)  # alive until the next launch on this stream has been enqueued behind them
+                host = self._status_host.pop() if self._status_host else None
+                if host is None or host.numel() < n:
+                    host = torch.empty(max(n, self.batch_capacity or 0), dtype=torch.int32, pin_memory=self.pinned)
+                host[:n].copy_(status, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(stream)
+            self.pending.append((done, host, n, paths))
         return n
+
+    def check_statuses(self, wait=False):
+        """Look at the decode statuses that have reached the host: every batch but the newest one is waited for (its decode
+        was enqueued at least one batch ago), the newest only if `wait`.  Raises JpegDecodeError naming the first bad file."""
+        while self.pending:
+            done, host, n, paths = self.pending[0]
+            if not (wait or len(self.pending) > 1 or done.query()):
+                break
+            done.synchronize()
+            self.pending.pop(0)
+            st = host[:n].numpy()
+            bad = np.flatnonzero(st)
+            if bad.size:
+                b = int(bad[0])
+                raise JpegDecodeError(f"{paths[b]}: {STATUS.get(int(st[b]), st[b])}")
+            self._status_host.append(host)
 
     def decode_next(self, next_paths=None):
         """Wait for the batch being read, launch its decode, start reading `next_paths`; returns luma [n, H, W]."""
@@ -216,6 +256,9 @@ class JpegFolderReader:
         first = batches[0]
         cap = max(len(first), self.batch_capacity or 0)
         luma = [torch.empty((cap, self.height, self.width), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        for buf in luma:
+            buf.record_stream(side)   # written on the side stream: if the consumer abandons the generator the allocator must not
+                                      # hand the memory out again before that stream is done with it
         side.wait_stream(main)  # the buffers exist for the side stream
         decoded, consumed = [None, None], [None, None]
         size_of = (lambda k: None) if sizes is None else (lambda k: sizes[k])
@@ -241,16 +284,14 @@ class JpegFolderReader:
                 decoded[nb].record(side)
         main.wait_stream(side)
 
-    def finish(self):
-        """Check every decode status (one host synchronisation) and release the reader threads."""
+    def finish(self, check=True):
+        """Check the decode statuses still pending (one host synchronisation) and release the reader threads.  `check=False`
+        on an error path: release only (the exception under way is the one to report)."""
         try:
-            for status, paths in self.statuses:
-                st = status.cpu().numpy()
-                if st.any():
-                    bad = int(np.flatnonzero(st)[0])
-                    raise JpegDecodeError(f"{paths[bad]}: {STATUS.get(int(st[bad]), st[bad])}")
+            if check:
+                self.check_statuses(wait=True)
         finally:
-            self.statuses = []
+            self.pending = []
             self.pool.shutdown(wait=False)
             for item in self.queue:  # an error path: file reads may still be writing into a staging buffer
                 try:
@@ -263,6 +304,6 @@ class JpegFolderReader:
                 for slot in self.slots:
                     if slot["event"] is not None:
                         slot["event"].synchronize()  # the last copy out of this buffer has finished
-                    if slot["buf"] is not None and len(_PINNED_POOL) < 8:
-                        _PINNED_POOL.append(slot["buf"])
+                    if slot["buf"] is not None:
+                        _pool_put(slot["buf"])
                     slot["buf"] = None

@@ -33,6 +33,7 @@ extern "C" {
 
 #define DF3D_DTYPE_F32 0
 #define DF3D_DTYPE_BF16 1
+#define DF3D_DTYPE_F16 2  /* IEEE half activations + weights, fp32 accumulate: the bf16 engine's kernels on the other 16-bit format */
 
 const char* df3d_last_error(void);
 int df3d_version(void);
@@ -43,11 +44,17 @@ int df3d_device_name(int dev, char* buf, int buflen);
 /* ------------------------------------------------------------------------------------------------
  * a1  input front-end of df2d's inference_folder (call site reference df3d/core.py:177-185): uint8 frames
  *     [n, H, W, C] (C = 1 or 3) -> float32 NHWC [n, OH, OW, 3]: optional left-right flip per view
- *     (flip_dev[n] uint8, may be NULL; the reference flips cameras ordering[4:]), bilinear resize with
- *     half-pixel centres, (v/255 - mean[c]) / std[c].  mean3/std3 are HOST float[3].
+ *     (flip_dev[n] uint8, may be NULL; the reference flips cameras ordering[4:]), resize, (v/255 - mean[c]) / std[c].
+ *     mean3/std3 are HOST float[3].  df2d's resize rule is not in the reference checkout, so it is an argument:
+ *     DF3D_RESIZE_BILINEAR (half-pixel centres, no antialias: cv2.INTER_LINEAR), DF3D_RESIZE_BILINEAR_ALIGN_CORNERS,
+ *     DF3D_RESIZE_AREA (overlap-weighted mean of the covered source rectangle: cv2.INTER_AREA).
+ *     (Round 3 added the `resize` argument to this function and to df3d_hg_forward_u8.)
  * ---------------------------------------------------------------------------------------------- */
+#define DF3D_RESIZE_BILINEAR 0
+#define DF3D_RESIZE_BILINEAR_ALIGN_CORNERS 1
+#define DF3D_RESIZE_AREA 2
 int df3d_preprocess_u8(const unsigned char* img_dev, const unsigned char* flip_dev, int n, int H, int W, int C,
-                       float* out_dev, int OH, int OW, const float* mean3_host, const float* std3_host, void* stream);
+                       float* out_dev, int OH, int OW, const float* mean3_host, const float* std3_host, int resize, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a1  JPEG front-end: n baseline JPEG files -> their luma planes, on the device.
@@ -284,11 +291,11 @@ int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_
                     size_t workspace_bytes, void* stream);
 /* The same forward pass fed with the camera frames themselves: frames_dev [n][frame_h][frame_w][frame_c] uint8 (frame_c = 1 or
  * 3), flip_dev [n] uint8 or NULL (non-zero: mirror the frame left-right).  The stem samples its input patches from the frames
- * with the arithmetic of df3d_preprocess_u8 (bilinear to the engine's input size, (v/255 - mean) / std), so the result is bit
+ * with the arithmetic of df3d_preprocess_u8 (`resize` rule to the engine's input size, (v/255 - mean) / std), so the result is bit
  * for bit df3d_hg_forward(df3d_preprocess_u8(frames)) without the float image in between (the call df2d's dataset +
  * network make per batch, behind reference df3d/core.py:177-185). */
 int df3d_hg_forward_u8(df3d_hg* h, const unsigned char* frames_dev, const unsigned char* flip_dev, int n, int frame_h, int frame_w,
-                       int frame_c, const float* mean3_host, const float* std3_host, float* heatmaps_dev, void* workspace_dev,
+                       int frame_c, const float* mean3_host, const float* std3_host, int resize, float* heatmaps_dev, void* workspace_dev,
                        size_t workspace_bytes, void* stream);
 /* algorithmic work of one forward over n views: FLOPs and activation bytes (fusion model M1 of
  * SURVEY.md 8d evaluated on this engine's own plan) */

@@ -56,6 +56,37 @@ def test_calibration_like_the_reference_test(native_lib, cuda, tmp_path, golden_
     px = g3["points2d"] * np.array([480.0, 960.0])
     want = og.reprojection_error(px, g3["points3d_wo_procrustes"], g3["R"], g3["tvec"], g3["intr"])
     assert abs(reprojection_error(px, g3["points3d_wo_procrustes"], g3["R"], g3["tvec"], g3["intr"], device=cuda) - want) < 1e-9
+    # a recording without a single joint seen by two cameras: nan (the reference only prints the number), not an exception
+    assert np.isnan(reprojection_error(np.zeros_like(px), g3["points3d_wo_procrustes"], g3["R"], g3["tvec"], g3["intr"], device=cuda))
+    # beyond config["ba_max_images"] the adjustment and its reported error use the same evenly strided subset, and say so once
+    import logging
+
+    from deepfly3d_amd.camera_network import CameraNetwork
+
+    class _Grab(logging.Handler):
+        def __init__(self):
+            super().__init__()
+            self.msgs = []
+
+        def emit(self, record):
+            self.msgs.append(record.getMessage())
+
+    grab = _Grab()
+    logging.getLogger("df3d.logger").addHandler(grab)
+    old_cap = config.get("ba_max_images")
+    config["ba_max_images"] = 8
+    try:
+        calib = {c: {k: g3[k][c] for k in ("R", "tvec", "intr", "distort")} for c in range(7)}
+        big = CameraNetwork(points2d=px, calib=calib)
+        big.triangulate()
+        sub = CameraNetwork(points2d=np.ascontiguousarray(px[:, ::2]), calib=calib)
+        sub.triangulate()
+        assert abs(big.reprojection_error() - sub.reprojection_error()) < 1e-12
+        big.reprojection_error()
+        assert sum("ba_max_images" in m and "RANDOM" in m for m in grab.msgs) == 1
+    finally:
+        config["ba_max_images"] = old_cap
+        logging.getLogger("df3d.logger").removeHandler(grab)
     # Core.get_points3d (reference df3d/core.py:332-343): Procrustes -> median-centre + axis swap -> One-Euro filter, against
     # the chain executed with the reference's own functions on the golden pose (the pose here comes from OUR bundle
     # adjustment, 1.5e-6 mm from the golden one)
@@ -193,6 +224,44 @@ def test_preprocess_kernel_against_torch(native_lib, cuda):
     ref = (ref - 0.22)[..., None].expand(-1, -1, -1, 3)
     assert out.shape == (3, 256, 512, 3)
     assert (out - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("rule", ["bilinear", "bilinear_align_corners", "area"])
+def test_every_resize_rule_against_its_restatement(native_lib, cuda, rule):
+    """df2d's resize rule is data (inference.PREPROCESS["resize"]): each candidate against oracle/preprocess.py (torch
+    interpolate for the two bilinear forms, overlap-weight matrices in float64 for cv2.INTER_AREA's definition), grey and
+    colour frames, flipped and not, the camera size and an odd one; and the network fed with the frames themselves
+    (df3d_hg_forward_u8) equals preprocess + forward bit for bit under every rule."""
+    from deepfly3d_amd import inference
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+    from oracle import preprocess as opre
+
+    g = torch.Generator().manual_seed(17)
+    mean, std = (0.22, 0.31, 0.18), (0.9, 1.1, 1.3)
+    saved = dict(inference.PREPROCESS)
+    inference.PREPROCESS.update(mean=mean, std=std, resize=rule)
+    try:
+        eng = HourglassEngine(synthetic_state_dict(3), dtype="f32", device=cuda)
+        for shape in ((3, 480, 960), (2, 301, 517, 3), (1, 256, 512)):
+            frames = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+            flip = torch.tensor([0, 1, 1][: shape[0]], dtype=torch.uint8)
+            got = inference.preprocess_u8(frames.to(cuda), flip.to(cuda), (256, 512)).cpu()
+            ref = opre.preprocess_u8(frames, flip, (256, 512), mean, std, rule)
+            err = float((got - ref).abs().max())
+            assert err < 2e-6, (rule, shape, err)   # values are O(1): float32 rounding of a handful of operations
+            x = inference.preprocess_u8(frames.to(cuda), flip.to(cuda), (256, 512))
+            assert torch.equal(eng.forward(x), eng.forward_u8(frames.to(cuda), flip.to(cuda), mean, std, resize=rule)), (rule, shape)
+        if rule != "bilinear":   # the rules really differ on a down-scale
+            frames = torch.randint(0, 256, (1, 480, 960), dtype=torch.uint8, generator=g).to(cuda)
+            a = inference.preprocess_u8(frames, None)
+            inference.PREPROCESS.update(resize="bilinear")
+            assert not torch.equal(a, inference.preprocess_u8(frames, None))
+    finally:
+        inference.PREPROCESS.clear()
+        inference.PREPROCESS.update(saved)
+    with pytest.raises(KeyError):
+        eng.forward_u8(torch.zeros((1, 8, 8), dtype=torch.uint8, device=cuda), resize="lanczos")
 
 
 def test_full_cli_run_on_sample_images(native_lib, cuda, tmp_path, golden_dir, monkeypatch):

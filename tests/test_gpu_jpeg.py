@@ -298,3 +298,43 @@ def test_folder_reader_grows_its_staging_buffer(native_lib, cuda, tmp_path):
             list(rd.stream([paths[:2] + [str(tmp_path / "camera_0_img_99.jpg")]]))
         finally:
             rd.finish()
+
+
+def test_folder_reader_fails_within_two_batches_of_a_bad_file(native_lib, cuda, tmp_path):
+    """A corrupt and a progressive frame in the middle of a six-batch folder: JpegDecodeError names the file while the
+    stream is still running -- at most two batches later, not in finish() after the whole folder has been inferred."""
+    import torch
+
+    from deepfly3d_amd import jpeg
+
+    rng = np.random.default_rng(5)
+    good = [_encode(rng.integers(0, 256, size=(96, 160), dtype=np.uint8), quality=80) for _ in range(24)]
+    cut = good[9][:60]                                                   # cut inside the header: "truncated file" (a cut inside the
+                                                                         # entropy-coded data decodes the intact rows, like libjpeg)
+    prog = io.BytesIO()
+    Image.fromarray(rng.integers(0, 256, size=(96, 160), dtype=np.uint8)).save(prog, "JPEG", quality=80, progressive=True)
+    for bad_index, blob, word in ((9, cut, "truncated"), (5, prog.getvalue(), "unsupported")):
+        folder = tmp_path / f"bad{bad_index}"
+        folder.mkdir()
+        paths = []
+        for i, b in enumerate(good):
+            paths.append(str(folder / f"camera_0_img_{i}.jpg"))
+            open(paths[-1], "wb").write(blob if i == bad_index else b)
+        batches = [paths[i : i + 4] for i in range(0, 24, 4)]             # the bad file sits in batch bad_index // 4
+        rd = jpeg.JpegFolderReader(160, 96, cuda)
+        seen = 0
+        with pytest.raises(jpeg.JpegDecodeError, match=word) as err:
+            try:
+                for luma in rd.stream(batches):
+                    seen += 1
+                    torch.cuda.synchronize()
+            finally:
+                rd.finish(check=False)
+        assert paths[bad_index] in str(err.value)
+        assert seen <= bad_index // 4 + 3 and seen < len(batches), (seen, bad_index)
+    # pending statuses are still checked by finish() when the consumer stops early
+    rd = jpeg.JpegFolderReader(160, 96, cuda)
+    paths_bad_last = [str(tmp_path / "bad9" / f"camera_0_img_{i}.jpg") for i in (8, 9)]
+    list(rd.stream([paths_bad_last]))
+    with pytest.raises(jpeg.JpegDecodeError):
+        rd.finish()

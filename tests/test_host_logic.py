@@ -315,3 +315,52 @@ def test_plot_2d_draws_the_pose(golden_dir):
     assert not changed[:, :5].any()
     only = net[0].plot_2d(1, points2d=np.where((np.arange(38) == 2)[:, None], px[0, 1], 0.0))
     assert 50 < np.any(only != img * 0 + np.asarray(net[0].plot_2d(1, points2d=np.zeros((38, 2)))), axis=-1).sum() < 400
+
+
+def test_mean_file_beside_the_checkpoint_is_adopted(tmp_path, monkeypatch):
+    """The reference names the normalisation mean's source: weights/mean.pth.tar next to the checkpoint (reference
+    df3d/config.py:37-39; bearpaw format {'mean': tensor[3], 'std': tensor[3]}).  load_state_dict() reads it; an explicit
+    DF3D_PREPROCESS mean wins; the file's std is applied only on request (bearpaw's color_normalize subtracts only)."""
+    import importlib
+
+    import torch
+
+    from deepfly3d_amd import inference
+
+    ckpt = tmp_path / "sh8_deepfly.tar"
+    torch.save({"state_dict": {"module.conv1.weight": torch.zeros(1)}, "epoch": 1}, ckpt)
+    torch.save({"mean": torch.tensor([0.2154, 0.2154, 0.2154]), "std": torch.tensor([0.25, 0.25, 0.25])}, tmp_path / "mean.pth.tar")
+    for k in ("DF3D_SYNTHETIC_WEIGHTS", "DF3D_PREPROCESS", "DF3D_MEAN", "DF3D_WEIGHTS"):
+        monkeypatch.delenv(k, raising=False)
+    try:
+        importlib.reload(inference)
+        assert inference.PREPROCESS == {"mean": (0.22, 0.22, 0.22), "std": (1.0, 1.0, 1.0), "resize": "bilinear"}
+        sd = inference.load_state_dict(str(ckpt))
+        assert list(sd) == ["conv1.weight"]
+        assert np.allclose(inference.PREPROCESS["mean"], 0.2154) and inference.PREPROCESS["std"] == (1.0, 1.0, 1.0)
+        assert inference._PREPROCESS_SOURCE["mean"].endswith("mean.pth.tar")
+        # explicit settings win over the file; resize is data too; the file's std only on request
+        monkeypatch.setenv("DF3D_PREPROCESS", '{"mean": [0.3], "resize": "area"}')
+        importlib.reload(inference)
+        inference.load_state_dict(str(ckpt))
+        assert inference.PREPROCESS["mean"] == (0.3, 0.3, 0.3) and inference.PREPROCESS["resize"] == "area"
+        monkeypatch.setenv("DF3D_PREPROCESS", '{"divide_by_std": true}')
+        importlib.reload(inference)
+        inference.load_state_dict(str(ckpt))
+        assert np.allclose(inference.PREPROCESS["mean"], 0.2154) and np.allclose(inference.PREPROCESS["std"], 0.25)
+        # a one-element mean (grey data set) is replicated; $DF3D_MEAN names a file elsewhere
+        other = tmp_path / "elsewhere" / "m.pth.tar"
+        other.parent.mkdir()
+        torch.save({"mean": torch.tensor([0.5])}, other)
+        monkeypatch.delenv("DF3D_PREPROCESS")
+        monkeypatch.setenv("DF3D_MEAN", str(other))
+        importlib.reload(inference)
+        inference.load_state_dict(str(ckpt))
+        assert inference.PREPROCESS["mean"] == (0.5, 0.5, 0.5)
+        monkeypatch.setenv("DF3D_PREPROCESS", '{"resize": "lanczos"}')
+        with pytest.raises(ValueError, match="resize must be one of"):
+            importlib.reload(inference)
+    finally:
+        for k in ("DF3D_PREPROCESS", "DF3D_MEAN"):
+            monkeypatch.delenv(k, raising=False)
+        importlib.reload(inference)
