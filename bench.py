@@ -12,14 +12,24 @@ fp32 with seeded synthetic weights (no checkpoints offline); fixed calib.pkl cam
 N > 1: every rank owns its own frame range (weak scaling) and the per-frame results are gathered to rank 0 once
 (RCCL, one packed `dist.gather`), inside the timed region.  Rank 0 prints ONE JSON line.
 
-The line's headline is configs[1] (fp32).  At N = 1 the same process then times configs[2] (bf16 hourglass, same
-frames) and attaches it as `config2_bf16` with its own roofline, so both precisions are under the driver's clock.
+The line's headline is configs[1] (fp32).  At N = 1 the same process then times, under the same driver clock,
+  config2_bf16   configs[2]: the same frames through the bf16 hourglass (all convolutions on MFMA, fp32 accumulate)
+  config2_f16    the same kernels on IEEE half: the 16-bit engine whose heat-map confidences stay inside the reference's
+                 own test tolerance (2e-3; bf16's are ~5e-3 off: tests/test_gpu_hourglass.py)
+  config4_share  a short share of configs[4]: rank 0 of 8 of a 16 000-frame stream (2 000 frames, f16), a bundle adjustment
+                 per 1 000-frame window beside the pipeline, the packed gather executed on a 1-rank RCCL group
+each hourglass leg with its own roofline block.
 
     python bench.py --rank-share 8 --stream-frames 100000 [--ba-window 1000] [--force-collective]
-runs ONE rank's share of BASELINE configs[3] / configs[4] on the one GPU at hand: rank 0's frame range of the
-100 k-frame stream sharded over 8 ranks (aligned to the bundle-adjustment window), streamed through the resident
-frame pool, one bundle adjustment per window interleaved, and -- with --force-collective -- the single packed gather
-executed on a 1-rank RCCL process group, all inside the timed region.
+runs ONE rank's full share of BASELINE configs[3] / configs[4] on the one GPU at hand (profiles/r03_rankshare_*.json).
+
+Roofline fractions (per kernel and for the dominant one), spelled out because a fused kernel has more than one byte count:
+  frac_mfma      algorithmic FLOPs / time / dense MFMA peak of the dtype
+  frac_hbm_min   (inputs read once + outputs written once, intermediates on chip) / time / 8 TB/s -- the least the launch can move
+  frac_hbm_m1    bytes the fusion model M1 of SURVEY.md 8(d) charges (every convolution's input and output) / time / 8 TB/s
+                 -- a convention: it exceeds what any kernel moves once convolutions are fused
+  frac_hbm_pmc   HBM bytes rocprofv3's counters saw ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, profiles/traffic.json) / time / 8 TB/s
+`bound` is the larger of frac_mfma and frac_hbm_pmc (frac_hbm_min when no counter pass covers the kernel); `frac` is that one.
 """
 import argparse
 import hashlib
@@ -37,12 +47,10 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}  # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 PEAK_HBM_GBS = 8000.0
-# which roof binds the hourglass per dtype (fp32: AI 55.6 FLOP/B > 19.7 balance -> FLOP-bound;
-# bf16 on MFMA: 323.7 MB/view of activation traffic in the fusion model M1 -> HBM-bound)
-BOUND = {"f32": "mfma", "bf16": "hbm", "f16": "hbm"}
+DTYPE_WORDS = {"f32": "fp32", "bf16": "bf16 (all convolutions on MFMA, fp32 accumulate)", "f16": "IEEE-half f16 (all convolutions on MFMA, fp32 accumulate)"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -60,9 +68,10 @@ def parse():
                     help="N = 1: create a 1-rank process group (RCCL) and execute the packed gather anyway")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the attached configs[2] (bf16) measurement")
+    ap.add_argument("--no-bf16-leg", "--no-legs", dest="no_legs", action="store_true",
+                    help="skip the attached legs (configs[2] in bf16 and f16, the configs[4] share)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def host_cores():
@@ -125,8 +134,8 @@ def cpu_baseline(state_dict, frames_cpu, calib, target_seconds):
 
 
 def measure_roofline(engine, dtype, run_steps, nprof):
-    """HIP events around every launch of each kernel class (same stream), over `nprof` steps; the dominant kernel
-    priced against the roof SURVEY.md 8(d) assigns to this dtype."""
+    """HIP events around every launch of each kernel class (same stream), over `nprof` steps; every kernel priced against
+    both roofs with every byte model (module docstring), the dominant kernel's larger fraction is the line's `frac`."""
     import ctypes
 
     from deepfly3d_amd import _native
@@ -135,54 +144,268 @@ def measure_roofline(engine, dtype, run_steps, nprof):
     _native.check(lib.df3d_hg_profile(engine.h, 1))
     run_steps(nprof)
     torch.cuda.synchronize()
-    per = []
-    buf = ctypes.create_string_buffer(128)
-    for k in range(lib.df3d_hg_profile_count(engine.h)):
-        ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-        _native.check(lib.df3d_hg_profile_read(engine.h, k, buf, 128, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n)))
-        if n.value:
-            per.append({"kernel": buf.value.decode(), "launches": n.value, "avg_us": 1e3 * ms.value / n.value, "total_ms": ms.value,
-                        "tflops": fl.value / ms.value / 1e9, "gbs_algorithmic": by.value / ms.value / 1e6})
-    per.sort(key=lambda d: -d["total_ms"])
-    _native.check(lib.df3d_hg_profile(engine.h, 0))
-    dom = per[0]
-    traffic = traffic_src = None
+    traffic, traffic_src = {}, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
-            tj = json.load(f)
-        traffic = tj.get(dom["kernel"])
-        traffic_src = (tj.get("_meta") or {}).get("kernel_source_sha")
-    bound = BOUND[dtype]
-    roof = {
+            traffic = json.load(f)
+        traffic_src = (traffic.get("_meta") or {}).get("kernel_source_sha")
+    per = []
+    buf = ctypes.create_string_buffer(128)
+    for k in range(lib.df3d_hg_profile_count(engine.h)):
+        ms, fl, by, m1, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        _native.check(lib.df3d_hg_profile_read(engine.h, k, buf, 128, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(m1), ctypes.byref(n)))
+        if not n.value:
+            continue
+        name = buf.value.decode()
+        sec = 1e-3 * ms.value / n.value   # average launch
+        pmc = traffic.get(name)
+        row = {"kernel": name, "launches": n.value, "avg_us": 1e6 * sec, "total_ms": ms.value, "tflops": fl.value / n.value / sec / 1e12,
+               "bytes_min": by.value / n.value, "bytes_m1": m1.value / n.value, "bytes_pmc": pmc}
+        row["frac_mfma"] = row["tflops"] / PEAK_TFLOPS[dtype]
+        row["frac_hbm_min"] = row["bytes_min"] / sec / 1e9 / PEAK_HBM_GBS
+        row["frac_hbm_m1"] = row["bytes_m1"] / sec / 1e9 / PEAK_HBM_GBS
+        row["frac_hbm_pmc"] = pmc / sec / 1e9 / PEAK_HBM_GBS if pmc else None
+        per.append(row)
+    per.sort(key=lambda d: -d["total_ms"])
+    _native.check(lib.df3d_hg_profile(engine.h, 0))
+    dom = per[0]
+    hbm_frac = dom["frac_hbm_pmc"] if dom["frac_hbm_pmc"] is not None else dom["frac_hbm_min"]
+    hbm_bytes = dom["bytes_pmc"] if dom["frac_hbm_pmc"] is not None else dom["bytes_min"]
+    bound = "mfma" if dom["frac_mfma"] >= hbm_frac else "hbm"
+    sec = dom["avg_us"] * 1e-6
+    return {
         "bound": bound,
         "kernel": dom["kernel"],
-        "achieved": dom["tflops"] if bound == "mfma" else dom["gbs_algorithmic"],
+        "achieved": dom["tflops"] if bound == "mfma" else hbm_bytes / sec / 1e9,
         "peak": PEAK_TFLOPS[dtype] if bound == "mfma" else PEAK_HBM_GBS,
         "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-        "algorithmic_bytes_model": "M1 (SURVEY.md 8d): every convolution reads its input and writes its output once",
-        "traffic": traffic,  # HBM bytes per launch from rocprofv3 PMC passes ((2 x FETCH_SIZE + WRITE_SIZE) x 1024), profiles/traffic.json
+        "frac": dom["frac_mfma"] if bound == "mfma" else hbm_frac,
+        "frac_is": "frac_mfma" if bound == "mfma" else ("frac_hbm_pmc" if dom["frac_hbm_pmc"] is not None else "frac_hbm_min"),
+        "fractions": {k: dom[k] for k in ("frac_mfma", "frac_hbm_min", "frac_hbm_m1", "frac_hbm_pmc")},
+        "fractions_legend": "frac_mfma: algorithmic FLOPs / dense MFMA peak; frac_hbm_min: inputs once + outputs once / 8 TB/s; frac_hbm_m1: bytes of the "
+                            "fusion model M1 (SURVEY.md 8d: every convolution's input and output) / 8 TB/s, a convention above what fused kernels move; "
+                            "frac_hbm_pmc: rocprofv3 FETCH/WRITE counters / 8 TB/s; bound = the larger of frac_mfma and frac_hbm_pmc",
+        "traffic": dom["bytes_pmc"],  # HBM bytes per launch from rocprofv3 PMC passes ((2 x FETCH_SIZE + WRITE_SIZE) x 1024), profiles/traffic.json
         "traffic_kernel_source_sha": traffic_src,
         "traffic_is_current": (traffic_src == kernel_source_sha()) if traffic_src else None,
         "avg_launch_us": dom["avg_us"],
-        "mfma_tflops": dom["tflops"],
-        "mfma_frac": dom["tflops"] / PEAK_TFLOPS[dtype],
-        "hbm_gbs_algorithmic": dom["gbs_algorithmic"],
-        "hbm_frac_algorithmic": dom["gbs_algorithmic"] / PEAK_HBM_GBS,
-        "hbm_gbs_pmc": (traffic / (dom["avg_us"] * 1e-6) / 1e9) if traffic else None,
         "kernels": per,
     }
-    roof["frac"] = roof["achieved"] / roof["peak"]
-    return roof
 
 
-def main():
-    a = parse()
+class Job:
+    """One workload on one engine: frames streamed from the resident pool through the pipeline in steps, optional bundle
+    adjustment per window on a worker thread, optional packed gather -- timed as the contract asks."""
+
+    def __init__(self, a, engine, frames, calib, dev, rank, world, total_frames, steps, ba_window, collective, force_collective):
+        from deepfly3d_amd.pipeline import FramePipeline
+
+        self.a, self.engine, self.frames, self.calib, self.dev = a, engine, frames, calib, dev
+        self.rank, self.world, self.total_frames, self.steps, self.ba_window = rank, world, total_frames, steps, ba_window
+        self.collective, self.force_collective = collective, force_collective
+        self.fps_step = a.frames_per_step
+        self.pool = frames.shape[0]
+        self.align = ba_window if ba_window > 0 else 1
+        self.pipe = FramePipeline(engine, calib["R"], calib["tvec"], calib["intr"])
+        self.outs = self.pipe.allocate_outputs(total_frames)
+        self.ba_px, self.ba_runs, self.ba_cams, self.ba_ms, self.ba_futures = None, [], [], [], []
+        self.ba_pool = self.ba_stream = None
+        self.timeline = {"enq": [], "ev": [], "ba": []} if os.environ.get("DF3D_BENCH_TIMELINE") else None
+        if ba_window > 0:
+            # geometry-consistent detections (SURVEY.md 8d), one set per window: golden-like pose tiled + jitter, projected through
+            # the adjusted cameras of the sample set, quantised to the heat-map grid (the random-weight network output is
+            # meaningless for BA); prepared before the timed region like the frames
+            from concurrent.futures import ThreadPoolExecutor
+
+            from deepfly3d_amd.synthetic import synthetic_ba_window
+
+            g3 = np.load(os.path.join(ROOT, "tests", "golden", "golden_3d.npz"))
+            nwin = -(-total_frames // ba_window)
+            self.ba_px = [synthetic_ba_window(g3["points3d_wo_procrustes"], g3["R"], g3["tvec"], g3["intr"], min(ba_window, total_frames - w * ba_window), rank, w)
+                          for w in range(nwin)]
+            # configs[4]: the re-calibration of a finished window runs on its own HIP stream from a worker thread (its inputs do
+            # not depend on the frames still in flight), so its ~150 small kernels and ~40 host synchronisations slot in beside the
+            # next batches' hourglass instead of draining the pipeline; every window is joined before the gather, inside the timed region
+            self.ba_pool = ThreadPoolExecutor(max_workers=1)
+            self.ba_stream = torch.cuda.Stream(device=dev)
+
+    def recalibrate(self, window_px):
+        from deepfly3d_amd.bundle_adjust import bundle_adjust
+
+        t_ba = time.perf_counter()
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.ba_stream):
+            Rn, tn, info = bundle_adjust(window_px, self.calib["R"], self.calib["tvec"], self.calib["intr"], device=self.dev, return_info=True)
+        self.ba_ms.append(round(1e3 * (time.perf_counter() - t_ba), 1))   # wall time of the solve (beside the pipeline when threaded)
+        if self.timeline is not None:
+            self.timeline["ba"].append((t_ba, time.perf_counter()))
+        return np.concatenate([Rn.reshape(7, 9), tn.reshape(7, 3)], axis=1), info["nfev"]
+
+    def step(self, i, record=True, solve=True):
+        tl = self.timeline
+        if tl is not None and record:
+            tl["enq"].append(time.perf_counter())
+        f0 = i * self.fps_step
+        n = min(self.fps_step, self.total_frames - f0)
+        lo = f0 % self.pool
+        self.pipe.run_batch(self.frames[lo : lo + n], *self.outs, f0)
+        if tl is not None and record:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            tl["ev"].append(ev)
+        # a window closes with this batch (the last window of the share may be shorter)
+        w = self.ba_window
+        if solve and self.ba_px is not None and ((f0 + n) // w > f0 // w or (f0 + n == self.total_frames and self.total_frames % w)):
+            closed = (f0 + n) // w - 1 if (f0 + n) // w > f0 // w else len(self.ba_px) - 1
+            fut = self.ba_pool.submit(self.recalibrate, self.ba_px[closed])
+            if record:
+                self.ba_futures.append(fut)
+            else:
+                fut.result()
+
+    def join_recalibrations(self):
+        for fut in self.ba_futures:
+            cams, nfev = fut.result()
+            self.ba_cams.append(cams)
+            self.ba_runs.append(nfev)
+        del self.ba_futures[:]
+
+    def gather(self):
+        from deepfly3d_amd import distributed as dd
+
+        if not self.collective:
+            return None
+        cams = None
+        if self.ba_window > 0:
+            cams = torch.from_numpy(np.stack(self.ba_cams) if self.ba_cams else np.zeros((0, 7, 12))).to(self.dev)
+        return dd.gather_results(*self.outs, num_frames=self.total_frames * self.world, rank=self.rank, world_size=self.world, align=self.align, cameras=cams,
+                                 force_collective=self.force_collective)
+
+    def run(self, warmup):
+        """W untimed steps, then exactly `steps` timed steps (+ joins + gather) between barrier + synchronize on both sides."""
+        dist = torch.distributed
+        for w in range(warmup):
+            self.step(w % self.steps, record=False, solve=False)
+        if self.ba_px is not None:
+            # the re-calibration has one-time costs of its own (allocator growth on its stream, the LSMR chunk's graph: ~0.7 s per
+            # call until buffers and graph settle) and no window closes inside the W warm-up steps: warm it on its worker thread,
+            # where its graph cache lives
+            for _ in range(2):
+                self.ba_pool.submit(self.recalibrate, self.ba_px[0]).result()
+            del self.ba_ms[:]
+        if self.collective and self.world == 1:
+            # a multi-rank run creates its RCCL communicator in the barrier below; the 1-rank group of --force-collective would
+            # create it inside the first gather, i.e. inside the timed region (0.9 s when nothing else hides it)
+            dist.all_reduce(torch.zeros(1, device=self.dev))
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        t_start = time.perf_counter()
+        tl = self.timeline
+        if tl is not None:
+            tl["ev0"] = torch.cuda.Event(enable_timing=True)
+            tl["ev0"].record()
+        for i in range(self.steps):
+            self.step(i)
+        marks = [time.perf_counter()]
+        self.join_recalibrations()
+        marks.append(time.perf_counter())
+        gathered = self.gather()
+        marks.append(time.perf_counter())
+        torch.cuda.synchronize()
+        marks.append(time.perf_counter())
+        if self.world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t_start
+        if tl is not None:   # development aid: host enqueue time, GPU completion time of every step, the solves' intervals
+            ev0 = tl["ev"][0]
+            done = [ev0.elapsed_time(e) for e in tl["ev"]]
+            enq = [1e3 * (x - t_start) for x in tl["enq"]]
+            print("TIMELINE step: enqueue_ms gpu_done_ms(from step 0's end)", file=sys.stderr)
+            for i in range(0, len(enq), max(1, len(enq) // 24)):
+                print(f"  step {i:3d}: {enq[i]:8.1f} {done[i]:8.1f}", file=sys.stderr)
+            print("  step 0 gpu done", round(tl["ev0"].elapsed_time(ev0), 1), "ms after the start; last step", round(done[-1], 1), "ms after step 0; elapsed", round(1e3 * elapsed, 1), file=sys.stderr)
+            print("  host marks (ms): loop end, joined, gather returned, synchronised:", [round(1e3 * (m - t_start), 1) for m in marks], file=sys.stderr)
+            print("  BA [start, end] ms:", [(round(1e3 * (a0 - t_start)), round(1e3 * (a1 - t_start))) for a0, a1 in tl["ba"][-len(self.ba_runs):]], file=sys.stderr)
+        if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        gather_ok = None
+        if self.collective and self.rank == 0 and self.world == 1:  # the 1-rank collective must hand back exactly what went in
+            gather_ok = all(torch.equal(g, o) for g, o in zip(gathered[:3], self.outs))
+        return elapsed, gather_ok
+
+    def roofline(self, dtype):
+        return measure_roofline(self.engine, dtype, lambda n: [self.step(i, record=False, solve=False) for i in range(n)], min(self.steps, 4))
+
+    def close(self):
+        if self.ba_pool is not None:
+            self.ba_pool.shutdown(wait=True)
+
+
+def ensure_one_rank_group(dev):
+    """--force-collective at N = 1: a 1-rank RCCL process group, so that the packed gather really executes."""
+    if not torch.distributed.is_initialized():
+        port = int(os.environ.get("MASTER_PORT", "29517"))
+        torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+
+
+def hourglass_leg(a, sd, dtype, frames, calib, dev, total_frames, config_words):
+    """configs[2]-style leg at N = 1: the headline's frames through another engine, timed like the headline."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    eng = HourglassEngine(sd, dtype=dtype, device=dev)
+    job = Job(a, eng, frames, calib, dev, 0, 1, total_frames, a.steps, 0, False, False)
+    elapsed, _ = job.run(max(1, a.warmup))
+    fl, by = eng.work(a.frames_per_step * 7)
+    sec = elapsed / a.steps
+    leg = {
+        "workload": f"{config_words}: {total_frames} frames x 7 views of 256x512x3, 2-stack hourglass {DTYPE_WORDS[dtype]}, arg-max + 38-joint layout + fp64 DLT with fixed calib.pkl",
+        "value": total_frames / elapsed, "unit": "frames/s", "steps": a.steps, "ms_per_step": 1e3 * sec, "dtype": dtype,
+        "hourglass_tflops_end_to_end": fl / sec / 1e12,
+        "hourglass_frac_mfma_end_to_end": fl / sec / 1e12 / PEAK_TFLOPS[dtype],
+        "hourglass_gbs_m1_end_to_end": by / sec / 1e9,
+        "hourglass_frac_hbm_m1_end_to_end": by / sec / 1e9 / PEAK_HBM_GBS,
+    }
+    if not a.no_roofline:
+        leg["roofline"] = job.roofline(dtype)
+    del job, eng
+    return leg
+
+
+def share_leg(a, sd, dtype, frames, calib, dev):
+    """A short share of configs[4] in-process: rank 0 of 8 ranks of a 16 000-frame stream (2 000 frames), one bundle adjustment
+    per 1 000-frame window beside the pipeline, the packed gather (frames + window cameras) executed on a 1-rank RCCL group."""
+    from deepfly3d_amd import distributed as dd
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    ensure_one_rank_group(dev)
+    t0, t1 = dd.shard_range(16000, 8, 0, 1000)
+    total = t1 - t0
+    steps = -(-total // a.frames_per_step)
+    eng = HourglassEngine(sd, dtype=dtype, device=dev)
+    job = Job(a, eng, frames, calib, dev, 0, 1, total, steps, 1000, True, True)
+    elapsed, ok = job.run(max(1, a.warmup))
+    out = {
+        "workload": f"BASELINE configs[4], a short share on one GPU: rank 0 of 8 ranks of a 16000-frame 7-view stream = {total} frames through the resident pool, "
+                    f"2-stack hourglass {DTYPE_WORDS[dtype]}, arg-max + 38-joint layout + fp64 DLT, bundle-adjustment re-calibration every 1000 frames, "
+                    "packed gather (frame records + window cameras) executed on a 1-rank RCCL group; the full 13 000-frame share: profiles/r03_rankshare_*.json",
+        "value": total / elapsed, "unit": "frames/s", "dtype": dtype, "frames": total, "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
+        "bundle_adjust_runs": len(job.ba_runs), "bundle_adjust_nfev": job.ba_runs, "bundle_adjust_wall_ms": job.ba_ms[-len(job.ba_runs):],
+        "gather_roundtrip_exact": ok, "collective_backend": torch.distributed.get_backend(),
+    }
+    job.close()
+    del job, eng
+    return out
+
+
+def main(argv=None):
+    a = parse(argv)
     from deepfly3d_amd import _native
     from deepfly3d_amd import distributed as dd
     from deepfly3d_amd.config import load_calibration
     from deepfly3d_amd.hourglass import HourglassEngine
-    from deepfly3d_amd.pipeline import FramePipeline
     from deepfly3d_amd.synthetic import synthetic_state_dict
 
     rank, world, local_rank = dd.init_from_env()
@@ -192,9 +415,8 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()  # (== local_rank on a node with one GPU per rank)
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
-    if a.force_collective and world == 1 and not torch.distributed.is_initialized():
-        port = int(os.environ.get("MASTER_PORT", "29517"))
-        torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    if a.force_collective and world == 1:
+        ensure_one_rank_group(dev)
     collective = dd.collective_needed(world, a.force_collective)
 
     fps_step = a.frames_per_step
@@ -205,11 +427,13 @@ def main():
         a.steps = -(-total_frames // fps_step)
     else:
         total_frames = a.steps * fps_step
+    if a.ba_window > 0 and total_frames % a.ba_window and world > 1:
+        # every rank sees the same arguments: all of them stop here, in front of any collective
+        raise SystemExit("per-GPU frames must be a multiple of --ba-window when N > 1")
     sd = synthetic_state_dict(0)
     engine = HourglassEngine(sd, dtype=a.dtype, device=dev)
     cal = load_calibration()
     calib = {k: np.stack([cal[c][k] for c in range(7)]) for k in ("R", "tvec", "intr", "distort")}
-    pipe = FramePipeline(engine, calib["R"], calib["tvec"], calib["intr"])
 
     pool = a.pool_frames or min(a.steps * fps_step, 1024)
     pool = max(fps_step, (pool // fps_step) * fps_step)
@@ -217,182 +441,43 @@ def main():
     frames = torch.empty((pool, 7, 256, 512, 3), dtype=torch.float32, device=dev)
     for i in range(0, pool, 64):  # bounded temporary memory
         frames[i : i + 64].uniform_(0.0, 1.0, generator=gen)
-    outs = pipe.allocate_outputs(total_frames)
 
-    ba_px, ba_runs, ba_cams = None, [], []
-    if a.ba_window > 0:
-        # geometry-consistent detections, one set per window: golden-like pose tiled + jitter, projected through
-        # the adjusted cameras of the sample set, quantised to the heat-map grid (the random-weight network output is
-        # meaningless for BA); prepared before the timed region like the frames
-        from deepfly3d_amd.bundle_adjust import bundle_adjust
-        from deepfly3d_amd.synthetic import synthetic_ba_window
-
-        g3 = np.load(os.path.join(ROOT, "tests", "golden", "golden_3d.npz"))
-        nwin = -(-total_frames // a.ba_window)
-        ba_px = [synthetic_ba_window(g3["points3d_wo_procrustes"], g3["R"], g3["tvec"], g3["intr"], min(a.ba_window, total_frames - w * a.ba_window), rank, w)
-                 for w in range(nwin)]
-
-    # configs[4]: the re-calibration of a finished window runs on its own HIP stream from a worker thread (its inputs do not
-    # depend on the frames still in flight), so its ~150 small kernels and ~40 host synchronisations slot in beside the next
-    # batches' hourglass instead of draining the pipeline; every window is joined before the gather, inside the timed region
-    ba_pool = ba_stream = None
-    ba_futures = []
-    if ba_px is not None:
-        from concurrent.futures import ThreadPoolExecutor
-
-        ba_pool = ThreadPoolExecutor(max_workers=1)
-        ba_stream = torch.cuda.Stream(device=dev)
-
-    ba_ms = []
-
-    def recalibrate(window_px):
-        t_ba = time.perf_counter()
-        with torch.cuda.device(dev), torch.cuda.stream(ba_stream):
-            Rn, tn, info = bundle_adjust(window_px, calib["R"], calib["tvec"], calib["intr"], device=dev, return_info=True)
-        ba_ms.append(round(1e3 * (time.perf_counter() - t_ba), 1))   # wall time of the solve (beside the pipeline when threaded)
-        if timeline is not None:
-            timeline["ba"].append((t_ba, time.perf_counter()))
-        return np.concatenate([Rn.reshape(7, 9), tn.reshape(7, 3)], axis=1), info["nfev"]
-
-    timeline = {"enq": [], "ev": [], "ba": []} if os.environ.get("DF3D_BENCH_TIMELINE") else None
-
-    def step(i, pipeline=pipe, record=True):
-        if timeline is not None and record:
-            timeline["enq"].append(time.perf_counter())
-        f0 = i * fps_step
-        n = min(fps_step, total_frames - f0)
-        lo = f0 % pool
-        pipeline.run_batch(frames[lo : lo + n], *outs, f0)
-        if timeline is not None and record:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            timeline["ev"].append(ev)
-        # a window closes with this batch (the last window of the share may be shorter)
-        if ba_px is not None and ((f0 + n) // a.ba_window > f0 // a.ba_window or (f0 + n == total_frames and total_frames % a.ba_window)):
-            closed = (f0 + n) // a.ba_window - 1 if (f0 + n) // a.ba_window > f0 // a.ba_window else len(ba_px) - 1
-            fut = ba_pool.submit(recalibrate, ba_px[closed])
-            if record:
-                ba_futures.append(fut)
-            else:
-                fut.result()
-
-    def join_recalibrations():
-        for fut in ba_futures:
-            cams, nfev = fut.result()
-            ba_cams.append(cams)
-            ba_runs.append(nfev)
-        del ba_futures[:]
-
-    def gather():
-        if not collective:
-            return
-        cams = None
-        if a.ba_window > 0:
-            cams = torch.from_numpy(np.stack(ba_cams) if ba_cams else np.zeros((0, 7, 12))).to(dev)
-        nf = total_frames * world
-        if a.ba_window > 0 and total_frames % a.ba_window and world > 1:
-            raise SystemExit("per-GPU frames must be a multiple of --ba-window when N > 1")
-        return dd.gather_results(*outs, num_frames=nf, rank=rank, world_size=world, align=align, cameras=cams, force_collective=a.force_collective)
-
-    for w in range(a.warmup):
-        step(w % a.steps, record=False)
-    if ba_px is not None:
-        # the re-calibration has one-time costs of its own (allocator growth on its stream, the LSMR chunk's graph: ~0.7 s per
-        # call until buffers and graph settle) and no window closes inside the W warm-up steps: warm it on its worker thread,
-        # where its graph cache lives
-        for _ in range(2):
-            ba_pool.submit(recalibrate, ba_px[0]).result()
-        del ba_ms[:]
-    if collective and world == 1:
-        # a multi-rank run creates its RCCL communicator in the barrier below; the 1-rank group of --force-collective would
-        # create it inside the first gather, i.e. inside the timed region (0.9 s when nothing else hides it)
-        torch.distributed.all_reduce(torch.zeros(1, device=dev))
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    t_start = time.perf_counter()
-    if timeline is not None:
-        timeline["ev0"] = torch.cuda.Event(enable_timing=True)
-        timeline["ev0"].record()
-    for i in range(a.steps):
-        step(i)
-    t_marks = [time.perf_counter()]
-    join_recalibrations()
-    t_marks.append(time.perf_counter())
-    gathered = gather()
-    t_marks.append(time.perf_counter())
-    torch.cuda.synchronize()
-    t_marks.append(time.perf_counter())
-    if world > 1:
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t_start
-    if timeline is not None:   # development aid: host enqueue time, GPU completion time of every step, the solves' intervals
-        ev0 = timeline["ev"][0]
-        done = [ev0.elapsed_time(e) for e in timeline["ev"]]
-        enq = [1e3 * (x - t_start) for x in timeline["enq"]]
-        print("TIMELINE step: enqueue_ms gpu_done_ms(from step 0's end)", file=sys.stderr)
-        for i in range(0, len(enq), max(1, len(enq) // 24)):
-            print(f"  step {i:3d}: {enq[i]:8.1f} {done[i]:8.1f}", file=sys.stderr)
-        print("  step 0 gpu done", round(timeline["ev0"].elapsed_time(ev0), 1), "ms after the start; last step", round(done[-1], 1), "ms after step 0; elapsed", round(1e3 * elapsed, 1), file=sys.stderr)
-        print("  host marks (ms): loop end, joined, gather returned, synchronised:", [round(1e3 * (m - t_start), 1) for m in t_marks], file=sys.stderr)
-        print("  BA [start, end] ms:", [(round(1e3 * (a0 - t_start)), round(1e3 * (a1 - t_start))) for a0, a1 in timeline["ba"][-len(ba_runs):]], file=sys.stderr)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    gather_ok = None
-    if collective and rank == 0 and world == 1:  # the 1-rank collective must hand back exactly what went in
-        gather_ok = all(torch.equal(g, o) for g, o in zip(gathered[:3], outs))
+    job = Job(a, engine, frames, calib, dev, rank, world, total_frames, a.steps, a.ba_window, collective, a.force_collective)
+    elapsed, gather_ok = job.run(a.warmup)
 
     roof = None
     if not a.no_roofline and rank == 0:
-        nprof = min(a.steps, 4)
-        saved_ba, ba_px = ba_px, None  # kernel timing only
-        roof = measure_roofline(engine, a.dtype, lambda n: [step(i, record=False) for i in range(n)], nprof)
-        ba_px = saved_ba
+        roof = job.roofline(a.dtype)
 
-    # configs[2] (bf16 hourglass, same frames and geometry) in the same process, under the same driver clock
-    leg = None
-    if a.dtype == "f32" and world == 1 and not a.no_bf16_leg and a.rank_share == 0 and a.ba_window == 0:
-        e16 = HourglassEngine(sd, dtype="bf16", device=dev)
-        p16 = FramePipeline(e16, calib["R"], calib["tvec"], calib["intr"])
-        for w in range(max(1, a.warmup)):
-            step(w % a.steps, pipeline=p16, record=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            step(i, pipeline=p16, record=False)
-        torch.cuda.synchronize()
-        el16 = time.perf_counter() - t0
-        fl16, by16 = e16.work(fps_step * 7)
-        leg = {
-            "workload": f"BASELINE configs[2]: {total_frames} frames x 7 views of 256x512x3, 2-stack hourglass bf16 (all convolutions on MFMA, fp32 accumulate), "
-                        "arg-max + 38-joint layout + fp64 DLT with fixed calib.pkl",
-            "value": total_frames / el16, "unit": "frames/s", "steps": a.steps, "ms_per_step": 1e3 * el16 / a.steps, "dtype": "bf16",
-            "hourglass_tflops_end_to_end": fl16 / (el16 / a.steps) / 1e12,
-            "hourglass_gbs_algorithmic_end_to_end": by16 / (el16 / a.steps) / 1e9,
-            "hbm_frac": by16 / (el16 / a.steps) / 1e9 / PEAK_HBM_GBS,
-        }
-        if not a.no_roofline:
-            leg["roofline"] = measure_roofline(e16, "bf16", lambda n: [step(i, pipeline=p16, record=False) for i in range(n)], min(a.steps, 4))
-        del p16, e16
+    # the attached legs (N = 1, plain configs[1] run only): same process, same driver clock
+    legs = {}
+    if a.dtype == "f32" and world == 1 and not a.no_legs and a.rank_share == 0 and a.ba_window == 0:
+        legs["config2_bf16"] = hourglass_leg(a, sd, "bf16", frames, calib, dev, total_frames, "BASELINE configs[2]")
+        legs["config2_f16"] = hourglass_leg(a, sd, "f16", frames, calib, dev, total_frames,
+                                            "BASELINE configs[2] on IEEE half (the 16-bit engine inside the reference's 2e-3 confidence tolerance)")
+        try:
+            legs["config4_share"] = share_leg(a, sd, "f16", frames, calib, dev)
+        except Exception as e:  # reporting only: never hide the headline
+            legs["config4_share"] = {"error": repr(e)}
 
     if rank == 0:
         ms_step = 1e3 * elapsed / a.steps
         fl, by = engine.work(fps_step * 7)
         per_step = total_frames / a.steps / fps_step  # < 1 when the last batch of a rank share is short
+        words = DTYPE_WORDS[a.dtype]
         if a.rank_share:
             cfg = 4 if a.ba_window else 3
             workload = (f"BASELINE configs[{cfg}], ONE rank's share on one GPU: rank 0 of {a.rank_share} ranks of a {a.stream_frames}-frame 7-view stream = "
-                        f"{total_frames} frames streamed through a {pool}-frame resident pool, 2-stack hourglass {a.dtype}, arg-max + 38-joint layout + fp64 DLT"
+                        f"{total_frames} frames streamed through a {pool}-frame resident pool, 2-stack hourglass {words}, arg-max + 38-joint layout + fp64 DLT"
                         + (f", bundle-adjustment re-calibration every {a.ba_window} frames" if a.ba_window else "")
                         + (", packed gather executed on a 1-rank RCCL group" if collective else ""))
         elif a.ba_window:
-            workload = (f"BASELINE configs[4] (per-GPU share): {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {a.dtype}, "
+            workload = (f"BASELINE configs[4] (per-GPU share): {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {words}, "
                         f"arg-max + 38-joint layout + fp64 DLT, bundle-adjustment re-calibration every {a.ba_window} frames")
         else:
-            workload = (f"BASELINE configs[{1 if a.dtype == 'f32' else 2}]: {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {a.dtype}, "
+            workload = (f"BASELINE configs[{1 if a.dtype == 'f32' else 2}]: {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {words}, "
                         "arg-max + 38-joint layout + fp64 DLT with fixed calib.pkl")
+        sec = ms_step * 1e-3
         line = {
             "metric": "frames/sec (7-view 2D->3D)",
             "value": world * total_frames / elapsed,
@@ -415,25 +500,26 @@ def main():
                 "collective_backend": torch.distributed.get_backend() if collective else None,
                 "gather_roundtrip_exact": gather_ok,
                 "bundle_adjust_every_frames": a.ba_window or None,
-                "bundle_adjust_runs_rank0": len(ba_runs) or None,
-                "bundle_adjust_nfev": ba_runs or None,
-                "bundle_adjust_wall_ms": ba_ms[-len(ba_runs):] if ba_runs else None,
-                "hourglass_tflops_end_to_end": per_step * fl / (ms_step * 1e-3) / 1e12,
-                "hourglass_gbs_algorithmic_end_to_end": per_step * by / (ms_step * 1e-3) / 1e9,
-                "hbm_frac": per_step * by / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                "hbm_frac_note": "hourglass activation bytes of the fusion model M1 (SURVEY.md 8d) / step time / 8 TB/s",
+                "bundle_adjust_runs_rank0": len(job.ba_runs) or None,
+                "bundle_adjust_nfev": job.ba_runs or None,
+                "bundle_adjust_wall_ms": job.ba_ms[-len(job.ba_runs):] if job.ba_runs else None,
+                "hourglass_tflops_end_to_end": per_step * fl / sec / 1e12,
+                "hourglass_frac_mfma_end_to_end": per_step * fl / sec / 1e12 / PEAK_TFLOPS[a.dtype],
+                "hourglass_gbs_m1_end_to_end": per_step * by / sec / 1e9,
+                "hourglass_frac_hbm_m1_end_to_end": per_step * by / sec / 1e9 / PEAK_HBM_GBS,
+                "hbm_m1_note": "hourglass activation bytes of the fusion model M1 (SURVEY.md 8d: a convention, above what the fused kernels move) / step time / 8 TB/s",
             },
         }
         if roof is not None:
             line["roofline"] = roof
-        if leg is not None:
-            line["config2_bf16"] = leg
+        line.update(legs)
         if not a.no_cpu_baseline and world == 1 and a.rank_share == 0:
             try:
                 line["cpu_baseline"] = cpu_baseline(sd, frames[:16].cpu(), calib, a.cpu_seconds)
             except Exception as e:  # the baseline is reporting only; never hide the GPU number
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
+    job.close()
     if torch.distributed.is_initialized():
         if world > 1:
             torch.distributed.barrier()   # rank 0 is still measuring the per-kernel table while the others are done: tear down together

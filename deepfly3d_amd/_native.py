@@ -103,7 +103,8 @@ PROTOTYPES = {
     "df3d_hg_work": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_double)]),
     "df3d_hg_profile": (c_int, [c_void_p, c_int]),
     "df3d_hg_profile_count": (c_int, [c_void_p]),
-    "df3d_hg_profile_read": (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int)]),
+    "df3d_hg_profile_read": (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int)]),
+    "df3d_hg_step_m1_bytes": (c_double, [c_void_p, c_int, c_int]),
     "df3d_hg_num_steps": (c_int, [c_void_p]),
     "df3d_hg_step_desc": (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int)]),
     "df3d_hg_forward_upto": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -52,6 +52,7 @@ struct Step {
     long long wstream2 = -1;          // ST_HEAD (bf16, not last): byte offset of the phase-C weight stream
     bool l1 = false;                  // ST_BOTTLENECK, bf16 64 -> 64 -> 64 -> 128: hg_bt_l1.h (wstream = its LDS weight image)
     bool pool_only = false;           // ... whose full-resolution output nobody reads: `out` IS the pooled tensor
+    double m1_elems = 0;              // activation elements per view this step moves in the fusion model M1
 };
 
 struct Allocator {
@@ -121,7 +122,7 @@ struct df3d_hg {
 
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
     bool profiling = false;
-    struct Timed { hipEvent_t a, b; int cls; double flops, bytes; };
+    struct Timed { hipEvent_t a, b; int cls; double flops, bytes, bytes_m1; };
     std::vector<std::string> kernel_names;  // class id -> kernel instantiation name (as rocprofv3 prints it, shortened)
     int kernel_class(const std::string& name) {
         for (size_t i = 0; i < kernel_names.size(); ++i)
@@ -137,6 +138,12 @@ struct df3d_hg {
     // byte offset of the weight streams in the caller's "lowp" buffer: behind the 16-bit copy of the blob (bf16 / f16), at its start (f32)
     size_t stream_base() const { return lp() ? (blob_floats * 2 + 255) & ~size_t(255) : 0; }
 
+    // every step-creating site brackets its accounting: m1_open() before the first elems_per_view update that belongs to the
+    // step, push_step(), m1_close() after the last one -> Step::m1_elems
+    double m1_mark = 0;
+    void m1_open() { m1_mark = elems_per_view; }
+    void push_step(const Step& st) { steps.push_back(st); }
+    void m1_close() { steps.back().m1_elems = elems_per_view - m1_mark; }
     int new_tensor(int h, int w, int c, int pitch = 0) {
         if (!pitch) pitch = c;
         TensorDesc t{alloc.alloc((size_t)h * w * pitch), h, w, c, pitch};
@@ -199,8 +206,10 @@ struct df3d_hg {
         st.res = res;
         st.conv = plan_conv(name, taps, ti.c, ti.pitch, cout, preact, relu, nchw_out);
         st.out = nchw_out ? -1 : new_tensor(ti.h, ti.w, cout, st.conv.cout_pad);
-        steps.push_back(st);
+        m1_open();
+        push_step(st);
         account_conv((double)ti.h * ti.w, taps, ti.c, cout, res >= 0);
+        m1_close();
         return st.out;
     }
     // x2 >= 0: the block's input is x + nearest-upsample(x2) (the sum an ST_UPADD step would have written into x)
@@ -220,6 +229,7 @@ struct df3d_hg {
             // the whole block in one kernel (hg_kernels.h: bottleneck_kernel); algorithmic work is accounted
             // exactly as for the separate convolutions (model M1), although far fewer bytes really move
             const bool ds = cin != cout;
+            m1_open();
             Step st;
             st.kind = ST_BOTTLENECK;
             st.name = name + ".conv3";
@@ -255,12 +265,13 @@ struct df3d_hg {
                     const int virt = new_virtual_tensor(tx.h, tx.w, cout);
                     pooled_of[virt] = st.out;
                     elems_per_view += (double)tx.h * tx.w * cout * 1.25;  // model M1 still counts the pooling pass
-                    steps.push_back(st);
+                    push_step(st);
                     const double px = (double)tx.h * tx.w;
                     account_conv(px, 1, cin, planes, false);
                     account_conv(px, 9, planes, planes, false);
                     account_conv(px, 1, cin, cout, false);
                     account_conv(px, 1, planes, cout, true);
+                    m1_close();
                     return virt;
                 }
             }
@@ -270,12 +281,13 @@ struct df3d_hg {
                 pooled_of[st.out] = st.pool_out;
                 elems_per_view += (double)tx.h * tx.w * cout * 1.25;  // model M1 still counts the pooling pass
             }
-            steps.push_back(st);
+            push_step(st);
             const double px = (double)tx.h * tx.w;
             account_conv(px, 1, cin, planes, false);
             account_conv(px, 9, planes, planes, false);
             if (ds) account_conv(px, 1, cin, cout, false);
             account_conv(px, 1, planes, cout, true);
+            m1_close();
             return st.out;
         }
         int a = conv(name + ".conv1", x, 1, planes, true, true, -1);
@@ -297,8 +309,10 @@ struct df3d_hg {
         st.in = x;
         st.res = -1;
         st.out = new_tensor(t.h / 2, t.w / 2, t.c, t.pitch);
-        steps.push_back(st);
+        m1_open();
+        push_step(st);
         elems_per_view += (double)t.h * t.w * t.c * 1.25;
+        m1_close();
         return st.out;
     }
     // hi += upsample(lo), in place on hi
@@ -310,8 +324,10 @@ struct df3d_hg {
         st.in = hi;
         st.res = lo;
         st.out = hi;
-        steps.push_back(st);
+        m1_open();
+        push_step(st);
         elems_per_view += (double)t.h * t.w * t.c * 2.25;
+        m1_close();
         return hi;
     }
     // Returns the up-path tensor; *lazy_lo receives the low-path tensor whose upsampled copy still has to be added to it
@@ -360,9 +376,11 @@ struct df3d_hg {
         st.conv.w_off = add_param("conv1", 0, 49, 3, 64, 3, 64, 64 * 184);  // [148][64] f32 used; slot sized for the bf16 [64][184] tile
         st.conv.b_off = add_param("conv1", 1, 49, 3, 64, 3, 64, 64);
         st.out = new_tensor(H / 2, W / 2, 64);
-        steps.push_back(st);
+        m1_open();
+        push_step(st);
         flops_per_view += 2.0 * (H / 2) * (W / 2) * 147 * 64;
         elems_per_view += (double)H * W * 3 + (double)(H / 2) * (W / 2) * 64;
+        m1_close();
         int x = st.out;
         int l1 = bottleneck("layer1.0", x, 64, true, -1, true);
         free_tensor(x);
@@ -401,6 +419,7 @@ struct df3d_hg {
                 st.conv = plan_conv("fc." + S + ".0", 1, 256, 256, 256, false, true, false);
                 st.conv2b = plan_conv("score." + S, 1, 256, 256, classes, false, false, last, kp);
                 const double px = (double)tr.h * tr.w;
+                m1_open();
                 account_conv(px, 1, 256, 256, false);
                 account_conv(px, 1, 256, classes, false);
                 if (!last) {
@@ -412,7 +431,8 @@ struct df3d_hg {
                 } else {
                     st.out = -1;
                 }
-                steps.push_back(st);
+                push_step(st);
+                m1_close();
                 free_tensor(r);
                 free_tensor(x);
                 x = st.out;
@@ -513,13 +533,16 @@ struct ScopedTimer {
     hipStream_t s;
     df3d_hg::Timed t;
     bool on;
-    ScopedTimer(df3d_hg* h_, hipStream_t s_, const std::string& name, double flops, double bytes) : h(h_), s(s_), on(h_->profiling) {
+    // bytes = the least this launch can move (inputs read once, outputs written once, intermediates on chip); bytes_m1 = what the
+    // fusion model M1 of SURVEY.md 8(d) charges for the same work (every convolution's input and output, pooling and upsample passes)
+    ScopedTimer(df3d_hg* h_, hipStream_t s_, const std::string& name, double flops, double bytes, double bytes_m1) : h(h_), s(s_), on(h_->profiling) {
         if (!on) return;
         t.a = get_event(h);
         t.b = get_event(h);
         t.cls = h->kernel_class(name);
         t.flops = flops;
         t.bytes = bytes;
+        t.bytes_m1 = bytes_m1;
         (void)hipEventRecord(t.a, s);
     }
     ~ScopedTimer() {
@@ -598,7 +621,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.u8 = h->u8in;
                 const int blocks = n * (h->H / 2 / 8) * (h->W / 2 / 16);
                 const double opx = (double)n * (h->H / 2) * (h->W / 2);
-                ScopedTimer tm(h, s, std::string(eb == 2 ? "stem_lp_kernel<" : "stem_kernel<") + tname + ">", 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb));
+                ScopedTimer tm(h, s, std::string(eb == 2 ? "stem_lp_kernel<" : "stem_kernel<") + tname + ">", 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb), st.m1_elems * n * eb);
                 if constexpr (sizeof(T) == 2)
                     hipLaunchKernelGGL((stem_lp_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
                 else
@@ -634,7 +657,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 const int bn_tile = (a.cout % 128 == 0) ? 128 : (a.cout % 64 == 0 ? 64 : 32);
                 ScopedTimer tm(h, s, std::string("conv_mfma_kernel<") + tname + ", " + std::to_string(st.conv.taps) + ", " + std::to_string(bn_tile) + ", " + std::to_string(rb) + ">",
                                2.0 * mm * st.conv.taps * st.conv.cin * st.conv.cout,
-                               mm * eb * (st.conv.cin + st.conv.cout + (st.res >= 0 ? st.conv.cout : 0)));
+                               mm * eb * (st.conv.cin + st.conv.cout + (st.res >= 0 ? st.conv.cout : 0)), st.m1_elems * n * eb);
                 if (int rc = launch_conv<T>(a, st.conv.taps, rb, s)) return rc;
                 break;
             }
@@ -670,7 +693,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                     r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd; r.s1 = a.s1; r.t1 = a.t1;
                     r.V = n; r.H = ti.h; r.W = ti.w;
                     ScopedTimer tm(h, s, std::string("bottleneck_l1_kernel<") + tname + ">", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl),
-                                   px * eb * (cin + (st.pool_only ? 0.5 * pl : 2.0 * pl)));
+                                   px * eb * (cin + (st.pool_only ? 0.5 * pl : 2.0 * pl)), st.m1_elems * n * eb);
                     const int tiles = n * (ti.h / L1_TH) * (ti.w / BT_TW);
                     if constexpr (sizeof(T) == 2) {
                         static unsigned attr_done = 0;
@@ -689,14 +712,14 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                     r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd; r.s1 = a.s1; r.t1 = a.t1;
                     r.V = n; r.H = ti.h; r.W = ti.w;
                     if (ds) {   // 16-bit layer2
-                        ScopedTimer tm(h, s, std::string("bottleneck_ring_kernel<") + tname + ", false, 128>", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl), px * eb * (cin + 2.0 * pl));
+                        ScopedTimer tm(h, s, std::string("bottleneck_ring_kernel<") + tname + ", false, 128>", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl), px * eb * (cin + 2.0 * pl), st.m1_elems * n * eb);
                         if constexpr (sizeof(T) == 2)
                             if (int rc = launch_ring_lp<T, false, 128>(r, n * (ti.h / BT_TH) * (ti.w / BT_TW), BR_LDS_BYTES, s)) return rc;
                         break;
                     }
                     ScopedTimer tm(h, s, eb == 2 ? std::string("bottleneck_ring_kernel<") + tname + (a.in2 ? ", true, 256>" : ", false, 256>")
                                                  : std::string("bottleneck_ring_f32_kernel<") + (a.in2 ? "true>" : "false>"),   // as rocprofv3 prints them
-                                   2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl));
+                                   2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl), st.m1_elems * n * eb);
                     const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
                     int lds_bytes = BR_LDS_BYTES;
 #ifdef DF3D_BT_TIMING
@@ -711,7 +734,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                     break;
                 }
                 ScopedTimer tm(h, s, std::string("bottleneck_kernel<") + tname + ", " + std::to_string(cin) + ", " + std::to_string(pl) + ", " + (ds ? "true" : "false") + ", " + (a.in2 ? "true" : "false") + ">",
-                               2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + (ds ? 2.0 * cin * pl : 0.0)), px * eb * (cin + 2.0 * pl));
+                               2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + (ds ? 2.0 * cin * pl : 0.0)), px * eb * (cin + 2.0 * pl), st.m1_elems * n * eb);
                 const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
                 if (int rc = launch_bottleneck<T>(a, cin, pl, blocks, s)) return rc;
                 break;
@@ -742,7 +765,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 const double mm = (double)a.M;
                 const double fl = 2.0 * mm * (256.0 * 256 + 256.0 * 19 + (st.last ? 0.0 : 256.0 * 256 + 19.0 * 256));
                 ScopedTimer tm(h, s, std::string("head_kernel<") + tname + ", " + (st.last ? "true" : "false") + ">", fl,
-                               mm * eb * (st.last ? 256.0 : 768.0) + (st.last ? mm * 19 * 4 : 0.0));
+                               mm * eb * (st.last ? 256.0 : 768.0) + (st.last ? mm * 19 * 4 : 0.0), st.m1_elems * n * eb);
                 const unsigned blocks = (unsigned)((a.M + 127) / 128);
                 if (st.last)
                     hipLaunchKernelGGL((head_kernel<T, true>), dim3(blocks), dim3(256), HeadCfg<T>::LDS_BYTES, s, a);
@@ -755,7 +778,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 const TensorDesc& to = h->tensors[st.out];
                 const int chunks = to.pitch * eb / 16;
                 const long long total = (long long)n * to.h * to.w * chunks;
-                ScopedTimer tm(h, s, std::string("pool2_kernel<") + tname + ">", 0.0, (double)total * 16 * 5);
+                ScopedTimer tm(h, s, std::string("pool2_kernel<") + tname + ">", 0.0, (double)total * 16 * 5, st.m1_elems * n * eb);
                 hipLaunchKernelGGL((pool2_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                                    reinterpret_cast<const u32x4*>(tptr(st.in)), reinterpret_cast<u32x4*>(tptr(st.out)),
                                    total, to.h, to.w, chunks);
@@ -766,7 +789,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 const TensorDesc& to = h->tensors[st.out];
                 const int chunks = to.pitch * eb / 16;
                 const long long total = (long long)n * to.h * to.w * chunks;
-                ScopedTimer tm(h, s, std::string("upadd_kernel<") + tname + ">", 0.0, (double)total * 16 * 2.25);
+                ScopedTimer tm(h, s, std::string("upadd_kernel<") + tname + ">", 0.0, (double)total * 16 * 2.25, st.m1_elems * n * eb);
                 hipLaunchKernelGGL((upadd_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                                    reinterpret_cast<const u32x4*>(tptr(st.in)), reinterpret_cast<const u32x4*>(tptr(st.res)),
                                    reinterpret_cast<u32x4*>(tptr(st.out)), total, to.h, to.w, chunks);
@@ -1026,12 +1049,12 @@ int df3d_hg_profile(df3d_hg* h, int enable) {
 
 int df3d_hg_profile_count(const df3d_hg* h) { return h ? (int)h->kernel_names.size() : 0; }
 
-int df3d_hg_profile_read(df3d_hg* h, int kernel_class, char* name_buf, int buflen, double* ms, double* flops, double* bytes,
+int df3d_hg_profile_read(df3d_hg* h, int kernel_class, char* name_buf, int buflen, double* ms, double* flops, double* bytes, double* bytes_m1,
                          int* launches) {
-    DF3D_CHECK_ARG(h && name_buf && buflen > 0 && ms && flops && bytes && launches, "null argument");
+    DF3D_CHECK_ARG(h && name_buf && buflen > 0 && ms && flops && bytes && bytes_m1 && launches, "null argument");
     DF3D_CHECK_ARG(kernel_class >= 0 && kernel_class < (int)h->kernel_names.size(), "kernel_class out of range");
     snprintf(name_buf, buflen, "%s", h->kernel_names[kernel_class].c_str());
-    *ms = *flops = *bytes = 0.0;
+    *ms = *flops = *bytes = *bytes_m1 = 0.0;
     *launches = 0;
     for (auto& t : h->timed) {
         if (t.cls != kernel_class) continue;
@@ -1041,12 +1064,18 @@ int df3d_hg_profile_read(df3d_hg* h, int kernel_class, char* name_buf, int bufle
         *ms += e;
         *flops += t.flops;
         *bytes += t.bytes;
+        *bytes_m1 += t.bytes_m1;
         *launches += 1;
     }
     return DF3D_OK;
 }
 
 int df3d_hg_num_steps(const df3d_hg* h) { return h ? (int)h->steps.size() : 0; }
+
+double df3d_hg_step_m1_bytes(const df3d_hg* h, int step, int n) {
+    if (!h || step < 0 || step >= (int)h->steps.size() || n <= 0) return 0.0;
+    return h->steps[step].m1_elems * n * h->elem_bytes();
+}
 
 int df3d_hg_step_desc(const df3d_hg* h, int step, char* name_buf, int buflen, int* hwc) {
     DF3D_CHECK_ARG(h && name_buf && hwc && buflen > 0, "null argument");

@@ -304,14 +304,19 @@ int df3d_hg_work(const df3d_hg* h, int n, double* flops, double* bytes);
  * for a measurement pass only).  Launches are grouped by kernel instantiation, named as rocprofv3 prints them
  * (e.g. "bottleneck_kernel<float, 256, 128, false>").  df3d_hg_profile(h, 1) clears previous samples;
  * df3d_hg_profile_count() = number of distinct kernels seen; df3d_hg_profile_read() waits for the events and
- * returns name, summed duration (ms), algorithmic FLOPs and bytes, and the launch count of kernel `index`. */
+ * returns name, summed duration (ms), algorithmic FLOPs, two byte figures and the launch count of kernel `index`:
+ * bytes = the minimum the launches can move (their inputs read once, their outputs written once, fused intermediates on
+ * chip), bytes_m1 = what the fusion model M1 of SURVEY.md 8(d) charges for the same plan steps (every convolution's input
+ * and output once, pooling and upsample passes) -- the convention df3d_hg_work() sums.  (Round 3 added bytes_m1.) */
 int df3d_hg_profile(df3d_hg* h, int enable);
 int df3d_hg_profile_count(const df3d_hg* h);
-int df3d_hg_profile_read(df3d_hg* h, int index, char* name_buf, int buflen, double* ms, double* flops, double* bytes,
+int df3d_hg_profile_read(df3d_hg* h, int index, char* name_buf, int buflen, double* ms, double* flops, double* bytes, double* bytes_m1,
                          int* launches);
 /* debugging / layer-wise parity: number of plan steps, and run only steps [0, upto) then copy the
  * tensor produced by step upto-1 (NHWC, engine dtype widened to float32) into out_dev */
 int df3d_hg_num_steps(const df3d_hg* h);
+/* model-M1 bytes of plan step `step` over n views (the steps' values sum to df3d_hg_work()'s bytes) */
+double df3d_hg_step_m1_bytes(const df3d_hg* h, int step, int n);
 int df3d_hg_step_desc(const df3d_hg* h, int step, char* name_buf, int buflen, int* n_h_w_c /*[3]: h, w, c*/);
 int df3d_hg_forward_upto(df3d_hg* h, const float* images_dev, int n, int upto, float* out_dev, void* workspace_dev,
                          size_t workspace_bytes, void* stream);

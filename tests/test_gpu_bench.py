@@ -1,0 +1,72 @@
+"""-m gpu: the bench.py contract executed -- the one JSON line at N = 1 (headline, roofline with every byte model, the
+attached 16-bit legs and the configs[4] share) and the N = 2 launch the driver uses (torch.distributed.run, here two ranks
+sharing the one GPU with gloo standing in for RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(stdout):
+    rows = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(rows) == 1, stdout[-3000:]
+    return json.loads(rows[0])
+
+
+def _check_roofline(roof, dtype):
+    assert roof["bound"] in ("mfma", "hbm") and roof["unit"] == ("TFLOP/s" if roof["bound"] == "mfma" else "GB/s")
+    fr = roof["fractions"]
+    assert set(fr) == {"frac_mfma", "frac_hbm_min", "frac_hbm_m1", "frac_hbm_pmc"}
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and roof["frac"] == fr[roof["frac_is"]]
+    hbm = fr["frac_hbm_pmc"] if fr["frac_hbm_pmc"] is not None else fr["frac_hbm_min"]
+    assert roof["frac"] == max(fr["frac_mfma"], hbm)
+    for k in roof["kernels"]:
+        assert k["bytes_min"] > 0 and k["bytes_m1"] >= 0 and 0 < k["frac_mfma"] < 1.0 and 0 < k["frac_hbm_min"] < 1.0
+    dom = roof["kernels"][0]
+    assert dom["kernel"] == roof["kernel"] and dom["bytes_m1"] > dom["bytes_min"]   # a fused kernel: M1 charges more than the launch can move
+
+
+def test_default_line_has_every_leg_and_every_fraction(native_lib, cuda):
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--frames-per-step", "32", "--cpu-seconds", "2"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f32" and d["unit"] == "frames/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert abs(d["value"] - 64 / (2 * d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "configs[1]" in d["config"]["workload"]
+    _check_roofline(d["roofline"], "f32")
+    assert d["roofline"]["bound"] == "mfma" and "bottleneck_ring_f32_kernel" in d["roofline"]["kernel"]
+    for key, dt in (("config2_bf16", "bf16"), ("config2_f16", "f16")):
+        leg = d[key]
+        assert leg["dtype"] == dt and leg["value"] > 2 * d["value"] and "configs[2]" in leg["workload"]
+        _check_roofline(leg["roofline"], dt)
+    sh = d["config4_share"]
+    assert "error" not in sh, sh
+    assert sh["frames"] == 2000 and sh["bundle_adjust_runs"] == 2 and sh["gather_roundtrip_exact"] is True and sh["collective_backend"] == "nccl"
+    assert sh["value"] > 100   # ran on the GPU (the CPU path does < 1 frame/s); its full-size form lives in profiles/r03_rankshare_*.json
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_two_ranks_over_gloo_share_the_gpu(native_lib, cuda):
+    """The driver's N > 1 launch line, on the one GPU at hand: both ranks run their own frame range, the gather executes (gloo),
+    rank 0 prints one line with n_gpus 2 and the aggregate rate -- about the 1-rank rate, since the two ranks share the device."""
+    env = dict(os.environ, DF3D_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    common = ["--steps", "3", "--warmup", "1", "--frames-per-step", "32", "--dtype", "f16", "--no-cpu-baseline", "--no-roofline"]
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29641",
+                          "bench.py", "--gpus", "2"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    d1, d2 = _line(one.stdout), _line(two.stdout)
+    assert d1["n_gpus"] == 1 and d1["config"]["collective_executed"] is False
+    assert d2["n_gpus"] == 2 and d2["config"]["collective_executed"] is True and d2["config"]["collective_backend"] == "gloo"
+    assert d2["config"]["frames_per_gpu"] == 96 and "config2_bf16" not in d2
+    assert abs(d2["value"] - 2 * 96 / (3 * d2["ms_per_step"] * 1e-3)) < 1e-6 * d2["value"]
+    # two ranks on ONE device: the aggregate is the device's rate, less the gloo gather through host memory and the interleaving
+    assert 0.4 * d1["value"] < d2["value"] < 1.3 * d1["value"], (d1["value"], d2["value"])
