@@ -98,6 +98,7 @@ class Core:
             self.db = PoseDB(self.output_folder)  # written by rank 0 above: loaded, not re-created
         self.camera_ordering = self.setup_camera_ordering(camera_ordering)
         self.camNet = self.points2d = self.points3d = self.conf = None
+        self._points2d_shard = None  # multi-GPU: this rank's frames of points2d (device tensor, normalised), kept for the sharded DLT
         if os.path.exists(self.save_path):
             self._resume(self.save_path)
 
@@ -188,6 +189,7 @@ class Core:
         )
         # 19 -> 38 layout on the device, then (N > 1) ONE gather of the device tensors: no host round trip before it
         points2d = ops.relayout_19_to_38(points19.contiguous(), self.camera_ordering)
+        self._points2d_shard = points2d if world > 1 else None
         if dd.collective_needed(world):
             gathered = dd.gather_packed([(points2d, 1), (conf, 1)], self.num_images)
             self.is_primary = rank == 0
@@ -217,13 +219,55 @@ class Core:
         """Write the manual corrections to the output folder (reference :345-347)."""
         self.db.dump()
 
+    def _triangulate_sharded(self):
+        """Multi-GPU form of the triangulation inside save(): the cameras are fixed by now (loaded from an earlier result, or
+        adjusted by calibrate_calc on rank 0), so rank 0 broadcasts them -- one record of a flag + the seven 3 x 4 projection
+        matrices -- every rank triangulates ITS frame range on its own GPU, and one gather brings points3d to rank 0
+        (Procrustes is sequence-global and stays there).  Every rank calls this; returns [T, 38, 3] on rank 0, None on the
+        others or when rank 0 holds no calibration.  Bit-identical to CameraNetwork.triangulate() on the gathered points."""
+        import torch.distributed as dist
+
+        from . import distributed as dd
+
+        rank, world = dd.current()
+        dev = dd.local_device() if self.device is None else torch.device(self.device)
+        rec = torch.zeros(1 + 7 * 12, dtype=torch.float64)
+        if rank == 0 and self.camNet is not None and self.camNet.has_calibration():
+            rec[0] = 1.0
+            rec[1:] = torch.from_numpy(np.stack([c.P for c in self.camNet.cam_list]).reshape(-1))
+        wire = dd._wire_tensor(rec.to(dev), None)
+        dist.broadcast(wire, src=0)
+        rec = wire.cpu()
+        if rec[0].item() == 0.0:
+            return None
+        t0, t1 = dd.shard_range(self.num_images, world, rank)
+        if self._points2d_shard is not None:
+            local = self._points2d_shard.to(dev)
+        elif self.points2d is not None:   # resumed from a result file: every rank holds the whole sequence
+            local = torch.from_numpy(np.ascontiguousarray(self.points2d[:, t0:t1])).to(dev)
+        else:
+            local = torch.zeros((7, 0, config["num_joints"], 2), dtype=torch.float64, device=dev)
+        if local.shape[1] != t1 - t0:
+            local = torch.zeros((7, t1 - t0, config["num_joints"], 2), dtype=torch.float64, device=dev)  # keeps the collective well-formed
+        px = (local * torch.tensor([float(v) for v in self.image_shape[::-1]], dtype=torch.float64, device=dev)).contiguous()
+        X = ops.triangulate(rec[1:].reshape(7, 3, 4).numpy(), px) if t1 > t0 else torch.zeros((0, config["num_joints"], 3), dtype=torch.float64, device=dev)
+        logger.debug(f"rank {rank} of {world}: triangulated frames [{t0}, {t1}) on {dev}")
+        full = dd.gather_frames(X, 0, self.num_images)
+        return None if full is None else full.cpu().numpy()
+
     def save(self):
         """Write df3d_result_*.pkl with the reference's schema and key order (reference :349-369)."""
+        from . import distributed as dd
+
+        pts3d_sharded = self._triangulate_sharded() if dd.current()[1] > 1 else None   # a collective: every rank takes part
         if not self.is_primary:
             return
         result = {"points2d": np.copy(self.points2d)}
         if self.camNet is not None and self.camNet.has_calibration():
-            self.camNet.triangulate()
+            if pts3d_sharded is not None:
+                self.camNet.points3d = pts3d_sharded
+            else:
+                self.camNet.triangulate()
             pts3d = self.camNet.points3d
             result["points3d_wo_procrustes"] = pts3d
             result["points3d"] = procrustes_separate(pts3d, device=self.device)

@@ -34,6 +34,8 @@ namespace hgk {
 struct BtRingArgs {
     const void* in;       // NHWC bf16 [V, H, W, 256]
     const void* in2;      // UP: NHWC bf16 [V, H/2, W/2, 256]; the block's input is in + nearest-upsample(in2), rounded to bf16
+    const void* add2;     // ADD2: NHWC [V, H/2, W/2, 256]; the block WRITES out + nearest-upsample(add2) -- the hourglass' up-path sum,
+                          // with upadd_kernel's roundings (the rounded block output plus the low-resolution tensor, rounded again)
     void* out;            // NHWC bf16 [V, H, W, 256]
     void* pool;           // optional NHWC bf16 [V, H/2, W/2, 256]: 2x2 max-pool of `out`
     void* pool_in;        // optional NHWC [V, H/2, W/2, 256]: 2x2 max-pool of the block's INPUT (for the hourglass level whose
@@ -165,9 +167,10 @@ __device__ unsigned long long br_dbg[8];
 
 // CIN = 256: the identity-skip block (out = ... + x); CIN = 128 (DS): the skip is a 1x1 convolution of the raw input, accumulated
 // into the same MFMA accumulators behind W3 (layer2), the x operand of which comes straight from global memory in MFMA layout
-template <typename T, bool UP, int CIN = 256>
+template <typename T, bool UP, int CIN = 256, bool ADD2 = false>
 __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     static_assert(sizeof(T) == 2, "16-bit storage formats only (the fp32 form is hg_bt_ring_f32.h)");
+    static_assert(!ADD2 || (!UP && CIN == 256), "the fused up-path sum is written by plain identity-skip blocks");
     constexpr int CO = 256, NT = 4;
     constexpr bool DS = CIN != 256;
     static_assert(!(UP && DS), "the upsample-add input exists for the identity-skip block only");
@@ -201,7 +204,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     const int ty0 = (b % tiles_y) * BT_TH;
     const int view = b / tiles_y;
     const unsigned char* const xin = reinterpret_cast<const unsigned char*>(p.in) + (size_t)view * p.H * p.W * CIN * 2;
-    const unsigned char* const xin2 = UP ? reinterpret_cast<const unsigned char*>(p.in2) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN * 2 : nullptr;
+    const unsigned char* const xin2 = UP ? reinterpret_cast<const unsigned char*>(p.in2) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN * 2
+                                    : ADD2 ? reinterpret_cast<const unsigned char*>(p.add2) + (size_t)view * (p.H / 2) * (p.W / 2) * CO * 2 : nullptr;
 
     // ---- the weight ring ----------------------------------------------------------------------------------
     const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
             // first double-step, after the DMA), or the first half's epilogue (8 stores, UP: 4 loads; the optional pool stores are
             // left out, which only makes the wait conservative); DS: the CIN / 16 input loads of the very first double-step, the
             // first half's 8 stores in front of the second half
-            constexpr int E0 = 8 + (UP ? 4 : 0);
+            constexpr int E0 = 8 + ((UP || ADD2) ? 4 : 0);
             if constexpr (DS) br_wait_vm(dd == 0 ? (nh == 0 ? 0 : 8) : (dd == 1 && nh == 0) ? CIN / 16 : 0);
             else br_wait_vm(dd == 1 ? 8 : nh == 0 ? 0 : E0);
             br_barrier();
@@ -515,8 +519,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
         // residual added; rows fully coalesced.  Only this wave touches its slice.
         constexpr int OP = 128 * 2 + 16;
         unsigned char* const slice = t1_lds + wave * (32 * OP);
-        u32x4 x2[UP ? 4 : 1];
-        if constexpr (UP) {
+        u32x4 x2[(UP || ADD2) ? 4 : 1];
+        if constexpr (UP || ADD2) {   // the low-resolution addend: UP of the residual (the block's input is the sum), ADD2 of the output
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int pw = 4 * c + (lane >> 4);
@@ -545,6 +549,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
                 v = add_chunk<T>(v, x4);
                 xres[4 * c] = x4[0], xres[4 * c + 1] = x4[1], xres[4 * c + 2] = x4[2], xres[4 * c + 3] = x4[3];   // (the block's input, for pool_in)
             }
+            if constexpr (ADD2) v = add_chunk<T>(v, x2[c & 3]);   // the rounded block output + the low-resolution tensor, rounded again
             fin[c] = v;
             *reinterpret_cast<u32x4*>(outs + ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CO + nh * 128 + (lane & 15) * 8) = v;
         }

@@ -56,8 +56,9 @@ __device__ __forceinline__ float br_relu(float x) {
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
-template <bool UP>
+template <bool UP, bool ADD2 = false>
 __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs p) {
+    static_assert(!(UP && ADD2), "the fused up-path sum is written by plain blocks");
     using T = float;
     constexpr int CIN = 256, CO = 256, NT = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -337,6 +338,18 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] += xv[r];
+            if constexpr (ADD2) {   // + nearest-upsample(add2): a second fp32 add, as upadd_kernel would have done on the stored tensor
+                // (registers r, r^1, r^8, r^9 share one half-resolution pixel: key = bits 1 and 2 of r; one value live at a time -- the
+                // kernel has no registers to spare)
+                const float* const lrow = reinterpret_cast<const float*>(p.add2) + ((size_t)view * (p.H / 2) * (p.W / 2) + (size_t)(ty0 / 2 + wave) * (p.W / 2) + tx0 / 2 + 2 * half) * CO + n;
+#pragma unroll
+                for (int key = 0; key < 4; ++key) {
+                    const float t = lrow[((key & 1) + 4 * (key >> 1)) * CO];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (((r >> 1) & 1) + 2 * ((r >> 2) & 1) == key) acc[i][r] += t;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;

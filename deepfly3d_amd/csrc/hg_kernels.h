@@ -726,6 +726,8 @@ __global__ __launch_bounds__(256) void f32_to_lp_kernel(const float* __restrict_
 struct BottleneckArgs {
     const void* in;     // NHWC [V, H, W, CIN]
     const void* in2;    // UP: NHWC [V, H/2, W/2, CIN]; the block's input is in + nearest-upsample(in2), rounded to T
+    const void* add2;   // ADD2: NHWC [V, H/2, W/2, 2*PL]; the block WRITES out + nearest-upsample(add2) (the hourglass' up-path sum,
+                        // what upadd_kernel would have made of `out`: same roundings, in the same order)
     void* out;          // NHWC [V, H, W, 2*PL]
     void* pool;         // optional NHWC [V, H/2, W/2, 2*PL]: 2x2 max-pool of `out`, written by the same epilogue
     const void* w1;     // [PL][CIN]
@@ -773,10 +775,11 @@ struct BtCfg {
     static constexpr int NT = PL / 32;                             // channel tiles of the intermediates
 };
 
-template <typename T, int CIN, int PL, bool DS, bool UP = false>
+template <typename T, int CIN, int PL, bool DS, bool UP = false, bool ADD2 = false>
 __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
     using C = BtCfg<T, CIN, PL, DS>;
     static_assert(!UP || !DS, "the upsample-add input exists for the identity-skip block only");
+    static_assert(!ADD2 || (!DS && !UP), "the fused up-path sum is written by plain identity-skip blocks");
     constexpr int EB = C::EB;
     constexpr int CO = C::CO;
     constexpr int NT = C::NT;
@@ -799,6 +802,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
     const unsigned char* const xin = reinterpret_cast<const unsigned char*>(p.in) + (size_t)view * p.H * p.W * CIN * EB;
     // UP: the low-resolution addend (the hourglass' up-path: x = in + upsample(in2), what upadd_kernel would have written)
     const unsigned char* const xin2 = UP ? reinterpret_cast<const unsigned char*>(p.in2) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN * EB : nullptr;
+    const unsigned char* const lo2 = ADD2 ? reinterpret_cast<const unsigned char*>(p.add2) + (size_t)view * (p.H / 2) * (p.W / 2) * CO * EB : nullptr;
 
     // validity of the 192 halo rows (inside the image?) as three 64-bit masks
     if (tid < BT_HROWS) {
@@ -1158,6 +1162,14 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][r] += xr[r];
                 }
+                if constexpr (ADD2) {   // + nearest-upsample(add2): a second fp32 add, as upadd_kernel would have done on the stored tensor
+                    float t4[4];
+#pragma unroll
+                    for (int key = 0; key < 4; ++key)
+                        t4[key] = reinterpret_cast<const float*>(lo2)[((size_t)(ty0 / 2 + wave) * (p.W / 2) + tx0 / 2 + (key & 1) + 4 * (key >> 1) + 2 * half) * CO + n];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] += t4[((r >> 1) & 1) + 2 * ((r >> 2) & 1)];
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -1187,13 +1199,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
             constexpr int OP = 128 * 2 + 16;                    // slice row pitch (bytes)
             unsigned char* const slice = t1_lds + wave * (32 * OP);
             const int odd = lane & 1;
-            u32x4 x2[UP ? 4 : 1];
-            if constexpr (UP) {  // low-resolution addend of the residual: pixel (row wave of the half-size tile, column pw/2);
-                                 // chunks c and c + 4 (the tile row below) share it
+            u32x4 x2[(UP || ADD2) ? 4 : 1];
+            if constexpr (UP || ADD2) {  // low-resolution addend (UP: of the residual; ADD2: of the output): pixel (row wave of the
+                                         // half-size tile, column pw/2); chunks c and c + 4 (the tile row below) share it
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int pw = 4 * c + (lane >> 4);
-                    x2[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin2) +
+                    x2[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(UP ? xin2 : lo2) +
                         ((size_t)(ty0 / 2 + wave) * (p.W / 2) + ((tx0 + (pw & 15)) >> 1)) * CIN + nh * 128 + (lane & 15) * 8);
                 }
             }
@@ -1218,6 +1230,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
                     if constexpr (UP) x4 = add_chunk<T>(x4, x2[c & 3]);
                     v = add_chunk<T>(v, x4);
                 }
+                if constexpr (ADD2) v = add_chunk<T>(v, x2[c & 3]);   // the rounded block output + the low-resolution tensor, rounded again
                 fin[c] = v;
                 *reinterpret_cast<u32x4*>(outs + ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CO + nh * 128 + (lane & 15) * 8) = v;
             }

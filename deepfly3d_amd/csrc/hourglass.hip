@@ -46,7 +46,8 @@ struct Step {
     ConvPlan conv2b, conv3b, conv4b;  // ST_HEAD: conv = fc, conv2b = score, conv3b = fc_, conv4b = score_
     bool last = false;
     int pool_out = -1;                // ST_BOTTLENECK: tensor receiving the fused 2x2 max-pool of `out`
-    int in2 = -1;                     // ST_BOTTLENECK: low-resolution addend of the input (fused upsample + add)
+    int in2 = -1;                     // ST_BOTTLENECK: low-resolution addend of the input (upsample + add fused on the consumer side)
+    int add2 = -1;                    // ST_BOTTLENECK: low-resolution addend of the OUTPUT (upsample + add fused into the producer's epilogue)
     long long wstream = -1;           // ST_BOTTLENECK, bf16 256 -> 128 -> 128 -> 256: byte offset of its weight stream behind the bf16 blob
     int pool_in = -1;                 // ST_BOTTLENECK (ring kernels): tensor receiving the 2x2 max-pool of the block's INPUT
     long long wstream2 = -1;          // ST_HEAD (bf16, not last): byte offset of the phase-C weight stream
@@ -102,7 +103,9 @@ struct df3d_hg {
     int classes = 19;
     int rb_override = 0;  // 0 = auto, 64 or 128: staged row bytes per K-step (tuning knob)
     int fuse = 1;         // 1 = 256->128->128->256 bottlenecks at >= 16x32 run as ONE fused kernel
-    int fuse_upadd = 0;   // 1 = the hourglass' upsample + add is folded into the consuming bottleneck's input load (default: on)
+    int fuse_upadd = 0;   // the hourglass' up1 + upsample(low3): 0 = a pass of its own (upadd_kernel); 1 (default) = added in the epilogue of
+                          // the bottleneck that produces up1 (the low path runs first) wherever the level's input already has a pooled
+                          // copy, consumer side otherwise; 2 = always folded into the input load of the consuming bottleneck (round 2)
     int l1 = 1;           // 1 = bf16 layer1 (64 -> 64 -> 64 -> 128) runs as the LDS-resident-weights kernel of hg_bt_l1.h
     int ring = 1;         // 1 = the 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring*.h)
     size_t stream_bytes = 0;  // weight streams of all ring bottlenecks (behind the bf16 copy of the blob)
@@ -216,7 +219,14 @@ struct df3d_hg {
     // only_pool: the caller reads nothing but the max-pooled copy of the output
     // pool_input: the caller also needs max-pool(x) and nobody has produced it: the bf16 ring kernel writes it on the side
     // (pooled_of[x] is set when that happened)
-    int bottleneck(const std::string& name, int x, int planes, bool want_pool = false, int x2 = -1, bool only_pool = false, bool pool_input = false) {
+    // a2 >= 0 (identity-skip blocks the fused kernels take; see can_add2): the block writes out + nearest-upsample(a2) under the
+    // step name `sum_name` (the tensor an ST_UPADD step would have made of `out`)
+    bool can_add2(int x) const {
+        const TensorDesc& t = tensors[x];
+        return fuse && t.c == 256 && t.h % 8 == 0 && t.w % 16 == 0;
+    }
+    int bottleneck(const std::string& name, int x, int planes, bool want_pool = false, int x2 = -1, bool only_pool = false, bool pool_input = false,
+                   int a2 = -1, const std::string& sum_name = std::string()) {
         const int cin = tensors[x].c, cout = 2 * planes;
         const TensorDesc tx = tensors[x];
         const bool shape_ok = (cin == 256 && planes == 128) || (cin == 128 && planes == 128) || (cin == 64 && planes == 64);
@@ -235,7 +245,9 @@ struct df3d_hg {
             st.name = name + ".conv3";
             st.in = x;
             st.in2 = x2;
-            if (x2 >= 0) elems_per_view += (double)tx.h * tx.w * cin * 2.25;  // model M1 still counts the upsample + add pass
+            st.add2 = a2;
+            if (a2 >= 0) st.name = sum_name;
+            if (x2 >= 0 || a2 >= 0) elems_per_view += (double)tx.h * tx.w * cin * 2.25;  // model M1 still counts the upsample + add pass
             st.res = ds ? -1 : x;
             st.conv = plan_conv(name + ".conv1", 1, cin, cin, planes, true, true, false);
             st.conv2b = plan_conv(name + ".conv2", 9, planes, planes, planes, false, true, false);
@@ -334,6 +346,27 @@ struct df3d_hg {
     // (the consumer -- always a bottleneck -- adds it while loading its input), or -1 when the sum was materialised.
     int hourglass(const std::string& name, int n, int x, int planes, int* lazy_lo) {
         const std::string lv = name + "." + std::to_string(n - 1);
+        if (fuse && fuse_upadd == 1 && can_add2(x) && pooled_of[x] >= 0) {
+            // LOW PATH FIRST, then up1 = bottleneck(x) whose epilogue adds upsample(low3) and writes the level's sum: the consumer is
+            // a plain block (no second operand in its input load).  Needs max-pool(x) before up1 runs, i.e. a producer that has
+            // already written it (everywhere except the second stack's input, which the branch below handles as in round 2).
+            int low = pool(lv + ".pool", x);   // = pooled_of[x]
+            int low1 = bottleneck(lv + ".1.0", low, planes, n > 1);
+            free_tensor(low);
+            int low2, inner_lo = -1;
+            if (n > 1)
+                low2 = hourglass(name, n - 1, low1, planes, &inner_lo);
+            else
+                low2 = bottleneck(lv + ".3.0", low1, planes);
+            free_tensor(low1);
+            int low3 = bottleneck(lv + ".2.0", low2, planes, false, inner_lo);
+            free_tensor(low2);
+            if (inner_lo >= 0) free_tensor(inner_lo);
+            int sum = bottleneck(lv + ".0.0", x, planes, false, -1, false, false, low3, lv + ".upadd");
+            free_tensor(low3);
+            *lazy_lo = -1;
+            return sum;
+        }
         int up1 = bottleneck(lv + ".0.0", x, planes, false, -1, false, true);
         int low = pool(lv + ".pool", x);
         int low1 = bottleneck(lv + ".1.0", low, planes, n > 1);
@@ -552,14 +585,14 @@ struct ScopedTimer {
     }
 };
 
-template <typename T, int CIN, int PL, bool DS, bool UP = false>
+template <typename T, int CIN, int PL, bool DS, bool UP = false, bool ADD2 = false>
 int launch_bottleneck_t(const BottleneckArgs& a, int blocks, hipStream_t s) {
     using C = BtCfg<T, CIN, PL, DS>;
     static unsigned attr_done = 0;
     if (first_use_on_this_device(attr_done))
-        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<T, CIN, PL, DS, UP>),
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_kernel<T, CIN, PL, DS, UP, ADD2>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    hipLaunchKernelGGL((bottleneck_kernel<T, CIN, PL, DS, UP>), dim3(blocks), dim3(256), C::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((bottleneck_kernel<T, CIN, PL, DS, UP, ADD2>), dim3(blocks), dim3(256), C::LDS_BYTES, s, a);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }
@@ -567,6 +600,7 @@ int launch_bottleneck_t(const BottleneckArgs& a, int blocks, hipStream_t s) {
 template <typename T>
 int launch_bottleneck(const BottleneckArgs& a, int cin, int pl, int blocks, hipStream_t s) {
     if (cin == 256 && pl == 128 && a.in2) return launch_bottleneck_t<T, 256, 128, false, true>(a, blocks, s);
+    if (cin == 256 && pl == 128 && a.add2) return launch_bottleneck_t<T, 256, 128, false, false, true>(a, blocks, s);
     if (cin == 256 && pl == 128) return launch_bottleneck_t<T, 256, 128, false>(a, blocks, s);
     if (cin == 128 && pl == 128) return launch_bottleneck_t<T, 128, 128, true>(a, blocks, s);
     if (cin == 64 && pl == 64) return launch_bottleneck_t<T, 64, 64, true>(a, blocks, s);
@@ -580,21 +614,21 @@ template <> struct TypeName<__hip_bfloat16> { static constexpr const char* value
 template <> struct TypeName<_Float16> { static constexpr const char* value = "_Float16"; };
 
 // one launcher per 16-bit element type (hipFuncSetAttribute is per instantiation and per device)
-template <typename T, bool UP, int CIN>
+template <typename T, bool UP, int CIN, bool ADD2 = false>
 int launch_ring_lp(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
     static unsigned attr_done = 0;
     if (first_use_on_this_device(attr_done))
-        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_kernel<T, UP, CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL((bottleneck_ring_kernel<T, UP, CIN>), dim3(blocks), dim3(256), lds_bytes, s, r);
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_kernel<T, UP, CIN, ADD2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL((bottleneck_ring_kernel<T, UP, CIN, ADD2>), dim3(blocks), dim3(256), lds_bytes, s, r);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }
-template <bool UP>
+template <bool UP, bool ADD2 = false>
 int launch_ring_f32(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
     static unsigned attr_done = 0;
     if (first_use_on_this_device(attr_done))
-        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<UP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL((bottleneck_ring_f32_kernel<UP>), dim3(blocks), dim3(256), lds_bytes, s, r);
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<UP, ADD2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL((bottleneck_ring_f32_kernel<UP, ADD2>), dim3(blocks), dim3(256), lds_bytes, s, r);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }
@@ -667,6 +701,7 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 BottleneckArgs a;
                 a.in = tptr(st.in);
                 a.in2 = st.in2 >= 0 ? tptr(st.in2) : nullptr;
+                a.add2 = st.add2 >= 0 ? tptr(st.add2) : nullptr;
                 a.out = tptr(st.out);
                 a.pool = st.pool_out >= 0 ? tptr(st.pool_out) : nullptr;
                 a.w1 = wb + st.conv.w_off * eb;
@@ -706,19 +741,20 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 }
                 if (st.wstream >= 0) {
                     BtRingArgs r;
-                    r.in = a.in; r.in2 = a.in2; r.out = a.out; r.pool = a.pool;
+                    r.in = a.in; r.in2 = a.in2; r.add2 = a.add2; r.out = a.out; r.pool = a.pool;
                     r.pool_in = st.pool_in >= 0 ? tptr(st.pool_in) : nullptr;
                     r.wstream = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream;
                     r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd; r.s1 = a.s1; r.t1 = a.t1;
                     r.V = n; r.H = ti.h; r.W = ti.w;
                     if (ds) {   // 16-bit layer2
-                        ScopedTimer tm(h, s, std::string("bottleneck_ring_kernel<") + tname + ", false, 128>", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl), px * eb * (cin + 2.0 * pl), st.m1_elems * n * eb);
+                        ScopedTimer tm(h, s, std::string("bottleneck_ring_kernel<") + tname + ", false, 128, false>", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl), px * eb * (cin + 2.0 * pl), st.m1_elems * n * eb);
                         if constexpr (sizeof(T) == 2)
                             if (int rc = launch_ring_lp<T, false, 128>(r, n * (ti.h / BT_TH) * (ti.w / BT_TW), BR_LDS_BYTES, s)) return rc;
                         break;
                     }
-                    ScopedTimer tm(h, s, eb == 2 ? std::string("bottleneck_ring_kernel<") + tname + (a.in2 ? ", true, 256>" : ", false, 256>")
-                                                 : std::string("bottleneck_ring_f32_kernel<") + (a.in2 ? "true>" : "false>"),   // as rocprofv3 prints them
+                    const char* const flags2 = a.in2 ? "true, false>" : a.add2 ? "false, true>" : "false, false>";
+                    ScopedTimer tm(h, s, eb == 2 ? std::string("bottleneck_ring_kernel<") + tname + (a.in2 ? ", true, 256, false>" : a.add2 ? ", false, 256, true>" : ", false, 256, false>")
+                                                 : std::string("bottleneck_ring_f32_kernel<") + flags2,   // as rocprofv3 prints them
                                    2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl), st.m1_elems * n * eb);
                     const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
                     int lds_bytes = BR_LDS_BYTES;
@@ -727,13 +763,15 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
 #endif
                     int rc;
                     if constexpr (sizeof(T) == 2)
-                        rc = a.in2 ? launch_ring_lp<T, true, 256>(r, blocks, lds_bytes, s) : launch_ring_lp<T, false, 256>(r, blocks, lds_bytes, s);
+                        rc = a.in2 ? launch_ring_lp<T, true, 256>(r, blocks, lds_bytes, s) : a.add2 ? launch_ring_lp<T, false, 256, true>(r, blocks, lds_bytes, s)
+                                                                                           : launch_ring_lp<T, false, 256>(r, blocks, lds_bytes, s);
                     else
-                        rc = a.in2 ? launch_ring_f32<true>(r, blocks, lds_bytes, s) : launch_ring_f32<false>(r, blocks, lds_bytes, s);
+                        rc = a.in2 ? launch_ring_f32<true>(r, blocks, lds_bytes, s) : a.add2 ? launch_ring_f32<false, true>(r, blocks, lds_bytes, s)
+                                                                                      : launch_ring_f32<false>(r, blocks, lds_bytes, s);
                     if (rc) return rc;
                     break;
                 }
-                ScopedTimer tm(h, s, std::string("bottleneck_kernel<") + tname + ", " + std::to_string(cin) + ", " + std::to_string(pl) + ", " + (ds ? "true" : "false") + ", " + (a.in2 ? "true" : "false") + ">",
+                ScopedTimer tm(h, s, std::string("bottleneck_kernel<") + tname + ", " + std::to_string(cin) + ", " + std::to_string(pl) + ", " + (ds ? "true" : "false") + ", " + (a.in2 ? "true" : "false") + ", " + (a.add2 ? "true" : "false") + ">",
                                2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + (ds ? 2.0 * cin * pl : 0.0)), px * eb * (cin + 2.0 * pl), st.m1_elems * n * eb);
                 const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
                 if (int rc = launch_bottleneck<T>(a, cin, pl, blocks, s)) return rc;
@@ -881,7 +919,7 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
         return DF3D_OK;
     }
     if (!strcmp(key, "fuse_upadd")) {
-        DF3D_CHECK_ARG(value == 0 || value == 1, "fuse_upadd must be 0 or 1");
+        DF3D_CHECK_ARG(value >= 0 && value <= 2, "fuse_upadd must be 0, 1 or 2");
         DF3D_CHECK_ARG(h->blob == nullptr, "set 'fuse_upadd' before df3d_hg_set_weights (it changes the plan)");
         h->fuse_upadd = value;
         h->build();

@@ -109,7 +109,9 @@ class HourglassEngine:
         if not fuse:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"fuse", 0), "df3d_hg_set_option")
         if fuse_upadd is not None:  # default: the library's choice (on)
-            _native.check(self.lib.df3d_hg_set_option(self.h, b"fuse_upadd", 1 if fuse_upadd else 0), "df3d_hg_set_option")
+            # True / 1: added in the epilogue of the bottleneck that produces the up-path tensor (default); 2: folded into the input load of
+            # the consuming bottleneck (round 2's form); False / 0: a pass of its own
+            _native.check(self.lib.df3d_hg_set_option(self.h, b"fuse_upadd", int(fuse_upadd)), "df3d_hg_set_option")
         if ring is not None:  # default: the library's choice (LDS-DMA weight ring in the 256 -> 128 -> 128 -> 256 bottlenecks)
             _native.check(self.lib.df3d_hg_set_option(self.h, b"ring", 1 if ring else 0), "df3d_hg_set_option")
         if l1 is not None:  # default: on (bf16): layer1 with LDS-resident weights, writing only the pooled tensor its consumer reads

@@ -323,12 +323,26 @@ def test_cli_two_ranks_match_one_rank(native_lib, cuda, tmp_path, golden_dir):
         base = tmp_path / tag
         base.mkdir()
         folder = _sample_folder(base, golden_dir)
-        r = subprocess.run(launcher + [folder, "-n", "2"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(launcher + [folder, "-n", "2", "-vv"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         files = [f for f in os.listdir(folder + "_df3d") if f.startswith("df3d_result")]
         assert len(files) == 1
         with open(os.path.join(folder + "_df3d", files[0]), "rb") as f:
             results.append(pickle.load(f))
+        if tag == "two":
+            # the 3-D stage is sharded too: with the cameras fixed (after the bundle adjustment on rank 0) BOTH ranks triangulate
+            # their own frame on their device, one more gather carries points3d to rank 0
+            log = r.stdout + r.stderr
+            assert "rank 0 of 2: triangulated frames [0, 1)" in log and "rank 1 of 2: triangulated frames [1, 2)" in log, log[-3000:]
+            # resume on two ranks (--skip-pose-estimation): every rank re-opens the result, the DLT is sharded again, same file
+            r2 = subprocess.run(launcher + [folder, "-n", "2", "-vv", "--skip-pose-estimation", "--video-3d"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+            assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+            assert "rank 1 of 2: triangulated frames [1, 2)" in r2.stdout + r2.stderr
+            with open(os.path.join(folder + "_df3d", files[0]), "rb") as f:
+                again = pickle.load(f)
+            for k in ("points2d", "heatmap_confidence", "camera_ordering"):
+                assert np.array_equal(again[k], results[-1][k]), k
+            assert np.allclose(again["points3d_wo_procrustes"], results[-1]["points3d_wo_procrustes"], atol=1e-6)
     one, two = results
     assert list(one.keys()) == list(two.keys())
     for k in ("points2d", "heatmap_confidence", "camera_ordering"):

@@ -261,19 +261,28 @@ def test_bf16_argmax_agreement_with_fp32(native_lib, cuda, oracle_net, images):
     assert same >= 0.7 and near >= 0.8
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
-def test_fused_upsample_add_is_bit_identical(native_lib, cuda, oracle_net, images, dtype):
-    """The upsample + add folded into the consuming bottleneck (default for bf16) against the separate upadd kernel:
-    8 launches fewer, bit-identical heat-maps -- the sum is rounded to the engine dtype exactly as upadd_kernel would
-    have stored it."""
+def test_fused_upsample_add_is_bit_identical(native_lib, cuda, oracle_net, images, dtype, mode):
+    """The hourglass' up1 + upsample(low3) without a pass of its own, against the separate upadd kernel: 8 launches fewer,
+    bit-identical heat-maps and plan steps -- the sum is rounded to the engine dtype exactly as upadd_kernel would have stored it.
+    mode 1 (default): the low path runs first and the bottleneck that produces up1 adds the low-resolution tensor in its
+    epilogue (seven of the eight levels: wherever the level's input already has a pooled copy); mode 2: folded into the input
+    load of the consuming bottleneck (round 2's form, which mode 1 keeps for the second stack's outermost level)."""
     from deepfly3d_amd.hourglass import HourglassEngine
 
     sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
     x = images.to(cuda)
-    on = HourglassEngine(sd, dtype=dtype, device=cuda, fuse_upadd=True)
-    off = HourglassEngine(sd, dtype=dtype, device=cuda, fuse_upadd=False)
+    on = HourglassEngine(sd, dtype=dtype, device=cuda, fuse_upadd=mode)
+    off = HourglassEngine(sd, dtype=dtype, device=cuda, fuse_upadd=0)
     assert len(off.steps()) - len(on.steps()) == 8
     assert torch.equal(on.forward(x), off.forward(x))
+    sums = [name for name, _ in on.steps() if name.endswith(".upadd")]
+    assert len(sums) == (7 if mode == 1 else 0)
+    index_off = {name: k for k, (name, _) in enumerate(off.steps(), start=1)}
+    for k, (name, hwc) in enumerate(on.steps(), start=1):
+        if name.endswith(".upadd") or name.endswith(".2.0.conv3") or name.startswith("res."):   # the sums and their consumers
+            assert torch.equal(on.forward_upto(x, k), off.forward_upto(x, index_off[name])), name
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32", "f16"])
