@@ -108,6 +108,14 @@ __device__ __forceinline__ void br_glds_stage(const void* sbase, unsigned voff, 
                  : "v"(voff), "s"(sbase), "s"(dst)
                  : "memory");
 }
+// one 1 KB LDS-DMA piece: lane l's 16 bytes, read from sbase + voff (voff per lane, 32 bit), land at dst + 16 l (dst wave-uniform)
+__device__ __forceinline__ void br_glds_piece(const void* sbase, unsigned voff, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(dst)
+                 : "memory");
+}
 // s_waitcnt vmcnt(n) for a value that is a compile-time constant after unrolling (the switch folds away)
 __device__ __forceinline__ void br_wait_vm(int n) {
 #define BR_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;

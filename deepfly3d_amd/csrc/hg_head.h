@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void bt_fc2_pack_kernel(const unsigned short* 
     *reinterpret_cast<u32x4*>(stream + (size_t)st * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(src);
 }
 
-template <typename T>
+template <typename T, bool LAST>
 struct HeadCfg {
     static constexpr int EB = Elem<T>::BYTES;
     static constexpr int RBA = 64;                                   // phase A staged row bytes
@@ -70,9 +70,10 @@ struct HeadCfg {
     static constexpr int STAGE_C = 128 * (RBC + 16);
     static constexpr int S1 = 2 * STAGE_A > WSC_BYTES ? 2 * STAGE_A : WSC_BYTES;
     static constexpr int S2 = S1 > 2 * STAGE_C ? S1 : 2 * STAGE_C;
-    static constexpr int RING_SLOTS = 6;                             // bf16: LDS-DMA ring of 8 KB weight stages ...
-    static constexpr int SLICE_PITCH = 64 * 2 + 16;                  // ... and, behind it, one 32 px x 64 ch epilogue slice per wave
-    static constexpr int RING_BYTES = EB == 2 ? RING_SLOTS * 8192 + 4 * 32 * SLICE_PITCH : 0;
+    static constexpr int RING_SLOTS = 6;                             // 16-bit: LDS-DMA ring of 8 KB weight stages ...
+    static constexpr int R_SLOTS = 3;                                // ... behind it three 8 KB K slices of the r tile (phase A: LDS-DMA too) ...
+    static constexpr int SLICE_PITCH = 64 * 2 + 16;                  // ... whose space the epilogue re-uses: one 32 px x 64 ch slice per wave
+    static constexpr int RING_BYTES = EB == 2 ? RING_SLOTS * 8192 + (LAST ? R_SLOTS * 8192 : 4 * 32 * SLICE_PITCH) : 0;   // (LAST has no phase C)
     static constexpr int STAGE_BYTES = S2 > RING_BYTES ? S2 : RING_BYTES;
     static constexpr int MISC = (256 + 32 + 256) * 4;                // bfc | bsc | bfc_ + bsc_
     static constexpr int LDS_BYTES = STAGE_BYTES + MISC;
@@ -80,7 +81,7 @@ struct HeadCfg {
 
 template <typename T, bool LAST>
 __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
-    using C = HeadCfg<T>;
+    using C = HeadCfg<T, LAST>;
     constexpr int EB = C::EB;
     constexpr int PER16 = Elem<T>::PER16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -103,49 +104,104 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[m][r] = 0.0f;
     if (EB == 2 && p.fcstream != nullptr) {
-        // bf16: Wfc arrives as pre-swizzled 8 KB stage images (two per 32-channel K step: row halves) through a six-slot LDS-DMA
-        // ring, two K steps ahead, one barrier per step; the r operand never touches LDS: lane (l31, half) loads the 16-byte chunks
-        // the MFMAs want from its own pixel -- ALL of them up front, so that no activation load sits in the in-order vector-memory
-        // queue between two weight stages (hg_bt_ring.h: vmcnt discipline).  Same MFMA K order as the staged form below.
-        constexpr int NSLOT = 6;
-        static_assert(NSLOT * BR_STAGE_BYTES <= C::STAGE_BYTES, "the Wfc ring lives in the stage area");
+        // 16-bit: Wfc arrives as pre-swizzled 8 KB stage images (two per 32-channel K step: row halves) through a six-slot LDS-DMA
+        // ring, two K steps ahead, one barrier per step.  The r operand:
+        //   LAST (RDMA): the same road -- per K step every wave copies the 64-byte K slice of ITS OWN 32 pixels (two 1 KB pieces,
+        //     16 pixels each, four lanes per pixel) into a three-slot ring: no registers, 64-byte segments instead of the 32-byte
+        //     ones a lane-per-pixel load makes, and only the wave itself reads them back (own vmcnt, no barrier involved).  Which
+        //     16-byte chunk of its pixel a lane fetches is chosen so that the fragment reads are bank-conflict-free: slot c of
+        //     pixel p holds chunk c ^ ((p >> 2) & 3).  1 650 -> 1 490 us on 896 views.
+        //   not LAST: lane (l31, half) loads the 16-byte chunks the MFMAs want from its own pixel -- ALL of them up front, so that no
+        //     activation load sits in the in-order queue between two weight stages.  (Measured with the DMA form: 3 460 us against
+        //     3 290; with phase C's skip values requested at the top of the kernel as well 4 000 -- 256 registers do not hold them
+        //     beside y's 128 accumulators.)
+        // Same MFMA K order as the staged form below in every case.
+        constexpr bool RDMA = LAST;
+        constexpr int NSLOT = 6, RSLOT = C::R_SLOTS;
+        static_assert(EB != 2 || !LAST || (NSLOT + RSLOT) * BR_STAGE_BYTES <= C::STAGE_BYTES, "the rings live in the stage area");
         const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)stage;
-        const unsigned wvoff = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 2048u + (unsigned)lane * 16u;
-        auto issue_step = [&](int s) {   // both stages of K step s; this wave copies pieces 2 wave, 2 wave + 1 of each
+        const unsigned wuni = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+        const unsigned wvoff = wuni * 2048u + (unsigned)lane * 16u;
+        // r pieces: lane -> (pixel 16 q + (lane >> 2) of the wave, chunk (lane & 3) ^ ((pixel >> 2) & 3)); rows past the end read the last pixel
+        const long long mw = m0 + (long long)wuni * 32;
+        const long long mb = mw < p.M ? mw : p.M - 1;   // uniform base pixel (a wave wholly past the end reads the last pixel: nothing of it is stored)
+        unsigned rvoff[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pl = 16 * q + (lane >> 2);
+            long long m = mw + pl;
+            if (m >= p.M) m = p.M - 1;
+            rvoff[q] = (unsigned)((m - mb) * 512 + (((lane & 3) ^ ((pl >> 2) & 3)) << 4));
+        }
+        const unsigned char* const rbase = reinterpret_cast<const unsigned char*>(p.r) + (size_t)mb * 512;
+        auto issue_step = [&](int s) {   // both weight stages of K step s (this wave copies pieces 2 wave, 2 wave + 1 of each) and the r slice
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
                 const int st = 2 * s + rh;
                 br_glds_stage(reinterpret_cast<const unsigned char*>(p.fcstream) + (size_t)st * BR_STAGE_BYTES, wvoff,
-                              ring_addr + (unsigned)(st % NSLOT) * BR_STAGE_BYTES + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 2048u);
+                              ring_addr + (unsigned)(st % NSLOT) * BR_STAGE_BYTES + wuni * 2048u);
+            }
+            if constexpr (RDMA) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    br_glds_piece(rbase + s * 64, rvoff[q], ring_addr + (unsigned)(NSLOT + s % RSLOT) * BR_STAGE_BYTES + wuni * 2048u + q * 1024u);
             }
         };
-        u32x4 rf[8][2];
-        {
-            long long m = m0 + wave * 32 + l31;
-            if (m >= p.M) m = p.M - 1;   // rows past the end compute on a valid pixel; nothing of them is stored
-            const unsigned char* const src = reinterpret_cast<const unsigned char*>(p.r) + ((size_t)m * 256 + half * 8) * 2;
+        u32x4 rfg[RDMA ? 1 : 8][2];
+        if constexpr (!RDMA) {
+            const long long m = mw + l31 < p.M ? mw + l31 : p.M - 1;   // rows past the end compute on a valid pixel; nothing of them is stored
+            const unsigned char* const src = rbase + ((size_t)(m - mb) * 256 + half * 8) * 2;
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) rf[s][j] = *reinterpret_cast<const u32x4*>(src + s * 64 + j * 32);
+                for (int j = 0; j < 2; ++j) rfg[s][j] = *reinterpret_cast<const u32x4*>(src + s * 64 + j * 32);
         }
         issue_step(0);
         issue_step(1);
         const unsigned char* const wf0 = stage + br_swz(l31, half);
         const unsigned char* const wf1 = stage + br_swz(l31, 2 + half);
+        // this lane's B fragments: pixel l31 of the wave, chunk 2 j + half -> slot (2 j + half) ^ ((l31 >> 2) & 3)
+        const unsigned char* const rfrag = stage + NSLOT * BR_STAGE_BYTES + wave * 2048 + l31 * 64;
+        const unsigned rsw = (unsigned)((l31 >> 2) & 3);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            br_wait_vm(s < 7 ? 4 : 0);   // the pieces of step s + 1 (requested one step ago) may still be in flight
+            br_wait_vm(s < 7 ? (RDMA ? 6 : 4) : 0);   // the pieces of step s + 1 (requested one step ago) may still be in flight
             br_barrier();                // (first step: also publishes the bias vectors)
             if (s + 2 < 8) issue_step(s + 2);   // into the slots step s - 1 has released
+            if constexpr (RDMA) {
+                u32x4 rf[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                u32x4 wfr[8];
+                for (int j = 0; j < 2; ++j) rf[j] = *reinterpret_cast<const u32x4*>(rfrag + (s % RSLOT) * BR_STAGE_BYTES + ((((unsigned)(2 * j + half)) ^ rsw) << 4));
+                // four groups of four MFMAs (K half j, row half of the stage pair), the four weight fragments of group g + 1 requested
+                // BEFORE the MFMAs of group g (hipcc otherwise serialises ds_read -> wait -> MFMA on one register quad: hg_bt_ring.h)
+                u32x4 wfr[2][4];
+                auto load_group = [&](int g, int buf) {
+                    const int j = g >> 1, rh = g & 1;
 #pragma unroll
-                for (int m = 0; m < 8; ++m)
-                    wfr[m] = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + ((2 * s + (m >> 2)) % NSLOT) * BR_STAGE_BYTES + (m & 3) * 2048);
+                    for (int m = 0; m < 4; ++m)
+                        wfr[buf][m] = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + ((2 * s + rh) % NSLOT) * BR_STAGE_BYTES + m * 2048);
+                };
+                load_group(0, 0);
 #pragma unroll
-                for (int m = 0; m < 8; ++m) mfma_chunk<T>(wfr[m], rf[s][j], y[m]);
+                for (int g = 0; g < 4; ++g) {
+                    if (g < 3) load_group(g + 1, (g + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) mfma_chunk<T>(wfr[g & 1][m], rf[g >> 1], y[4 * (g & 1) + m]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // (the hand-pipelined form above measured 4-5 % SLOWER here, same box: with 64 registers of r fragments beside y's
+                // 128 accumulators hipcc's own schedule of the eight fragment reads is the better one)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    u32x4 wfr[8];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+                        wfr[m] = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + ((2 * s + (m >> 2)) % NSLOT) * BR_STAGE_BYTES + (m & 3) * 2048);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) mfma_chunk<T>(wfr[m], rfg[s][j], y[m]);
+                }
             }
         }
         __syncthreads();   // every wave is done with the ring before the stage area is reused

@@ -108,6 +108,8 @@ struct df3d_hg {
                           // copy, consumer side otherwise; 2 = always folded into the input load of the consuming bottleneck (round 2)
     int l1 = 1;           // 1 = bf16 layer1 (64 -> 64 -> 64 -> 128) runs as the LDS-resident-weights kernel of hg_bt_l1.h
     int ring = 1;         // 1 = the 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring*.h)
+    int chain_views = 0;  // > 0: chains of full-resolution steps run in chunks of this many views (Infinity Cache residency); 0 = off
+    std::vector<int> chain_end;   // step i starts a chain [i, chain_end[i]) (chain_end[i] = i + 1: no chain)
     size_t stream_bytes = 0;  // weight streams of all ring bottlenecks (behind the bf16 copy of the blob)
     hgk::StemU8 u8in{nullptr, nullptr, 0, 0, 0, {{0, 0, 0}, {1, 1, 1}, 0}};   // df3d_hg_forward_u8: the stem's input for the duration of that call
     std::vector<TensorDesc> tensors;
@@ -160,9 +162,23 @@ struct df3d_hg {
         pooled_of.push_back(-1);
         return (int)tensors.size() - 1;
     }
+    // While a chain of full-resolution steps is being planned (see chain_end) frees are postponed to its end: the chain runs
+    // chunk by chunk, so a tensor released inside it must not lend its memory to a later tensor of the same chain (whose slice
+    // for chunk c could overlap the released tensor's slice for chunk c + 1, which is still to be written and read).
+    bool defer_frees = false;
+    std::vector<int> deferred;
     void free_tensor(int id) {
+        if (defer_frees) {
+            deferred.push_back(id);
+            return;
+        }
         const TensorDesc& t = tensors[id];
         if (t.off != VIRTUAL_OFF) alloc.release(t.off, (size_t)t.h * t.w * t.pitch);
+    }
+    void end_chain() {
+        defer_frees = false;
+        for (int id : deferred) free_tensor(id);
+        deferred.clear();
     }
     size_t add_param(const std::string& name, int kind, int taps, int cin, int cout, int cin_pad, int cout_pad, size_t count,
                      int kperm = 0) {
@@ -362,6 +378,7 @@ struct df3d_hg {
             int low3 = bottleneck(lv + ".2.0", low2, planes, false, inner_lo);
             free_tensor(low2);
             if (inner_lo >= 0) free_tensor(inner_lo);
+            if (n == 4) defer_frees = true;   // outermost level: this step, the stack's residual block and its head form a chain
             int sum = bottleneck(lv + ".0.0", x, planes, false, -1, false, false, low3, lv + ".upadd");
             free_tensor(low3);
             *lazy_lo = -1;
@@ -399,6 +416,8 @@ struct df3d_hg {
         stream_bytes = 0;
         alloc = Allocator();
         flops_per_view = elems_per_view = 0;
+        deferred.clear();
+        defer_frees = true;   // stem .. layer3 form a chain
         // stem
         Step st;
         st.kind = ST_STEM;
@@ -423,6 +442,7 @@ struct df3d_hg {
         free_tensor(p1);
         x = bottleneck("layer3.0", l2, 128, true);
         free_tensor(l2);
+        end_chain();
         for (int s = 0; s < num_stacks; ++s) {
             const std::string S = std::to_string(s);
             int ylo = -1;
@@ -468,6 +488,7 @@ struct df3d_hg {
                 m1_close();
                 free_tensor(r);
                 free_tensor(x);
+                end_chain();
                 x = st.out;
                 continue;
             }
@@ -487,8 +508,27 @@ struct df3d_hg {
                 free_tensor(f);
                 free_tensor(x);
             }
+            end_chain();
         }
         act_elems_per_view = alloc.peak;
+        // chains: maximal runs of consecutive steps, each of which reads only the previous step's output (and tensors written
+        // before the chain began) at the network's top resolutions
+        chain_end.assign(steps.size(), 0);
+        for (size_t i = 0; i < steps.size(); ++i) chain_end[i] = (int)i + 1;
+        auto big = [&](const Step& st) {
+            if (st.kind != ST_STEM && st.kind != ST_BOTTLENECK && st.kind != ST_HEAD) return false;
+            const int ref = st.kind == ST_STEM ? st.out : st.in;
+            return tensors[ref].h * 4 >= H / 4 * 4 && tensors[ref].h >= H / 4;   // 64 x 128 and above for the 256 x 512 input
+        };
+        for (size_t i = 0; i < steps.size();) {
+            size_t j = i;
+            if (big(steps[i])) {
+                j = i + 1;
+                while (j < steps.size() && big(steps[j]) && steps[j].in == steps[j - 1].out && steps[j].kind != ST_STEM) ++j;
+                chain_end[i] = (int)j;
+            }
+            i = std::max(j, i + 1);
+        }
     }
 };
 
@@ -634,13 +674,20 @@ int launch_ring_f32(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t 
 }
 
 template <typename T>
-int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps, unsigned char* act, hipStream_t s) {
+int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* heatmaps_all, unsigned char* act, hipStream_t s) {
     const int eb = sizeof(T);
     const char* const tname = TypeName<T>::value;   // as rocprofv3 prints the template argument
-    auto tptr = [&](int id) -> unsigned char* { return act + h->tensors[id].off * (size_t)n * eb; };
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(eb == 4 ? (const void*)h->blob : h->lowp);
-    for (int i = 0; i < upto; ++i) {
+    // one plan step on the views [v0, v0 + n) of the batch: every tensor is [views][h][w][pitch], so a view range is a
+    // contiguous slice of each (the whole batch: v0 = 0, n = n_all)
+    auto launch = [&](int i, int v0, int n) -> int {
         const Step& st = h->steps[i];
+        auto tptr = [&](int id) -> unsigned char* {
+            const TensorDesc& t = h->tensors[id];
+            return act + (t.off * (size_t)n_all + (size_t)v0 * t.h * t.w * t.pitch) * eb;
+        };
+        const float* const images = images_all ? images_all + (size_t)v0 * h->H * h->W * 3 : nullptr;
+        float* const heatmaps = heatmaps_all ? heatmaps_all + (size_t)v0 * h->classes * (h->H / 4) * (h->W / 4) : nullptr;
         switch (st.kind) {
             case ST_STEM: {
                 StemArgs a;
@@ -653,6 +700,10 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.H = h->H;
                 a.W = h->W;
                 a.u8 = h->u8in;
+                if (a.u8.frames) {
+                    a.u8.frames += (size_t)v0 * a.u8.FH * a.u8.FW * a.u8.FC;
+                    if (a.u8.flip) a.u8.flip += v0;
+                }
                 const int blocks = n * (h->H / 2 / 8) * (h->W / 2 / 16);
                 const double opx = (double)n * (h->H / 2) * (h->W / 2);
                 ScopedTimer tm(h, s, std::string(eb == 2 ? "stem_lp_kernel<" : "stem_kernel<") + tname + ">", 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb), st.m1_elems * n * eb);
@@ -797,18 +848,21 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 a.M = (long long)n * ti.h * ti.w;
                 a.HW = ti.h * ti.w;
                 const void* fn = st.last ? reinterpret_cast<const void*>(head_kernel<T, true>) : reinterpret_cast<const void*>(head_kernel<T, false>);
+                using HeadLast = HeadCfg<T, true>;
+                using HeadMid = HeadCfg<T, false>;
+                const int head_lds = st.last ? HeadLast::LDS_BYTES : HeadMid::LDS_BYTES;
                 static unsigned attr_done[2] = {0, 0};
                 if (first_use_on_this_device(attr_done[st.last]))
-                    DF3D_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, HeadCfg<T>::LDS_BYTES));
+                    DF3D_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, head_lds));
                 const double mm = (double)a.M;
                 const double fl = 2.0 * mm * (256.0 * 256 + 256.0 * 19 + (st.last ? 0.0 : 256.0 * 256 + 19.0 * 256));
                 ScopedTimer tm(h, s, std::string("head_kernel<") + tname + ", " + (st.last ? "true" : "false") + ">", fl,
                                mm * eb * (st.last ? 256.0 : 768.0) + (st.last ? mm * 19 * 4 : 0.0), st.m1_elems * n * eb);
                 const unsigned blocks = (unsigned)((a.M + 127) / 128);
                 if (st.last)
-                    hipLaunchKernelGGL((head_kernel<T, true>), dim3(blocks), dim3(256), HeadCfg<T>::LDS_BYTES, s, a);
+                    hipLaunchKernelGGL((head_kernel<T, true>), dim3(blocks), dim3(256), head_lds, s, a);
                 else
-                    hipLaunchKernelGGL((head_kernel<T, false>), dim3(blocks), dim3(256), HeadCfg<T>::LDS_BYTES, s, a);
+                    hipLaunchKernelGGL((head_kernel<T, false>), dim3(blocks), dim3(256), head_lds, s, a);
                 DF3D_LAUNCH_CHECK();
                 break;
             }
@@ -835,6 +889,23 @@ int run_steps(df3d_hg* h, const float* images, int n, int upto, float* heatmaps,
                 break;
             }
         }
+        return DF3D_OK;
+    };
+    // Chains: runs of consecutive full-resolution steps are walked in chunks of `chain_views` views, so that what one step
+    // writes is still in the 256 MB Infinity Cache when the next one reads it (a whole 896-view batch moves 3.8 GB per
+    // tensor: nothing survives from one launch to the next).  The steps of a chain only read tensors of their own view range.
+    for (int i = 0; i < upto;) {
+        int j = i + 1;
+        const int cv = h->chain_views;
+        if (cv > 0 && cv < n_all && h->chain_end[i] > i + 1) {
+            j = std::min(h->chain_end[i], upto);
+            for (int v0 = 0; v0 < n_all; v0 += cv)
+                for (int k = i; k < j; ++k)
+                    if (int rc = launch(k, v0, std::min(cv, n_all - v0))) return rc;
+        } else if (int rc = launch(i, 0, n_all)) {
+            return rc;
+        }
+        i = j;
     }
     return DF3D_OK;
 }
@@ -937,6 +1008,11 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
         DF3D_CHECK_ARG(h->blob == nullptr, "set 'ring' before df3d_hg_set_weights (it changes the low-precision buffer)");
         h->ring = value;
         h->build();
+        return DF3D_OK;
+    }
+    if (!strcmp(key, "chain_views")) {
+        DF3D_CHECK_ARG(value >= 0, "chain_views must be >= 0");
+        h->chain_views = value;
         return DF3D_OK;
     }
     if (!strcmp(key, "row_bytes")) {

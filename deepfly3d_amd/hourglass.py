@@ -6,6 +6,7 @@ batches of views, hand back heat-maps.  All arithmetic happens in libdf3d_hip.so
 device memory and the stream.  BatchNorm folding (pure parameter preprocessing, float64 numpy) happens here.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -95,7 +96,8 @@ def pack_state_dict(engine_handle, state_dict):
 class HourglassEngine:
     """The device engine: `forward(images_nhwc) -> heat-maps (n, 19, H/4, W/4)` on the current torch stream."""
 
-    def __init__(self, state_dict, dtype="f32", num_stacks=2, device=None, height=256, width=512, row_bytes=0, fuse=True, fuse_upadd=None, ring=None, l1=None):
+    def __init__(self, state_dict, dtype="f32", num_stacks=2, device=None, height=256, width=512, row_bytes=0, fuse=True, fuse_upadd=None, ring=None, l1=None,
+                 chain_views=None):
         _native.require_gpu()
         self.lib = _native.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -118,6 +120,10 @@ class HourglassEngine:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"l1", 1 if l1 else 0), "df3d_hg_set_option")
         if row_bytes:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"row_bytes", row_bytes), "df3d_hg_set_option")
+        if chain_views is None and os.environ.get("DF3D_CHAIN_VIEWS"):
+            chain_views = int(os.environ["DF3D_CHAIN_VIEWS"])
+        if chain_views is not None:  # chains of full-resolution steps in chunks of this many views (0 = whole batch per launch)
+            _native.check(self.lib.df3d_hg_set_option(self.h, b"chain_views", int(chain_views)), "df3d_hg_set_option")
         blob = pack_state_dict(self.h, state_dict)
         self.blob = torch.from_numpy(blob).to(self.device)
         lowp_bytes = self.lib.df3d_hg_lowp_bytes(self.h)

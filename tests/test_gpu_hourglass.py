@@ -384,3 +384,28 @@ def test_default_kernels_match_the_register_staged_kernels_on_small_and_odd_shap
     new = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width)
     old = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, ring=False, l1=False)
     assert torch.equal(new.forward(img), old.forward(img))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_view_chunked_chains_are_bit_identical(native_lib, cuda, dtype):
+    """`chain_views`: the chains of full-resolution steps (stem .. layer3; per stack: the outermost up-path block, the residual
+    block and the head) walked in chunks of a few views, so that one step's output is still in the Infinity Cache when the next
+    step reads it.  Views are independent and a chain's tensors do not share memory, so every chunk size -- dividing the batch
+    or not, larger than the batch -- gives bit-identical heat-maps and plan steps."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    sd = synthetic_state_dict(0)
+    img = torch.rand((11, 256, 512, 3), generator=torch.Generator().manual_seed(21), dtype=torch.float32).to(cuda)
+    whole = HourglassEngine(sd, dtype=dtype, device=cuda, chain_views=0)
+    ref = whole.forward(img).clone()
+    for cv in (1, 4, 11, 64):
+        eng = HourglassEngine(sd, dtype=dtype, device=cuda, chain_views=cv)
+        assert torch.equal(eng.forward(img), ref), cv
+        for k in (4, len(eng.steps()) - 1):
+            assert torch.equal(eng.forward_upto(img, k), whole.forward_upto(img, k)), (cv, k)
+    u8 = torch.randint(0, 256, (5, 480, 960), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).to(cuda)
+    flip = torch.tensor([0, 1, 0, 1, 1], dtype=torch.uint8, device=cuda)
+    a = HourglassEngine(sd, dtype=dtype, device=cuda, chain_views=2).forward_u8(u8, flip, (0.2, 0.2, 0.2), (1.0, 1.0, 1.0))
+    assert torch.equal(a, whole.forward_u8(u8, flip, (0.2, 0.2, 0.2), (1.0, 1.0, 1.0)))
