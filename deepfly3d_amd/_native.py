@@ -9,7 +9,8 @@ from ctypes import POINTER, Structure, c_char, c_char_p, c_double, c_float, c_in
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DF3D_LIB") or os.path.join(_HERE, "libdf3d_hip.so")  # DF3D_LIB: developer override (kernel A/B builds)
 
-DF3D_ENOSPC = -5  # include/df3d_hip.h
+DF3D_EINVAL = -1  # include/df3d_hip.h
+DF3D_ENOSPC = -5
 DF3D_EIO = -6
 DF3D_DTYPE_F32 = 0
 DF3D_DTYPE_BF16 = 1

@@ -1088,8 +1088,13 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
         }
         DF3D_LAUNCH_CHECK();
         h->lowp = lowp_dev;
+    } else if (h->stream_bytes && lowp_dev == nullptr) {
+        // round 1's contract for f32 engines (no scratch buffer): honoured by falling back to the register-staged kernels, which
+        // need no weight streams and give bit-identical results.  The parameter manifest does not depend on the option, so the
+        // caller's blob stays valid.
+        h->ring = 0;
+        h->build();
     } else if (h->stream_bytes) {
-        DF3D_CHECK_ARG(lowp_dev != nullptr, "the engine needs a df3d_hg_lowp_bytes() device buffer for its weight streams");
         DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(lowp_dev) & 255) == 0, "lowp buffer must be 256-byte aligned");
         for (const Step& st : h->steps) {
             if (st.kind != ST_BOTTLENECK || st.wstream < 0) continue;

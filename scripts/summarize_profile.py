@@ -8,7 +8,27 @@
 import collections, csv, glob, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+def demangle(name):
+    """rocprofv3 leaves names with a _Float16 template argument mangled (its demangler does not know the DF16_ code, nor does
+    GNU c++filt): demangle with DF16_ spelled as the older half-precision code Dh, and name the type as the source does."""
+    if not name.startswith("_Z"):
+        return name
+    import shutil
+    import subprocess
+
+    tool = shutil.which("c++filt")
+    if not tool:
+        return name
+    out = subprocess.run([tool, name.replace("DF16_", "Dh")], capture_output=True, text=True).stdout.strip()
+    if not out or out.startswith("_Z"):
+        return name
+    out = re.sub(r"<half\b", "<_Float16", out)
+    return out if out.startswith("void ") else "void " + out
+
+
 def short(name):
+    name = demangle(name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     return name[:110]

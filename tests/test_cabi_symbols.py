@@ -55,7 +55,7 @@ def test_argument_validation_without_gpu(native_lib):
     # forward before weights are set is a state error, never a silent success
     rc = native_lib.df3d_hg_forward(h, ctypes.c_void_p(256), 1, ctypes.c_void_p(256), ctypes.c_void_p(256), 1 << 40, None)
     assert rc == -3 and b"weights" in native_lib.df3d_last_error()
-    assert native_lib.df3d_hg_set_option(h, b"fuse_upadd", 2) == -1 and native_lib.df3d_hg_set_option(h, b"no_such_knob", 1) == -1
+    assert native_lib.df3d_hg_set_option(h, b"fuse_upadd", 3) == -1 and native_lib.df3d_hg_set_option(h, b"no_such_knob", 1) == -1
     native_lib.df3d_hg_destroy(h)
     # front-end and sequence tail
     p16 = ctypes.c_void_p(4096)

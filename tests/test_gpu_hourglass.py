@@ -409,3 +409,24 @@ def test_view_chunked_chains_are_bit_identical(native_lib, cuda, dtype):
     flip = torch.tensor([0, 1, 0, 1, 1], dtype=torch.uint8, device=cuda)
     a = HourglassEngine(sd, dtype=dtype, device=cuda, chain_views=2).forward_u8(u8, flip, (0.2, 0.2, 0.2), (1.0, 1.0, 1.0))
     assert torch.equal(a, whole.forward_u8(u8, flip, (0.2, 0.2, 0.2), (1.0, 1.0, 1.0)))
+
+
+@pytest.mark.gpu
+def test_f32_set_weights_without_a_scratch_buffer_falls_back_to_the_register_staged_kernels(native_lib, cuda):
+    """Round 1's C-ABI contract for f32 engines -- df3d_hg_set_weights(h, blob, NULL, stream) -- still works: the engine
+    switches to the kernels that need no weight streams (bit-identical results) instead of failing with EINVAL."""
+    from deepfly3d_amd import _native
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    img = torch.rand((2, 256, 512, 3), generator=torch.Generator().manual_seed(5), dtype=torch.float32).to(cuda)
+    eng = HourglassEngine(synthetic_state_dict(0), dtype="f32", device=cuda)
+    ref = eng.forward(img).clone()
+    assert eng.lib.df3d_hg_lowp_bytes(eng.h) > 0
+    _native.check(eng.lib.df3d_hg_set_weights(eng.h, eng.blob.data_ptr(), None, torch.cuda.current_stream().cuda_stream), "df3d_hg_set_weights")
+    assert eng.lib.df3d_hg_lowp_bytes(eng.h) == 0
+    eng._ws = None
+    assert torch.equal(eng.forward(img), ref)
+    # a 16-bit engine cannot do without its 16-bit copy of the blob: still an error, with a message
+    e16 = HourglassEngine(synthetic_state_dict(0), dtype="f16", device=cuda)
+    assert e16.lib.df3d_hg_set_weights(e16.h, e16.blob.data_ptr(), None, None) == _native.DF3D_EINVAL
