@@ -41,6 +41,8 @@ struct BtRingArgs {
     void* pool_in;        // optional NHWC [V, H/2, W/2, 256]: 2x2 max-pool of the block's INPUT (for the hourglass level whose
                           // input no fused producer has pooled: its skip values pass through the epilogue anyway)
     const void* wstream;  // br_nstage(CIN, DS) x BR_STAGE_BYTES: pre-swizzled stage images (bt_ring_pack_kernel)
+    const void* t1in;     // fp32 split form (hg_c1_f32.h): [V, H, W, 128] f32 = relu(W1' relu(bn1 x) + b1'), from conv1_ring_f32_kernel
+    const void* zeros;    // ... and >= 256 bytes of zeros (the padding of the 3x3 convolution for halo pixels outside the image)
     const float* b1;      // [128] (bn2 folded)
     const float* b2;      // [128] (bn3 folded)
     const float* b3;      // [256]
@@ -114,6 +116,14 @@ __device__ __forceinline__ void br_glds_piece(const void* sbase, unsigned voff, 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(dst)
+                 : "memory");
+}
+// the same with a full 64-bit address per lane (lanes of one piece may read from unrelated places)
+__device__ __forceinline__ void br_glds_piece64(const void* vaddr, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(vaddr), "s"(dst)
                  : "memory");
 }
 // s_waitcnt vmcnt(n) for a value that is a compile-time constant after unrolling (the switch folds away)

@@ -56,9 +56,14 @@ __device__ __forceinline__ float br_relu(float x) {
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
-template <bool UP, bool ADD2 = false>
+// TAIL (hg_c1_f32.h): phase 1 is not computed here -- t1 = relu(W1' relu(bn1 x) + b1') was written to HBM for every pixel by
+// conv1_ring_f32_kernel and its 10 x 18 halo tile arrives by LDS-DMA, one 64-channel half at a time (lane -> (halo pixel,
+// 16-byte slot), fetching the chunk that belongs in that slot of the swizzled tile; halo pixels outside the image fetch from a
+// page of zeros = the 3x3 convolution's padding).  The W1 stages of the stream are skipped: the tail walks 88 of the 104.
+template <bool UP, bool ADD2 = false, bool TAIL = false>
 __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs p) {
     static_assert(!(UP && ADD2), "the fused up-path sum is written by plain blocks");
+    static_assert(!(UP && TAIL), "the split form exists for blocks whose input is a stored tensor");
     using T = float;
     constexpr int CIN = 256, CO = 256, NT = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -91,20 +96,28 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
 
     // ---- the weight ring (every stage index below is a compile-time constant: all loops are unrolled) ----------------------
     const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
-    auto ring_issue = [&](int s) {   // stage s -> ring slot s % 4; this wave copies pieces 2 wave, 2 wave + 1
-        if (s < BRF_NSTAGE) {
-            const unsigned dst = ring_addr + (unsigned)(s % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048;
-            br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)s * BR_STAGE_BYTES, wvoff, dst);
+    // stage counter q -> ring slot q % 4; TAIL skips the W1 stages of the stream (q counts W2 kh 0 | W2 kh 1 | W3)
+    constexpr int NQ = TAIL ? BRF_NSTAGE - 2 * BRF_W1_STAGES : BRF_NSTAGE;
+    auto stream_index = [](int q) { return !TAIL ? q : q < BRF_W2_STAGES ? BRF_W1_STAGES + q : q < 2 * BRF_W2_STAGES ? 2 * BRF_W1_STAGES + q : 2 * BRF_W1_STAGES + q; };
+    auto ring_issue = [&](int q) {   // this wave copies pieces 2 wave, 2 wave + 1
+        if (q < NQ) {
+            const unsigned dst = ring_addr + (unsigned)(q % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048;
+            br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)stream_index(q) * BR_STAGE_BYTES, wvoff, dst);
         }
     };
     const unsigned char* const wf0 = ring + br_swz(l31, half);
     const unsigned char* const wf1 = ring + br_swz(l31, 2 + half);
 
     // coefficients -> LDS, t2 start values (b2) straight into the accumulators, b3 waits in a register until bn1 is dead
-    coef_lds[tid] = p.s1[tid];
-    coef_lds[256 + tid] = p.t1[tid];
-    if (tid < 128) coef_lds[512 + tid] = p.b1[tid];
-    const float late_b3 = p.b3[tid];
+    float late_b3 = 0.0f;
+    if constexpr (TAIL) {
+        coef_lds[256 + tid] = p.b3[tid];   // no bn1, no b1 here: b3 sits in its place from the start
+    } else {
+        coef_lds[tid] = p.s1[tid];
+        coef_lds[256 + tid] = p.t1[tid];
+        if (tid < 128) coef_lds[512 + tid] = p.b1[tid];
+        late_b3 = p.b3[tid];
+    }
     const float* const b1_lds = coef_lds + 512;
     const float* const b3_lds = coef_lds + 256;
     f32x16 t2[NT];
@@ -169,6 +182,25 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
         }
     };
 
+    // TAIL: the t1 halo tile of half kh by LDS-DMA.  Piece pc (1 KB) = halo pixels 4 pc .. 4 pc + 3, lane -> (pixel 4 pc + (lane >> 4),
+    // slot lane & 15), fetching chunk slot ^ swizzle(pixel) of that pixel's 256-byte half row; this wave copies pieces wave, wave + 4, ...
+    const unsigned t1_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)t1_lds;
+    auto t1_issue = [&](int kh) {
+        const unsigned char* const tin = reinterpret_cast<const unsigned char*>(p.t1in) + (size_t)view * p.H * p.W * 512;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int pc = wave + 4 * k;
+            if (pc < BT_HALO / 4) {
+                const int hp = 4 * pc + (lane >> 4);
+                const int hy = hp / BT_HW, hx = hp % BT_HW;
+                const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+                const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                const unsigned chunk = (unsigned)((lane & 15) ^ br_t1_swz(hp));
+                const unsigned char* const src = ok ? tin + ((size_t)y * p.W + x) * 512 + kh * 256 + chunk * 16 : reinterpret_cast<const unsigned char*>(p.zeros) + chunk * 16;
+                br_glds_piece64(src, t1_addr + (unsigned)pc * 1024u);
+            }
+        }
+    };
     const int py = 2 * wave + (l31 >> 4), px = l31 & 15;   // this wave's 32 pixels (phases 2, 3)
     const unsigned char* const t1_lane = t1_lds + (py * BT_HW + px) * BR_T1_PITCH;
     unsigned tsw[3];
@@ -180,75 +212,84 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
         const int base = kh * BRF_KH_STAGES;
-        // ---- phase 1 (half kh): t1^T = relu(W1' relu(bn1 x)^T + b1') on the halo, 16 K steps of 16 floats ---------------
-#pragma unroll
-        for (int k = 0; k < DX; ++k) loadx(k, k);
-        br_barrier();   // kh = 0: coefficients / masks visible; kh = 1: every wave has finished reading the first t1 half
-        BR_STAMP(kh == 0 ? 0 : 3);
-        f32x16 acc[3];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {   // register 4 t + e <-> channel 64 kh + 32 ct + 8 t + 4 half + e
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(b1_lds + kh * 64 + ct * 32 + 8 * t + 4 * half);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][4 * t + e] = bb[e];
-        }
-#pragma unroll
-        for (int xs = 0; xs < 16; ++xs) {
-            storex(xs, xs % DX);
-            const int st = base + (xs >> 1);     // W1 stage of this step: two K steps per stage
-            // stages requested after `st` so far: st + 1, st + 2 (only st + 1 at the start of the second half, whose first
-            // two stages were requested by the last double-step of the first half's phase 2)
-            if ((xs & 1) == 0) br_wait_vm(kh == 1 && xs == 0 ? 2 : 4);
-            br_barrier();
-            if ((xs & 1) == 0) {
-                if (kh == 1 && xs == 0) ring_issue(st + 2);
-                ring_issue(st + 3);
+        if constexpr (TAIL) {
+            br_barrier();   // kh = 0: masks and b3 visible; kh = 1: every wave has finished reading the first t1 half
+            BR_STAMP(kh == 0 ? 0 : 3);
+            t1_issue(kh);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces (and the weight stages requested before them) have landed;
+                                                                // the barrier of the first double-step below publishes the tile
+            BR_STAMP(2);
+        } else {
+            // ---- phase 1 (half kh): t1^T = relu(W1' relu(bn1 x)^T + b1') on the halo, 16 K steps of 16 floats ---------------
+    #pragma unroll
+            for (int k = 0; k < DX; ++k) loadx(k, k);
+            br_barrier();   // kh = 0: coefficients / masks visible; kh = 1: every wave has finished reading the first t1 half
+            BR_STAMP(kh == 0 ? 0 : 3);
+            f32x16 acc[3];
+    #pragma unroll
+            for (int t = 0; t < 4; ++t) {   // register 4 t + e <-> channel 64 kh + 32 ct + 8 t + 4 half + e
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b1_lds + kh * 64 + ct * 32 + 8 * t + 4 * half);
+    #pragma unroll
+                for (int i = 0; i < 3; ++i)
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][4 * t + e] = bb[e];
             }
-            if (xs + DX < 16) loadx(xs + DX, xs % DX);
-            const unsigned char* const sx = t1_lds + (xs % 3) * BR_XSTAGE;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (st % BR_RING) * BR_STAGE_BYTES + (xs & 1) * 4096 + ct * 2048);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * BR_XPITCH + j * 32 + half * 16);
-                    mfma_chunk<T>(wf, xf, acc[i]);
+    #pragma unroll
+            for (int xs = 0; xs < 16; ++xs) {
+                storex(xs, xs % DX);
+                const int st = base + (xs >> 1);     // W1 stage of this step: two K steps per stage
+                // stages requested after `st` so far: st + 1, st + 2 (only st + 1 at the start of the second half, whose first
+                // two stages were requested by the last double-step of the first half's phase 2)
+                if ((xs & 1) == 0) br_wait_vm(kh == 1 && xs == 0 ? 2 : 4);
+                br_barrier();
+                if ((xs & 1) == 0) {
+                    if (kh == 1 && xs == 0) ring_issue(st + 2);
+                    ring_issue(st + 3);
+                }
+                if (xs + DX < 16) loadx(xs + DX, xs % DX);
+                const unsigned char* const sx = t1_lds + (xs % 3) * BR_XSTAGE;
+    #pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (st % BR_RING) * BR_STAGE_BYTES + (xs & 1) * 4096 + ct * 2048);
+    #pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * BR_XPITCH + j * 32 + half * 16);
+                        mfma_chunk<T>(wf, xf, acc[i]);
+                    }
                 }
             }
-        }
-        br_barrier();   // every wave is done with the x ring: the t1 half may overwrite it
-        BR_STAMP(1);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int hp = (rt0 + i) * 32 + l31;
-            const unsigned keep = 0u - (unsigned)((valid_lds[(rt0 + i) >> 1] >> (((rt0 + i) & 1) * 32 + l31)) & 1ull);
-            unsigned char* const trow = t1_lds + hp * BR_T1_PITCH;
-            const int sw = br_t1_swz(hp);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                u32x4 w;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(br_relu(acc[i][4 * t + e])) & keep;
-                if (hp < BT_HALO) *reinterpret_cast<u32x4*>(trow + (((ct * 8 + 2 * t + half) ^ sw) << 4)) = w;
+            br_barrier();   // every wave is done with the x ring: the t1 half may overwrite it
+            BR_STAMP(1);
+    #pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int hp = (rt0 + i) * 32 + l31;
+                const unsigned keep = 0u - (unsigned)((valid_lds[(rt0 + i) >> 1] >> (((rt0 + i) & 1) * 32 + l31)) & 1ull);
+                unsigned char* const trow = t1_lds + hp * BR_T1_PITCH;
+                const int sw = br_t1_swz(hp);
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    u32x4 w;
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(br_relu(acc[i][4 * t + e])) & keep;
+                    if (hp < BT_HALO) *reinterpret_cast<u32x4*>(trow + (((ct * 8 + 2 * t + half) ^ sw) << 4)) = w;
+                }
             }
+            if (kh == 1) coef_lds[256 + tid] = late_b3;   // bn1 is dead: b3 takes the shift vector's place (read in phase 3)
+            BR_STAMP(2);
         }
-        if (kh == 1) coef_lds[256 + tid] = late_b3;   // bn1 is dead: b3 takes the shift vector's place (read in phase 3)
-        BR_STAMP(2);
 
         // ---- phase 2 (half kh): t2^T += W2'[:, half] (*) t1 half, two stages per barrier --------------------------------
 #pragma unroll
         for (int d = 0; d < BRF_W2_STAGES / 2; ++d) {
-            const int s0 = base + BRF_W1_STAGES + 2 * d;
-            br_wait_vm(d == 0 ? 2 : 0);   // d = 0: phase 1 has already requested stage s0 + 2
+            const int s0 = TAIL ? BRF_W2_STAGES * kh + 2 * d : base + BRF_W1_STAGES + 2 * d;   // stage counter (see ring_issue)
+            br_wait_vm(TAIL ? 0 : d == 0 ? 2 : 0);   // d = 0: phase 1 has already requested stage s0 + 2
             br_barrier();                 // (first iteration: also publishes the t1 half)
-            if (d > 0) ring_issue(s0 + 2);
+            if (d > 0 || (TAIL && kh == 1)) ring_issue(s0 + 2);   // (fused: phase 1 requested it; TAIL, kh = 0: the prologue did)
             ring_issue(s0 + 3);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int s = s0 + u;
-                const int q = s - base - BRF_W1_STAGES, tap = q >> 2, kc = q & 3;
+                const int q = TAIL ? s - BRF_W2_STAGES * kh : s - base - BRF_W1_STAGES, tap = q >> 2, kc = q & 3;
                 const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -285,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
         };
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) {
-            const int s0 = 2 * BRF_KH_STAGES + 8 * nh + 2 * dd;
+            const int s0 = (TAIL ? 2 * BRF_W2_STAGES : 2 * BRF_KH_STAGES) + 8 * nh + 2 * dd;
             br_wait_vm(0);   // the pair was requested a whole double-step ago
             br_barrier();
             ring_issue(s0 + 2);

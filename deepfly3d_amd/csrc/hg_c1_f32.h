@@ -1,0 +1,154 @@
+// fp32: the pre-activation bottleneck 256 -> 128 -> 128 -> 256 as TWO launches ("split" form of hg_bt_ring_f32.h):
+//
+//   conv1_ring_f32_kernel      t1 = relu(W1' relu(bn1 x) + b1')  for EVERY pixel of the level, once      -> HBM [px][128] f32
+//   bottleneck_tail_f32_kernel the 3x3, the last 1x1 and the skip on 8 x 16 tiles; the t1 halo tile arrives by LDS-DMA
+//
+// Why: the fused kernel is matrix-pipe bound (0.89 busy) and computes conv1 on the 10 x 18 halo of every 8 x 16 tile:
+// 192 MFMA rows for 128 pixels, 7.7 % of all its MFMAs are recomputation.  conv1 is pixel-wise, so computing it once per
+// pixel and reading it back with the halo trades those MFMAs for HBM bytes the fp32 path has to spare (it runs at 1.4 of
+// 8 TB/s): +0.5 KB/px written, the tail reads 0.72 KB/px of t1 instead of 1.4 KB/px of x.  MFMA work 27.3 instead of
+// 29.4 MMAC per tile.  Same MFMA K order in every accumulator as the fused kernel (the bias is the start value, K
+// ascending), so t1 -- and with it the block's output -- is BIT-IDENTICAL to the fused form.
+//
+// conv1: a workgroup owns 128 consecutive pixels (the op is pixel-wise: no tiles, no halo), wave w the pixel row tiles
+// 2 (w >> 1), +1 and the channel tiles 2 (w & 1), +1: 64 accumulators, four LDS fragment reads per four MFMA chunks.
+// W1' streams through the 4-slot LDS-DMA ring as 16 stages (K slice of 16 floats x 128 rows); x is staged global -> registers ->
+// bn1 + ReLU -> LDS three K steps ahead, exactly like phase 1 of the fused kernel.
+#pragma once
+#include "hg_bt_ring_f32.h"
+
+namespace hgk {
+
+struct Conv1Args {
+    const void* in;       // NHWC f32 [M, 256]
+    void* t1;             // [M, 128] f32: relu(W1' relu(bn1 x) + b1')
+    const void* wstream;  // C1_NSTAGE x BR_STAGE_BYTES (bt_c1_pack_f32_kernel)
+    const float* b1;      // [128] (bn2 folded)
+    const float* s1;      // [256] bn1 scale
+    const float* t1c;     // [256] bn1 shift
+    long long M;          // pixels
+};
+
+constexpr int C1_NSTAGE = 16;
+constexpr int C1_XPITCH = 64 + 16;
+constexpr int C1_XSTAGE = 128 * C1_XPITCH;                                   // 10 240
+constexpr int C1_LDS_BYTES = BR_RING_BYTES + 3 * C1_XSTAGE + 512 * 4 + 128 * 4;   // ring | x ring | bn1 scale, shift | b1
+
+// fp32 blob -> conv1 weight stream: stage s = K slice [16 s, 16 s + 16) of the 128 rows of W1' [128][256]
+__global__ __launch_bounds__(256) void bt_c1_pack_f32_kernel(const float* __restrict__ w1, unsigned char* __restrict__ stream) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= C1_NSTAGE * 512) return;
+    const int s = idx >> 9, r = (idx >> 2) & 127, c = idx & 3;
+    *reinterpret_cast<u32x4*>(stream + (size_t)s * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(w1 + (size_t)r * 256 + 16 * s + 4 * c);
+}
+
+__global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
+    using T = float;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const ring = smem;
+    unsigned char* const xr = smem + BR_RING_BYTES;
+    float* const coef_lds = reinterpret_cast<float*>(smem + BR_RING_BYTES + 3 * C1_XSTAGE);   // [0..255] scale, [256..511] shift, [512..639] b1
+    const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const long long m0 = (long long)blockIdx.x * 128;
+
+    const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
+    auto ring_issue = [&](int s) {
+        if (s < C1_NSTAGE) br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)s * BR_STAGE_BYTES, wvoff,
+                                         ring_addr + (unsigned)(s % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048);
+    };
+    const unsigned char* const wf0 = ring + br_swz(l31, half);
+    const unsigned char* const wf1 = ring + br_swz(l31, 2 + half);
+
+    coef_lds[tid] = p.s1[tid];
+    coef_lds[256 + tid] = p.t1c[tid];
+    if (tid < 128) coef_lds[512 + tid] = p.b1[tid];
+    ring_issue(0);
+    ring_issue(1);
+    ring_issue(2);
+
+    // x staging: thread -> (row = (tid >> 2) + 64 i, 16-byte chunk = tid & 3) of a 16-float K step; rows past the end read the last pixel
+    constexpr int XP = 2, DX = 3;
+    const int xchunk = tid & 3;
+    const unsigned char* xp[XP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        long long m = m0 + (tid >> 2) + 64 * i;
+        if (m >= p.M) m = p.M - 1;
+        xp[i] = reinterpret_cast<const unsigned char*>(p.in) + ((size_t)m * 256 + xchunk * 4) * 4;
+    }
+    u32x4 rx[DX][XP];
+    auto loadx = [&](int s, int slot) {
+#pragma unroll
+        for (int i = 0; i < XP; ++i) rx[slot][i] = *reinterpret_cast<const u32x4*>(xp[i] + s * 64);
+    };
+    auto storex = [&](int s, int slot) {
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(coef_lds + s * 16 + xchunk * 4);
+        const f32x4 ct_ = *reinterpret_cast<const f32x4*>(coef_lds + 256 + s * 16 + xchunk * 4);
+        unsigned char* const sx = xr + (s % 3) * C1_XSTAGE;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const f32x4 v = __builtin_bit_cast(f32x4, rx[slot][i]);
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(br_relu(fmaf(v[e], cs[e], ct_[e])));
+            *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * C1_XPITCH + xchunk * 16) = o;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < DX; ++k) loadx(k, k);
+
+    const int rt0 = 2 * (wave >> 1), ct0 = 2 * (wave & 1);
+    br_barrier();   // coefficients visible
+    f32x16 acc[2][2];   // [pixel row tile][channel tile]; register r <-> pixel (r & 3) + 8 (r >> 2) + 4 half, lane l31 <-> channel
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float bias = coef_lds[512 + (ct0 + j) * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bias;
+    }
+#pragma unroll
+    for (int s = 0; s < C1_NSTAGE; ++s) {
+        storex(s, s % DX);
+        // operations issued after stage s's two DMA pieces: the next two stages' pieces (4) and the x loads requested since
+        // (XP per K step while any remain; the prologue's DX steps sit in front of stages 1 and 2 for s = 0)
+        auto cx = [](int k) { return k < C1_NSTAGE ? XP : 0; };
+        br_wait_vm(s == 0 ? 4 + DX * XP : s == 1 ? 4 + DX * XP + cx(DX) : s == 2 ? 4 + DX * XP + cx(DX) + cx(DX + 1)
+                                                                            : 4 + cx(s - 3 + DX) + cx(s - 2 + DX) + cx(s - 1 + DX));
+        br_barrier();
+        ring_issue(s + 3);
+        if (s + DX < C1_NSTAGE) loadx(s + DX, s % DX);
+        const unsigned char* const sx = xr + (s % 3) * C1_XSTAGE;
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2) {   // the K step's two 8-float halves
+            u32x4 wf[2], xf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const u32x4*>((j2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + (ct0 + j) * 2048);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * C1_XPITCH + j2 * 32 + half * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mfma_chunk<T>(xf[i], wf[j], acc[i][j]);
+        }
+    }
+    // epilogue: ReLU, 4-byte stores of 128 contiguous bytes per (pixel, channel tile)
+    float* const out = reinterpret_cast<float*>(p.t1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long m = m0 + (rt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < p.M) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) out[(size_t)m * 128 + (ct0 + j) * 32 + l31] = br_relu(acc[i][j][r]);
+            }
+        }
+}
+
+}  // namespace hgk

@@ -18,6 +18,7 @@
 #include "hg_bt_l1.h"
 #include "hg_head.h"
 #include "hg_bt_ring_f32.h"
+#include "hg_c1_f32.h"
 
 using namespace hgk;
 
@@ -54,6 +55,8 @@ struct Step {
     bool l1 = false;                  // ST_BOTTLENECK, bf16 64 -> 64 -> 64 -> 128: hg_bt_l1.h (wstream = its LDS weight image)
     bool pool_only = false;           // ... whose full-resolution output nobody reads: `out` IS the pooled tensor
     double m1_elems = 0;              // activation elements per view this step moves in the fusion model M1
+    int t1 = -1;                      // ST_BOTTLENECK, fp32 split form (hg_c1_f32.h): the tensor conv1's kernel writes and the tail kernel reads
+    long long wstream_c1 = -1;        // ... and the byte offset of conv1's weight stream
 };
 
 struct Allocator {
@@ -108,6 +111,8 @@ struct df3d_hg {
                           // copy, consumer side otherwise; 2 = always folded into the input load of the consuming bottleneck (round 2)
     int l1 = 1;           // 1 = bf16 layer1 (64 -> 64 -> 64 -> 128) runs as the LDS-resident-weights kernel of hg_bt_l1.h
     int ring = 1;         // 1 = the 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring*.h)
+    int split1 = 1;       // fp32: 1 (default) = plain 256 -> 128 -> 128 -> 256 blocks run as conv1 (every pixel once) + tail (hg_c1_f32.h), bit-identical
+    size_t zero_off = 0;  // byte offset of 256 zero bytes behind the weight streams (split form: the 3x3 padding of the tail's LDS-DMA)
     int chain_views = 0;  // > 0: chains of full-resolution steps run in chunks of this many views (Infinity Cache residency); 0 = off
     std::vector<int> chain_end;   // step i starts a chain [i, chain_end[i]) (chain_end[i] = i + 1: no chain)
     size_t stream_bytes = 0;  // weight streams of all ring bottlenecks (behind the bf16 copy of the blob)
@@ -282,6 +287,11 @@ struct df3d_hg {
                     pooled_of[x] = st.pool_in;
                     elems_per_view += (double)tx.h * tx.w * cin * 1.25;  // model M1 still counts the pooling pass
                 }
+                if (split1 && !lp() && x2 < 0) {   // fp32 split form: conv1 on every pixel once, the rest on tiles
+                    st.wstream_c1 = (long long)stream_bytes;
+                    stream_bytes += (size_t)C1_NSTAGE * BR_STAGE_BYTES;
+                    st.t1 = new_tensor(tx.h, tx.w, planes);
+                }
             }
             if (l1 && lp() && cin == 64 && planes == 64 && tx.h % 16 == 0 && tx.w % 16 == 0) {
                 st.l1 = true;   // all weights resident in LDS (hg_bt_l1.h)
@@ -316,6 +326,7 @@ struct df3d_hg {
             if (ds) account_conv(px, 1, cin, cout, false);
             account_conv(px, 1, planes, cout, true);
             m1_close();
+            if (st.t1 >= 0) free_tensor(st.t1);
             return st.out;
         }
         int a = conv(name + ".conv1", x, 1, planes, true, true, -1);
@@ -511,6 +522,8 @@ struct df3d_hg {
             end_chain();
         }
         act_elems_per_view = alloc.peak;
+        zero_off = stream_bytes;
+        if (split1 && !lp()) stream_bytes += 256;
         // chains: maximal runs of consecutive steps, each of which reads only the previous step's output (and tensors written
         // before the chain began) at the network's top resolutions
         chain_end.assign(steps.size(), 0);
@@ -663,12 +676,12 @@ int launch_ring_lp(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }
-template <bool UP, bool ADD2 = false>
+template <bool UP, bool ADD2 = false, bool TAIL = false>
 int launch_ring_f32(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
     static unsigned attr_done = 0;
     if (first_use_on_this_device(attr_done))
-        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<UP, ADD2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL((bottleneck_ring_f32_kernel<UP, ADD2>), dim3(blocks), dim3(256), lds_bytes, s, r);
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<UP, ADD2, TAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL((bottleneck_ring_f32_kernel<UP, ADD2, TAIL>), dim3(blocks), dim3(256), lds_bytes, s, r);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }
@@ -793,6 +806,7 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                 if (st.wstream >= 0) {
                     BtRingArgs r;
                     r.in = a.in; r.in2 = a.in2; r.add2 = a.add2; r.out = a.out; r.pool = a.pool;
+                    r.t1in = nullptr; r.zeros = nullptr;
                     r.pool_in = st.pool_in >= 0 ? tptr(st.pool_in) : nullptr;
                     r.wstream = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream;
                     r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd; r.s1 = a.s1; r.t1 = a.t1;
@@ -803,10 +817,29 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                             if (int rc = launch_ring_lp<T, false, 128>(r, n * (ti.h / BT_TH) * (ti.w / BT_TW), BR_LDS_BYTES, s)) return rc;
                         break;
                     }
-                    const char* const flags2 = a.in2 ? "true, false>" : a.add2 ? "false, true>" : "false, false>";
+                    const bool split = eb == 4 && st.t1 >= 0;
+                    if (split) {   // fp32 split form: conv1 for every pixel of the level, then the tail on tiles
+                        if constexpr (sizeof(T) == 4) {
+                            Conv1Args c;
+                            c.in = a.in;
+                            c.t1 = tptr(st.t1);
+                            c.wstream = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream_c1;
+                            c.b1 = a.b1; c.s1 = a.s1; c.t1c = a.t1;
+                            c.M = (long long)n * ti.h * ti.w;
+                            r.t1in = c.t1;
+                            r.zeros = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + h->zero_off;
+                            ScopedTimer tc(h, s, "conv1_ring_f32_kernel", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);
+                            static unsigned attr_c1 = 0;
+                            if (first_use_on_this_device(attr_c1))
+                                DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_ring_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+                            hipLaunchKernelGGL(conv1_ring_f32_kernel, dim3((unsigned)((c.M + 127) / 128)), dim3(256), C1_LDS_BYTES, s, c);
+                            DF3D_LAUNCH_CHECK();
+                        }
+                    }
+                    const char* const flags2 = split ? (a.add2 ? "false, true, true>" : "false, false, true>") : a.in2 ? "true, false, false>" : a.add2 ? "false, true, false>" : "false, false, false>";
                     ScopedTimer tm(h, s, eb == 2 ? std::string("bottleneck_ring_kernel<") + tname + (a.in2 ? ", true, 256, false>" : a.add2 ? ", false, 256, true>" : ", false, 256, false>")
                                                  : std::string("bottleneck_ring_f32_kernel<") + flags2,   // as rocprofv3 prints them
-                                   2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl), st.m1_elems * n * eb);
+                                   2.0 * px * ((split ? 0.0 : (double)cin * pl) + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl + (split ? pl : 0)), st.m1_elems * n * eb);
                     const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
                     int lds_bytes = BR_LDS_BYTES;
 #ifdef DF3D_BT_TIMING
@@ -817,8 +850,10 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                         rc = a.in2 ? launch_ring_lp<T, true, 256>(r, blocks, lds_bytes, s) : a.add2 ? launch_ring_lp<T, false, 256, true>(r, blocks, lds_bytes, s)
                                                                                            : launch_ring_lp<T, false, 256>(r, blocks, lds_bytes, s);
                     else
-                        rc = a.in2 ? launch_ring_f32<true>(r, blocks, lds_bytes, s) : a.add2 ? launch_ring_f32<false, true>(r, blocks, lds_bytes, s)
-                                                                                      : launch_ring_f32<false>(r, blocks, lds_bytes, s);
+                        rc = split ? (a.add2 ? launch_ring_f32<false, true, true>(r, blocks, lds_bytes, s) : launch_ring_f32<false, false, true>(r, blocks, lds_bytes, s))
+                             : a.in2 ? launch_ring_f32<true>(r, blocks, lds_bytes, s)
+                             : a.add2 ? launch_ring_f32<false, true>(r, blocks, lds_bytes, s)
+                                      : launch_ring_f32<false>(r, blocks, lds_bytes, s);
                     if (rc) return rc;
                     break;
                 }
@@ -1010,6 +1045,13 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
         h->build();
         return DF3D_OK;
     }
+    if (!strcmp(key, "split1")) {
+        DF3D_CHECK_ARG(value == 0 || value == 1, "split1 must be 0 or 1");
+        DF3D_CHECK_ARG(h->blob == nullptr, "set 'split1' before df3d_hg_set_weights (it changes the plan and the weight streams)");
+        h->split1 = value;
+        h->build();
+        return DF3D_OK;
+    }
     if (!strcmp(key, "chain_views")) {
         DF3D_CHECK_ARG(value >= 0, "chain_views must be >= 0");
         h->chain_views = value;
@@ -1101,7 +1143,12 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
             hipLaunchKernelGGL(bt_ring_pack_f32_kernel, dim3((BRF_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
                                blob_dev + st.conv.w_off, blob_dev + st.conv2b.w_off, blob_dev + st.conv3b.w_off,
                                reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
+            if (st.wstream_c1 >= 0)
+                hipLaunchKernelGGL(bt_c1_pack_f32_kernel, dim3((C1_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
+                                   blob_dev + st.conv.w_off, reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_c1);
         }
+        if (h->split1)
+            DF3D_HIP(hipMemsetAsync(reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + h->zero_off, 0, 256, df3d::as_stream(stream)));
         DF3D_LAUNCH_CHECK();
         h->lowp = lowp_dev;
     }

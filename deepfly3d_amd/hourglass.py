@@ -97,7 +97,7 @@ class HourglassEngine:
     """The device engine: `forward(images_nhwc) -> heat-maps (n, 19, H/4, W/4)` on the current torch stream."""
 
     def __init__(self, state_dict, dtype="f32", num_stacks=2, device=None, height=256, width=512, row_bytes=0, fuse=True, fuse_upadd=None, ring=None, l1=None,
-                 chain_views=None):
+                 chain_views=None, split1=None):
         _native.require_gpu()
         self.lib = _native.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -108,7 +108,7 @@ class HourglassEngine:
         self.h = h
         self.height, self.width = height, width
         _native.check(self.lib.df3d_hg_set_input(self.h, height, width), "df3d_hg_set_input")
-        if not fuse:
+        if not fuse or os.environ.get("DF3D_FUSE") == "0":   # (DF3D_FUSE=0: developer switch, every convolution as a launch of its own)
             _native.check(self.lib.df3d_hg_set_option(self.h, b"fuse", 0), "df3d_hg_set_option")
         if fuse_upadd is not None:  # default: the library's choice (on)
             # True / 1: added in the epilogue of the bottleneck that produces the up-path tensor (default); 2: folded into the input load of
@@ -120,6 +120,10 @@ class HourglassEngine:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"l1", 1 if l1 else 0), "df3d_hg_set_option")
         if row_bytes:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"row_bytes", row_bytes), "df3d_hg_set_option")
+        if split1 is None and os.environ.get("DF3D_SPLIT1"):
+            split1 = int(os.environ["DF3D_SPLIT1"])
+        if split1 is not None and dtype == "f32":  # fp32: conv1 of the identity-skip bottlenecks as a launch of its own (csrc/hg_c1_f32.h), bit-identical
+            _native.check(self.lib.df3d_hg_set_option(self.h, b"split1", 1 if split1 else 0), "df3d_hg_set_option")
         if chain_views is None and os.environ.get("DF3D_CHAIN_VIEWS"):
             chain_views = int(os.environ["DF3D_CHAIN_VIEWS"])
         if chain_views is not None:  # chains of full-resolution steps in chunks of this many views (0 = whole batch per launch)

@@ -430,3 +430,26 @@ def test_f32_set_weights_without_a_scratch_buffer_falls_back_to_the_register_sta
     # a 16-bit engine cannot do without its 16-bit copy of the blob: still an error, with a message
     e16 = HourglassEngine(synthetic_state_dict(0), dtype="f16", device=cuda)
     assert e16.lib.df3d_hg_set_weights(e16.h, e16.blob.data_ptr(), None, None) == _native.DF3D_EINVAL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("height,width,n", [(256, 512, 3), (128, 256, 2), (64, 192, 1)])
+def test_fp32_split_conv1_is_bit_identical(native_lib, cuda, oracle_net, height, width, n):
+    """fp32 `split1`: the first 1x1 convolution of the identity-skip bottlenecks computed ONCE per pixel by a kernel of its own
+    (csrc/hg_c1_f32.h) instead of on every tile's halo, the tile kernel pulling its t1 halo by LDS-DMA (out-of-image pixels from
+    a page of zeros): same accumulation order, so every plan step and the heat-maps are bit-identical to the fused kernels
+    (image borders, the pooled-input side output, the fused up-path sums, tile counts that are not powers of two)."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
+    img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(11 * height + width), dtype=torch.float32).to(cuda)
+    on = HourglassEngine(sd, dtype="f32", device=cuda, height=height, width=width, split1=1)
+    off = HourglassEngine(sd, dtype="f32", device=cuda, height=height, width=width, split1=0)
+    assert [s[0] for s in on.steps()] == [s[0] for s in off.steps()]
+    for k in range(1, len(on.steps()) + 1):
+        a, b = on.forward_upto(img, k), off.forward_upto(img, k)
+        assert torch.equal(a, b), f"step {k} {on.steps()[k - 1][0]} differs: max |diff| {(a - b).abs().max().item():.3e}"
+    first = on.forward(img).clone()
+    assert torch.equal(first, off.forward(img))
+    for _ in range(3):
+        assert torch.equal(on.forward(img), first)
