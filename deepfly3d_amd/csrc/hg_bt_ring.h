@@ -58,8 +58,10 @@ constexpr int BR_W1_STAGES = 8, BR_W2_STAGES = 36, BR_W3_STAGES = 8;
 constexpr int BR_NSTAGE = BR_W1_STAGES + BR_W2_STAGES + BR_W3_STAGES;   // 52
 constexpr int BR_T1_PITCH = 128 * 2;                    // bytes per halo pixel of the t1 tile: no padding, 16-byte chunks XOR-swizzled
 constexpr int BR_T1_BYTES = BT_HALO * BR_T1_PITCH;      // 46 080 (the 12 pad rows of the sixth MFMA row tile are not stored)
-constexpr int BR_XPITCH = 64 + 16;                      // staged x rows: 32 channels + pad
-constexpr int BR_XSTAGE = BT_HROWS * BR_XPITCH;         // 15 360; three of them inside the t1 region
+constexpr int BR_XPITCH = 64;                           // staged x rows: one 64-byte K step, no padding: 16-byte chunk c of row r sits in slot
+                                                        // c ^ ((r >> 2) & 3) (br_xslot), which makes the 32-row fragment reads and the row-pair
+                                                        // stores bank-conflict-free (round 3: the padded 80-byte rows cost 13-15 % of the LDS cycles)
+constexpr int BR_XSTAGE = BT_HROWS * BR_XPITCH;         // 12 288; three of them inside the t1 region
 constexpr int BR_RING_BYTES = BR_RING * BR_STAGE_BYTES;
 constexpr int BR_COEF_BYTES = 512 * 4 + 128 * 4;        // phase 1: bn1 scale [256] | shift [256]; afterwards b2 [128] | b3 [256]; then b1 [128]
 constexpr int BR_LDS_BYTES = BR_RING_BYTES + BR_T1_BYTES + BR_COEF_BYTES + 64;
@@ -69,6 +71,7 @@ __device__ __forceinline__ int br_t1_swz(int hp) { return (hp % BT_HW) & 15; }
 static_assert(3 * BR_XSTAGE <= BR_T1_BYTES, "the x ring lives inside the t1 region");
 static_assert(2 * BR_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 
+__device__ __forceinline__ int br_xslot(int row, int chunk) { return ((chunk ^ ((row >> 2) & 3)) << 4); }   // byte offset inside a staged x row
 __host__ __device__ constexpr int br_swz(int r, int c) { return (r >> 2) * 256 + (((((r & 3) << 2) | c) ^ ((r >> 3) & 3)) << 4); }
 
 // stages of one bottleneck's stream: W1 (CIN / 32) | W2 (36) | per 128-channel output half: W3 (4) and, with the 1x1 skip
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
 #if !defined(BR_ABL) || BR_ABL != 6   // ablation 6: no bn1 + ReLU arithmetic
             v = br_preact<T>(v, coef);
 #endif
-            *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * BR_XPITCH + xchunk * 16) = v;
+            *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * BR_XPITCH + br_xslot(tid >> 2, xchunk)) = v;
         }
     };
 #pragma unroll
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
             for (int j = 0; j < 2; ++j) {
                 wfr[j] = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + ct * 2048);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) xfr[j][i] = *reinterpret_cast<const u32x4*>(sx + (i * 32 + l31) * BR_XPITCH + j * 32 + half * 16);
+                for (int i = 0; i < 6; ++i) xfr[j][i] = *reinterpret_cast<const u32x4*>(sx + (i * 32 + l31) * BR_XPITCH + br_xslot(l31, 2 * j + half));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

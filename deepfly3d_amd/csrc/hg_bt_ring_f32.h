@@ -63,7 +63,6 @@ __device__ __forceinline__ float br_relu(float x) {
 template <bool UP, bool ADD2 = false, bool TAIL = false>
 __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs p) {
     static_assert(!(UP && ADD2), "the fused up-path sum is written by plain blocks");
-    static_assert(!(UP && TAIL), "the split form exists for blocks whose input is a stored tensor");
     using T = float;
     constexpr int CIN = 256, CO = 256, NT = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(br_relu(fmaf(v[e], cs[e], ct_[e]))) & xkeep[i];
-            *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * BR_XPITCH + xchunk * 16) = o;
+            *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * BR_XPITCH + br_xslot(tid >> 2, xchunk)) = o;
         }
     };
 
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
                     const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (st % BR_RING) * BR_STAGE_BYTES + (xs & 1) * 4096 + ct * 2048);
     #pragma unroll
                     for (int i = 0; i < 3; ++i) {
-                        const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * BR_XPITCH + j * 32 + half * 16);
+                        const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * BR_XPITCH + br_xslot(l31, 2 * j + half));
                         mfma_chunk<T>(wf, xf, acc[i]);
                     }
                 }

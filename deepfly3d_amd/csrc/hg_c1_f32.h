@@ -21,6 +21,8 @@ namespace hgk {
 
 struct Conv1Args {
     const void* in;       // NHWC f32 [M, 256]
+    const void* in2;      // UP: NHWC f32 [V, H/2, W/2, 256]: the block's input is in + nearest-upsample(in2) (one fp32 add, as upadd_kernel)
+    int H, W;             // UP: the level's size (M = V * H * W)
     void* t1;             // [M, 128] f32: relu(W1' relu(bn1 x) + b1')
     const void* wstream;  // C1_NSTAGE x BR_STAGE_BYTES (bt_c1_pack_f32_kernel)
     const float* b1;      // [128] (bn2 folded)
@@ -30,8 +32,8 @@ struct Conv1Args {
 };
 
 constexpr int C1_NSTAGE = 16;
-constexpr int C1_XPITCH = 64 + 16;
-constexpr int C1_XSTAGE = 128 * C1_XPITCH;                                   // 10 240
+constexpr int C1_XPITCH = 64;                                                 // unpadded, chunks swizzled (br_xslot)
+constexpr int C1_XSTAGE = 128 * C1_XPITCH;                                   // 8 192
 constexpr int C1_LDS_BYTES = BR_RING_BYTES + 3 * C1_XSTAGE + 512 * 4 + 128 * 4;   // ring | x ring | bn1 scale, shift | b1
 
 // fp32 blob -> conv1 weight stream: stage s = K slice [16 s, 16 s + 16) of the 128 rows of W1' [128][256]
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(256) void bt_c1_pack_f32_kernel(const float* __rest
     *reinterpret_cast<u32x4*>(stream + (size_t)s * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(w1 + (size_t)r * 256 + 16 * s + 4 * c);
 }
 
+template <bool UP>
 __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
     using T = float;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -71,19 +74,30 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
     ring_issue(2);
 
     // x staging: thread -> (row = (tid >> 2) + 64 i, 16-byte chunk = tid & 3) of a 16-float K step; rows past the end read the last pixel
-    constexpr int XP = 2, DX = 3;
+    constexpr int XP = 2, DX = UP ? 2 : 3, LX = UP ? 2 * XP : XP;   // LX: vector-memory loads per thread and K step
     const int xchunk = tid & 3;
     const unsigned char* xp[XP];
+    const unsigned char* xq[UP ? XP : 1];
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
         long long m = m0 + (tid >> 2) + 64 * i;
         if (m >= p.M) m = p.M - 1;
         xp[i] = reinterpret_cast<const unsigned char*>(p.in) + ((size_t)m * 256 + xchunk * 4) * 4;
+        if constexpr (UP) {
+            const long long hw = (long long)p.H * p.W, view = m / hw;
+            const int pix = (int)(m - view * hw), y = pix / p.W, x = pix - y * p.W;
+            xq[i] = reinterpret_cast<const unsigned char*>(p.in2) + ((((size_t)view * (p.H / 2) + (y >> 1)) * (p.W / 2) + (x >> 1)) * 256 + xchunk * 4) * 4;
+        }
     }
     u32x4 rx[DX][XP];
+    u32x4 rb[UP ? DX : 1][XP];
     auto loadx = [&](int s, int slot) {
 #pragma unroll
         for (int i = 0; i < XP; ++i) rx[slot][i] = *reinterpret_cast<const u32x4*>(xp[i] + s * 64);
+        if constexpr (UP) {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) rb[slot][i] = *reinterpret_cast<const u32x4*>(xq[i] + s * 64);
+        }
     };
     auto storex = [&](int s, int slot) {
         const f32x4 cs = *reinterpret_cast<const f32x4*>(coef_lds + s * 16 + xchunk * 4);
@@ -91,11 +105,12 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
         unsigned char* const sx = xr + (s % 3) * C1_XSTAGE;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            const f32x4 v = __builtin_bit_cast(f32x4, rx[slot][i]);
+            f32x4 v = __builtin_bit_cast(f32x4, rx[slot][i]);
+            if constexpr (UP) v += __builtin_bit_cast(f32x4, rb[slot][i]);   // x = in + upsample(in2), what upadd_kernel would have stored
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(br_relu(fmaf(v[e], cs[e], ct_[e])));
-            *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * C1_XPITCH + xchunk * 16) = o;
+            *reinterpret_cast<u32x4*>(sx + ((tid >> 2) + 64 * i) * C1_XPITCH + br_xslot(tid >> 2, xchunk)) = o;
         }
     };
 #pragma unroll
@@ -117,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
         storex(s, s % DX);
         // operations issued after stage s's two DMA pieces: the next two stages' pieces (4) and the x loads requested since
         // (XP per K step while any remain; the prologue's DX steps sit in front of stages 1 and 2 for s = 0)
-        auto cx = [](int k) { return k < C1_NSTAGE ? XP : 0; };
-        br_wait_vm(s == 0 ? 4 + DX * XP : s == 1 ? 4 + DX * XP + cx(DX) : s == 2 ? 4 + DX * XP + cx(DX) + cx(DX + 1)
+        auto cx = [](int k) { return k < C1_NSTAGE ? LX : 0; };
+        br_wait_vm(s == 0 ? 4 + DX * LX : s == 1 ? 4 + DX * LX + cx(DX) : s == 2 ? 4 + DX * LX + cx(DX) + cx(DX + 1)
                                                                             : 4 + cx(s - 3 + DX) + cx(s - 2 + DX) + cx(s - 1 + DX));
         br_barrier();
         ring_issue(s + 3);
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const u32x4*>((j2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + (ct0 + j) * 2048);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * C1_XPITCH + j2 * 32 + half * 16);
+            for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * C1_XPITCH + br_xslot(l31, 2 * j2 + half));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll

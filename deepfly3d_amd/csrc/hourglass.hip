@@ -57,6 +57,7 @@ struct Step {
     double m1_elems = 0;              // activation elements per view this step moves in the fusion model M1
     int t1 = -1;                      // ST_BOTTLENECK, fp32 split form (hg_c1_f32.h): the tensor conv1's kernel writes and the tail kernel reads
     long long wstream_c1 = -1;        // ... and the byte offset of conv1's weight stream
+    int chain = -1;                   // >= 0: planned inside chain number `chain` (frees postponed: its tensors share no memory)
 };
 
 struct Allocator {
@@ -112,6 +113,7 @@ struct df3d_hg {
     int l1 = 1;           // 1 = bf16 layer1 (64 -> 64 -> 64 -> 128) runs as the LDS-resident-weights kernel of hg_bt_l1.h
     int ring = 1;         // 1 = the 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring*.h)
     int split1 = 1;       // fp32: 1 (default) = plain 256 -> 128 -> 128 -> 256 blocks run as conv1 (every pixel once) + tail (hg_c1_f32.h), bit-identical
+    bool uses_zero_page = false;
     size_t zero_off = 0;  // byte offset of 256 zero bytes behind the weight streams (split form: the 3x3 padding of the tail's LDS-DMA)
     int chain_views = 0;  // > 0: chains of full-resolution steps run in chunks of this many views (Infinity Cache residency); 0 = off
     std::vector<int> chain_end;   // step i starts a chain [i, chain_end[i]) (chain_end[i] = i + 1: no chain)
@@ -152,7 +154,10 @@ struct df3d_hg {
     // step, push_step(), m1_close() after the last one -> Step::m1_elems
     double m1_mark = 0;
     void m1_open() { m1_mark = elems_per_view; }
-    void push_step(const Step& st) { steps.push_back(st); }
+    void push_step(const Step& st) {
+        steps.push_back(st);
+        steps.back().chain = defer_frees ? plan_chain : -1;
+    }
     void m1_close() { steps.back().m1_elems = elems_per_view - m1_mark; }
     int new_tensor(int h, int w, int c, int pitch = 0) {
         if (!pitch) pitch = c;
@@ -171,6 +176,7 @@ struct df3d_hg {
     // chunk by chunk, so a tensor released inside it must not lend its memory to a later tensor of the same chain (whose slice
     // for chunk c could overlap the released tensor's slice for chunk c + 1, which is still to be written and read).
     bool defer_frees = false;
+    int plan_chain = 0;
     std::vector<int> deferred;
     void free_tensor(int id) {
         if (defer_frees) {
@@ -182,6 +188,7 @@ struct df3d_hg {
     }
     void end_chain() {
         defer_frees = false;
+        ++plan_chain;
         for (int id : deferred) free_tensor(id);
         deferred.clear();
     }
@@ -287,7 +294,7 @@ struct df3d_hg {
                     pooled_of[x] = st.pool_in;
                     elems_per_view += (double)tx.h * tx.w * cin * 1.25;  // model M1 still counts the pooling pass
                 }
-                if (split1 && !lp() && x2 < 0) {   // fp32 split form: conv1 on every pixel once, the rest on tiles
+                if (split1 && !lp()) {   // fp32 split form: conv1 on every pixel once, the rest on tiles
                     st.wstream_c1 = (long long)stream_bytes;
                     stream_bytes += (size_t)C1_NSTAGE * BR_STAGE_BYTES;
                     st.t1 = new_tensor(tx.h, tx.w, planes);
@@ -428,6 +435,7 @@ struct df3d_hg {
         alloc = Allocator();
         flops_per_view = elems_per_view = 0;
         deferred.clear();
+        plan_chain = 0;
         defer_frees = true;   // stem .. layer3 form a chain
         // stem
         Step st;
@@ -523,7 +531,9 @@ struct df3d_hg {
         }
         act_elems_per_view = alloc.peak;
         zero_off = stream_bytes;
-        if (split1 && !lp()) stream_bytes += 256;
+        uses_zero_page = false;
+        for (const Step& st : steps) uses_zero_page = uses_zero_page || st.t1 >= 0;
+        if (uses_zero_page) stream_bytes += 256;
         // chains: maximal runs of consecutive steps, each of which reads only the previous step's output (and tensors written
         // before the chain began) at the network's top resolutions
         chain_end.assign(steps.size(), 0);
@@ -537,7 +547,9 @@ struct df3d_hg {
             size_t j = i;
             if (big(steps[i])) {
                 j = i + 1;
-                while (j < steps.size() && big(steps[j]) && steps[j].in == steps[j - 1].out && steps[j].kind != ST_STEM) ++j;
+                while (j < steps.size() && big(steps[j]) && steps[j].in == steps[j - 1].out && steps[j].kind != ST_STEM && steps[i].chain >= 0 &&
+                       steps[j].chain == steps[i].chain)
+                    ++j;
                 chain_end[i] = (int)j;
             }
             i = std::max(j, i + 1);
@@ -822,21 +834,29 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                         if constexpr (sizeof(T) == 4) {
                             Conv1Args c;
                             c.in = a.in;
+                            c.in2 = a.in2;
+                            c.H = ti.h;
+                            c.W = ti.w;
                             c.t1 = tptr(st.t1);
                             c.wstream = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream_c1;
                             c.b1 = a.b1; c.s1 = a.s1; c.t1c = a.t1;
                             c.M = (long long)n * ti.h * ti.w;
                             r.t1in = c.t1;
                             r.zeros = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + h->zero_off;
-                            ScopedTimer tc(h, s, "conv1_ring_f32_kernel", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);
-                            static unsigned attr_c1 = 0;
-                            if (first_use_on_this_device(attr_c1))
-                                DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_ring_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
-                            hipLaunchKernelGGL(conv1_ring_f32_kernel, dim3((unsigned)((c.M + 127) / 128)), dim3(256), C1_LDS_BYTES, s, c);
+                            ScopedTimer tc(h, s, a.in2 ? "conv1_ring_f32_kernel<true>" : "conv1_ring_f32_kernel<false>", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);
+                            static unsigned attr_c1[2] = {0, 0};
+                            const void* const fn = a.in2 ? reinterpret_cast<const void*>(conv1_ring_f32_kernel<true>) : reinterpret_cast<const void*>(conv1_ring_f32_kernel<false>);
+                            if (first_use_on_this_device(attr_c1[a.in2 ? 1 : 0]))
+                                DF3D_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+                            if (a.in2)
+                                hipLaunchKernelGGL(conv1_ring_f32_kernel<true>, dim3((unsigned)((c.M + 127) / 128)), dim3(256), C1_LDS_BYTES, s, c);
+                            else
+                                hipLaunchKernelGGL(conv1_ring_f32_kernel<false>, dim3((unsigned)((c.M + 127) / 128)), dim3(256), C1_LDS_BYTES, s, c);
                             DF3D_LAUNCH_CHECK();
                         }
                     }
-                    const char* const flags2 = split ? (a.add2 ? "false, true, true>" : "false, false, true>") : a.in2 ? "true, false, false>" : a.add2 ? "false, true, false>" : "false, false, false>";
+                    const char* const flags2 = split ? (a.in2 ? "true, false, true>" : a.add2 ? "false, true, true>" : "false, false, true>")
+                                                     : a.in2 ? "true, false, false>" : a.add2 ? "false, true, false>" : "false, false, false>";
                     ScopedTimer tm(h, s, eb == 2 ? std::string("bottleneck_ring_kernel<") + tname + (a.in2 ? ", true, 256, false>" : a.add2 ? ", false, 256, true>" : ", false, 256, false>")
                                                  : std::string("bottleneck_ring_f32_kernel<") + flags2,   // as rocprofv3 prints them
                                    2.0 * px * ((split ? 0.0 : (double)cin * pl) + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl + (split ? pl : 0)), st.m1_elems * n * eb);
@@ -850,7 +870,8 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                         rc = a.in2 ? launch_ring_lp<T, true, 256>(r, blocks, lds_bytes, s) : a.add2 ? launch_ring_lp<T, false, 256, true>(r, blocks, lds_bytes, s)
                                                                                            : launch_ring_lp<T, false, 256>(r, blocks, lds_bytes, s);
                     else
-                        rc = split ? (a.add2 ? launch_ring_f32<false, true, true>(r, blocks, lds_bytes, s) : launch_ring_f32<false, false, true>(r, blocks, lds_bytes, s))
+                        rc = split ? (a.in2 ? launch_ring_f32<true, false, true>(r, blocks, lds_bytes, s)
+                                      : a.add2 ? launch_ring_f32<false, true, true>(r, blocks, lds_bytes, s) : launch_ring_f32<false, false, true>(r, blocks, lds_bytes, s))
                              : a.in2 ? launch_ring_f32<true>(r, blocks, lds_bytes, s)
                              : a.add2 ? launch_ring_f32<false, true>(r, blocks, lds_bytes, s)
                                       : launch_ring_f32<false>(r, blocks, lds_bytes, s);
@@ -1147,7 +1168,7 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
                 hipLaunchKernelGGL(bt_c1_pack_f32_kernel, dim3((C1_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
                                    blob_dev + st.conv.w_off, reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_c1);
         }
-        if (h->split1)
+        if (h->uses_zero_page)
             DF3D_HIP(hipMemsetAsync(reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + h->zero_off, 0, 256, df3d::as_stream(stream)));
         DF3D_LAUNCH_CHECK();
         h->lowp = lowp_dev;

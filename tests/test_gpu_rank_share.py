@@ -115,7 +115,7 @@ def test_rank_share_stream_with_ba_windows_and_rccl_gather(native_lib, cuda, gol
     finally:
         dist.gather = real
     torch.cuda.synchronize()
-    assert calls == [(True, torch.uint8, (1, T * 5704 + 13 * 672))]
+    assert calls == [(True, torch.uint8, (1, 8 + T * 5704 + 13 * 672))]   # window count (8 B) | frame records | window cameras
     assert g2 is not p2 and torch.equal(g2, p2) and torch.equal(gc, conf) and torch.equal(g3d, p3) and torch.equal(gcam, cam_t)
     # Procrustes (sequence-global) after the gather, as rank 0 does: the assembled result has the reference's schema
     out = dd.assemble_result(g2.cpu().numpy(), gc.cpu().numpy(), g3d.cpu().numpy(),
