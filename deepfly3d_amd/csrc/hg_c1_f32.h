@@ -34,7 +34,9 @@ struct Conv1Args {
 constexpr int C1_NSTAGE = 16;
 constexpr int C1_XPITCH = 64;                                                 // unpadded, chunks swizzled (br_xslot)
 constexpr int C1_XSTAGE = 128 * C1_XPITCH;                                   // 8 192
-constexpr int C1_LDS_BYTES = BR_RING_BYTES + 3 * C1_XSTAGE + 512 * 4 + 128 * 4;   // ring | x ring | bn1 scale, shift | b1
+constexpr int C1_XSLOTS = 2;   // x ring: step s is staged into slot s % 2 while slot (s - 1) % 2 may still be read; the slot was last read in
+                               // step s - 2, which every wave has left before anyone passes the barrier of step s - 1
+constexpr int C1_LDS_BYTES = BR_RING_BYTES + C1_XSLOTS * C1_XSTAGE + 512 * 4 + 128 * 4;   // ring | x ring | bn1 scale, shift | b1: 50.5 KB
 
 // fp32 blob -> conv1 weight stream: stage s = K slice [16 s, 16 s + 16) of the 128 rows of W1' [128][256]
 __global__ __launch_bounds__(256) void bt_c1_pack_f32_kernel(const float* __restrict__ w1, unsigned char* __restrict__ stream) {
@@ -45,12 +47,12 @@ __global__ __launch_bounds__(256) void bt_c1_pack_f32_kernel(const float* __rest
 }
 
 template <bool UP>
-__global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
+__global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {   // (three workgroups per CU fit -- 118 registers, 50.5 KB -- and measured no faster)
     using T = float;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;
     unsigned char* const xr = smem + BR_RING_BYTES;
-    float* const coef_lds = reinterpret_cast<float*>(smem + BR_RING_BYTES + 3 * C1_XSTAGE);   // [0..255] scale, [256..511] shift, [512..639] b1
+    float* const coef_lds = reinterpret_cast<float*>(smem + BR_RING_BYTES + C1_XSLOTS * C1_XSTAGE);   // [0..255] scale, [256..511] shift, [512..639] b1
     const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
     auto storex = [&](int s, int slot) {
         const f32x4 cs = *reinterpret_cast<const f32x4*>(coef_lds + s * 16 + xchunk * 4);
         const f32x4 ct_ = *reinterpret_cast<const f32x4*>(coef_lds + 256 + s * 16 + xchunk * 4);
-        unsigned char* const sx = xr + (s % 3) * C1_XSTAGE;
+        unsigned char* const sx = xr + (s % C1_XSLOTS) * C1_XSTAGE;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             f32x4 v = __builtin_bit_cast(f32x4, rx[slot][i]);
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
         br_barrier();
         ring_issue(s + 3);
         if (s + DX < C1_NSTAGE) loadx(s + DX, s % DX);
-        const unsigned char* const sx = xr + (s % 3) * C1_XSTAGE;
+        const unsigned char* const sx = xr + (s % C1_XSLOTS) * C1_XSTAGE;
 #pragma unroll
         for (int j2 = 0; j2 < 2; ++j2) {   // the K step's two 8-float halves
             u32x4 wf[2], xf[2];
