@@ -29,7 +29,7 @@ def cycles_upto(k):
     return list(buf)
 
 
-for target in ("hg.0.hg.3.0.0.conv3", "hg.0.hg.2.0.0.conv3", "res.1.0.conv3"):
+for target in ("layer3.0.conv3", "hg.0.hg.3.upadd", "res.0.0.conv3", "hg.0.hg.2.upadd"):
     k = names.index(target) + 1
     before, after = cycles_upto(k - 1), cycles_upto(k)
     own = [a - b for a, b in zip(after, before)]
