@@ -350,7 +350,7 @@ def test_cli_two_ranks_match_one_rank(native_lib, cuda, tmp_path, golden_dir):
     assert np.allclose(one["points3d_wo_procrustes"], two["points3d_wo_procrustes"], atol=1e-9)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_full_size_workload_properties(native_lib, cuda, golden_dir, dtype):
     """BASELINE configs[1] / configs[2] at FULL size (1 000 frames x 7 views of 256x512x3, one GPU), checked through
     size-independent properties: the run is deterministic (bit-identical twice), every frame's result is independent
@@ -392,7 +392,7 @@ def test_full_size_workload_properties(native_lib, cuda, golden_dir, dtype):
         assert np.abs(p3[t].cpu().numpy() - X[0]).max() < 1e-6 * max(1.0, np.abs(X).max())
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_forward_from_camera_frames_equals_preprocess_then_forward(native_lib, cuda, dtype):
     """df3d_hg_forward_u8 (the stem samples the uint8 frames itself) is bit for bit df3d_hg_forward(df3d_preprocess_u8(frames)):
     grey and 3-channel frames, flipped and not, a frame size that is not a multiple of the network input, non-trivial mean / std."""

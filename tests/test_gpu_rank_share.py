@@ -56,7 +56,7 @@ def test_rank_share_stream_with_ba_windows_and_rccl_gather(native_lib, cuda, gol
     t0, t1 = dd.shard_range(stream, ranks, 0, window)
     assert (t0, t1) == (0, 13_000) and dd.shard_range(stream, ranks, 7, window) == (88_000, 100_000)
     T = t1 - t0
-    eng = HourglassEngine(synthetic_state_dict(0), dtype="bf16", device=cuda)
+    eng = HourglassEngine(synthetic_state_dict(0), dtype="f16", device=cuda)
     c = np.load(f"{golden_dir}/calib.npz")
     g3 = np.load(f"{golden_dir}/golden_3d.npz")
     pipe = FramePipeline(eng, c["R"], c["tvec"], c["intr"])
@@ -138,8 +138,8 @@ def test_bench_rank_share_modes():
     cfg = line["config"]
     assert cfg["frames_per_gpu"] == 12_500 and line["steps"] == 98 and cfg["collective_executed"] and cfg["collective_backend"] == "nccl"
     assert cfg["gather_roundtrip_exact"] is True and "configs[3]" in cfg["workload"] and line["dtype"] == "f32" and line["value"] > 100
-    line = _bench("--rank-share", "8", "--stream-frames", "100000", "--ba-window", "1000", "--force-collective", "--dtype", "bf16")
+    line = _bench("--rank-share", "8", "--stream-frames", "100000", "--ba-window", "1000", "--force-collective", "--dtype", "f16")
     cfg = line["config"]
     assert cfg["frames_per_gpu"] == 13_000 and cfg["bundle_adjust_runs_rank0"] == 13 and cfg["collective_executed"]
     assert cfg["gather_roundtrip_exact"] is True and "configs[4]" in cfg["workload"] and line["value"] > 500
-    print("rank share: configs[4] bf16", round(line["value"], 1), "frames/s")
+    print("rank share: configs[4] f16", round(line["value"], 1), "frames/s")

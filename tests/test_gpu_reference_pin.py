@@ -39,7 +39,7 @@ def _run(core_cls, folder, out, dtype):
 
 
 @needs_weights
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
 def test_pose_estimation_against_the_reference_golden(native_lib, cuda, tmp_path, golden_dir, monkeypatch, dtype):
     """Needs no code edit the day the checkpoint arrives: the normalisation mean is read from mean.pth.tar beside it
     (reference df3d/config.py:37-39) or $DF3D_MEAN / $DF3D_PREPROCESS; the resize rule -- the one preprocessing choice no
