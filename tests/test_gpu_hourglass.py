@@ -6,7 +6,7 @@ Floating point: fp32 kernels sum in a different order than torch's CPU convoluti
 relative to the tensor's max magnitude, a few times the measured error and no more (a kernel regression that loses
 a decimal digit must fail):
     fp32  5e-5  (measured 1.4e-6 .. 1e-5 over steps and shapes)
-    f16   2.5e-3 (measured ~1e-3: IEEE-half operands, 2^-12 per rounding, ~100 convolutions)
+    f16   4e-3  (measured 1.1e-3 on peaked maps .. 2.8e-3 on flat random ones: IEEE-half operands, 2^-12 per rounding, ~100 convolutions)
     bf16  1.5e-2 (measured 7.7e-3: 2^-9 per rounding)
 """
 import numpy as np
@@ -19,7 +19,7 @@ from oracle import hourglass_torch as oh
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 5e-5
-F16_TOL = 2.5e-3
+F16_TOL = 4e-3
 BF16_TOL = 1.5e-2
 LP_TOL = {"bf16": BF16_TOL, "f16": F16_TOL}
 # the reference's confidence tolerance: atol 2e-3 on peaks ~1 (reference tests/test_df3d.py:173-178); here relative to max |heat-map|
