@@ -391,6 +391,15 @@ struct StemArgs {
     StemU8 u8;
 };
 
+// one 1 KB LDS-DMA piece (the helper of hg_bt_ring.h, needed here before that header): lane l's 16 bytes from sbase + voff -> dst + 16 l
+__device__ __forceinline__ void stem_glds_piece(const void* sbase, unsigned voff, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(dst)
+                 : "memory");
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
     constexpr int PR = 21, PC = 37, PROW = 112;  // patch rows, cols, floats per patch row (111 padded)
@@ -406,8 +415,16 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
     const int view = b / tiles_y;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < KTOT * 64 / 4; i += 256)
-        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
+    {   // the [148][64] fp32 weight matrix as it lies: 37 one-KB pieces by LDS-DMA (no registers, no ds_write; runs under the patch staging)
+        const unsigned wl_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)wl;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        static_assert(KTOT * 64 * 4 == 37 * 1024, "37 whole pieces");
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const int pc = wv + 4 * k;
+            if (pc < 37) stem_glds_piece(p.w, (unsigned)pc * 1024u + (unsigned)(tid & 63) * 16u, wl_addr + (unsigned)pc * 1024u);
+        }
+    }
     const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
     const float* img = p.img + (size_t)view * p.H * p.W * 3;
     // one item = one patch pixel (three contiguous floats): index arithmetic and bounds test per pixel, not per value
@@ -436,6 +453,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
         dst[2] = v2;
     }
     if (tid < PR) patch[tid * PROW + PC * 3] = 0.0f;   // the pad cell behind the 111 values of a row
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's weight pieces have landed
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -496,9 +514,18 @@ __global__ __launch_bounds__(256) void stem_lp_kernel(StemArgs p) {
     const int view = b / tiles_y;
     const int tid = threadIdx.x;
 
-    // weights: the [64][184] bf16 tile was laid out once by stem_relayout_kernel (wl[n][ky*24 + kk] = w[ky*21 + kk][n])
-    for (int i = tid; i < 64 * WPITCH / 8; i += 256)
-        reinterpret_cast<u32x4*>(wl)[i] = reinterpret_cast<const u32x4*>(p.w_bf16)[i];
+    // weights: the [64][184] 16-bit tile was laid out once by stem_relayout_kernel (wl[n][ky*24 + kk] = w[ky*21 + kk][n]); it is
+    // copied as it lies, 23 one-KB pieces, by LDS-DMA (no registers, no ds_write: the copy runs under the patch staging below)
+    {
+        const unsigned wl_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)wl;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        static_assert(64 * WPITCH * 2 == 23 * 1024, "23 whole pieces");
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int pc = wv + 4 * k;
+            if (pc < 23) stem_glds_piece(p.w_bf16, (unsigned)pc * 1024u + (unsigned)(tid & 63) * 16u, wl_addr + (unsigned)pc * 1024u);
+        }
+    }
     const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
     const float* img = p.img + (size_t)view * p.H * p.W * 3;
     // one item = one patch pixel (three contiguous floats): the index arithmetic and the bounds test are per pixel, not per value
@@ -531,6 +558,7 @@ __global__ __launch_bounds__(256) void stem_lp_kernel(StemArgs p) {
         const int r = i / (PROW - PC * 3), c = i - r * (PROW - PC * 3);
         patch[i < PR * (PROW - PC * 3) ? r * PROW + PC * 3 + c : PR * PROW + (i - PR * (PROW - PC * 3))] = 0;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's weight pieces have landed
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6;
