@@ -46,8 +46,13 @@ __global__ __launch_bounds__(256) void bt_c1_pack_f32_kernel(const float* __rest
     *reinterpret_cast<u32x4*>(stream + (size_t)s * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(w1 + (size_t)r * 256 + 16 * s + 4 * c);
 }
 
+// PERSISTENT: a workgroup walks pixel tiles tile, tile + gridDim.x, ... with the pipeline running across tile boundaries -- the
+// coefficients are staged once, stage (s + 3) % 16 and the x loads of step s + DX belong to the NEXT tile during a tile's last
+// steps (the weights are the same for every tile), so no tile after the first has a prologue.  Every tile issues exactly the same
+// vector-memory operations in the same order (the last tile re-reads its own rows and re-requests stages it will not use), which
+// keeps the counted waits valid; the kernel drains the queue before it ends.
 template <bool UP>
-__global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {   // (three workgroups per CU fit -- 118 registers, 50.5 KB -- and measured no faster)
+__global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {   // (three workgroups per CU fit -- 50.5 KB -- and measured no faster)
     using T = float;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;
@@ -58,12 +63,14 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {  
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const long long m0 = (long long)blockIdx.x * 128;
+    const long long ntiles = (p.M + 127) / 128;
+    long long tile = blockIdx.x;
+    if (tile >= ntiles) return;
 
     const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
-    auto ring_issue = [&](int s) {
-        if (s < C1_NSTAGE) br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)s * BR_STAGE_BYTES, wvoff,
-                                         ring_addr + (unsigned)(s % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048);
+    auto ring_issue = [&](int s) {   // stage s (of 16; the same for every tile) -> ring slot s % 4
+        br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)s * BR_STAGE_BYTES, wvoff,
+                      ring_addr + (unsigned)(s % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048);
     };
     const unsigned char* const wf0 = ring + br_swz(l31, half);
     const unsigned char* const wf1 = ring + br_swz(l31, 2 + half);
@@ -76,29 +83,35 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {  
     ring_issue(2);
 
     // x staging: thread -> (row = (tid >> 2) + 64 i, 16-byte chunk = tid & 3) of a 16-float K step; rows past the end read the last pixel
-    constexpr int XP = 2, DX = UP ? 2 : 3, LX = UP ? 2 * XP : XP;   // LX: vector-memory loads per thread and K step
+    constexpr int XP = 2, DX = UP ? 2 : 4, LX = UP ? 2 * XP : XP;   // DX divides 16: the register slots repeat from tile to tile
+    static_assert(C1_NSTAGE % DX == 0 && C1_NSTAGE % C1_XSLOTS == 0 && C1_NSTAGE % BR_RING == 0, "slot patterns repeat per tile");
     const int xchunk = tid & 3;
-    const unsigned char* xp[XP];
+    const unsigned char* xp[XP];            // this tile's rows
     const unsigned char* xq[UP ? XP : 1];
+    const unsigned char* xn[XP];            // the next tile's rows
+    const unsigned char* xqn[UP ? XP : 1];
+    auto rows_of = [&](long long t, const unsigned char* (&px)[XP], const unsigned char* (&pq)[UP ? XP : 1]) {
 #pragma unroll
-    for (int i = 0; i < XP; ++i) {
-        long long m = m0 + (tid >> 2) + 64 * i;
-        if (m >= p.M) m = p.M - 1;
-        xp[i] = reinterpret_cast<const unsigned char*>(p.in) + ((size_t)m * 256 + xchunk * 4) * 4;
-        if constexpr (UP) {
-            const long long hw = (long long)p.H * p.W, view = m / hw;
-            const int pix = (int)(m - view * hw), y = pix / p.W, x = pix - y * p.W;
-            xq[i] = reinterpret_cast<const unsigned char*>(p.in2) + ((((size_t)view * (p.H / 2) + (y >> 1)) * (p.W / 2) + (x >> 1)) * 256 + xchunk * 4) * 4;
+        for (int i = 0; i < XP; ++i) {
+            long long m = t * 128 + (tid >> 2) + 64 * i;
+            if (m >= p.M) m = p.M - 1;
+            px[i] = reinterpret_cast<const unsigned char*>(p.in) + ((size_t)m * 256 + xchunk * 4) * 4;
+            if constexpr (UP) {
+                const long long hw = (long long)p.H * p.W, view = m / hw;
+                const int pix = (int)(m - view * hw), y = pix / p.W, x = pix - y * p.W;
+                pq[i] = reinterpret_cast<const unsigned char*>(p.in2) + ((((size_t)view * (p.H / 2) + (y >> 1)) * (p.W / 2) + (x >> 1)) * 256 + xchunk * 4) * 4;
+            }
         }
-    }
+    };
+    rows_of(tile, xp, xq);
     u32x4 rx[DX][XP];
     u32x4 rb[UP ? DX : 1][XP];
-    auto loadx = [&](int s, int slot) {
+    auto loadx = [&](bool next_tile, int s, int slot) {
 #pragma unroll
-        for (int i = 0; i < XP; ++i) rx[slot][i] = *reinterpret_cast<const u32x4*>(xp[i] + s * 64);
+        for (int i = 0; i < XP; ++i) rx[slot][i] = *reinterpret_cast<const u32x4*>((next_tile ? xn[i] : xp[i]) + s * 64);
         if constexpr (UP) {
 #pragma unroll
-            for (int i = 0; i < XP; ++i) rb[slot][i] = *reinterpret_cast<const u32x4*>(xq[i] + s * 64);
+            for (int i = 0; i < XP; ++i) rb[slot][i] = *reinterpret_cast<const u32x4*>((next_tile ? xqn[i] : xq[i]) + s * 64);
         }
     };
     auto storex = [&](int s, int slot) {
@@ -116,56 +129,79 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {  
         }
     };
 #pragma unroll
-    for (int k = 0; k < DX; ++k) loadx(k, k);
+    for (int k = 0; k < DX; ++k) loadx(false, k, k);
 
     const int rt0 = 2 * (wave >> 1), ct0 = 2 * (wave & 1);
+    float* const out = reinterpret_cast<float*>(p.t1);
     br_barrier();   // coefficients visible
-    f32x16 acc[2][2];   // [pixel row tile][channel tile]; register r <-> pixel (r & 3) + 8 (r >> 2) + 4 half, lane l31 <-> channel
+    bool first = true;
+    for (;;) {
+        const long long nxt = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;   // (last tile: its own rows again, see above)
+        rows_of(nxt, xn, xqn);
+        f32x16 acc[2][2];   // [pixel row tile][channel tile]; register r <-> pixel (r & 3) + 8 (r >> 2) + 4 half, lane l31 <-> channel
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float bias = coef_lds[512 + (ct0 + j) * 32 + l31];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = bias;
-    }
-#pragma unroll
-    for (int s = 0; s < C1_NSTAGE; ++s) {
-        storex(s, s % DX);
-        // operations issued after stage s's two DMA pieces: the next two stages' pieces (4) and the x loads requested since
-        // (XP per K step while any remain; the prologue's DX steps sit in front of stages 1 and 2 for s = 0)
-        auto cx = [](int k) { return k < C1_NSTAGE ? LX : 0; };
-        br_wait_vm(s == 0 ? 4 + DX * LX : s == 1 ? 4 + DX * LX + cx(DX) : s == 2 ? 4 + DX * LX + cx(DX) + cx(DX + 1)
-                                                                            : 4 + cx(s - 3 + DX) + cx(s - 2 + DX) + cx(s - 1 + DX));
-        br_barrier();
-        ring_issue(s + 3);
-        if (s + DX < C1_NSTAGE) loadx(s + DX, s % DX);
-        const unsigned char* const sx = xr + (s % C1_XSLOTS) * C1_XSTAGE;
-#pragma unroll
-        for (int j2 = 0; j2 < 2; ++j2) {   // the K step's two 8-float halves
-            u32x4 wf[2], xf[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const u32x4*>((j2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + (ct0 + j) * 2048);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * C1_XPITCH + br_xslot(l31, 2 * j2 + half));
+        for (int j = 0; j < 2; ++j) {
+            const float bias = coef_lds[512 + (ct0 + j) * 32 + l31];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mfma_chunk<T>(xf[i], wf[j], acc[i][j]);
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = bias;
         }
-    }
-    // epilogue: ReLU, 4-byte stores of 128 contiguous bytes per (pixel, channel tile)
-    float* const out = reinterpret_cast<float*>(p.t1);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int s = 0; s < C1_NSTAGE; ++s) {
+            storex(s, s % DX);
+            // Operations issued after stage s's two DMA pieces.  Steady state: the x loads of the step that requested it (LX), then
+            // two more steps' pieces and loads: 4 + 3 LX.  First tile: the prologue's three stages and DX x steps come first.  Later
+            // tiles, s < 3: the previous tile's 64 stores sit in between as well -- more than the counter's six bits hold: wait for 63.
+            const int steady = 4 + 3 * LX;
+            const int n_first = s == 0 ? 4 + DX * LX : s == 1 ? 4 + DX * LX + LX : s == 2 ? 4 + DX * LX + 2 * LX : steady;
+            const int n_later = s < 3 ? 63 : steady;
+            if (n_first == n_later) {
+                br_wait_vm(n_first);
+            } else if (first) {
+                br_wait_vm(n_first);
+            } else {
+                br_wait_vm(n_later);
+            }
+            br_barrier();
+            ring_issue((s + 3) % C1_NSTAGE);
+            if (s + DX < C1_NSTAGE) loadx(false, s + DX, s % DX);
+            else loadx(true, s + DX - C1_NSTAGE, s % DX);
+            const unsigned char* const sx = xr + (s % C1_XSLOTS) * C1_XSTAGE;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long m = m0 + (rt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m < p.M) {
+            for (int j2 = 0; j2 < 2; ++j2) {   // the K step's two 8-float halves
+                u32x4 wf[2], xf[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const u32x4*>((j2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + (ct0 + j) * 2048);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * C1_XPITCH + br_xslot(l31, 2 * j2 + half));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mfma_chunk<T>(xf[i], wf[j], acc[i][j]);
+            }
+        }
+        // epilogue: ReLU, 4-byte stores of 128 contiguous bytes per (pixel, channel tile): 64 per lane, unconditional (M is a multiple
+        // of 128: the launcher checks it -- every level the fused kernels take has whole 8 x 16 tiles)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = tile * 128 + (rt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) out[(size_t)m * 128 + (ct0 + j) * 32 + l31] = br_relu(acc[i][j][r]);
             }
+        if (nxt == tile) break;
+        tile = nxt;
+        first = false;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            xp[i] = xn[i];
+            if constexpr (UP) xq[i] = xqn[i];
         }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-requested stages and rows of the last tile have landed: nothing of this
+                                                        // workgroup writes LDS after it ends
 }
 
 }  // namespace hgk

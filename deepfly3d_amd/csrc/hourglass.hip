@@ -848,10 +848,15 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                             const void* const fn = a.in2 ? reinterpret_cast<const void*>(conv1_ring_f32_kernel<true>) : reinterpret_cast<const void*>(conv1_ring_f32_kernel<false>);
                             if (first_use_on_this_device(attr_c1[a.in2 ? 1 : 0]))
                                 DF3D_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+                            if (c.M % 128) {
+                                df3d::set_error("conv1 of the split bottleneck needs whole 128-pixel tiles (M = %lld)", c.M);
+                                return DF3D_EINVAL;
+                            }
+                            const unsigned c1_grid = (unsigned)std::min<long long>(c.M / 128, 2LL * cu_count());   // persistent: two workgroups per CU
                             if (a.in2)
-                                hipLaunchKernelGGL(conv1_ring_f32_kernel<true>, dim3((unsigned)((c.M + 127) / 128)), dim3(256), C1_LDS_BYTES, s, c);
+                                hipLaunchKernelGGL(conv1_ring_f32_kernel<true>, dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
                             else
-                                hipLaunchKernelGGL(conv1_ring_f32_kernel<false>, dim3((unsigned)((c.M + 127) / 128)), dim3(256), C1_LDS_BYTES, s, c);
+                                hipLaunchKernelGGL(conv1_ring_f32_kernel<false>, dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
                             DF3D_LAUNCH_CHECK();
                         }
                     }
