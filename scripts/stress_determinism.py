@@ -10,13 +10,13 @@ dev = torch.device("cuda:0")
 sd = synthetic_state_dict(0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 bad = 0
-for dtype in ("bf16", "f32"):
+for dtype in ("f16", "bf16", "f32"):
     eng = HourglassEngine(sd, dtype=dtype, device=dev)
     for n in (1, 7, 35, 120):
         img = torch.rand((n, 256, 512, 3), generator=torch.Generator().manual_seed(n), dtype=torch.float32).to(dev)
         ref = eng.forward(img).clone()
         # a second engine's launches on another stream keep the memory system busy while the first repeats
-        other = HourglassEngine(sd, dtype="bf16" if dtype == "f32" else "f32", device=dev)
+        other = HourglassEngine(sd, dtype="f16" if dtype == "f32" else "f32", device=dev)
         side = torch.cuda.Stream()
         noise = torch.rand((21, 256, 512, 3), device=dev)
         diffs = 0
