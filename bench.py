@@ -347,7 +347,14 @@ class Job:
 def ensure_one_rank_group(dev):
     """--force-collective at N = 1: a 1-rank RCCL process group, so that the packed gather really executes."""
     if not torch.distributed.is_initialized():
-        port = int(os.environ.get("MASTER_PORT", "29517"))
+        if os.environ.get("MASTER_PORT"):
+            port = int(os.environ["MASTER_PORT"])
+        else:   # any free port: nothing else has to find this one-rank group
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
         torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
 
 
