@@ -602,7 +602,12 @@ int launch_conv_rb(const ConvArgs& a, int rb, hipStream_t s) {
 
 template <typename T>
 int launch_conv(const ConvArgs& a, int taps, int rb, hipStream_t s) {
-    const int bn = (a.cout % 128 == 0) ? 128 : (a.cout % 64 == 0 ? 64 : 32);
+    int bn = (a.cout % 128 == 0) ? 128 : (a.cout % 64 == 0 ? 64 : 32);
+    // a launch too small to fill the chip with 128-channel tiles (the 4 x 8 hourglass level: 224 workgroups for 896 views) takes
+    // narrower ones: four times the workgroups, each with a quarter of the weights to pull -- the same K order per output, so the
+    // same bits
+    const long long wgs128 = ((a.M + BM - 1) / BM) * (a.cout / bn);
+    if (bn == 128 && wgs128 < 2LL * cu_count()) bn = taps == 1 ? 32 : 64;
     if (taps == 1) {
         if (bn == 128) return launch_conv_rb<T, 1, 128>(a, rb, s);
         if (bn == 64) return launch_conv_rb<T, 1, 64>(a, rb, s);
@@ -764,7 +769,8 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                 int rb = (st.conv.cin_pad % ke128 == 0) ? 128 : 64;
                 if (h->rb_override == 64) rb = 64;
                 const double mm = (double)a.M;
-                const int bn_tile = (a.cout % 128 == 0) ? 128 : (a.cout % 64 == 0 ? 64 : 32);
+                int bn_tile = (a.cout % 128 == 0) ? 128 : (a.cout % 64 == 0 ? 64 : 32);
+                if (bn_tile == 128 && ((a.M + BM - 1) / BM) * (a.cout / bn_tile) < 2LL * cu_count()) bn_tile = st.conv.taps == 1 ? 32 : 64;   // as launch_conv picks
                 ScopedTimer tm(h, s, std::string("conv_mfma_kernel<") + tname + ", " + std::to_string(st.conv.taps) + ", " + std::to_string(bn_tile) + ", " + std::to_string(rb) + ">",
                                2.0 * mm * st.conv.taps * st.conv.cin * st.conv.cout,
                                mm * eb * (st.conv.cin + st.conv.cout + (st.res >= 0 ? st.conv.cout : 0)), st.m1_elems * n * eb);
