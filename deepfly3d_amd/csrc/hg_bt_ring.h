@@ -390,7 +390,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
 #pragma unroll
     for (int d = 0; d < BR_W2_STAGES / 2; ++d) {
         const int s0 = NS1 + 2 * d;
-#if !defined(BR_ABL) || BR_ABL != 4
+#if defined(BR_ABL) && (BR_ABL == 7 || BR_ABL == 8)   // ablation: every wave waits for its own DMA pieces, no barrier (timing of a private-ring phase 2)
+        br_wait_vm(d == 0 ? 2 : 0);
+        if (d == 0) br_barrier();
+#elif !defined(BR_ABL) || BR_ABL != 4
         br_wait_vm(d == 0 ? 2 : 0);   // d = 0: phase 1 has already requested stage 10
         br_barrier();                 // (first iteration: also publishes the t1 tile and b2 / b3)
 #else
@@ -479,7 +482,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
             constexpr int E0 = 8 + ((UP || ADD2) ? 4 : 0);
             if constexpr (DS) br_wait_vm(dd == 0 ? (nh == 0 ? 0 : 8) : (dd == 1 && nh == 0) ? CIN / 16 : 0);
             else br_wait_vm(dd == 1 ? 8 : nh == 0 ? 0 : E0);
+#if defined(BR_ABL) && BR_ABL == 8
+            if (dd == 0 && nh == 0) br_barrier();
+#else
             br_barrier();
+#endif
             if (s0 + 3 < NSTAGE) {
                 ring_issue(s0 + 2);
                 ring_issue(s0 + 3);

@@ -53,6 +53,11 @@ __global__ __launch_bounds__(256) void bt_c1_pack_f32_kernel(const float* __rest
 // keeps the counted waits valid; the kernel drains the queue before it ends.
 template <bool UP>
 __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {   // (three workgroups per CU fit -- 50.5 KB -- and measured no faster)
+    // Also measured, same box, none of them faster for the plain form (1 043 us per average launch; matrix pipe 0.83 busy at 2.30 GHz,
+    // the lowest clock of the fp32 kernels): x requested 2 / 4 / 8 K steps ahead (1 057-1 063 us: not latency); the step's eight
+    // fragments requested right behind the barrier, the previous step's second half multiplied first and the next step's x staged
+    // under the MFMAs (1 051-1 057; UP form 4 410 -> 4 200); transposed accumulators with sixteen 16-byte stores per lane
+    // instead of 64 four-byte ones (1 071).
     using T = float;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;

@@ -16,6 +16,17 @@ __global__ __launch_bounds__(256) void bt_fc_pack_kernel(const unsigned short* _
     *reinterpret_cast<u32x4*>(stream + (size_t)st * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(src);
 }
 
+// float32 blob -> Wfc stage stream: 16 K steps (16 channels = 64 bytes) x 2 row halves, the same 128-row x 64-byte stage image
+constexpr int HD_FC_STAGES_F32 = 32;
+__global__ __launch_bounds__(256) void bt_fc_pack_f32_kernel(const float* __restrict__ wfc, unsigned char* __restrict__ stream) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= HD_FC_STAGES_F32 * 512) return;
+    const int st = idx >> 9, r = (idx >> 2) & 127, c = idx & 3;
+    const int s = st >> 1, rh = st & 1;
+    const float* const src = wfc + (size_t)(rh * 128 + r) * 256 + 16 * s + 4 * c;   // Wfc [256][256]
+    *reinterpret_cast<u32x4*>(stream + (size_t)st * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(src);
+}
+
 // =====================================================================================================
 // Fused stack head:   y = relu(Wfc r + bfc)                       (fc, BN folded; 256 -> 256)
 //                     score = Wsc y + bsc                          (256 -> 19, padded to 32)
@@ -73,7 +84,7 @@ struct HeadCfg {
     static constexpr int RING_SLOTS = 6;                             // 16-bit: LDS-DMA ring of 8 KB weight stages ...
     static constexpr int R_SLOTS = 3;                                // ... behind it three 8 KB K slices of the r tile (phase A: LDS-DMA too) ...
     static constexpr int SLICE_PITCH = 64 * 2 + 16;                  // ... whose space the epilogue re-uses: one 32 px x 64 ch slice per wave
-    static constexpr int RING_BYTES = EB == 2 ? RING_SLOTS * 8192 + (LAST ? R_SLOTS * 8192 : 4 * 32 * SLICE_PITCH) : 0;   // (LAST has no phase C)
+    static constexpr int RING_BYTES = RING_SLOTS * 8192 + (LAST || EB == 4 ? R_SLOTS * 8192 : 4 * 32 * SLICE_PITCH);   // (LAST has no phase C; float32: the r ring in both)
     static constexpr int STAGE_BYTES = S2 > RING_BYTES ? S2 : RING_BYTES;
     static constexpr int MISC = (256 + 32 + 256) * 4;                // bfc | bsc | bfc_ + bsc_
     static constexpr int LDS_BYTES = STAGE_BYTES + MISC;
@@ -103,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
     for (int m = 0; m < 8; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[m][r] = 0.0f;
-    if (EB == 2 && p.fcstream != nullptr) {
-        // 16-bit: Wfc arrives as pre-swizzled 8 KB stage images (two per 32-channel K step: row halves) through a six-slot LDS-DMA
+    if (p.fcstream != nullptr) {
+        // Wfc arrives as pre-swizzled 8 KB stage images (two per 64-byte K step -- 32 channels in 16-bit, 16 in float32: row halves) through a six-slot LDS-DMA
         // ring, two K steps ahead, one barrier per step.  The r operand:
         //   LAST (RDMA): the same road -- per K step every wave copies the 64-byte K slice of ITS OWN 32 pixels (two 1 KB pieces,
         //     16 pixels each, four lanes per pixel) into a three-slot ring: no registers, 64-byte segments instead of the 32-byte
@@ -115,10 +126,12 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
         //     activation load sits in the in-order queue between two weight stages.  (Measured with the DMA form: 3 460 us against
         //     3 290; with phase C's skip values requested at the top of the kernel as well 4 000 -- 256 registers do not hold them
         //     beside y's 128 accumulators.)
+        //   float32: the DMA form in both heads (the register form would need 128 registers of r fragments).
         // Same MFMA K order as the staged form below in every case.
-        constexpr bool RDMA = LAST;
+        constexpr bool RDMA = LAST || EB == 4;
+        constexpr int NSTEP = 256 * EB / 64;
         constexpr int NSLOT = 6, RSLOT = C::R_SLOTS;
-        static_assert(EB != 2 || !LAST || (NSLOT + RSLOT) * BR_STAGE_BYTES <= C::STAGE_BYTES, "the rings live in the stage area");
+        static_assert(!RDMA || (NSLOT + RSLOT) * BR_STAGE_BYTES <= C::STAGE_BYTES, "the rings live in the stage area");
         const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)stage;
         const unsigned wuni = (unsigned)__builtin_amdgcn_readfirstlane(wave);
         const unsigned wvoff = wuni * 2048u + (unsigned)lane * 16u;
@@ -131,9 +144,9 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
             const int pl = 16 * q + (lane >> 2);
             long long m = mw + pl;
             if (m >= p.M) m = p.M - 1;
-            rvoff[q] = (unsigned)((m - mb) * 512 + (((lane & 3) ^ ((pl >> 2) & 3)) << 4));
+            rvoff[q] = (unsigned)((m - mb) * (256 * EB) + (((lane & 3) ^ ((pl >> 2) & 3)) << 4));
         }
-        const unsigned char* const rbase = reinterpret_cast<const unsigned char*>(p.r) + (size_t)mb * 512;
+        const unsigned char* const rbase = reinterpret_cast<const unsigned char*>(p.r) + (size_t)mb * (256 * EB);
         auto issue_step = [&](int s) {   // both weight stages of K step s (this wave copies pieces 2 wave, 2 wave + 1 of each) and the r slice
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
@@ -164,10 +177,10 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
         const unsigned char* const rfrag = stage + NSLOT * BR_STAGE_BYTES + wave * 2048 + l31 * 64;
         const unsigned rsw = (unsigned)((l31 >> 2) & 3);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            br_wait_vm(s < 7 ? (RDMA ? 6 : 4) : 0);   // the pieces of step s + 1 (requested one step ago) may still be in flight
+        for (int s = 0; s < NSTEP; ++s) {
+            br_wait_vm(s < NSTEP - 1 ? (RDMA ? 6 : 4) : 0);   // the pieces of step s + 1 (requested one step ago) may still be in flight
             br_barrier();                // (first step: also publishes the bias vectors)
-            if (s + 2 < 8) issue_step(s + 2);   // into the slots step s - 1 has released
+            if (s + 2 < NSTEP) issue_step(s + 2);   // into the slots step s - 1 has released
             if constexpr (RDMA) {
                 u32x4 rf[2];
 #pragma unroll

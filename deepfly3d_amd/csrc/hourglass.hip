@@ -477,10 +477,10 @@ struct df3d_hg {
                 Step st;
                 st.kind = ST_HEAD;
                 st.last = last;
-                if (ring && lp()) {   // Wfc through the LDS-DMA stage ring (hg_head.h)
+                if (ring) {   // Wfc through the LDS-DMA stage ring (hg_head.h)
                     st.wstream = (long long)stream_bytes;
-                    stream_bytes += (size_t)HD_FC_STAGES * BR_STAGE_BYTES;
-                    if (!last) {
+                    stream_bytes += (size_t)(lp() ? HD_FC_STAGES : HD_FC_STAGES_F32) * BR_STAGE_BYTES;
+                    if (!last && lp()) {
                         st.wstream2 = (long long)stream_bytes;
                         stream_bytes += (size_t)HD_FC2_STAGES * BR_STAGE_BYTES;
                     }
@@ -1171,6 +1171,9 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
     } else if (h->stream_bytes) {
         DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(lowp_dev) & 255) == 0, "lowp buffer must be 256-byte aligned");
         for (const Step& st : h->steps) {
+            if (st.kind == ST_HEAD && st.wstream >= 0)
+                hipLaunchKernelGGL(bt_fc_pack_f32_kernel, dim3((HD_FC_STAGES_F32 * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
+                                   blob_dev + st.conv.w_off, reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
             if (st.kind != ST_BOTTLENECK || st.wstream < 0) continue;
             hipLaunchKernelGGL(bt_ring_pack_f32_kernel, dim3((BRF_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
                                blob_dev + st.conv.w_off, blob_dev + st.conv2b.w_off, blob_dev + st.conv3b.w_off,
