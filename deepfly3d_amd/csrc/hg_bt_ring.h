@@ -353,7 +353,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
+#if defined(BR_ABL) && BR_ABL == 9   // ablation 9: no MFMAs anywhere (the memory floor of the kernel's access pattern)
+                for (int i = 0; i < 6; ++i) asm volatile("" ::"v"(wfr[j]), "v"(xfr[j][i]));
+#else
                 for (int i = 0; i < 6; ++i) mfma_chunk<T>(wfr[j], xfr[j][i], acc[i]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         br_barrier();   // every wave is done with the x ring: the t1 tile may overwrite it
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
 #endif
 #pragma unroll
             for (int m = 0; m < NT; ++m) {
-#if defined(BR_ABL) && BR_ABL == 1   // ablation: no MFMAs (the fragments stay live)
+#if defined(BR_ABL) && (BR_ABL == 1 || BR_ABL == 9)   // ablation: no MFMAs (the fragments stay live)
                 asm volatile("" ::"v"(wfr[g & 1][m]), "v"(tfr[g & 1]));
 #else
                 mfma_chunk<T>(wfr[g & 1][m], tfr[g & 1], t2[m]);
@@ -537,7 +541,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 const u32x4 tf = dd < 2 ? t2f[2 * dd + (g >> 1)][g & 1] : xc[DS ? 2 * (2 * (dd - 2) + (g >> 1)) + (g & 1) : 0];
 #pragma unroll
+#if defined(BR_ABL) && BR_ABL == 9
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(w3r[g & 1][i]), "v"(tf));
+#else
                 for (int i = 0; i < 4; ++i) acc[i] = Lp<T>::mfma(w3r[g & 1][i], tf, acc[i]);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
