@@ -28,6 +28,9 @@
 // has landed for this wave; the barrier that follows makes that true for all four waves.  A smaller N is always safe.
 #pragma once
 #include "hg_kernels.h"
+#ifndef BR_ABLM
+#define BR_ABLM 0   // development builds: ablation mask (1 no MFMAs, 2 no weight DMA, 4 no x loads, 8 no residual loads, 16 no output stores)
+#endif
 
 namespace hgk {
 
@@ -231,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     // ---- the weight ring ----------------------------------------------------------------------------------
     const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
     auto ring_issue = [&](int s) {   // stage s -> ring slot s % 4; this wave copies pieces 2 wave, 2 wave + 1
+        if (BR_ABLM & 2) return;   // (ablation mask, development builds only: no weight DMA)
         const unsigned dst = ring_addr + (unsigned)(s % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048;
         br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)s * BR_STAGE_BYTES, wvoff, dst);
     };
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     u32x4 rb[UP ? DX : 1][XP];
     auto loadx = [&](int s, int slot) {   // out-of-image halo rows read pixel (0, 0) (a valid address); the t1 epilogue zeroes what comes of them
 #pragma unroll
-#if defined(BR_ABL) && BR_ABL == 5   // ablation: no x loads (registers only)
+#if (defined(BR_ABL) && BR_ABL == 5) || (BR_ABLM & 4)   // ablation: no x loads (registers only)
         for (int i = 0; i < XP; ++i) rx[slot][i] = u32x4{(unsigned)s, (unsigned)tid, 0u, 0u};
 #else
         for (int i = 0; i < XP; ++i) rx[slot][i] = *reinterpret_cast<const u32x4*>(xp[i] + s * 64);
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-#if defined(BR_ABL) && BR_ABL == 9   // ablation 9: no MFMAs anywhere (the memory floor of the kernel's access pattern)
+#if (defined(BR_ABL) && BR_ABL == 9) || (BR_ABLM & 1)   // ablation 9: no MFMAs anywhere (the memory floor of the kernel's access pattern)
                 for (int i = 0; i < 6; ++i) asm volatile("" ::"v"(wfr[j]), "v"(xfr[j][i]));
 #else
                 for (int i = 0; i < 6; ++i) mfma_chunk<T>(wfr[j], xfr[j][i], acc[i]);
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
 #endif
 #pragma unroll
             for (int m = 0; m < NT; ++m) {
-#if defined(BR_ABL) && (BR_ABL == 1 || BR_ABL == 9)   // ablation: no MFMAs (the fragments stay live)
+#if (defined(BR_ABL) && (BR_ABL == 1 || BR_ABL == 9)) || (BR_ABLM & 1)   // ablation: no MFMAs (the fragments stay live)
                 asm volatile("" ::"v"(wfr[g & 1][m]), "v"(tfr[g & 1]));
 #else
                 mfma_chunk<T>(wfr[g & 1][m], tfr[g & 1], t2[m]);
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const int pw = 4 * c + (lane >> 4);
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin) +
+                        const u32x4 v = (BR_ABLM & 8) ? u32x4{(unsigned)pw, (unsigned)tid, 0u, 0u} : *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(xin) +
                             ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CIN + nh * 128 + (lane & 15) * 8);
                         xres[4 * c + 0] = v[0];
                         xres[4 * c + 1] = v[1];
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 const u32x4 tf = dd < 2 ? t2f[2 * dd + (g >> 1)][g & 1] : xc[DS ? 2 * (2 * (dd - 2) + (g >> 1)) + (g & 1) : 0];
 #pragma unroll
-#if defined(BR_ABL) && BR_ABL == 9
+#if (defined(BR_ABL) && BR_ABL == 9) || (BR_ABLM & 1)
                 for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(w3r[g & 1][i]), "v"(tf));
 #else
                 for (int i = 0; i < 4; ++i) acc[i] = Lp<T>::mfma(w3r[g & 1][i], tf, acc[i]);
@@ -587,6 +591,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
             }
             if constexpr (ADD2) v = add_chunk<T>(v, x2[c & 3]);   // the rounded block output + the low-resolution tensor, rounded again
             fin[c] = v;
+            if ((BR_ABLM & 16) && v[0] != 0x12345678u) continue;   // (ablation: practically no output stores)
             *reinterpret_cast<u32x4*>(outs + ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CO + nh * 128 + (lane & 15) * 8) = v;
         }
         if (!DS && p.pool_in) {   // same lane geometry as the pooling of `out` below
