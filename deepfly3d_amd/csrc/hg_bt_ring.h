@@ -16,6 +16,9 @@
 //     K-steps ahead, into a 3-deep LDS ring that lives in the not-yet-written t1 region, one barrier per step; the
 //     bn1 scale / shift vectors sit in LDS so that no other vector-memory operation sits in the in-order queue.
 //
+//   * W2D (round 3, the engine's default; template flag): the 36 W2 stages skip the ring -- phase 2 runs channel-split, every wave
+//     loading its own 1 KB MFMA fragments straight from global memory (see the template's comment); the ring then carries W1 | W3.
+//
 // LDS per workgroup: ring 32 KB (4 stages) + t1 45 KB (180 rows x 256 B, XOR-swizzled instead of padded) + coefficients
 // 2.5 KB + masks = 81 472 B -> two workgroups per CU.
 //
@@ -44,6 +47,7 @@ struct BtRingArgs {
     void* pool_in;        // optional NHWC [V, H/2, W/2, 256]: 2x2 max-pool of the block's INPUT (for the hourglass level whose
                           // input no fused producer has pooled: its skip values pass through the epilogue anyway)
     const void* wstream;  // br_nstage(CIN, DS) x BR_STAGE_BYTES: pre-swizzled stage images (bt_ring_pack_kernel)
+    const void* w2d;      // W2D kernels: W2' as 72 x 4 one-KB MFMA A fragments (bt_w2d_pack_kernel): group (tap, kc, K half), wave's 32 rows
     const void* t1in;     // fp32 split form (hg_c1_f32.h): [V, H, W, 128] f32 = relu(W1' relu(bn1 x) + b1'), from conv1_ring_f32_kernel
     const void* zeros;    // ... and >= 256 bytes of zeros (the padding of the 3x3 convolution for halo pixels outside the image)
     const float* b1;      // [128] (bn2 folded)
@@ -102,6 +106,22 @@ __global__ __launch_bounds__(256) void bt_ring_pack_kernel(const unsigned short*
         else src = wd + ((size_t)nh * 128 + r) * cin + 32 * (k - 4) + 8 * c;  // Wd [256][CIN]
     }
     *reinterpret_cast<u32x4*>(stream + (size_t)s * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(src);
+}
+
+// 16-bit blob -> the direct-load form of W2' (W2D kernels): block (g, w) = 1 KB = the MFMA A fragment of rows 32 w .. 32 w + 31 for
+// group g = (tap * 4 + kc) * 2 + j: lane (l31, half) holds the 8 K values 32 kc + 8 (2 j + half) .. of row 32 w + l31 -- the very
+// 16 bytes the ring form reads from chunk 2 j + half of stage image tap * 4 + kc
+constexpr int BR_W2D_GROUPS = 2 * BR_W2_STAGES;           // 72
+constexpr int BR_W2D_BYTES = BR_W2D_GROUPS * 4 * 1024;    // 294 912
+constexpr int BR_W2D_DEPTH = 12;                          // fragments in flight per wave (one per four MFMAs)
+__global__ __launch_bounds__(256) void bt_w2d_pack_kernel(const unsigned short* __restrict__ w2, unsigned char* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= BR_W2D_GROUPS * 256) return;
+    const int lane = idx & 63, w = (idx >> 6) & 3, g = idx >> 8;
+    const int j = g & 1, q = g >> 1, tap = q >> 2, kc = q & 3;
+    const int l31 = lane & 31, half = lane >> 5;
+    const unsigned short* const src = w2 + ((size_t)tap * 128 + 32 * w + l31) * 128 + 32 * kc + 8 * (2 * j + half);   // W2 [9][128][128]
+    *reinterpret_cast<u32x4*>(out + (size_t)idx * 16) = *reinterpret_cast<const u32x4*>(src);
 }
 
 // LDS-DMA of one 8 KB stage: this wave's two 1 KB pieces (lane l's 16 bytes land at dst + 16 l; dst wave-uniform, in M0).
@@ -191,7 +211,11 @@ __device__ unsigned long long br_dbg[8];
 
 // CIN = 256: the identity-skip block (out = ... + x); CIN = 128 (DS): the skip is a 1x1 convolution of the raw input, accumulated
 // into the same MFMA accumulators behind W3 (layer2), the x operand of which comes straight from global memory in MFMA layout
-template <typename T, bool UP, int CIN = 256, bool ADD2 = false>
+// W2D: the 3x3's weights do not go through the ring: in phase 2 wave w computes t2 channels 32 w .. 32 w + 31 for ALL 128 pixels and
+// loads its own A fragments straight from global memory into registers (L2 hits, BR_W2D_DEPTH ahead) -- no DMA into LDS, no
+// barrier in the phase, four LDS fragment reads per four MFMAs instead of five; t2 then crosses to the pixel-owning waves
+// through the dead t1 region.  Same products in the same K order in every accumulator: bit-identical to the ring form.
+template <typename T, bool UP, int CIN = 256, bool ADD2 = false, bool W2D = false>
 __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     static_assert(sizeof(T) == 2, "16-bit storage formats only (the fp32 form is hg_bt_ring_f32.h)");
     static_assert(!ADD2 || (!UP && CIN == 256), "the fused up-path sum is written by plain identity-skip blocks");
@@ -200,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     static_assert(!(UP && DS), "the upsample-add input exists for the identity-skip block only");
     constexpr int NS1 = CIN / 32;                        // W1 stages = K steps of phase 1
     constexpr int NSD = DS ? CIN / 32 : 0;               // skip-convolution stages per output half
-    constexpr int NSTAGE = br_nstage(CIN, DS);
+    constexpr int NSTAGE = br_nstage(CIN, DS) - (W2D ? BR_W2_STAGES : 0);   // stages that go through the ring
     constexpr int LX = UP ? 6 : 3;   // vector-memory loads per thread and x step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;
@@ -236,7 +260,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     auto ring_issue = [&](int s) {   // stage s -> ring slot s % 4; this wave copies pieces 2 wave, 2 wave + 1
         if (BR_ABLM & 2) return;   // (ablation mask, development builds only: no weight DMA)
         const unsigned dst = ring_addr + (unsigned)(s % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048;
-        br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)s * BR_STAGE_BYTES, wvoff, dst);
+        const int si = (W2D && s >= NS1) ? s + BR_W2_STAGES : s;   // W2D: the ring sequence is W1 | W3 (| Wd), the stream keeps W2 in between
+        br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)si * BR_STAGE_BYTES, wvoff, dst);
     };
     // fragment addresses inside a stage: rows 32 m + l31, chunk 2 j + half (+ slot * 8192 + m * 2048 as immediates)
     const unsigned char* const wf0 = ring + br_swz(l31, half);
@@ -393,6 +418,62 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     unsigned tsw[3];   // ((tile column + kx) & 15 ^ half) << 4: the swizzle term of this lane's t1 fragment, per kx
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) tsw[kx] = (unsigned)((((px + kx) & 15) ^ half) << 4);
+    u32x4 t2f[NT][2];   // ReLU(t2) rounded to 16 bits: the B operands of phase 3 (tile kc, registers 8 q2 .. 8 q2 + 7 -> four dwords)
+    if constexpr (W2D) {
+        constexpr int NG = BR_W2D_GROUPS, D = BR_W2D_DEPTH;
+        static_assert(NG % D == 0, "the fragment queue's slots repeat");
+        const unsigned char* const wsrc = reinterpret_cast<const unsigned char*>(p.w2d) + ((size_t)wave * 64 + lane) * 16;   // group g: + 4096 g
+        u32x4 wq[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) wq[k] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)k * 4096);
+        br_barrier();   // publishes the t1 tile and b2 / b3 (the ring rests: phase 1 has requested the first three W3 stages)
+#pragma unroll
+        for (int m = 0; m < NT; ++m)   // accumulator m = pixel tile m (tile rows 2 m, 2 m + 1); register 4 q + e <-> channel 32 wave + 8 q + 4 half + e
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b2_lds + 32 * wave + 8 * q + 4 * half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
+            }
+        const unsigned char* const t1_px = t1_lds + ((l31 >> 4) * BT_HW + px) * BR_T1_PITCH;   // pixel l31 of tile 0; tile m: + m * 2 * BT_HW rows
+        u32x4 tfr[2][NT];
+        auto load_t = [&](int g, int buf) {
+            const int j = g & 1, q = g >> 1, tap = q >> 2, kc = q & 3;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int m = 0; m < NT; ++m)
+                tfr[buf][m] = *reinterpret_cast<const u32x4*>(t1_px + ((2 * m + ky) * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
+        };
+        load_t(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load_t(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NT; ++m) mfma_chunk<T>(wq[g % D], tfr[g & 1][m], t2[m]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + D < NG) wq[g % D] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)(g + D) * 4096);
+        }
+        // t2 crosses to the waves that own the pixels in phase 3: 128 rows x 256 B in the dead t1 region; chunk (kc, q2, half) of a
+        // row = the 16 bytes t2f[kc][q2] of lane (pixel, half), in slot chunk ^ (row & 15)
+        br_barrier();   // every wave is done reading t1
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint2 w;
+                w.x = br_relu_pk(Lp<T>::pack2(t2[m][4 * t + 0], t2[m][4 * t + 1]));
+                w.y = br_relu_pk(Lp<T>::pack2(t2[m][4 * t + 2], t2[m][4 * t + 3]));
+                const int chunk = wave * 4 + (t >> 1) * 2 + half;
+                *reinterpret_cast<uint2*>(t1_lds + (32 * m + l31) * 256 + ((chunk ^ (l31 & 15)) << 4) + (t & 1) * 8) = w;
+            }
+        br_barrier();
+#pragma unroll
+        for (int kc = 0; kc < NT; ++kc)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+                t2f[kc][q2] = *reinterpret_cast<const u32x4*>(t1_lds + (32 * wave + l31) * 256 + (((kc * 4 + q2 * 2 + half) ^ (l31 & 15)) << 4));
+    } else {
     // two stages per barrier: the pair (s0, s0 + 1) was requested one double-step earlier, the pair after it goes into the two
     // slots the previous double-step has just released
 #pragma unroll
@@ -457,21 +538,21 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // ReLU + rounding to bf16 once: the B operands of phase 3 (tile kc, registers 8 q2 .. 8 q2 + 7 -> four dwords)
-    u32x4 t2f[NT][2];
+    // ReLU + rounding to bf16 once
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
         for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
             for (int e = 0; e < 4; ++e) t2f[m][q2][e] = br_relu_pk(Lp<T>::pack2(t2[m][8 * q2 + 2 * e], t2[m][8 * q2 + 2 * e + 1]));
+    }
 
     BR_STAMP(3);
     // ---- phase 3: out^T = W3 t2^T + b3 (+ x) -------------------------------------------------------------------
     // transposed like phase 1 (A = W3 rows, B = the t2 registers): accumulator register 4 t + e of channel tile i holds, for
     // pixel l31 of the wave, output channel 128 nh + 32 i + 8 t + 4 half + e -> 8-byte stores into the wave's LDS slice
     unsigned char* const outp = reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * CO * 2;
-    constexpr int S3 = NS1 + BR_W2_STAGES;   // first W3 stage
+    constexpr int S3 = W2D ? NS1 : NS1 + BR_W2_STAGES;   // first W3 stage (ring numbering)
     constexpr int PER_NH = 4 + NSD;          // stages per 128-channel output half: W3 (4), then the skip convolution's (DS)
     // DS: the raw input of this lane's pixel as MFMA B operands -- K chunk kc = channels 16 kc + 8 half .. (requested once, in the
     // first double-step, straight from global memory: tile pixel (2 wave + (l31 >> 4), l31 & 15))
@@ -496,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
             br_barrier();
 #endif
             if (s0 + 3 < NSTAGE) {
-                ring_issue(s0 + 2);
+                if (!(W2D && nh == 0 && dd == 0)) ring_issue(s0 + 2);   // (W2D: phase 1, three stages ahead, has requested it)
                 ring_issue(s0 + 3);
             }
             if (dd == 0) {

@@ -56,6 +56,7 @@ struct Step {
     bool pool_only = false;           // ... whose full-resolution output nobody reads: `out` IS the pooled tensor
     double m1_elems = 0;              // activation elements per view this step moves in the fusion model M1
     int t1 = -1;                      // ST_BOTTLENECK, fp32 split form (hg_c1_f32.h): the tensor conv1's kernel writes and the tail kernel reads
+    long long wstream_w2d = -1;       // ... 16-bit W2D: byte offset of the direct-load form of W2'
     long long wstream_c1 = -1;        // ... and the byte offset of conv1's weight stream
     int chain = -1;                   // >= 0: planned inside chain number `chain` (frees postponed: its tensors share no memory)
 };
@@ -112,6 +113,7 @@ struct df3d_hg {
                           // copy, consumer side otherwise; 2 = always folded into the input load of the consuming bottleneck (round 2)
     int l1 = 1;           // 1 = bf16 layer1 (64 -> 64 -> 64 -> 128) runs as the LDS-resident-weights kernel of hg_bt_l1.h
     int ring = 1;         // 1 = the 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring*.h)
+    int w2d = 1;          // 16-bit ring bottlenecks: 1 (default) = the 3x3's weights as direct per-wave fragment loads (hg_bt_ring.h W2D), bit-identical
     int split1 = 1;       // fp32: 1 (default) = plain 256 -> 128 -> 128 -> 256 blocks run as conv1 (every pixel once) + tail (hg_c1_f32.h), bit-identical
     bool uses_zero_page = false;
     size_t zero_off = 0;  // byte offset of 256 zero bytes behind the weight streams (split form: the 3x3 padding of the tail's LDS-DMA)
@@ -285,10 +287,18 @@ struct df3d_hg {
                 // layer2: the same ring kernel with 128 input channels and the skip convolution as eight more stages
                 st.wstream = (long long)stream_bytes;
                 stream_bytes += (size_t)br_nstage(128, true) * BR_STAGE_BYTES;
+                if (w2d) {
+                    st.wstream_w2d = (long long)stream_bytes;
+                    stream_bytes += (size_t)BR_W2D_BYTES;
+                }
             }
             if (ring && cin == 256 && planes == 128) {   // weights through the LDS-DMA ring (hg_bt_ring.h, hg_bt_ring_f32.h)
                 st.wstream = (long long)stream_bytes;
                 stream_bytes += (size_t)(lp() ? BR_NSTAGE : BRF_NSTAGE) * BR_STAGE_BYTES;
+                if (w2d && lp()) {
+                    st.wstream_w2d = (long long)stream_bytes;
+                    stream_bytes += (size_t)BR_W2D_BYTES;
+                }
                 if (pool_input && x2 < 0 && pooled_of[x] < 0) {
                     st.pool_in = new_tensor(tx.h / 2, tx.w / 2, cin);
                     pooled_of[x] = st.pool_in;
@@ -684,14 +694,18 @@ template <> struct TypeName<__hip_bfloat16> { static constexpr const char* value
 template <> struct TypeName<_Float16> { static constexpr const char* value = "_Float16"; };
 
 // one launcher per 16-bit element type (hipFuncSetAttribute is per instantiation and per device)
-template <typename T, bool UP, int CIN, bool ADD2 = false>
-int launch_ring_lp(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
+template <typename T, bool UP, int CIN, bool ADD2, bool W2D>
+int launch_ring_lp_(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
     static unsigned attr_done = 0;
     if (first_use_on_this_device(attr_done))
-        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_kernel<T, UP, CIN, ADD2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL((bottleneck_ring_kernel<T, UP, CIN, ADD2>), dim3(blocks), dim3(256), lds_bytes, s, r);
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_kernel<T, UP, CIN, ADD2, W2D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL((bottleneck_ring_kernel<T, UP, CIN, ADD2, W2D>), dim3(blocks), dim3(256), lds_bytes, s, r);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
+}
+template <typename T, bool UP, int CIN, bool ADD2 = false>
+int launch_ring_lp(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
+    return r.w2d ? launch_ring_lp_<T, UP, CIN, ADD2, true>(r, blocks, lds_bytes, s) : launch_ring_lp_<T, UP, CIN, ADD2, false>(r, blocks, lds_bytes, s);
 }
 template <bool UP, bool ADD2 = false, bool TAIL = false>
 int launch_ring_f32(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
@@ -827,10 +841,11 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                     r.t1in = nullptr; r.zeros = nullptr;
                     r.pool_in = st.pool_in >= 0 ? tptr(st.pool_in) : nullptr;
                     r.wstream = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream;
+                    r.w2d = st.wstream_w2d >= 0 ? reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream_w2d : nullptr;
                     r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd; r.s1 = a.s1; r.t1 = a.t1;
                     r.V = n; r.H = ti.h; r.W = ti.w;
                     if (ds) {   // 16-bit layer2
-                        ScopedTimer tm(h, s, std::string("bottleneck_ring_kernel<") + tname + ", false, 128, false>", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl), px * eb * (cin + 2.0 * pl), st.m1_elems * n * eb);
+                        ScopedTimer tm(h, s, std::string("bottleneck_ring_kernel<") + tname + ", false, 128, false, " + (r.w2d ? "true>" : "false>"), 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl), px * eb * (cin + 2.0 * pl), st.m1_elems * n * eb);
                         if constexpr (sizeof(T) == 2)
                             if (int rc = launch_ring_lp<T, false, 128>(r, n * (ti.h / BT_TH) * (ti.w / BT_TW), BR_LDS_BYTES, s)) return rc;
                         break;
@@ -868,7 +883,7 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                     }
                     const char* const flags2 = split ? (a.in2 ? "true, false, true>" : a.add2 ? "false, true, true>" : "false, false, true>")
                                                      : a.in2 ? "true, false, false>" : a.add2 ? "false, true, false>" : "false, false, false>";
-                    ScopedTimer tm(h, s, eb == 2 ? std::string("bottleneck_ring_kernel<") + tname + (a.in2 ? ", true, 256, false>" : a.add2 ? ", false, 256, true>" : ", false, 256, false>")
+                    ScopedTimer tm(h, s, eb == 2 ? std::string("bottleneck_ring_kernel<") + tname + (a.in2 ? ", true, 256, false, " : a.add2 ? ", false, 256, true, " : ", false, 256, false, ") + (r.w2d ? "true>" : "false>")
                                                  : std::string("bottleneck_ring_f32_kernel<") + flags2,   // as rocprofv3 prints them
                                    2.0 * px * ((split ? 0.0 : (double)cin * pl) + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl + (split ? pl : 0)), st.m1_elems * n * eb);
                     const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
@@ -1077,6 +1092,13 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
         h->build();
         return DF3D_OK;
     }
+    if (!strcmp(key, "w2d")) {
+        DF3D_CHECK_ARG(value == 0 || value == 1, "w2d must be 0 or 1");
+        DF3D_CHECK_ARG(h->blob == nullptr, "set 'w2d' before df3d_hg_set_weights (it changes the weight streams)");
+        h->w2d = value;
+        h->build();
+        return DF3D_OK;
+    }
     if (!strcmp(key, "split1")) {
         DF3D_CHECK_ARG(value == 0 || value == 1, "split1 must be 0 or 1");
         DF3D_CHECK_ARG(h->blob == nullptr, "set 'split1' before df3d_hg_set_weights (it changes the plan and the weight streams)");
@@ -1155,6 +1177,9 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
                                    reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
                 continue;
             }
+            if (st.wstream_w2d >= 0)
+                hipLaunchKernelGGL(bt_w2d_pack_kernel, dim3((BR_W2D_GROUPS * 256 + 255) / 256), dim3(256), 0, df3d::as_stream(stream), lp + st.conv2b.w_off,
+                                   reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_w2d);
             const bool dsb = st.conv.cin != 2 * st.conv.cout;   // layer2: 128 -> 128 -> 128 -> 256 with the skip convolution
             hipLaunchKernelGGL(bt_ring_pack_kernel, dim3((br_nstage(st.conv.cin, dsb) * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
                                lp + st.conv.w_off, lp + st.conv2b.w_off, lp + st.conv3b.w_off, dsb ? lp + st.conv4b.w_off : nullptr, st.conv.cin,

@@ -97,7 +97,7 @@ class HourglassEngine:
     """The device engine: `forward(images_nhwc) -> heat-maps (n, 19, H/4, W/4)` on the current torch stream."""
 
     def __init__(self, state_dict, dtype="f32", num_stacks=2, device=None, height=256, width=512, row_bytes=0, fuse=True, fuse_upadd=None, ring=None, l1=None,
-                 chain_views=None, split1=None):
+                 chain_views=None, split1=None, w2d=None):
         _native.require_gpu()
         self.lib = _native.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -124,6 +124,10 @@ class HourglassEngine:
             split1 = int(os.environ["DF3D_SPLIT1"])
         if split1 is not None and dtype == "f32":  # fp32: conv1 of the identity-skip bottlenecks as a launch of its own (csrc/hg_c1_f32.h), bit-identical
             _native.check(self.lib.df3d_hg_set_option(self.h, b"split1", 1 if split1 else 0), "df3d_hg_set_option")
+        if w2d is None and os.environ.get("DF3D_W2D"):
+            w2d = int(os.environ["DF3D_W2D"])
+        if w2d is not None and dtype != "f32":  # 16-bit: the 3x3's weights of the ring bottlenecks as direct per-wave fragment loads (csrc/hg_bt_ring.h), bit-identical
+            _native.check(self.lib.df3d_hg_set_option(self.h, b"w2d", 1 if w2d else 0), "df3d_hg_set_option")
         if chain_views is None and os.environ.get("DF3D_CHAIN_VIEWS"):
             chain_views = int(os.environ["DF3D_CHAIN_VIEWS"])
         if chain_views is not None:  # chains of full-resolution steps in chunks of this many views (0 = whole batch per launch)

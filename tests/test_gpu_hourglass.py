@@ -433,6 +433,29 @@ def test_f32_set_weights_without_a_scratch_buffer_falls_back_to_the_register_sta
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("height,width,n", [(256, 512, 3), (128, 256, 2), (64, 192, 1)])
+def test_direct_w2_fragments_are_bit_identical(native_lib, cuda, oracle_net, dtype, height, width, n):
+    """16-bit `w2d`: in the ring bottlenecks (and layer2) the 3x3's weights come as per-wave MFMA fragments straight from global
+    memory, phase 2 runs channel-split and barrier-free, and t2 crosses to the pixel-owning waves through LDS (csrc/hg_bt_ring.h,
+    W2D) -- same products in the same K order: every plan step and the heat-maps equal the LDS-DMA ring form bit for bit."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
+    img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(13 * height + width), dtype=torch.float32).to(cuda)
+    on = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, w2d=1)
+    off = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, w2d=0)
+    assert [s[0] for s in on.steps()] == [s[0] for s in off.steps()]
+    for k in range(1, len(on.steps()) + 1):
+        a, b = on.forward_upto(img, k), off.forward_upto(img, k)
+        assert torch.equal(a, b), f"step {k} {on.steps()[k - 1][0]} differs: max |diff| {(a.float() - b.float()).abs().max().item():.3e}"
+    first = on.forward(img).clone()
+    assert torch.equal(first, off.forward(img))
+    for _ in range(3):
+        assert torch.equal(on.forward(img), first)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("height,width,n", [(256, 512, 3), (128, 256, 2), (64, 192, 1)])
 def test_fp32_split_conv1_is_bit_identical(native_lib, cuda, oracle_net, height, width, n):
     """fp32 `split1`: the first 1x1 convolution of the identity-skip bottlenecks computed ONCE per pixel by a kernel of its own
