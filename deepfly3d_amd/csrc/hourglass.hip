@@ -891,6 +891,9 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
 #ifdef DF3D_BT_TIMING
                     if (const char* e = getenv("BR_LDS")) lds_bytes = atoi(e);   // development: force one workgroup per CU (> 80 KB)
 #endif
+#ifdef BR_FORCE_LDS
+                    lds_bytes = BR_FORCE_LDS;   // development builds: one workgroup per CU (> 80 KB)
+#endif
                     int rc;
                     if constexpr (sizeof(T) == 2)
                         rc = a.in2 ? launch_ring_lp<T, true, 256>(r, blocks, lds_bytes, s) : a.add2 ? launch_ring_lp<T, false, 256, true>(r, blocks, lds_bytes, s)
