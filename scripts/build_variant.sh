@@ -1,0 +1,28 @@
+#!/bin/bash
+# Development builds of libdf3d_hip.so with extra -D switches, for same-box A/B runs through DF3D_LIB (scripts/abl_bench.sh):
+#
+#   bash scripts/build_variant.sh NAME [-DFLAG ...]        ->  scratch/variants/libdf3d_hip_NAME.so   (scratch/ is git-ignored)
+#
+# Only hourglass.hip is recompiled; every other object comes from the regular build (python -m deepfly3d_amd.build).
+# Switches the kernels understand (none is defined in the product build):
+#   -DDF3D_BT_TIMING        per-phase s_memtime sums of wave 0 of the ring kernels (scripts/probe_ring.py, probe_l1.py); the atomics cost ~17 %
+#   -DBR_ABL=n              16-bit ring kernel: 1 no phase-2 MFMAs | 3 no phase-2 weight DMA | 4 phase 2 without waits / barriers |
+#                           5 no x loads | 6 no bn1 arithmetic | 7, 8 phases 2(-3) without barriers | 9 no MFMAs at all
+#   -DBR_ABLM=mask          16-bit ring kernel, combinable: 1 no MFMAs, 2 no weight DMA, 4 no x loads, 8 no residual loads, 16 no output stores
+#   -DBR_FORCE_LDS=90000    ring kernels at ONE workgroup per CU
+#   -DBR_SETPRIO            s_setprio around the phase-2 MFMAs
+set -e
+cd "$(dirname "$0")/.."
+name=$1; shift
+mkdir -p scratch/variants
+objs=""
+for f in deepfly3d_amd/csrc/*.hip; do
+  b=$(basename $f)
+  [ $b = hourglass.hip ] && continue
+  [ -f deepfly3d_amd/csrc/_obj/$b.o ] || { echo "run python -m deepfly3d_amd.build first"; exit 1; }
+  objs="$objs deepfly3d_amd/csrc/_obj/$b.o"
+done
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=fast "$@" -Iinclude -c deepfly3d_amd/csrc/hourglass.hip -o scratch/variants/hourglass_$name.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o scratch/variants/libdf3d_hip_$name.so $objs scratch/variants/hourglass_$name.o
+rm -f scratch/variants/hourglass_$name.o
+echo scratch/variants/libdf3d_hip_$name.so

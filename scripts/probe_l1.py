@@ -1,5 +1,5 @@
-"""Development probe: per-phase cycle breakdown of bottleneck_l1_kernel (timing build: bash scratch/build_timing.sh;
-DF3D_LIB=scratch/timing/libdf3d_hip_timing.so python scripts/probe_l1.py [views])"""
+"""Development probe: per-phase cycle breakdown of bottleneck_l1_kernel (timing build: bash scripts/build_variant.sh;
+DF3D_LIB=scratch/variants/libdf3d_hip_timing.so python scripts/probe_l1.py [views])"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
 """Development probe: per-phase cycle breakdown of bottleneck_ring_kernel (needs the timing build:
-bash scratch/build_timing.sh; DF3D_LIB=scratch/timing/libdf3d_hip_timing.so python scripts/probe_ring.py [views])"""
+bash scripts/build_variant.sh timing -DDF3D_BT_TIMING; DF3D_LIB=scratch/variants/libdf3d_hip_timing.so python scripts/probe_ring.py [views])"""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
