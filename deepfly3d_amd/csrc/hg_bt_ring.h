@@ -270,11 +270,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     // bn1 coefficients and b1 -> LDS; b2 / b3 wait in two registers and replace the bn1 coefficients after phase 1
     // (the only plain loads before the ring starts); halo validity masks
     //   coef_lds: phase 1: [0..255] scale, [256..511] shift; afterwards [0..127] b2, [128..383] b3;  [512..639] b1
-    if (tid < CIN) {
-        coef_lds[tid] = p.s1[tid];
-        coef_lds[256 + tid] = p.t1[tid];
-    }
-    if (tid < 128) coef_lds[512 + tid] = p.b1[tid];
+    // (the loads now, the LDS stores behind the first weight stages and x steps: a store in front of them would make the wave sit
+    // out the coefficients' round trip before it requests anything else)
+    const float pre_s1 = tid < CIN ? p.s1[tid] : 0.0f, pre_t1 = tid < CIN ? p.t1[tid] : 0.0f, pre_b1 = p.b1[tid & 127];
     const float late_b2 = p.b2[tid & 127], late_b3 = DS ? p.b3[tid] + p.bd[tid] : p.b3[tid];
     const float* const b1_lds = coef_lds + 512;
     const float* const b2_lds = coef_lds;
@@ -340,6 +338,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
     };
 #pragma unroll
     for (int k = 0; k < DX; ++k) loadx(k, k);
+    if (tid < CIN) {
+        coef_lds[tid] = pre_s1;
+        coef_lds[256 + tid] = pre_t1;
+    }
+    if (tid < 128) coef_lds[512 + tid] = pre_b1;
 
     const int py = 2 * wave + (l31 >> 4), px = l31 & 15;   // this wave's 32 pixels (phases 2, 3)
     {

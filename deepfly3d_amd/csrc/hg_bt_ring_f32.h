@@ -108,14 +108,34 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
     const unsigned char* const wf1 = ring + br_swz(l31, 2 + half);
 
     // coefficients -> LDS, t2 start values (b2) straight into the accumulators, b3 waits in a register until bn1 is dead
-    float late_b3 = 0.0f;
-    if constexpr (TAIL) {
-        coef_lds[256 + tid] = p.b3[tid];   // no bn1, no b1 here: b3 sits in its place from the start
-    } else {
-        coef_lds[tid] = p.s1[tid];
-        coef_lds[256 + tid] = p.t1[tid];
-        if (tid < 128) coef_lds[512 + tid] = p.b1[tid];
-        late_b3 = p.b3[tid];
+    // TAIL: the t1 halo tile of half kh by LDS-DMA.  Piece pc (1 KB) = halo pixels 4 pc .. 4 pc + 3, lane -> (pixel 4 pc + (lane >> 4),
+    // slot lane & 15), fetching chunk slot ^ swizzle(pixel) of that pixel's 256-byte half row; this wave copies pieces wave, wave + 4, ...
+    const unsigned t1_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)t1_lds;
+    auto t1_issue = [&](int kh) {
+        const unsigned char* const tin = reinterpret_cast<const unsigned char*>(p.t1in) + (size_t)view * p.H * p.W * 512;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int pc = wave + 4 * k;
+            if (pc < BT_HALO / 4) {
+                const int hp = 4 * pc + (lane >> 4);
+                const int hy = hp / BT_HW, hx = hp % BT_HW;
+                const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+                const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                const unsigned chunk = (unsigned)((lane & 15) ^ br_t1_swz(hp));
+                const unsigned char* const src = ok ? tin + ((size_t)y * p.W + x) * 512 + kh * 256 + chunk * 16 : reinterpret_cast<const unsigned char*>(p.zeros) + chunk * 16;
+                br_glds_piece64(src, t1_addr + (unsigned)pc * 1024u);
+            }
+        }
+    };
+    if constexpr (TAIL) t1_issue(0);   // first of all: its latency runs under the rest of the prologue (nobody else touches the t1 region yet)
+    // (loaded now, stored to LDS behind the first DMA requests: a store in front of them would make the wave sit out the
+    // coefficients' round trip before it requests anything else)
+    float late_b3 = p.b3[tid];
+    float pre_s1 = 0.0f, pre_t1 = 0.0f, pre_b1 = 0.0f;
+    if constexpr (!TAIL) {
+        pre_s1 = p.s1[tid];
+        pre_t1 = p.t1[tid];
+        pre_b1 = p.b1[tid & 127];
     }
     const float* const b1_lds = coef_lds + 512;
     const float* const b3_lds = coef_lds + 256;
@@ -138,6 +158,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
     ring_issue(0);
     ring_issue(1);
     ring_issue(2);
+    if constexpr (TAIL) {
+        coef_lds[256 + tid] = late_b3;   // no bn1, no b1 here: b3 sits in its place from the start
+    } else {
+        coef_lds[tid] = pre_s1;
+        coef_lds[256 + tid] = pre_t1;
+        if (tid < 128) coef_lds[512 + tid] = pre_b1;
+    }
 
     // x staging: thread -> (row = (tid + 256 i) >> 2, 16-byte chunk = tid & 3) of a 16-float K step
     constexpr int XP = 3;
@@ -181,25 +208,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
         }
     };
 
-    // TAIL: the t1 halo tile of half kh by LDS-DMA.  Piece pc (1 KB) = halo pixels 4 pc .. 4 pc + 3, lane -> (pixel 4 pc + (lane >> 4),
-    // slot lane & 15), fetching chunk slot ^ swizzle(pixel) of that pixel's 256-byte half row; this wave copies pieces wave, wave + 4, ...
-    const unsigned t1_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)t1_lds;
-    auto t1_issue = [&](int kh) {
-        const unsigned char* const tin = reinterpret_cast<const unsigned char*>(p.t1in) + (size_t)view * p.H * p.W * 512;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const int pc = wave + 4 * k;
-            if (pc < BT_HALO / 4) {
-                const int hp = 4 * pc + (lane >> 4);
-                const int hy = hp / BT_HW, hx = hp % BT_HW;
-                const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-                const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-                const unsigned chunk = (unsigned)((lane & 15) ^ br_t1_swz(hp));
-                const unsigned char* const src = ok ? tin + ((size_t)y * p.W + x) * 512 + kh * 256 + chunk * 16 : reinterpret_cast<const unsigned char*>(p.zeros) + chunk * 16;
-                br_glds_piece64(src, t1_addr + (unsigned)pc * 1024u);
-            }
-        }
-    };
     const int py = 2 * wave + (l31 >> 4), px = l31 & 15;   // this wave's 32 pixels (phases 2, 3)
     const unsigned char* const t1_lane = t1_lds + (py * BT_HW + px) * BR_T1_PITCH;
     unsigned tsw[3];
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
         if constexpr (TAIL) {
             br_barrier();   // kh = 0: masks and b3 visible; kh = 1: every wave has finished reading the first t1 half
             BR_STAMP(kh == 0 ? 0 : 3);
-            t1_issue(kh);
+            if (kh == 1) t1_issue(kh);   // (half 0 was requested at the top of the kernel)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces (and the weight stages requested before them) have landed;
                                                                 // the barrier of the first double-step below publishes the tile
             BR_STAMP(2);

@@ -104,9 +104,16 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
     const int half = lane >> 5, l31 = lane & 31;
     const long long m0 = (long long)blockIdx.x * 128;
     float* const bout_lds = bsc_lds + 32;   // not LAST: bfc_ + bsc_ (the sum the epilogue adds), staged once instead of 32 global loads per pass
-    bfc_lds[tid] = p.bfc[tid];
-    if (tid < 32) bsc_lds[tid] = p.bsc[tid];
-    if constexpr (!LAST) bout_lds[tid] = p.bfc_[tid] + p.bsc_[tid];
+    // the bias vectors: loaded now, stored to LDS behind the first DMA requests (a store in front of them would make the wave sit out
+    // this round trip before it requests anything else); published by the first barrier of phase A
+    const float pre_bfc = p.bfc[tid], pre_bsc = p.bsc[tid & 31];
+    float pre_bout = 0.0f;
+    if constexpr (!LAST) pre_bout = p.bfc_[tid] + p.bsc_[tid];
+    auto publish_bias = [&]() {
+        bfc_lds[tid] = pre_bfc;
+        if (tid < 32) bsc_lds[tid] = pre_bsc;
+        if constexpr (!LAST) bout_lds[tid] = pre_bout;
+    };
 
     // ================= phase A: y^T = Wfc r^T ==========================================================
     f32x16 y[8];
@@ -171,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
         }
         issue_step(0);
         issue_step(1);
+        publish_bias();
         const unsigned char* const wf0 = stage + br_swz(l31, half);
         const unsigned char* const wf1 = stage + br_swz(l31, 2 + half);
         // this lane's B fragments: pixel l31 of the wave, chunk 2 j + half -> slot (2 j + half) ^ ((l31 >> 2) & 3)
@@ -219,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
         }
         __syncthreads();   // every wave is done with the ring before the stage area is reused
     } else {
+        publish_bias();
         constexpr int RB = C::RBA, PITCH = RB + 16, CPR = RB / 16, RPP = 256 / CPR;   // 4 chunks per row, 64 rows per pass
         constexpr int KE = RB / EB, NSTEPS = 256 / KE;
         constexpr int WP = 256 / RPP, RP = 128 / RPP;                                  // 4 and 2 passes
@@ -294,10 +303,19 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
     {
         // stage the whole padded Wsc [32][256] (the last barrier of phase A has passed: the stage area is free)
         constexpr int CH = 256 * EB / 16;   // 16-byte chunks per row
-        for (int i = tid; i < 32 * CH; i += 256) {
-            const int row = i / CH, ch = i % CH;
-            *reinterpret_cast<u32x4*>(stage + row * C::WSC_PITCH + ch * 16) =
-                *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.wsc) + ((size_t)row * 256) * EB + ch * 16);
+        // all of a thread's chunks are requested before the first is stored (rolled, the loop was 4 -- float32: 8 -- load -> store
+        // round trips in series in every workgroup)
+        constexpr int NW = 32 * CH / 256;
+        u32x4 wv[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int i = tid + 256 * k, row = i / CH, ch = i % CH;
+            wv[k] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.wsc) + ((size_t)row * 256) * EB + ch * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int i = tid + 256 * k, row = i / CH, ch = i % CH;
+            *reinterpret_cast<u32x4*>(stage + row * C::WSC_PITCH + ch * 16) = wv[k];
         }
         __syncthreads();
         const unsigned char* const wrow = stage + l31 * C::WSC_PITCH;

@@ -400,20 +400,22 @@ __device__ __forceinline__ void stem_glds_piece(const void* sbase, unsigned voff
                  : "memory");
 }
 
+// PERSISTENT (round 3): a workgroup walks tiles b, b + gridDim.x, ...: the 37 KB weight matrix enters LDS ONCE per workgroup (it was
+// 1.2 x the tile's output bytes, per tile), and the next tile's patch is gathered into registers before the K loop and written to the
+// other patch buffer behind it, so that no tile after the first waits for its input.  Same MFMA order: bit-identical.
 template <typename T>
-__global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
+__global__ __launch_bounds__(256, 3) void stem_kernel(StemArgs p) {
     constexpr int PR = 21, PC = 37, PROW = 112;  // patch rows, cols, floats per patch row (111 padded)
     constexpr int KTOT = 148;
-    __shared__ float patch[PR * PROW];
+    constexpr int NIT = (PR * PC + 255) / 256;   // patch pixels per thread (4; the last round is partial)
+    __shared__ float patch2[1][PR * PROW];   // ONE buffer: 47 KB per workgroup keep three workgroups on a CU (two buffers, two workgroups: 8 % slower)
     __shared__ float wl[KTOT * 64];
     const int OH = p.H / 2, OW = p.W / 2;
     const int tiles_x = OW / 16, tiles_y = OH / 8;
-    int b = blockIdx.x;
-    const int tx0 = (b % tiles_x) * 16;
-    b /= tiles_x;
-    const int ty0 = (b % tiles_y) * 8;
-    const int view = b / tiles_y;
+    const int ntiles = p.V * tiles_y * tiles_x;
     const int tid = threadIdx.x;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
 
     {   // the [148][64] fp32 weight matrix as it lies: 37 one-KB pieces by LDS-DMA (no registers, no ds_write; runs under the patch staging)
         const unsigned wl_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)wl;
@@ -425,34 +427,58 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
             if (pc < 37) stem_glds_piece(p.w, (unsigned)pc * 1024u + (unsigned)(tid & 63) * 16u, wl_addr + (unsigned)pc * 1024u);
         }
     }
-    const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
-    const float* img = p.img + (size_t)view * p.H * p.W * 3;
     // one item = one patch pixel (three contiguous floats): index arithmetic and bounds test per pixel, not per value
-    for (int i = tid; i < PR * PC; i += 256) {
-        const int r = i / PC, pxl = i - r * PC;
-        const int y = iy0 + r, x = ix0 + pxl;
-        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
-        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
-            if (p.u8.frames) {
-                float res[3];
-                df3d_pre::pixel(p.u8.frames + (size_t)view * p.u8.FH * p.u8.FW * p.u8.FC, p.u8.FH, p.u8.FW, p.u8.FC, p.u8.flip && p.u8.flip[view], p.H, p.W, y, x,
-                                p.u8.nm, res);
-                v0 = res[0];
-                v1 = res[1];
-                v2 = res[2];
-            } else {
-                const float* const src = img + ((size_t)y * p.W + x) * 3;
-                v0 = src[0];
-                v1 = src[1];
-                v2 = src[2];
+    float pv[NIT][3];
+    auto gather = [&](int t) {
+        int b = t;
+        const int tx0 = (b % tiles_x) * 16;
+        b /= tiles_x;
+        const int ty0 = (b % tiles_y) * 8;
+        const int view = b / tiles_y;
+        const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
+        const float* img = p.img + (size_t)view * p.H * p.W * 3;
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int i = tid + 256 * j;
+            const int r = i / PC, pxl = i - r * PC;
+            const int y = iy0 + r, x = ix0 + pxl;
+            float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+            if (i < PR * PC && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+                if (p.u8.frames) {
+                    float res[3];
+                    df3d_pre::pixel(p.u8.frames + (size_t)view * p.u8.FH * p.u8.FW * p.u8.FC, p.u8.FH, p.u8.FW, p.u8.FC, p.u8.flip && p.u8.flip[view], p.H, p.W, y,
+                                    x, p.u8.nm, res);
+                    v0 = res[0];
+                    v1 = res[1];
+                    v2 = res[2];
+                } else {
+                    const float* const src = img + ((size_t)y * p.W + x) * 3;
+                    v0 = src[0];
+                    v1 = src[1];
+                    v2 = src[2];
+                }
+            }
+            pv[j][0] = v0;
+            pv[j][1] = v1;
+            pv[j][2] = v2;
+        }
+    };
+    auto scatter = [&](float* patch) {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int i = tid + 256 * j;
+            if (i < PR * PC) {
+                const int r = i / PC, pxl = i - r * PC;
+                float* const dst = patch + r * PROW + 3 * pxl;
+                dst[0] = pv[j][0];
+                dst[1] = pv[j][1];
+                dst[2] = pv[j][2];
             }
         }
-        float* const dst = patch + r * PROW + 3 * pxl;
-        dst[0] = v0;
-        dst[1] = v1;
-        dst[2] = v2;
-    }
-    if (tid < PR) patch[tid * PROW + PC * 3] = 0.0f;   // the pad cell behind the 111 values of a row
+        if (tid < PR) patch[tid * PROW + PC * 3] = 0.0f;   // the pad cell behind the 111 values of a row
+    };
+    gather(tile);
+    scatter(patch2[0]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's weight pieces have landed
     __syncthreads();
 
@@ -461,34 +487,77 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs p) {
     const int py = wave * 2 + (m >> 4), px = m & 15;
     const int a_base = (2 * py) * PROW + 6 * px;
     const int khalf = lane >> 5;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
-#pragma unroll 2
-    for (int s = 0; s < KTOT / 2; ++s) {
-        const int k = 2 * s + khalf;
-        const int ky = k / 21, kk = k - ky * 21;
-        const float a = (k < 147) ? patch[a_base + ky * PROW + kk] : 0.0f;
-        const float b0 = wl[k * 64 + (lane & 31)];
-        const float b1 = wl[k * 64 + 32 + (lane & 31)];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-    }
     const int n = lane & 31;
     const float bias0 = p.bias[n], bias1 = p.bias[32 + n];
+    for (;;) {
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) gather(next);   // requested now, consumed behind the K loop
+        const float* const patch = patch2[0];
+        f32x16 acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int mm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int oy = ty0 + wave * 2 + (mm >> 4), ox = tx0 + (mm & 15);
-        const size_t o = (((size_t)view * OH + oy) * OW + ox) * 64;
-        const float v0 = fmaxf(acc0[r] + bias0, 0.0f), v1 = fmaxf(acc1[r] + bias1, 0.0f);
-        if constexpr (sizeof(T) == 4) {
-            reinterpret_cast<float*>(p.out)[o + n] = v0;
-            reinterpret_cast<float*>(p.out)[o + 32 + n] = v1;
-        } else {
-            reinterpret_cast<unsigned short*>(p.out)[o + n] = Lp<T>::from_f32(v0);
-            reinterpret_cast<unsigned short*>(p.out)[o + 32 + n] = Lp<T>::from_f32(v1);
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+        // K step s multiplies k = 2 s (lanes 0..31) and k = 2 s + 1 (lanes 32..63); tap k lies at patch offset (k / 21) * PROW + k % 21.
+        // Fully unrolled with every LDS address a register + an immediate: the offset of the ODD tap is the even one's + 1, or + PROW - 20
+        // where the pair straddles two patch rows -- two base registers.  Reads run one group of four steps ahead of the MFMAs (the
+        // rolled loop spent ten VALU instructions on k / 21 and waited for each step's three reads in front of its two MFMAs: 0.59
+        // matrix-pipe busy).  Same products, same order: bit-identical.
+        const float* const pa = patch + a_base + khalf;                  // odd tap = even tap + 1
+        const float* const pb = patch + a_base + khalf * (PROW - 20);    // ... or first tap of the next patch row
+        const float* const wb = wl + khalf * 64 + (lane & 31);
+        constexpr int G = 4, NG = (KTOT / 2 + G - 1) / G;                // 74 steps in 19 groups (the last has two)
+        float fa[2][G], fb0[2][G], fb1[2][G];
+        auto load_group = [&](int g, int buf) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int s = g * G + i;
+                if (s >= KTOT / 2) break;
+                const int k0 = 2 * s, off0 = (k0 / 21) * PROW + k0 % 21;
+                const bool straddle = k0 % 21 == 20;
+                float a = straddle ? pb[off0] : pa[off0];
+                if (k0 + 1 >= 147) a = khalf ? 0.0f : a;   // the 148th tap is padding
+                fa[buf][i] = a;
+                fb0[buf][i] = wb[k0 * 64];
+                fb1[buf][i] = wb[k0 * 64 + 32];
+            }
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load_group(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                if (g * G + i >= KTOT / 2) break;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i], fb0[g & 1][i], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i], fb1[g & 1][i], acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        int b = tile;
+        const int tx0 = (b % tiles_x) * 16;
+        b /= tiles_x;
+        const int ty0 = (b % tiles_y) * 8;
+        const int view = b / tiles_y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int oy = ty0 + wave * 2 + (mm >> 4), ox = tx0 + (mm & 15);
+            const size_t o = (((size_t)view * OH + oy) * OW + ox) * 64;
+            const float v0 = fmaxf(acc0[r] + bias0, 0.0f), v1 = fmaxf(acc1[r] + bias1, 0.0f);
+            if constexpr (sizeof(T) == 4) {
+                reinterpret_cast<float*>(p.out)[o + n] = v0;
+                reinterpret_cast<float*>(p.out)[o + 32 + n] = v1;
+            } else {
+                reinterpret_cast<unsigned short*>(p.out)[o + n] = Lp<T>::from_f32(v0);
+                reinterpret_cast<unsigned short*>(p.out)[o + 32 + n] = Lp<T>::from_f32(v1);
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();   // every wave is done reading the patch
+        scatter(patch2[0]);
+        __syncthreads();
+        tile = next;
     }
 }
 
@@ -528,12 +597,18 @@ __global__ __launch_bounds__(256) void stem_lp_kernel(StemArgs p) {
     }
     const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
     const float* img = p.img + (size_t)view * p.H * p.W * 3;
-    // one item = one patch pixel (three contiguous floats): the index arithmetic and the bounds test are per pixel, not per value
-    for (int i = tid; i < PR * PC; i += 256) {
+    // one item = one patch pixel (three contiguous floats): the index arithmetic and the bounds test are per pixel, not per value.
+    // ALL of a thread's items are requested before the first is stored (as a rolled loop the staging was four load -> store round
+    // trips in series: this kernel has 22 MFMAs per wave and lives on its prologue)
+    constexpr int NIT = (PR * PC + 255) / 256;
+    float pv[NIT][3];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int i = tid + 256 * j;
         const int r = i / PC, pxl = i - r * PC;
         const int y = iy0 + r, x = ix0 + pxl;
         float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
-        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+        if (i < PR * PC && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
             if (p.u8.frames) {
                 float res[3];
                 df3d_pre::pixel(p.u8.frames + (size_t)view * p.u8.FH * p.u8.FW * p.u8.FC, p.u8.FH, p.u8.FW, p.u8.FC, p.u8.flip && p.u8.flip[view], p.H, p.W, y, x,
@@ -548,10 +623,20 @@ __global__ __launch_bounds__(256) void stem_lp_kernel(StemArgs p) {
                 v2 = src[2];
             }
         }
-        unsigned short* const dst = patch + r * PROW + 3 * pxl;
-        dst[0] = Lp<T>::from_f32(v0);
-        dst[1] = Lp<T>::from_f32(v1);
-        dst[2] = Lp<T>::from_f32(v2);
+        pv[j][0] = v0;
+        pv[j][1] = v1;
+        pv[j][2] = v2;
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int i = tid + 256 * j;
+        if (i < PR * PC) {
+            const int r = i / PC, pxl = i - r * PC;
+            unsigned short* const dst = patch + r * PROW + 3 * pxl;
+            dst[0] = Lp<T>::from_f32(pv[j][0]);
+            dst[1] = Lp<T>::from_f32(pv[j][1]);
+            dst[2] = Lp<T>::from_f32(pv[j][2]);
+        }
     }
     // the pad cells behind the 111 values of a row and behind the last row (read by the last K slots against zero weights) are zero
     for (int i = tid; i < PR * (PROW - PC * 3) + 64; i += 256) {

@@ -754,7 +754,7 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                 if constexpr (sizeof(T) == 2)
                     hipLaunchKernelGGL((stem_lp_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
                 else
-                    hipLaunchKernelGGL((stem_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
+                    hipLaunchKernelGGL((stem_kernel<T>), dim3(std::min(blocks, 3 * cu_count())), dim3(256), 0, s, a);   // persistent: weights once per workgroup
                 DF3D_LAUNCH_CHECK();
                 break;
             }
