@@ -1095,6 +1095,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
                 const int ky = tap / 3, kx = tap - 3 * ky;
                 const unsigned char* const tb = t1_lds + ((py + ky) * BT_HW + (px + kx)) * C::T1_PITCH + kc * RB + half * 16;
                 const unsigned char* const wrow = sw + l31 * PITCH + half * 16;
+                // (requesting the fragments of two K chunks before their eight MFMA groups, pinned with sched_barrier, made the fp32
+                // layer1 form 2-3 % SLOWER -- at three workgroups per CU hipcc's own interleaving is the better one)
 #pragma unroll
                 for (int j = 0; j < RB / 32; ++j) {
                     const u32x4 tf = *reinterpret_cast<const u32x4*>(tb + j * 32);
