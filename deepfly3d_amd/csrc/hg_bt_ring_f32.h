@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
     // slot lane & 15), fetching chunk slot ^ swizzle(pixel) of that pixel's 256-byte half row; this wave copies pieces wave, wave + 4, ...
     const unsigned t1_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)t1_lds;
     auto t1_issue = [&](int kh) {
+#ifdef BRF_NO_T1DMA   // development builds: the tail without its t1 halo DMA (what that traffic and its exposed latency cost)
+        return;
+#endif
         const unsigned char* const tin = reinterpret_cast<const unsigned char*>(p.t1in) + (size_t)view * p.H * p.W * 512;
 #pragma unroll
         for (int k = 0; k < 12; ++k) {

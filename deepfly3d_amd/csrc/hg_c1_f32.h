@@ -38,12 +38,14 @@ constexpr int C1_XSLOTS = 2;   // x ring: step s is staged into slot s % 2 while
                                // step s - 2, which every wave has left before anyone passes the barrier of step s - 1
 constexpr int C1_LDS_BYTES = BR_RING_BYTES + C1_XSLOTS * C1_XSTAGE + 512 * 4 + 128 * 4;   // ring | x ring | bn1 scale, shift | b1: 50.5 KB
 
-// fp32 blob -> conv1 weight stream: stage s = K slice [16 s, 16 s + 16) of the 128 rows of W1' [128][256]
-__global__ __launch_bounds__(256) void bt_c1_pack_f32_kernel(const float* __restrict__ w1, unsigned char* __restrict__ stream) {
+// fp32 blob -> conv1 weight stream: stage s = K slice [16 s, 16 s + 16) of the cout (128, or layer1's 64: the upper half of the
+// stage image stays unused) rows of W1' [cout][cin]
+__global__ __launch_bounds__(256) void bt_c1_pack_f32_kernel(const float* __restrict__ w1, unsigned char* __restrict__ stream, int cin = 256, int cout = 128) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= C1_NSTAGE * 512) return;
+    if (idx >= (cin / 16) * 512) return;
     const int s = idx >> 9, r = (idx >> 2) & 127, c = idx & 3;
-    *reinterpret_cast<u32x4*>(stream + (size_t)s * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(w1 + (size_t)r * 256 + 16 * s + 4 * c);
+    if (r >= cout) return;
+    *reinterpret_cast<u32x4*>(stream + (size_t)s * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(w1 + (size_t)r * cin + 16 * s + 4 * c);
 }
 
 // PERSISTENT: a workgroup walks pixel tiles tile, tile + gridDim.x, ... with the pipeline running across tile boundaries -- the
@@ -51,8 +53,13 @@ __global__ __launch_bounds__(256) void bt_c1_pack_f32_kernel(const float* __rest
 // steps (the weights are the same for every tile), so no tile after the first has a prologue.  Every tile issues exactly the same
 // vector-memory operations in the same order (the last tile re-reads its own rows and re-requests stages it will not use), which
 // keeps the counted waits valid; the kernel drains the queue before it ends.
-template <bool UP>
-__global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {   // (three workgroups per CU fit -- 50.5 KB -- and measured no faster)
+// CIN / COUT: 256 -> 128 (the identity-skip bottlenecks) or 64 -> 64 (layer1: four K steps, one channel tile per wave, and only
+// the lower half of every stage image travels)
+template <bool UP, int CIN = 256, int COUT = 128>
+__global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
+    static_assert((CIN == 256 && COUT == 128) || (CIN == 64 && COUT == 64 && !UP), "instantiated shapes");
+    constexpr int NST = CIN / 16;       // K steps = weight stages
+    constexpr int NCT = COUT / 64;      // channel tiles per wave   // (three workgroups per CU fit -- 50.5 KB -- and measured no faster)
     // Also measured, same box, none of them faster for the plain form (1 043 us per average launch; matrix pipe 0.83 busy at 2.30 GHz,
     // the lowest clock of the fp32 kernels): x requested 2 / 4 / 8 K steps ahead (1 057-1 063 us: not latency); the step's eight
     // fragments requested right behind the barrier, the previous step's second half multiplied first and the next step's x staged
@@ -73,23 +80,30 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {  
     if (tile >= ntiles) return;
 
     const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
-    auto ring_issue = [&](int s) {   // stage s (of 16; the same for every tile) -> ring slot s % 4
-        br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)s * BR_STAGE_BYTES, wvoff,
-                      ring_addr + (unsigned)(s % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048);
+    auto ring_issue = [&](int s) {   // stage s (the same for every tile) -> ring slot s % 4
+        if constexpr (COUT == 128)
+            br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)s * BR_STAGE_BYTES, wvoff,
+                          ring_addr + (unsigned)(s % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048);
+        else   // 64 rows = the stage image's lower 4 KB: one 1 KB piece per wave
+            br_glds_piece(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)s * BR_STAGE_BYTES, (unsigned)wave * 1024u + (unsigned)lane * 16u,
+                          ring_addr + (unsigned)(s % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 1024);
     };
+    constexpr int NPC = COUT == 128 ? 2 : 1;   // DMA pieces per wave and stage
     const unsigned char* const wf0 = ring + br_swz(l31, half);
     const unsigned char* const wf1 = ring + br_swz(l31, 2 + half);
 
-    coef_lds[tid] = p.s1[tid];
-    coef_lds[256 + tid] = p.t1c[tid];
-    if (tid < 128) coef_lds[512 + tid] = p.b1[tid];
+    if (tid < CIN) {
+        coef_lds[tid] = p.s1[tid];
+        coef_lds[256 + tid] = p.t1c[tid];
+    }
+    if (tid < COUT) coef_lds[512 + tid] = p.b1[tid];
     ring_issue(0);
     ring_issue(1);
     ring_issue(2);
 
     // x staging: thread -> (row = (tid >> 2) + 64 i, 16-byte chunk = tid & 3) of a 16-float K step; rows past the end read the last pixel
     constexpr int XP = 2, DX = UP ? 2 : 4, LX = UP ? 2 * XP : XP;   // DX divides 16: the register slots repeat from tile to tile
-    static_assert(C1_NSTAGE % DX == 0 && C1_NSTAGE % C1_XSLOTS == 0 && C1_NSTAGE % BR_RING == 0, "slot patterns repeat per tile");
+    static_assert(NST % DX == 0 && NST % C1_XSLOTS == 0 && NST % BR_RING == 0, "slot patterns repeat per tile");
     const int xchunk = tid & 3;
     const unsigned char* xp[XP];            // this tile's rows
     const unsigned char* xq[UP ? XP : 1];
@@ -100,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {  
         for (int i = 0; i < XP; ++i) {
             long long m = t * 128 + (tid >> 2) + 64 * i;
             if (m >= p.M) m = p.M - 1;
-            px[i] = reinterpret_cast<const unsigned char*>(p.in) + ((size_t)m * 256 + xchunk * 4) * 4;
+            px[i] = reinterpret_cast<const unsigned char*>(p.in) + ((size_t)m * CIN + xchunk * 4) * 4;
             if constexpr (UP) {
                 const long long hw = (long long)p.H * p.W, view = m / hw;
                 const int pix = (int)(m - view * hw), y = pix / p.W, x = pix - y * p.W;
@@ -136,16 +150,16 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {  
 #pragma unroll
     for (int k = 0; k < DX; ++k) loadx(false, k, k);
 
-    const int rt0 = 2 * (wave >> 1), ct0 = 2 * (wave & 1);
+    const int rt0 = 2 * (wave >> 1), ct0 = NCT * (wave & 1);
     float* const out = reinterpret_cast<float*>(p.t1);
     br_barrier();   // coefficients visible
     bool first = true;
     for (;;) {
         const long long nxt = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;   // (last tile: its own rows again, see above)
         rows_of(nxt, xn, xqn);
-        f32x16 acc[2][2];   // [pixel row tile][channel tile]; register r <-> pixel (r & 3) + 8 (r >> 2) + 4 half, lane l31 <-> channel
+        f32x16 acc[2][NCT];   // [pixel row tile][channel tile]; register r <-> pixel (r & 3) + 8 (r >> 2) + 4 half, lane l31 <-> channel
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NCT; ++j) {
             const float bias = coef_lds[512 + (ct0 + j) * 32 + l31];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -153,14 +167,14 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {  
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = bias;
         }
 #pragma unroll
-        for (int s = 0; s < C1_NSTAGE; ++s) {
+        for (int s = 0; s < NST; ++s) {
             storex(s, s % DX);
             // Operations issued after stage s's two DMA pieces.  Steady state: the x loads of the step that requested it (LX), then
             // two more steps' pieces and loads: 4 + 3 LX.  First tile: the prologue's three stages and DX x steps come first.  Later
-            // tiles, s < 3: the previous tile's 64 stores sit in between as well -- more than the counter's six bits hold: wait for 63.
-            const int steady = 4 + 3 * LX;
-            const int n_first = s == 0 ? 4 + DX * LX : s == 1 ? 4 + DX * LX + LX : s == 2 ? 4 + DX * LX + 2 * LX : steady;
-            const int n_later = s < 3 ? 63 : steady;
+            // tiles, s < 3: the previous tile's 64 (COUT = 64: 32) stores sit in between as well -- 64 are more than the counter's six bits hold: wait for 63.
+            const int steady = 2 * NPC + 3 * LX;
+            const int n_first = s == 0 ? 2 * NPC + DX * LX : s == 1 ? 2 * NPC + DX * LX + LX : s == 2 ? 2 * NPC + DX * LX + 2 * LX : steady;
+            const int n_later = s < 3 ? (steady + 32 * NCT < 63 ? steady + 32 * NCT : 63) : steady;   // + the previous tile's stores (a smaller count is safe, a larger one is not)
             if (n_first == n_later) {
                 br_wait_vm(n_first);
             } else if (first) {
@@ -169,21 +183,21 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {  
                 br_wait_vm(n_later);
             }
             br_barrier();
-            ring_issue((s + 3) % C1_NSTAGE);
-            if (s + DX < C1_NSTAGE) loadx(false, s + DX, s % DX);
-            else loadx(true, s + DX - C1_NSTAGE, s % DX);
+            ring_issue((s + 3) % NST);
+            if (s + DX < NST) loadx(false, s + DX, s % DX);
+            else loadx(true, s + DX - NST, s % DX);
             const unsigned char* const sx = xr + (s % C1_XSLOTS) * C1_XSTAGE;
 #pragma unroll
             for (int j2 = 0; j2 < 2; ++j2) {   // the K step's two 8-float halves
-                u32x4 wf[2], xf[2];
+                u32x4 wf[NCT], xf[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const u32x4*>((j2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + (ct0 + j) * 2048);
+                for (int j = 0; j < NCT; ++j) wf[j] = *reinterpret_cast<const u32x4*>((j2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + (ct0 + j) * 2048);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * C1_XPITCH + br_xslot(l31, 2 * j2 + half));
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) mfma_chunk<T>(xf[i], wf[j], acc[i][j]);
+                    for (int j = 0; j < NCT; ++j) mfma_chunk<T>(xf[i], wf[j], acc[i][j]);
             }
         }
         // epilogue: ReLU, 4-byte stores of 128 contiguous bytes per (pixel, channel tile): 64 per lane, unconditional (M is a multiple
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {  
             for (int r = 0; r < 16; ++r) {
                 const long long m = tile * 128 + (rt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) out[(size_t)m * 128 + (ct0 + j) * 32 + l31] = br_relu(acc[i][j][r]);
+                for (int j = 0; j < NCT; ++j) out[(size_t)m * COUT + (ct0 + j) * 32 + l31] = br_relu(acc[i][j][r]);
             }
         if (nxt == tile) break;
         tile = nxt;
