@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void bt_c1_pack_f32_kernel(const float* __rest
 // the lower half of every stage image travels)
 template <bool UP, int CIN = 256, int COUT = 128>
 __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
-    static_assert((CIN == 256 && COUT == 128) || (CIN == 64 && COUT == 64 && !UP), "instantiated shapes");
+    static_assert((CIN == 256 && COUT == 128) || (CIN == 128 && COUT == 128 && !UP) || (CIN == 64 && COUT == 64 && !UP), "instantiated shapes");
     constexpr int NST = CIN / 16;       // K steps = weight stages
     constexpr int NCT = COUT / 64;      // channel tiles per wave   // (three workgroups per CU fit -- 50.5 KB -- and measured no faster)
     // Also measured, same box, none of them faster for the plain form (1 043 us per average launch; matrix pipe 0.83 busy at 2.30 GHz,

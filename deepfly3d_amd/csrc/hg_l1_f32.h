@@ -214,4 +214,206 @@ __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
     }
 }
 
+// =====================================================================================================================
+// fp32 layer2 (128 -> 128 -> 128 -> 256 with the 1x1 skip convolution, 64 x 128 pixels per view) in the same split form:
+//   conv1_ring_f32_kernel<false, 128, 128>   t1 for every pixel, once                                          -> HBM [px][128] f32
+//   layer2_tail_f32_kernel                   as layer1's tail, with the t1 tile built and consumed in two 64-channel halves (kh) and
+//                                            the output in two 128-channel halves (nh), like the identity-skip tail (hg_bt_ring_f32.h)
+// Replaces bottleneck_kernel<float, 128, 128, true> bit for bit (t2: bias, half kh 0 tap-major, then half kh 1; out: b3 + bd, W3 over
+// t2's 128 channels ascending, then Wd over x's 128).
+// Weight stream (104 stages, bt_l2f_pack_kernel): per kh 36 x W2' (tap, 16-float K slice of the half; 128 rows), then per nh
+// 8 x W3 (K slice k) and 8 x Wd (K slice k).
+// =====================================================================================================================
+constexpr int L2F_W2_STAGES = 36;                       // per t1 half
+constexpr int L2F_NH_STAGES = 16;                       // per output half: 8 x W3, 8 x Wd
+constexpr int L2F_NSTAGE = 2 * L2F_W2_STAGES + 2 * L2F_NH_STAGES;   // 104
+constexpr int L2F_LDS_BYTES = BR_RING_BYTES + BR_T1_BYTES + 256 * 4;
+
+__global__ __launch_bounds__(256) void bt_l2f_pack_kernel(const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ wd,
+                                                          unsigned char* __restrict__ stream) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L2F_NSTAGE * 512) return;
+    const int s = idx >> 9, r = (idx >> 2) & 127, c = idx & 3;
+    const float* src;
+    if (s < 2 * L2F_W2_STAGES) {
+        const int kh = s / L2F_W2_STAGES, q = s % L2F_W2_STAGES, tap = q >> 2, kc = q & 3;
+        src = w2 + ((size_t)tap * 128 + r) * 128 + kh * 64 + 16 * kc + 4 * c;     // W2 [9][128][128]
+    } else {
+        const int k = s - 2 * L2F_W2_STAGES, nh = k / L2F_NH_STAGES, k16 = k % L2F_NH_STAGES;
+        if (k16 < 8) src = w3 + ((size_t)nh * 128 + r) * 128 + 16 * k16 + 4 * c;  // W3 [256][128]
+        else src = wd + ((size_t)nh * 128 + r) * 128 + 16 * (k16 - 8) + 4 * c;    // Wd [256][128]
+    }
+    *reinterpret_cast<u32x4*>(stream + (size_t)s * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(src);
+}
+
+// BtRingArgs: in = x [V, H, W, 128], t1in = [V, H, W, 128], zeros, out = [V, H, W, 256], wstream, b2 [128], b3 [256], bd [256].
+__global__ __launch_bounds__(256, 2) void layer2_tail_f32_kernel(BtRingArgs p) {
+    using T = float;
+    constexpr int CIN = 128, CO = 256, NT = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const ring = smem;
+    unsigned char* const t1_lds = smem + BR_RING_BYTES;
+    float* const b3_lds = reinterpret_cast<float*>(smem + BR_RING_BYTES + BR_T1_BYTES);
+    const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
+    const unsigned t1_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)t1_lds;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tiles_x = p.W / BT_TW, tiles_y = p.H / BT_TH;
+    int b;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int tx0 = (b % tiles_x) * BT_TW;
+    b /= tiles_x;
+    const int ty0 = (b % tiles_y) * BT_TH;
+    const int view = b / tiles_y;
+
+    const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
+    auto ring_issue = [&](int q) {
+        if (q < L2F_NSTAGE)
+            br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)q * BR_STAGE_BYTES, wvoff,
+                          ring_addr + (unsigned)(q % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048);
+    };
+    const unsigned char* const wf0 = ring + br_swz(l31, half);
+    const unsigned char* const wf1 = ring + br_swz(l31, 2 + half);
+    // the 64-channel half kh of the t1 halo tile by LDS-DMA (see layer1_tail_f32_kernel; a t1 row is 512 B here)
+    auto t1_issue = [&](int kh) {
+        const unsigned char* const tin = reinterpret_cast<const unsigned char*>(p.t1in) + (size_t)view * p.H * p.W * 512;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int pc = wave + 4 * k;
+            if (pc < BT_HALO / 4) {
+                const int hp = 4 * pc + (lane >> 4);
+                const int hy = hp / BT_HW, hx = hp % BT_HW;
+                const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+                const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                const unsigned chunk = (unsigned)((lane & 15) ^ br_t1_swz(hp));
+                const unsigned char* const src = ok ? tin + ((size_t)y * p.W + x) * 512 + kh * 256 + chunk * 16 : reinterpret_cast<const unsigned char*>(p.zeros) + chunk * 16;
+                br_glds_piece64(src, t1_addr + (unsigned)pc * 1024u);
+            }
+        }
+    };
+    t1_issue(0);
+    ring_issue(0);
+    ring_issue(1);
+    ring_issue(2);
+    const float pre_b = p.b3[tid] + p.bd[tid];   // (the register-staged kernel's expression: one float add)
+    f32x16 t2[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + 32 * m + 8 * q + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t2[m][4 * q + e] = bb[e];
+        }
+    b3_lds[tid] = pre_b;
+
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
+    const unsigned char* const t1_lane = t1_lds + (py * BT_HW + px) * BR_T1_PITCH;
+    unsigned tsw[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) tsw[kx] = (unsigned)((((px + kx) & 15) ^ half) << 4);
+    const unsigned char* const xpix = reinterpret_cast<const unsigned char*>(p.in) + (((size_t)view * p.H + (ty0 + py)) * p.W + (tx0 + px)) * (CIN * 4) + half * 16;
+
+    // ---- phase 2, per t1 half: t2^T += W2'[:, half] (*) t1 half, two stages per barrier ---------------------------------------
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        if (kh == 1) {
+            br_barrier();   // every wave has finished reading the first t1 half
+            t1_issue(1);
+        }
+#pragma unroll
+        for (int d = 0; d < L2F_W2_STAGES / 2; ++d) {
+            const int s0 = L2F_W2_STAGES * kh + 2 * d;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // d = 0: the t1 pieces too
+            br_barrier();                                       // (very first: also publishes b3 + bd)
+            if (d > 0 || kh == 1) ring_issue(s0 + 2);           // (kh = 0, d = 0: the prologue requested it)
+            ring_issue(s0 + 3);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = 2 * d + u, tap = q >> 2, kc = q & 3;
+                const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32x4 tf = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) {
+                        const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + ((s0 + u) % BR_RING) * BR_STAGE_BYTES + m * 2048);
+                        mfma_chunk<T>(wf, tf, t2[m]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t2[m][r] = br_relu(t2[m][r]);
+
+    // ---- phase 3, per output half: out = W3 relu(t2) + Wd x + (b3 + bd) ----------------------------------------------------------
+    float* const outp = reinterpret_cast<float*>(p.out) + (size_t)view * p.H * p.W * CO;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+        f32x16 acc[4];
+        f32x4 xfr[2][2];   // the skip convolution's A operand for one double-step: K slices 2 dd', 2 dd' + 1, chunks 2 jj + half (requested a double-step ahead)
+#pragma unroll
+        for (int dd = 0; dd < 8; ++dd) {
+            const int s0 = 2 * L2F_W2_STAGES + L2F_NH_STAGES * nh + 2 * dd;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            br_barrier();
+            ring_issue(s0 + 2);
+            ring_issue(s0 + 3);
+            f32x4 xcur[2][2];
+            if (dd >= 4) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) xcur[u][jj] = xfr[u][jj];
+            }
+            if (dd >= 3 && dd < 7) {   // x slices of the NEXT double-step (the vmcnt(0) at its head waits for them)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) xfr[u][jj] = *reinterpret_cast<const f32x4*>(xpix + (2 * (dd - 3) + u) * 64 + jj * 32);
+            }
+            if (dd == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float bias = b3_lds[nh * 128 + i * 32 + l31];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] = bias;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s = s0 + u, k = (2 * dd + u) & 7;   // 16-float K slice of t2's (dd < 4) or x's 128 channels
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = dd < 4 ? t2[k >> 1][8 * (k & 1) + 4 * jj + e] : xcur[u][jj][e];
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wf[e], acc[i], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = nh * 128 + i * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                outp[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n] = acc[i][r];
+            }
+        }
+    }
+}
+
 }  // namespace hgk

@@ -57,6 +57,7 @@ struct Step {
     bool pool_only = false;           // ... whose full-resolution output nobody reads: `out` IS the pooled tensor
     double m1_elems = 0;              // activation elements per view this step moves in the fusion model M1
     int t1 = -1;                      // ST_BOTTLENECK, fp32 split form (hg_c1_f32.h): the tensor conv1's kernel writes and the tail kernel reads
+    bool l2f = false;                 // ST_BOTTLENECK, fp32 layer2 128 -> 128 -> 128 -> 256 + skip convolution: conv1 + tail (hg_l1_f32.h)
     bool l1f = false;                 // ST_BOTTLENECK, fp32 layer1 64 -> 64 -> 64 -> 128 + skip convolution: conv1 + tail (hg_l1_f32.h)
     long long wstream_w2d = -1;       // ... 16-bit W2D: byte offset of the direct-load form of W2'
     long long wstream_c1 = -1;        // ... and the byte offset of conv1's weight stream
@@ -319,6 +320,14 @@ struct df3d_hg {
                 stream_bytes += (size_t)L1F_NSTAGE * BR_STAGE_BYTES;
                 st.wstream_c1 = (long long)stream_bytes;
                 stream_bytes += (size_t)(64 / 16) * BR_STAGE_BYTES;
+                st.t1 = new_tensor(tx.h, tx.w, planes);
+            }
+            if (ring && split1 && !lp() && cin == 128 && planes == 128 && ds && x2 < 0 && a2 < 0 && !want_pool && tx.h % BT_TH == 0 && tx.w % BT_TW == 0) {
+                st.l2f = true;   // fp32 layer2, the same split form
+                st.wstream = (long long)stream_bytes;
+                stream_bytes += (size_t)L2F_NSTAGE * BR_STAGE_BYTES;
+                st.wstream_c1 = (long long)stream_bytes;
+                stream_bytes += (size_t)(128 / 16) * BR_STAGE_BYTES;
                 st.t1 = new_tensor(tx.h, tx.w, planes);
             }
             if (l1 && lp() && cin == 64 && planes == 64 && tx.h % 16 == 0 && tx.w % 16 == 0) {
@@ -846,6 +855,43 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                     }
                     break;
                 }
+                if (st.l2f) {
+                    if constexpr (sizeof(T) == 4) {
+                        const unsigned char* const sb = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base();
+                        Conv1Args c;
+                        c.in = a.in;
+                        c.in2 = nullptr;
+                        c.H = ti.h;
+                        c.W = ti.w;
+                        c.t1 = tptr(st.t1);
+                        c.wstream = sb + st.wstream_c1;
+                        c.b1 = a.b1; c.s1 = a.s1; c.t1c = a.t1;
+                        c.M = (long long)n * ti.h * ti.w;
+                        {
+                            ScopedTimer tc(h, s, "conv1_ring_f32_kernel<false, 128, 128>", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);
+                            static unsigned attr_c1 = 0;
+                            if (first_use_on_this_device(attr_c1))
+                                DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_ring_f32_kernel<false, 128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+                            const unsigned c1_grid = (unsigned)std::min<long long>(c.M / 128, 2LL * cu_count());
+                            hipLaunchKernelGGL((conv1_ring_f32_kernel<false, 128, 128>), dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
+                            DF3D_LAUNCH_CHECK();
+                        }
+                        BtRingArgs r{};
+                        r.in = a.in; r.out = a.out;
+                        r.t1in = c.t1;
+                        r.zeros = sb + h->zero_off;
+                        r.wstream = sb + st.wstream;
+                        r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd;
+                        r.V = n; r.H = ti.h; r.W = ti.w;
+                        ScopedTimer tm(h, s, "layer2_tail_f32_kernel", 2.0 * px * (9.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl), px * 4.0 * (cin + pl + 2.0 * pl), st.m1_elems * n * eb);
+                        static unsigned attr_t = 0;
+                        if (first_use_on_this_device(attr_t))
+                            DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer2_tail_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L2F_LDS_BYTES));
+                        hipLaunchKernelGGL(layer2_tail_f32_kernel, dim3(n * (ti.h / BT_TH) * (ti.w / BT_TW)), dim3(256), L2F_LDS_BYTES, s, r);
+                        DF3D_LAUNCH_CHECK();
+                    }
+                    break;
+                }
                 if (st.l1f) {
                     if constexpr (sizeof(T) == 4) {
                         const unsigned char* const sb = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base();
@@ -1251,6 +1297,13 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
                 hipLaunchKernelGGL(bt_fc_pack_f32_kernel, dim3((HD_FC_STAGES_F32 * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
                                    blob_dev + st.conv.w_off, reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
             if (st.kind != ST_BOTTLENECK || st.wstream < 0) continue;
+            if (st.l2f) {
+                hipLaunchKernelGGL(bt_l2f_pack_kernel, dim3((L2F_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv2b.w_off,
+                                   blob_dev + st.conv3b.w_off, blob_dev + st.conv4b.w_off, reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
+                hipLaunchKernelGGL(bt_c1_pack_f32_kernel, dim3(((128 / 16) * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv.w_off,
+                                   reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_c1, 128, 128);
+                continue;
+            }
             if (st.l1f) {
                 hipLaunchKernelGGL(bt_l1f_pack_kernel, dim3((L1F_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv2b.w_off,
                                    blob_dev + st.conv3b.w_off, blob_dev + st.conv4b.w_off, reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
