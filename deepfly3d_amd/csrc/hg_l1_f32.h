@@ -134,21 +134,26 @@ __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
                 for (int jj = 0; jj < 2; ++jj) xfr[k][jj] = *reinterpret_cast<const f32x4*>(xpix + k * 64 + jj * 32);
         }
         const int ky = d / 3, kx = d - 3 * ky;
+        // eight groups (stage u, K slice sub of the stage, 8-float chunk j) of one t1 fragment, two weight fragments and eight MFMAs;
+        // the three fragments of group g + 1 are requested before the MFMAs of group g (hipcc on its own requests them one MFMA
+        // ahead and then waits: 0.82 matrix-pipe busy)
+        u32x4 tfv[2], wfv[2][NT];
+        auto load_group = [&](int g, int buf) {
+            const int u = g >> 2, sub = (g >> 1) & 1, j = g & 1, kc = 2 * u + sub;
+            tfv[buf] = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int m = 0; m < NT; ++m)
+                wfv[buf][m] = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + ((s0 + u) % BR_RING) * BR_STAGE_BYTES + (2 * sub + m) * 2048);
+        };
+        load_group(0, 0);
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                const int kc = 2 * u + sub;
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) load_group(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const u32x4 tf = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
-#pragma unroll
-                    for (int m = 0; m < NT; ++m) {
-                        const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + ((s0 + u) % BR_RING) * BR_STAGE_BYTES + (2 * sub + m) * 2048);
-                        mfma_chunk<T>(wf, tf, t2[m]);
-                    }
-                }
-            }
+            for (int m = 0; m < NT; ++m) mfma_chunk<T>(wfv[g & 1][m], tfv[g & 1], t2[m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
     for (int m = 0; m < NT; ++m)
@@ -172,21 +177,28 @@ __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
                 for (int r = 0; r < 16; ++r) acc[i][r] = bias;
             }
         }
+        // four groups (stage u, chunk jj) of four weight fragments and sixteen MFMAs, the fragments one group ahead
+        f32x4 w3v[2][4];
+        auto load_w3 = [&](int g, int buf) {
+            const int u = g >> 1, jj = g & 1;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int s = s0 + u, k = (2 * dd + u) & 3;   // 16-float K slice of t2's (dd < 2) or x's 64 channels
+            for (int i = 0; i < 4; ++i) w3v[buf][i] = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + ((s0 + u) % BR_RING) * BR_STAGE_BYTES + i * 2048);
+        };
+        load_w3(0, 0);
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) load_w3(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int u = g >> 1, jj = g & 1, k = (2 * dd + u) & 3;   // 16-float K slice of t2's (dd < 2) or x's 64 channels
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        // t2 tile k >> 1, registers 8 (k & 1) + 4 jj + e <-> channels 16 k + 8 jj + 4 half + e: chunk 2 jj + half of the slice
-                        const float a = dd < 2 ? t2[k >> 1][8 * (k & 1) + 4 * jj + e] : xfr[k][jj][e];
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wf[e], acc[i], 0, 0, 0);
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    // t2 tile k >> 1, registers 8 (k & 1) + 4 jj + e <-> channels 16 k + 8 jj + 4 half + e: chunk 2 jj + half of the slice
+                    const float a = dd < 2 ? t2[k >> 1][8 * (k & 1) + 4 * jj + e] : xfr[k][jj][e];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w3v[g & 1][i][e], acc[i], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ---- epilogue: D[row = pixel (r & 3) + 8 (r >> 2) + 4 half of the wave][col = channel 32 i + l31]; 2x2 max-pool inside the lane
