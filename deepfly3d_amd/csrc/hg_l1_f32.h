@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
         const int ky = d / 3, kx = d - 3 * ky;
         // eight groups (stage u, K slice sub of the stage, 8-float chunk j) of one t1 fragment, two weight fragments and eight MFMAs;
         // the three fragments of group g + 1 are requested before the MFMAs of group g (hipcc on its own requests them one MFMA
-        // ahead and then waits: 0.82 matrix-pipe busy)
+        // ahead and then waits: 24.1 -> 23.4 ms.  With SIXTEEN MFMAs per group -- layer2's tail, the identity-skip tails -- the same
+        // hand-pipelining made the kernels 1-4 % slower: there hipcc's own order is the better one)
         u32x4 tfv[2], wfv[2][NT];
         auto load_group = [&](int g, int buf) {
             const int u = g >> 2, sub = (g >> 1) & 1, j = g & 1, kc = 2 * u + sub;
