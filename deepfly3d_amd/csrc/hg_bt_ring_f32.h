@@ -375,7 +375,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) xv[r] = xr[i][r];
             } else {
+#ifdef BRF_NO_LATE_RES   // development builds: what the two residual tiles requested in the epilogue cost
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xv[r] = 0.0f;
+#else
                 load_res(i, xv);
+#endif
             }
             if constexpr (UP) {
                 // the wave's two tile rows share ONE half-resolution row and neighbouring columns one pixel: registers r, r^1, r^8,
