@@ -461,7 +461,10 @@ def test_fp32_split_conv1_is_bit_identical(native_lib, cuda, oracle_net, height,
     """fp32 `split1`: the first 1x1 convolution of the identity-skip bottlenecks computed ONCE per pixel by a kernel of its own
     (csrc/hg_c1_f32.h) instead of on every tile's halo, the tile kernel pulling its t1 halo by LDS-DMA (out-of-image pixels from
     a page of zeros): same accumulation order, so every plan step and the heat-maps are bit-identical to the fused kernels
-    (image borders, the pooled-input side output, the fused up-path sums, tile counts that are not powers of two)."""
+    (image borders, the pooled-input side output, the fused up-path sums, tile counts that are not powers of two).  The same
+    switch moves layer1 and layer2 -- the bottlenecks with the 1x1 skip convolution -- from the register-staged round-1 kernel to
+    conv1 + their own tail kernels (csrc/hg_l1_f32.h: the skip convolution accumulated behind W3 in the same accumulators, its x
+    operand straight from global memory, layer1's pooled copy): bit-identical as well, so every plan step is compared."""
     from deepfly3d_amd.hourglass import HourglassEngine
 
     sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
