@@ -284,8 +284,8 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
  * for bit; set before the weights);  "row_bytes" = 0 (auto) | 64 | 128 bytes staged per operand row per K-step;
  * "ring" = 1 (default) | 0: weights through LDS-DMA stage rings (see df3d_hg_lowp_bytes) or register-staged;  "l1" = 1
  * (default) | 0: bf16 layer1 as the LDS-resident-weights kernel that writes only the pooled tensor -- both set before the
- * weights, both bit-identical to their 0 form;  "split1" = 1 (default) | 0 (fp32): conv1 of the identity-skip bottlenecks once per
- * pixel in a kernel of its own;  "w2d" = 1 (default) | 0 (16-bit): the 3x3's weights of the ring bottlenecks as per-wave MFMA
+ * weights, both bit-identical to their 0 form;  "split1" = 1 (default) | 0 (fp32): conv1 of every bottleneck (layer1 / layer2 included) once per
+ * pixel in a kernel of its own, the rest in tail kernels (17 MB more workspace per view: query df3d_hg_workspace_bytes);  "w2d" = 1 (default) | 0 (16-bit): the 3x3's weights of the ring bottlenecks as per-wave MFMA
  * fragments loaded straight from global memory (288 KB more stream space per bottleneck) -- both before the weights, both
  * bit-identical to their 0 form;  "chain_views" = 0 (default) | n: chains of full-resolution steps in chunks of n views */
 int df3d_hg_set_option(df3d_hg* h, const char* key, int value);
