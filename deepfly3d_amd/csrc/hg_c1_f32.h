@@ -32,6 +32,9 @@ struct Conv1Args {
 };
 
 constexpr int C1_NSTAGE = 16;
+#ifndef C1_ABLM
+#define C1_ABLM 0   // development builds: ablation mask (1 no MFMAs, 2 no weight DMA, 4 no x loads, 8 no t1 stores)
+#endif
 constexpr int C1_XPITCH = 64;                                                 // unpadded, chunks swizzled (br_xslot)
 constexpr int C1_XSTAGE = 128 * C1_XPITCH;                                   // 8 192
 constexpr int C1_XSLOTS = 2;   // x ring: step s is staged into slot s % 2 while slot (s - 1) % 2 may still be read; the slot was last read in
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
 
     const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
     auto ring_issue = [&](int s) {   // stage s (the same for every tile) -> ring slot s % 4
+        if (C1_ABLM & 2) return;
         if constexpr (COUT == 128)
             br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)s * BR_STAGE_BYTES, wvoff,
                           ring_addr + (unsigned)(s % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048);
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
     u32x4 rb[UP ? DX : 1][XP];
     auto loadx = [&](bool next_tile, int s, int slot) {
 #pragma unroll
-        for (int i = 0; i < XP; ++i) rx[slot][i] = *reinterpret_cast<const u32x4*>((next_tile ? xn[i] : xp[i]) + s * 64);
+        for (int i = 0; i < XP; ++i) rx[slot][i] = (C1_ABLM & 4) ? u32x4{(unsigned)s, (unsigned)tid, 0u, 0u} : *reinterpret_cast<const u32x4*>((next_tile ? xn[i] : xp[i]) + s * 64);
         if constexpr (UP) {
 #pragma unroll
             for (int i = 0; i < XP; ++i) rb[slot][i] = *reinterpret_cast<const u32x4*>((next_tile ? xqn[i] : xq[i]) + s * 64);
@@ -197,7 +201,10 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < NCT; ++j) mfma_chunk<T>(xf[i], wf[j], acc[i][j]);
+                    for (int j = 0; j < NCT; ++j) {
+                        if (C1_ABLM & 1) asm volatile("" ::"v"(xf[i]), "v"(wf[j]));
+                        else mfma_chunk<T>(xf[i], wf[j], acc[i][j]);
+                    }
             }
         }
         // epilogue: ReLU, 4-byte stores of 128 contiguous bytes per (pixel, channel tile): 64 per lane, unconditional (M is a multiple
@@ -208,7 +215,10 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
             for (int r = 0; r < 16; ++r) {
                 const long long m = tile * 128 + (rt0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
-                for (int j = 0; j < NCT; ++j) out[(size_t)m * COUT + (ct0 + j) * 32 + l31] = br_relu(acc[i][j][r]);
+                for (int j = 0; j < NCT; ++j) {
+                    if ((C1_ABLM & 8) && acc[i][j][r] != 12345.678f) continue;
+                    out[(size_t)m * COUT + (ct0 + j) * 32 + l31] = br_relu(acc[i][j][r]);
+                }
             }
         if (nxt == tile) break;
         tile = nxt;

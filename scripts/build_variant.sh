@@ -11,6 +11,7 @@
 #   -DBR_ABLM=mask          16-bit ring kernel, combinable: 1 no MFMAs, 2 no weight DMA, 4 no x loads, 8 no residual loads, 16 no output stores
 #   -DBR_FORCE_LDS=90000    ring kernels at ONE workgroup per CU
 #   -DBR_SETPRIO            s_setprio around the phase-2 MFMAs
+#   -DC1_ABLM=mask          fp32 conv1 kernel: 1 no MFMAs, 2 no weight DMA, 4 no x loads, 8 no t1 stores
 #   -DBRF_NO_T1DMA          fp32 tail kernels without their t1 halo DMA;  -DBRF_NO_LATE_RES  without the residual tiles requested in the epilogue
 set -e
 cd "$(dirname "$0")/.."
