@@ -958,7 +958,7 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                             c.M = (long long)n * ti.h * ti.w;
                             r.t1in = c.t1;
                             r.zeros = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + h->zero_off;
-                            ScopedTimer tc(h, s, a.in2 ? "conv1_ring_f32_kernel<true, 256, 128>" : "conv1_ring_f32_kernel<false, 256, 128>",   // (as rocprofv3 prints them) 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);
+                            ScopedTimer tc(h, s, a.in2 ? "conv1_ring_f32_kernel<true, 256, 128>" : "conv1_ring_f32_kernel<false, 256, 128>", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);   // (as rocprofv3 prints them)
                             static unsigned attr_c1[2] = {0, 0};
                             const void* const fn = a.in2 ? reinterpret_cast<const void*>(conv1_ring_f32_kernel<true>) : reinterpret_cast<const void*>(conv1_ring_f32_kernel<false>);
                             if (first_use_on_this_device(attr_c1[a.in2 ? 1 : 0]))
