@@ -87,14 +87,50 @@ def host_cores():
 
 
 def kernel_source_sha():
-    """sha256 over the HIP sources: profiles/traffic.json records the value it was collected with (no .git on the GPU box)."""
-    h = hashlib.sha256()
-    src = os.path.join(ROOT, "deepfly3d_amd", "csrc")
-    for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(src, name), "rb").read())
-    return h.hexdigest()[:16]
+    """sha256 over WHAT THE GPU RUNS of the hourglass kernels -- the gfx950 code objects inside the library in use (its
+    `.hip_fatbin` section: one clang offload bundle per .hip file; the bundles that hold `hgk::` kernels) -- not over the source
+    text: a comment or a host-side edit leaves it unchanged, so `profiles/traffic.json` (which records the value it was
+    collected with; there is no .git on the GPU box) only goes stale when a kernel really changed.  Falls back to the source
+    text when the library cannot be parsed."""
+    import struct
+
+    try:
+        from deepfly3d_amd import _native
+
+        blob = open(_native.library_path(), "rb").read()
+        shoff = struct.unpack_from("<Q", blob, 0x28)[0]
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", blob, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQ", blob, shoff + i * shentsize) for i in range(shnum)]
+        stroff = secs[shstrndx][4]
+        fat = None
+        for name, _typ, _flags, _addr, off, size in secs:
+            end = blob.index(b"\0", stroff + name)
+            if blob[stroff + name:end] == b".hip_fatbin":
+                fat = blob[off:off + size]
+        if fat is None:
+            raise ValueError("no .hip_fatbin section")
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = []
+        pos = fat.find(magic)
+        while pos >= 0:
+            starts.append(pos)
+            pos = fat.find(magic, pos + 1)
+        bundles = [fat[a:b] for a, b in zip(starts, starts[1:] + [len(fat)])]
+        mine = [x.rstrip(b"\0") for x in bundles if b"_ZN3hgk" in x]
+        if not mine:
+            raise ValueError("no hourglass code object in the library")
+        h = hashlib.sha256()
+        for x in sorted(mine):
+            h.update(x)
+        return h.hexdigest()[:16]
+    except Exception:   # noqa: BLE001  (an unreadable library: hash the sources instead)
+        h = hashlib.sha256()
+        src = os.path.join(ROOT, "deepfly3d_amd", "csrc")
+        for name in sorted(os.listdir(src)):
+            if name.endswith((".hip", ".h")):
+                h.update(name.encode())
+                h.update(open(os.path.join(src, name), "rb").read())
+        return "src:" + h.hexdigest()[:12]
 
 
 def cpu_baseline(state_dict, frames_cpu, calib, target_seconds):

@@ -9,6 +9,7 @@ from ctypes import POINTER, Structure, c_char, c_char_p, c_double, c_float, c_in
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DF3D_LIB") or os.path.join(_HERE, "libdf3d_hip.so")  # DF3D_LIB: developer override (kernel A/B builds)
 
+ABI_VERSION = 400  # DF3D_ABI_VERSION of include/df3d_hip.h: the revision these prototypes were written against
 DF3D_EINVAL = -1  # include/df3d_hip.h
 DF3D_ENOSPC = -5
 DF3D_EIO = -6
@@ -139,8 +140,17 @@ def load():
         fn.argtypes = args
     if missing:
         raise NativeLibraryError(f"{LIB_PATH} lacks symbols {missing}; rebuild with `python -m deepfly3d_amd.build --force`")
+    got = lib.df3d_version()
+    if got != ABI_VERSION:   # a stale build (or a DF3D_LIB variant of another revision) would take arguments in the wrong slots
+        raise NativeLibraryError(f"{LIB_PATH} has ABI revision {got}, these bindings were written for {ABI_VERSION}; "
+                                 "rebuild with `python -m deepfly3d_amd.build --force`")
     _lib = lib
     return lib
+
+
+def library_path():
+    """Path of the shared library in use (DF3D_LIB or the in-tree build)."""
+    return LIB_PATH
 
 
 def check(rc, what=""):

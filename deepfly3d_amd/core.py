@@ -201,14 +201,21 @@ class Core:
 
     def calibrate_calc(self, min_img_id, max_img_id):
         """Bundle adjustment from the shipped initial calibration (reference :229-250; like the reference the
-        image-id range is accepted and unused)."""
-        if not self.is_primary:
-            return
-        calib = load_calibration()
-        reordered = {int(cidx): calib[idx] for idx, cidx in enumerate(self.camera_ordering)}
-        self.camNet = CameraNetwork(self.points2d * self.image_shape[::-1], calib=reordered, image_path=self._image_path, device=self.device)
-        self.camNet.bundle_adjust(update_intrinsic=False, update_distort=False)
-        print(f"Reprojection error is {self.camNet.reprojection_error()}")
+        image-id range is accepted and unused).  Multi-GPU: rank 0 solves, EVERY rank calls this and leaves it together --
+        a failure on rank 0 (the solver, the disk) is raised on all ranks (`distributed.agree`)."""
+        from . import distributed as dd
+
+        error = None
+        if self.is_primary:
+            try:
+                calib = load_calibration()
+                reordered = {int(cidx): calib[idx] for idx, cidx in enumerate(self.camera_ordering)}
+                self.camNet = CameraNetwork(self.points2d * self.image_shape[::-1], calib=reordered, image_path=self._image_path, device=self.device)
+                self.camNet.bundle_adjust(update_intrinsic=False, update_distort=False)
+                print(f"Reprojection error is {self.camNet.reprojection_error()}")
+            except Exception as e:  # noqa: BLE001  (re-raised by agree, on every rank)
+                error = e
+        dd.agree(error, "calibrate_calc")
 
     def get_points3d(self):
         """Pose for the 3-D video: array[image_id][joint_id] = (x, y, z) after Procrustes, median-centring + axis swap
@@ -241,18 +248,27 @@ class Core:
         if rec[0].item() == 0.0:
             return None
         t0, t1 = dd.shard_range(self.num_images, world, rank)
-        if self._points2d_shard is not None:
-            local = self._points2d_shard.to(dev)
-        elif self.points2d is not None:   # resumed from a result file: every rank holds the whole sequence
-            local = torch.from_numpy(np.ascontiguousarray(self.points2d[:, t0:t1])).to(dev)
-        else:
-            local = torch.zeros((7, 0, config["num_joints"], 2), dtype=torch.float64, device=dev)
-        if local.shape[1] != t1 - t0:
-            local = torch.zeros((7, t1 - t0, config["num_joints"], 2), dtype=torch.float64, device=dev)  # keeps the collective well-formed
-        px = (local * torch.tensor([float(v) for v in self.image_shape[::-1]], dtype=torch.float64, device=dev)).contiguous()
+        scale = torch.tensor([float(v) for v in self.image_shape[::-1]], dtype=torch.float64, device=dev)
+        # This rank's frames, in pixels.  A rank that holds a camera network (rank 0 after calibrate_calc; every rank after
+        # reopening a result) reads them from IT, as CameraNetwork.triangulate() does single-GPU -- corrections written in place by
+        # corrected_points2d_matrix() are then part of the triangulation; the other ranks use the shard their own inference left.
+        px, bad = None, None
+        if self.camNet is not None and self.camNet.points2d is not None and self.camNet.points2d.shape[1] == self.num_images:
+            px = torch.from_numpy(np.ascontiguousarray(self.camNet.points2d[:, t0:t1])).to(dev)
+        elif self._points2d_shard is not None:
+            px = self._points2d_shard.to(dev) * scale
+        elif self.points2d is not None:
+            px = torch.from_numpy(np.ascontiguousarray(self.points2d[:, t0:t1])).to(dev) * scale
+        if px is None or px.shape[1] != t1 - t0:
+            # e.g. a reopened result whose length is not this run's num_images: NOT silently zeros (round-3 advisor finding) --
+            # the collective below still runs well-formed, then every rank raises
+            bad = ValueError(f"rank {rank}: {0 if px is None else px.shape[1]} frames of 2-D points for the frame range [{t0}, {t1}) of {self.num_images}")
+            px = torch.zeros((7, t1 - t0, config["num_joints"], 2), dtype=torch.float64, device=dev)
+        px = px.contiguous()
         X = ops.triangulate(rec[1:].reshape(7, 3, 4).numpy(), px) if t1 > t0 else torch.zeros((0, config["num_joints"], 3), dtype=torch.float64, device=dev)
         logger.debug(f"rank {rank} of {world}: triangulated frames [{t0}, {t1}) on {dev}")
         full = dd.gather_frames(X, 0, self.num_images)
+        dd.agree(bad, "the sharded triangulation")
         return None if full is None else full.cpu().numpy()
 
     def save(self):
@@ -260,8 +276,15 @@ class Core:
         from . import distributed as dd
 
         pts3d_sharded = self._triangulate_sharded() if dd.current()[1] > 1 else None   # a collective: every rank takes part
-        if not self.is_primary:
-            return
+        error = None
+        if self.is_primary:
+            try:
+                self._write_result(pts3d_sharded)
+            except Exception as e:  # noqa: BLE001  (ENOSPC, a failing Procrustes, ...: re-raised by agree, on every rank)
+                error = e
+        dd.agree(error, "save")   # rank 0 failing here must not leave its peers in the NEXT step's collectives alone
+
+    def _write_result(self, pts3d_sharded=None):
         result = {"points2d": np.copy(self.points2d)}
         if self.camNet is not None and self.camNet.has_calibration():
             if pts3d_sharded is not None:

@@ -20,6 +20,8 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "preprocess_math.h"
 
 namespace hgk {
@@ -743,6 +745,14 @@ __device__ __forceinline__ u32x4 max_chunk(u32x4 a, u32x4 b) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], y[i]);
         return __builtin_bit_cast(u32x4, x);
+    } else if constexpr (std::is_same<T, _Float16>::value) {
+        // IEEE half has a packed maximum of its own: one instruction per two values (the ordered-integer detour of the bf16 form
+        // costs seven).  Inline assembly on purpose: the builtin brings a NaN-quieting v_pk_max_f16 per operand; pooled values only
+        // ever go to stores and lane shuffles, never straight into an MFMA (see br_relu_pk on that hazard)
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm("v_pk_max_f16 %0, %1, %2" : "=v"(o[i]) : "v"(a[i]), "v"(b[i]));
+        return o;
     } else {
         return bf16_key_chunk(bf16_key_max_chunk(bf16_key_chunk(a), bf16_key_chunk(b)));
     }

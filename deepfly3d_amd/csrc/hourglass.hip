@@ -117,6 +117,8 @@ struct df3d_hg {
     int l1 = 1;           // 1 = bf16 layer1 (64 -> 64 -> 64 -> 128) runs as the LDS-resident-weights kernel of hg_bt_l1.h
     int ring = 1;         // 1 = the 256 -> 128 -> 128 -> 256 bottlenecks take their weights through the LDS-DMA ring (hg_bt_ring*.h)
     int w2d = 1;          // 16-bit ring bottlenecks: 1 (default) = the 3x3's weights as direct per-wave fragment loads (hg_bt_ring.h W2D), bit-identical
+    int ring2 = 1;        // 16-bit ring bottlenecks (with w2d): 1 (default) = round 4's form (hg_bt_ring.h MODE 2: phase 3 without DMA round trips on its
+                          // path, streaming output stores); 0 = round 3's kernels (the A/B); bit-identical either way
     int split1 = 1;       // fp32: 1 (default) = plain 256 -> 128 -> 128 -> 256 blocks run as conv1 (every pixel once) + tail (hg_c1_f32.h), bit-identical
     bool uses_zero_page = false;
     size_t zero_off = 0;  // byte offset of 256 zero bytes behind the weight streams (split form: the 3x3 padding of the tail's LDS-DMA)
@@ -714,18 +716,23 @@ template <> struct TypeName<__hip_bfloat16> { static constexpr const char* value
 template <> struct TypeName<_Float16> { static constexpr const char* value = "_Float16"; };
 
 // one launcher per 16-bit element type (hipFuncSetAttribute is per instantiation and per device)
-template <typename T, bool UP, int CIN, bool ADD2, bool W2D>
+template <typename T, bool UP, int CIN, bool ADD2, int MODE>
 int launch_ring_lp_(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
     static unsigned attr_done = 0;
     if (first_use_on_this_device(attr_done))
-        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_kernel<T, UP, CIN, ADD2, W2D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL((bottleneck_ring_kernel<T, UP, CIN, ADD2, W2D>), dim3(blocks), dim3(256), lds_bytes, s, r);
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_kernel<T, UP, CIN, ADD2, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL((bottleneck_ring_kernel<T, UP, CIN, ADD2, MODE>), dim3(blocks), dim3(256), lds_bytes, s, r);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }
+// the ring kernel's MODE (hg_bt_ring.h) of a launch: 0 = all weights through the ring, 1 = W2D (round 3), 2 = W2D + the round-4 form (option `ring2`)
+inline int ring_mode(const BtRingArgs& r, int ring2) { return !r.w2d ? 0 : ring2 ? 2 : 1; }
 template <typename T, bool UP, int CIN, bool ADD2 = false>
-int launch_ring_lp(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
-    return r.w2d ? launch_ring_lp_<T, UP, CIN, ADD2, true>(r, blocks, lds_bytes, s) : launch_ring_lp_<T, UP, CIN, ADD2, false>(r, blocks, lds_bytes, s);
+int launch_ring_lp(const BtRingArgs& r, int ring2, int blocks, int lds_bytes, hipStream_t s) {
+    const int mode = ring_mode(r, ring2);
+    return mode == 2 ? launch_ring_lp_<T, UP, CIN, ADD2, 2>(r, blocks, lds_bytes, s)
+           : mode    ? launch_ring_lp_<T, UP, CIN, ADD2, 1>(r, blocks, lds_bytes, s)
+                     : launch_ring_lp_<T, UP, CIN, ADD2, 0>(r, blocks, lds_bytes, s);
 }
 template <bool UP, bool ADD2 = false, bool TAIL = false>
 int launch_ring_f32(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
@@ -939,9 +946,9 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                     r.b1 = a.b1; r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd; r.s1 = a.s1; r.t1 = a.t1;
                     r.V = n; r.H = ti.h; r.W = ti.w;
                     if (ds) {   // 16-bit layer2
-                        ScopedTimer tm(h, s, std::string("bottleneck_ring_kernel<") + tname + ", false, 128, false, " + (r.w2d ? "true>" : "false>"), 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl), px * eb * (cin + 2.0 * pl), st.m1_elems * n * eb);
+                        ScopedTimer tm(h, s, std::string("bottleneck_ring_kernel<") + tname + ", false, 128, false, " + std::to_string(ring_mode(r, h->ring2)) + ">", 2.0 * px * ((double)cin * pl + 9.0 * pl * pl + 2.0 * pl * pl + 2.0 * cin * pl), px * eb * (cin + 2.0 * pl), st.m1_elems * n * eb);
                         if constexpr (sizeof(T) == 2)
-                            if (int rc = launch_ring_lp<T, false, 128>(r, n * (ti.h / BT_TH) * (ti.w / BT_TW), BR_LDS_BYTES, s)) return rc;
+                            if (int rc = launch_ring_lp<T, false, 128>(r, h->ring2, n * (ti.h / BT_TH) * (ti.w / BT_TW), BR_LDS_BYTES, s)) return rc;
                         break;
                     }
                     const bool split = eb == 4 && st.t1 >= 0;
@@ -977,7 +984,7 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                     }
                     const char* const flags2 = split ? (a.in2 ? "true, false, true>" : a.add2 ? "false, true, true>" : "false, false, true>")
                                                      : a.in2 ? "true, false, false>" : a.add2 ? "false, true, false>" : "false, false, false>";
-                    ScopedTimer tm(h, s, eb == 2 ? std::string("bottleneck_ring_kernel<") + tname + (a.in2 ? ", true, 256, false, " : a.add2 ? ", false, 256, true, " : ", false, 256, false, ") + (r.w2d ? "true>" : "false>")
+                    ScopedTimer tm(h, s, eb == 2 ? std::string("bottleneck_ring_kernel<") + tname + (a.in2 ? ", true, 256, false, " : a.add2 ? ", false, 256, true, " : ", false, 256, false, ") + std::to_string(ring_mode(r, h->ring2)) + ">"
                                                  : std::string("bottleneck_ring_f32_kernel<") + flags2,   // as rocprofv3 prints them
                                    2.0 * px * ((split ? 0.0 : (double)cin * pl) + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl + (split ? pl : 0)), st.m1_elems * n * eb);
                     const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
@@ -990,8 +997,8 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
 #endif
                     int rc;
                     if constexpr (sizeof(T) == 2)
-                        rc = a.in2 ? launch_ring_lp<T, true, 256>(r, blocks, lds_bytes, s) : a.add2 ? launch_ring_lp<T, false, 256, true>(r, blocks, lds_bytes, s)
-                                                                                           : launch_ring_lp<T, false, 256>(r, blocks, lds_bytes, s);
+                        rc = a.in2 ? launch_ring_lp<T, true, 256>(r, h->ring2, blocks, lds_bytes, s) : a.add2 ? launch_ring_lp<T, false, 256, true>(r, h->ring2, blocks, lds_bytes, s)
+                                                                                           : launch_ring_lp<T, false, 256>(r, h->ring2, blocks, lds_bytes, s);
                     else
                         rc = split ? (a.in2 ? launch_ring_f32<true, false, true>(r, blocks, lds_bytes, s)
                                       : a.add2 ? launch_ring_f32<false, true, true>(r, blocks, lds_bytes, s) : launch_ring_f32<false, false, true>(r, blocks, lds_bytes, s))
@@ -1117,9 +1124,10 @@ extern "C" {
 #ifdef DF3D_BT_TIMING
 // development build only: read and clear the per-phase cycle sums of bottleneck_ring_kernel
 int df3d_dbg_ring_cycles(unsigned long long* out8) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hgk::br_dbg), 64) != hipSuccess) return -1;
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(hgk::br_dbg), z, 64) == hipSuccess ? 0 : -1;
+    // (twelve counters since round 4: out8 must hold 12 values)
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hgk::br_dbg), 96) != hipSuccess) return -1;
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(hgk::br_dbg), z, 96) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -1194,6 +1202,11 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
         DF3D_CHECK_ARG(h->blob == nullptr, "set 'w2d' before df3d_hg_set_weights (it changes the weight streams)");
         h->w2d = value;
         h->build();
+        return DF3D_OK;
+    }
+    if (!strcmp(key, "ring2")) {
+        DF3D_CHECK_ARG(value == 0 || value == 1, "ring2 must be 0 or 1");
+        h->ring2 = value;
         return DF3D_OK;
     }
     if (!strcmp(key, "split1")) {

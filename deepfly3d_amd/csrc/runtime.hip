@@ -16,7 +16,7 @@ extern "C" {
 
 const char* df3d_last_error(void) { return df3d::g_err; }
 
-int df3d_version(void) { return 100; }
+int df3d_version(void) { return DF3D_ABI_VERSION; }
 
 int df3d_device_count(void) {
     int n = 0;

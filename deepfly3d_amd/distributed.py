@@ -74,6 +74,32 @@ def _wire_tensor(t, group):
     return t
 
 
+class RemoteRankError(RuntimeError):
+    """Another rank failed in a section every rank has to leave together (see `agree`)."""
+
+
+def agree(error=None, what="", group=None):
+    """Make a rank-local failure collective.  Every rank calls this at the same point with the exception it caught in the
+    section before it (or None); ONE small all-reduce tells everybody whether anybody failed.  Without a failure it returns;
+    with one, the ranks that failed re-raise their own exception and the others raise RemoteRankError -- so that a caller that
+    catches per-folder errors and moves on (cli.run_in_folders) moves on with ALL ranks, instead of leaving the peers blocked in
+    the next collective of a folder rank 0 has already abandoned (round-3 advisor finding: broadcast / barrier mismatch until the
+    back-end's timeout).  A no-op without a process group."""
+    rank, world = current()
+    if world <= 1:
+        if error is not None:
+            raise error
+        return
+    flag = torch.tensor([0 if error is None else rank + 1], dtype=torch.int32)
+    wire = _wire_tensor(flag, group)
+    dist.all_reduce(wire, op=dist.ReduceOp.MAX, group=group)
+    worst = int(wire.cpu()[0])
+    if error is not None:
+        raise error
+    if worst:
+        raise RemoteRankError(f"rank {worst - 1} failed{' in ' + what if what else ''}; this rank (rank {rank}) abandons the step with it")
+
+
 def _gather_rows(rows, counts, rank, world_size, group=None, force_collective=False):
     """ONE `dist.gather` of a [n_r, width] uint8 record table per rank (n_r = counts[rank]) to rank 0, which
     returns the concatenation in rank order; other ranks return None.  Shards are padded to the longest one.

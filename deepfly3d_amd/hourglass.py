@@ -22,14 +22,6 @@ def _np(v):
     return np.asarray(v, dtype=np.float64)
 
 
-def _bn_affine(sd, prefix):
-    """Eval-mode BatchNorm as y = x * s + t."""
-    g, b = _np(sd[prefix + ".weight"]), _np(sd[prefix + ".bias"])
-    m, v = _np(sd[prefix + ".running_mean"]), _np(sd[prefix + ".running_var"])
-    s = g / np.sqrt(v + BN_EPS)
-    return s, b - m * s
-
-
 def _following_bn(name):
     """Name of the BatchNorm that directly follows convolution `name` (and is folded into it), or None."""
     if name == "conv1":
@@ -47,31 +39,109 @@ def _input_bn(name):
     return name[: -len("conv1")] + "bn1" if name.endswith(".conv1") and name != "conv1" else None
 
 
-def pack_state_dict(engine_handle, state_dict):
-    """Fill the engine's float32 parameter blob from a state_dict, following the manifest the C library exports."""
+class CheckpointMismatch(ValueError):
+    """The state_dict is not the network the engine was built for (see `describe_state_dict`, `pack_state_dict`)."""
+
+
+_IGNORED_SUFFIXES = ("num_batches_tracked",)
+
+
+def describe_state_dict(state_dict):
+    """What architecture a bearpaw-style hourglass state_dict describes, read off its key set and tensor shapes:
+    {"num_stacks", "num_blocks" (bottlenecks per residual unit), "depth" (hourglass levels), "feats" (trunk width), "num_classes"}.
+    Entries are None where the keys that would tell are absent.  (App. B's constants -- one block, depth 4, 256 features --
+    are recall, not a reference fact; config.py:33,36 pin only the stacks and the 19 classes: a checkpoint is asked, not assumed.)"""
+    import re
+
+    def max_index(pattern):
+        found = [int(m.group(1)) for k in state_dict for m in [re.match(pattern, k)] if m]
+        return max(found) + 1 if found else None
+
+    def shape(name):
+        v = state_dict.get(name)
+        return tuple(v.shape) if v is not None else None
+
+    blocks = [max_index(r"layer[123]\.(\d+)\."), max_index(r"res\.\d+\.(\d+)\."), max_index(r"hg\.\d+\.hg\.\d+\.\d+\.(\d+)\.")]
+    blocks = [b for b in blocks if b is not None]
+    fc, sc = shape("fc.0.0.weight"), shape("score.0.weight")
+    return {
+        "num_stacks": max_index(r"hg\.(\d+)\."),
+        "num_blocks": max(blocks) if blocks else None,
+        "depth": max_index(r"hg\.\d+\.hg\.(\d+)\."),
+        "feats": fc[0] // 2 if fc else None,
+        "num_classes": sc[0] if sc else None,
+    }
+
+
+def _listing(keys, limit=16):
+    """Keys grouped by module: `layer1.1.bn1.{bias,running_mean,...}`, at most `limit` modules."""
+    groups = {}
+    for k in sorted(keys):
+        mod, _, field = k.rpartition(".")
+        groups.setdefault(mod, []).append(field)
+    items = [f"{m}.{f[0]}" if len(f) == 1 else f"{m}.{{{','.join(f)}}}" for m, f in groups.items()]
+    return ", ".join(items[:limit]) + (f", ... ({len(keys)} keys in {len(items)} modules)" if len(items) > limit else "")
+
+
+def pack_state_dict(engine_handle, state_dict, strict=True):
+    """Fill the engine's float32 parameter blob from a state_dict, following the manifest the C library exports.
+
+    strict (default): the state_dict must be EXACTLY the engine's network -- every key the manifest asks for present with the
+    manifest's shape, and no parameter left over (only BatchNorm's `num_batches_tracked` counters are ignored).  A checkpoint with
+    more stacks than the engine, with more than one bottleneck per residual unit (`layer1.1.*`, `hg.0.hg.3.0.1.*`: bearpaw's
+    `num_blocks` > 1) or with another width would otherwise load "successfully" and produce wrong poses without a word; it raises
+    CheckpointMismatch naming the missing and the unconsumed keys instead (reference: df3d/config.py:30-39 names the one
+    checkpoint the reference loads; its architecture is not in the checkout)."""
     lib = _native.load()
     n = lib.df3d_hg_num_params(engine_handle)
     blob = np.zeros(lib.df3d_hg_blob_floats(engine_handle), dtype=np.float32)
     d = _native.HGParam()
     cache = {}
+    consumed, missing, wrong = set(), set(), []
+
+    def take(key):
+        if key not in state_dict:
+            missing.add(key)
+            return None
+        consumed.add(key)
+        return _np(state_dict[key])
+
+    def take_bn(prefix):
+        parts = [take(prefix + sfx) for sfx in (".weight", ".bias", ".running_mean", ".running_var")]
+        if any(x is None for x in parts):
+            return None
+        g, b, m, v = parts
+        s = g / np.sqrt(v + BN_EPS)
+        return s, b - m * s
+
     for i in range(n):
         _native.check(lib.df3d_hg_param_desc(engine_handle, i, ctypes.byref(d)), "df3d_hg_param_desc")
         name = d.name.decode()
         if name not in cache:
-            w = _np(state_dict[name + ".weight"])  # (cout, cin, kh, kw)
-            b = _np(state_dict[name + ".bias"])
+            w, b = take(name + ".weight"), take(name + ".bias")  # (cout, cin, kh, kw)
             bn = _following_bn(name)
             if bn is not None:
-                s, t = _bn_affine(state_dict, bn)
-                w = w * s[:, None, None, None]
-                b = b * s + t
+                st = take_bn(bn)
+                if st is not None and w is not None and b is not None:
+                    s, t = st
+                    if s.shape[0] != w.shape[0]:
+                        wrong.append(f"{bn}: {s.shape[0]} channels behind a convolution with {w.shape[0]} outputs")
+                        w = None
+                    else:
+                        w = w * s[:, None, None, None]
+                        b = b * s + t
+                else:
+                    w = None
             cache = {name: (w, b)}
         w, b = cache[name]
         view = blob[d.offset : d.offset + d.count]
         if d.kind == 0:
+            if w is None:
+                continue
+            if w.ndim != 4 or (w.shape[0], w.shape[1], w.shape[2] * w.shape[3]) != (d.cout, d.cin, d.taps):
+                wrong.append(f"{name}.weight: state_dict shape {tuple(w.shape)}, engine ({d.cout}, {d.cin}, {d.taps} taps)")
+                continue
             cout, cin, kh, kw = w.shape
-            if (cout, cin, kh * kw) != (d.cout, d.cin, d.taps):
-                raise ValueError(f"{name}: state_dict shape {w.shape} does not match engine ({d.cout},{d.cin},{d.taps})")
             if d.taps == 49:  # stem: [148][64], k = ky*21 + kx*3 + c
                 packed = np.zeros((d.count // 64, 64))  # rows 0..146 used (the slot is larger: see df3d_hip.h)
                 packed[:147] = w.transpose(2, 3, 1, 0).reshape(147, 64)
@@ -86,10 +156,44 @@ def pack_state_dict(engine_handle, state_dict):
                     packed = packed[:, :, idx]
             view[:] = packed.ravel().astype(np.float32)
         elif d.kind == 1:
+            if b is None or w is None:
+                continue
+            if b.shape != (d.cout,):
+                wrong.append(f"{name}.bias: state_dict shape {tuple(b.shape)}, engine ({d.cout},)")
+                continue
             view[: d.cout] = b.astype(np.float32)
         else:
-            s, t = _bn_affine(state_dict, _input_bn(name))
-            view[: d.cin] = (s if d.kind == 2 else t).astype(np.float32)
+            key = (_input_bn(name), "in")
+            if key not in cache:
+                cache[key] = take_bn(_input_bn(name))
+            st = cache[key]
+            if st is None:
+                continue
+            if st[0].shape != (d.cin,):
+                wrong.append(f"{_input_bn(name)}: {st[0].shape[0]} channels, engine {d.cin}")
+                continue
+            view[: d.cin] = (st[0] if d.kind == 2 else st[1]).astype(np.float32)
+    if strict:
+        left = {k for k in state_dict if k not in consumed and not k.endswith(_IGNORED_SUFFIXES)}
+        if missing or left or wrong:
+            desc = describe_state_dict(state_dict)
+            why = []
+            if desc["num_blocks"] is not None and desc["num_blocks"] > 1:
+                why.append(f"the checkpoint has {desc['num_blocks']} bottlenecks per residual unit (bearpaw num_blocks = {desc['num_blocks']}); "
+                           "this engine implements num_blocks = 1 only")
+            stacks = {int(k.split(".")[1]) for k in consumed if k.startswith("hg.")}
+            if desc["num_stacks"] is not None and stacks and desc["num_stacks"] != max(stacks) + 1:
+                why.append(f"the checkpoint has {desc['num_stacks']} stacks, the engine was built for {max(stacks) + 1} "
+                           "(config['num_stacks'], reference df3d/config.py:33)")
+            msg = "state_dict does not match the engine's network" + (": " + "; ".join(why) if why else "") + "."
+            if wrong:
+                msg += " Shapes: " + "; ".join(wrong[:8]) + ("; ..." if len(wrong) > 8 else "") + "."
+            if missing:
+                msg += f" Missing keys: {_listing(missing)}."
+            if left:
+                msg += f" Unconsumed keys: {_listing(left)}."
+            msg += f" (checkpoint describes {desc})"
+            raise CheckpointMismatch(msg)
     return blob
 
 
@@ -97,7 +201,7 @@ class HourglassEngine:
     """The device engine: `forward(images_nhwc) -> heat-maps (n, 19, H/4, W/4)` on the current torch stream."""
 
     def __init__(self, state_dict, dtype="f32", num_stacks=2, device=None, height=256, width=512, row_bytes=0, fuse=True, fuse_upadd=None, ring=None, l1=None,
-                 chain_views=None, split1=None, w2d=None):
+                 chain_views=None, split1=None, w2d=None, ring2=None):
         _native.require_gpu()
         self.lib = _native.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -128,6 +232,10 @@ class HourglassEngine:
             w2d = int(os.environ["DF3D_W2D"])
         if w2d is not None and dtype != "f32":  # 16-bit: the 3x3's weights of the ring bottlenecks as direct per-wave fragment loads (csrc/hg_bt_ring.h), bit-identical
             _native.check(self.lib.df3d_hg_set_option(self.h, b"w2d", 1 if w2d else 0), "df3d_hg_set_option")
+        if ring2 is None and os.environ.get("DF3D_RING2"):
+            ring2 = int(os.environ["DF3D_RING2"])
+        if ring2 is not None and dtype != "f32":  # 16-bit: 1 (default) = round 4's ring bottleneck (csrc/hg_bt_ring.h MODE 2), 0 = round 3's; bit-identical
+            _native.check(self.lib.df3d_hg_set_option(self.h, b"ring2", 1 if ring2 else 0), "df3d_hg_set_option")
         if chain_views is None and os.environ.get("DF3D_CHAIN_VIEWS"):
             chain_views = int(os.environ["DF3D_CHAIN_VIEWS"])
         if chain_views is not None:  # chains of full-resolution steps in chunks of this many views (0 = whole batch per launch)

@@ -36,6 +36,11 @@ extern "C" {
 #define DF3D_DTYPE_F16 2  /* IEEE half activations + weights, fp32 accumulate: the bf16 engine's kernels on the other 16-bit format */
 
 const char* df3d_last_error(void);
+/* ABI revision of the library: DF3D_ABI_VERSION of the header it was built from.  It changes whenever an entry point's signature or
+ * a struct layout does (round 3 inserted `resize` into df3d_preprocess_u8 / df3d_hg_forward_u8 and `bytes_m1` into
+ * df3d_hg_profile_read: 300; round 4: 400); a caller compares it with the header it compiled against before its first call
+ * (deepfly3d_amd/_native.py:load does). */
+#define DF3D_ABI_VERSION 400
 int df3d_version(void);
 /* number of visible HIP devices (<0 on error); name of device `dev` copied to buf */
 int df3d_device_count(void);

@@ -4,8 +4,13 @@ set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd "$R"
 for lib in default ${LIBS:-}; do
-  if [ $lib = default ]; then unset DF3D_LIB; else export DF3D_LIB=$R/$lib; fi
-  python bench.py --dtype ${DT:-f16} --steps 2 --warmup 1 --no-cpu-baseline --no-legs 2>/dev/null | python -c "
+  envs=""
+  case $lib in
+    default) unset DF3D_LIB;;
+    *=*) unset DF3D_LIB; envs=$lib;;   # VAR=VALUE: the default library with that environment (e.g. DF3D_RING2=0)
+    *) export DF3D_LIB=$R/$lib;;
+  esac
+  env $envs python bench.py --dtype ${DT:-f16} --steps 2 --warmup 1 --no-cpu-baseline --no-legs 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

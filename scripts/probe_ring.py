@@ -15,10 +15,10 @@ lib = _native.load()
 img = torch.rand((views, 256, 512, 3), device=dev)
 steps = eng.steps()
 names = [n for n, _ in steps]
-buf = (ctypes.c_ulonglong * 8)()
-labels = ["prologue", "phase1 K loop", "t1 epilogue", "phase2", "phase3a K", "epilogue a", "phase3b K", "epilogue b"]
+buf = (ctypes.c_ulonglong * 12)()
+labels = ["prologue", "phase1 K loop", "t1 epilogue", "t2 crossing (W2D) / phase2", "phase3a K", "epilogue a", "phase3b K", "epilogue b", "phase2 loop (W2D)", "-", "-", "-"]
 if dtype == "f32":  # both t1 halves are summed into the phase-1 / phase-2 slots ("phase2" = second-half entry barrier + both phase 2)
-    labels = ["prologue", "phase1 K loops (2)", "t1 epilogues (2)", "phase2 (2) + entry", "phase3a K", "epilogue a", "phase3b K", "epilogue b"]
+    labels = ["prologue", "phase1 K loops (2)", "t1 epilogues (2)", "phase2 (2) + entry", "phase3a K", "epilogue a", "phase3b K", "epilogue b", "-", "-", "-", "-"]
 eng.forward(img); torch.cuda.synchronize()
 lib.df3d_dbg_ring_cycles.argtypes = [ctypes.c_void_p]
 lib.df3d_dbg_ring_cycles(buf)
@@ -38,4 +38,5 @@ for target in ("layer3.0.conv3", "hg.0.hg.3.upadd", "res.0.0.conv3", "hg.0.hg.2.
     tot = sum(own)
     print(f"{target} {hwc}: {tiles} tiles, wave-0 cycles per tile {tot / tiles:.0f}")
     for l, v in zip(labels, own):
+        if l == "-": continue
         print(f"   {l:14s} {v / tiles:9.0f} cycles  {100.0 * v / tot:5.1f} %")

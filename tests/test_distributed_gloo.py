@@ -135,6 +135,68 @@ def test_wrong_window_count_fails_behind_the_collective_not_in_front_of_it(tmp_p
     assert out[2] == "returned"
 
 
+def _failing_rank0_worker(rank, world, port, outdir, golden):
+    """cli.run's sequence on a Core whose 2-D stage is given: save -> calibrate_calc -> save, with rank 0 failing first in the
+    bundle adjustment, then in the result write."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import datetime
+    import pickle
+
+    from deepfly3d_amd import camera_network, core as core_mod, distributed as dd
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    g2 = np.load(os.path.join(golden, "golden_2d.npz"))
+    c = core_mod.Core.__new__(core_mod.Core)
+    c.dtype, c.device, c.is_primary = "f32", None, rank == 0
+    c._input_folder, c._output_folder = outdir, outdir
+    c.num_images, c.max_img_id, c.image_shape = 15, 14, [960, 480]
+    c._image_path = os.path.join(outdir, "camera_{cam_id}_img_{img_id}.jpg")
+    c.camera_ordering = np.arange(7)
+    c.points2d, c.conf = (g2["points2d"], g2["heatmap_confidence"]) if rank == 0 else (None, None)
+    c.camNet = c.points3d = c._points2d_shard = None
+    outcomes = []
+
+    def attempt(fn, *a):
+        try:
+            fn(*a)
+            outcomes.append("ok")
+        except Exception as e:  # noqa: BLE001
+            outcomes.append(f"{type(e).__name__}: {e}")
+
+    def boom(self, **kw):
+        raise RuntimeError("the solver blew up")
+
+    camera_network.CameraNetwork.bundle_adjust = boom
+    attempt(c.save)                      # 2-D only: fine everywhere
+    attempt(c.calibrate_calc, 0, 14)     # rank 0 fails -> EVERY rank raises, nobody is left in a collective
+    real_dump = pickle.dump
+    core_mod.pickle.dump = lambda *a, **kw: (_ for _ in ()).throw(OSError(28, "No space left on device"))
+    c.camNet = None
+    attempt(c.save)                      # rank 0 fails writing -> every rank raises
+    core_mod.pickle.dump = real_dump
+    attempt(c.save)                      # and the ranks are still in step: the next collective step works
+    dist.barrier()
+    with open(os.path.join(outdir, f"outcome{rank}.txt"), "w") as f:
+        f.write("\n".join(outcomes))
+    dist.destroy_process_group()
+
+
+def test_a_failure_on_rank0_between_the_saves_is_raised_on_every_rank(tmp_path, golden_dir):
+    """Round-3 advisor finding: calibrate_calc / the result write run on rank 0 only; when they raised there, cli.run_in_folders
+    moved rank 0 on to the next folder while its peers sat in the abandoned folder's next collective (mismatched broadcast / barrier
+    until the back-end's timeout).  `distributed.agree` makes the failure collective: rank 0 re-raises its exception, every other
+    rank raises RemoteRankError at the same point, and all of them are in step for whatever comes next."""
+    port = _free_port()
+    mp.spawn(_failing_rank0_worker, args=(2, port, str(tmp_path), str(golden_dir)), nprocs=2, join=True)
+    out = [open(os.path.join(tmp_path, f"outcome{r}.txt")).read().split("\n") for r in range(2)]
+    assert out[0] == ["ok", "RuntimeError: the solver blew up", "OSError: [Errno 28] No space left on device", "ok"]
+    assert out[1][0] == "ok" and out[1][3] == "ok"
+    assert out[1][1].startswith("RemoteRankError: rank 0 failed in calibrate_calc")
+    assert out[1][2].startswith("RemoteRankError: rank 0 failed in save")
+    assert os.path.exists(os.path.join(tmp_path, "df3d_result_" + str(tmp_path).replace("/", "_") + ".pkl"))
+
+
 def test_one_rank_group_executes_the_collective():
     """A 1-rank process group with force_collective runs the real `dist.gather` (what the GPU box does on RCCL with
     its single GPU) and returns the same tensors."""

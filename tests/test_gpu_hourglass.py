@@ -456,6 +456,29 @@ def test_direct_w2_fragments_are_bit_identical(native_lib, cuda, oracle_net, dty
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("height,width,n", [(256, 512, 3), (64, 192, 1)])
+def test_round4_ring_bottleneck_is_bit_identical_to_round3s(native_lib, cuda, oracle_net, dtype, height, width, n):
+    """`ring2` (default on, csrc/hg_bt_ring.h MODE 2): each output half's W3 stages sit in the ring a whole phase before their K loop (two
+    barriers and no DMA round trip on phase 3's path), the residual values are requested a phase ahead, the output leaves through
+    streaming (nt) stores.  Same products, same order, same roundings: every plan step equals round 3's kernels (`ring2=0`) bit for bit."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
+    img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(17 * height + width), dtype=torch.float32).to(cuda)
+    on = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, ring2=1)
+    off = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, ring2=0)
+    assert on.steps() == off.steps()
+    for k in range(1, len(on.steps()) + 1):
+        a, b = on.forward_upto(img, k), off.forward_upto(img, k)
+        assert torch.equal(a, b), f"step {k} {on.steps()[k - 1][0]} differs: max |diff| {(a - b).abs().max().item():.3e}"
+    first = on.forward(img).clone()
+    assert torch.equal(first, off.forward(img))
+    for _ in range(3):
+        assert torch.equal(on.forward(img), first)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("height,width,n", [(256, 512, 3), (128, 256, 2), (64, 192, 1)])
 def test_fp32_split_conv1_is_bit_identical(native_lib, cuda, oracle_net, height, width, n):
     """fp32 `split1`: the first 1x1 convolution of the identity-skip bottlenecks computed ONCE per pixel by a kernel of its own

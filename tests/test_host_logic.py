@@ -102,6 +102,63 @@ def test_bn_folding_and_packing_reproduce_the_oracle_layer(native_lib):
     assert wsc[4] == 32 and np.all(wsc[0].reshape(1, 256, 32)[0, :, 19:] == 0)
 
 
+def test_checkpoint_packing_is_strict(native_lib):
+    """A checkpoint the engine does not understand must not load "successfully" (round-3 review): bearpaw's num_blocks > 1
+    (`layer1.1.*`, `hg.0.hg.3.0.1.*`), more stacks than the engine, a missing parameter or another width raise
+    CheckpointMismatch naming the keys; `num_batches_tracked` counters (torch's BatchNorm book-keeping) are ignored.
+    Reference: df3d/config.py:30-39 (the one checkpoint the reference loads, `num_stacks`)."""
+    from deepfly3d_amd import _native
+    from deepfly3d_amd.hourglass import CheckpointMismatch, describe_state_dict, pack_state_dict
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    def handle(stacks):
+        h = ctypes.c_void_p()
+        assert native_lib.df3d_hg_create(_native.DF3D_DTYPE_F32, stacks, ctypes.byref(h)) == 0
+        return h
+
+    h2 = handle(2)
+    sd = synthetic_state_dict(0)
+    assert describe_state_dict(sd) == {"num_stacks": 2, "num_blocks": 1, "depth": 4, "feats": 128, "num_classes": 19}
+    ok = dict(sd)
+    ok["bn1.num_batches_tracked"] = np.array(7)
+    ok["hg.1.hg.0.2.0.bn3.num_batches_tracked"] = np.array(7)
+    assert np.array_equal(pack_state_dict(h2, ok), pack_state_dict(h2, sd, strict=False))
+    # num_blocks = 2: a second bottleneck per residual unit
+    two = dict(sd)
+    for k, v in sd.items():
+        if k.startswith("layer1.0.") and "downsample" not in k:
+            two["layer1.1." + k[len("layer1.0."):]] = v
+        if k.startswith("hg.0.hg.3.0.0."):
+            two["hg.0.hg.3.0.1." + k[len("hg.0.hg.3.0.0."):]] = v
+    with pytest.raises(CheckpointMismatch) as e:
+        pack_state_dict(h2, two)
+    assert "num_blocks = 2" in str(e.value) and "layer1.1.bn1.{bias," in str(e.value) and "hg.0.hg.3.0.1." in str(e.value) and "Unconsumed" in str(e.value)
+    assert pack_state_dict(h2, two, strict=False).shape == pack_state_dict(h2, sd).shape   # (the old behaviour, on request)
+    # a 4-stack checkpoint in a 2-stack engine, and the other way round
+    four = synthetic_state_dict(0, num_stacks=4)
+    with pytest.raises(CheckpointMismatch) as e:
+        pack_state_dict(h2, four)
+    assert "4 stacks" in str(e.value) and "built for 2" in str(e.value) and "fc.2.0.weight" in str(e.value) or "hg.2." in str(e.value)
+    h4 = handle(4)
+    assert pack_state_dict(h4, four).size > pack_state_dict(h2, sd).size
+    with pytest.raises(CheckpointMismatch) as e:
+        pack_state_dict(h4, sd)
+    assert "Missing keys" in str(e.value) and "hg.2." in str(e.value)
+    # one parameter missing; one with another shape
+    less = {k: v for k, v in sd.items() if k != "res.1.0.bn2.running_var"}
+    with pytest.raises(CheckpointMismatch) as e:
+        pack_state_dict(h2, less)
+    assert "Missing keys: res.1.0.bn2.running_var." in str(e.value)
+    wide = dict(sd)
+    wide["score.1.weight"] = np.zeros((21, 256, 1, 1), np.float32)
+    wide["score.1.bias"] = np.zeros(21, np.float32)
+    with pytest.raises(CheckpointMismatch) as e:
+        pack_state_dict(h2, wide)
+    assert "score.1.weight" in str(e.value) and "(21, 256, 1, 1)" in str(e.value)
+    native_lib.df3d_hg_destroy(h2)
+    native_lib.df3d_hg_destroy(h4)
+
+
 def test_synthetic_state_dict_matches_oracle_module_shapes():
     from deepfly3d_amd.synthetic import synthetic_state_dict
     from oracle import hourglass_torch as oh
