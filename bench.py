@@ -23,6 +23,11 @@ each hourglass leg with its own roofline block.
     python bench.py --rank-share 8 --stream-frames 100000 [--ba-window 1000] [--force-collective]
 runs ONE rank's full share of BASELINE configs[3] / configs[4] on the one GPU at hand (profiles/r03_rankshare_*.json).
 
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --strong --stream-frames 100000 [--ba-window 1000] [--dtype f16]
+is BASELINE's 8-GPU table in one shot: configs[3] (with --ba-window: configs[4]) STRONG-scaled -- the one stream sharded by frame over the N
+ranks, one packed gather, Procrustes over the whole sequence on rank 0, all inside the timed region; `"scaling": "strong"`, per-rank frames
+and rank 0's tail (gather / Procrustes ms) on the line.  N = 1 runs the whole stream on one GPU (the same pipeline as the default line).
+
 Roofline fractions (per kernel and for the dominant one), spelled out because a fused kernel has more than one byte count:
   frac_mfma      algorithmic FLOPs / time / dense MFMA peak of the dtype
   frac_hbm_min   (inputs read once + outputs written once, intermediates on chip) / time / 8 TB/s -- the least the launch can move
@@ -64,6 +69,10 @@ def parse(argv=None):
     ap.add_argument("--rank-share", type=int, default=0,
                     help="run rank 0's share of a --stream-frames stream sharded over this many ranks (configs[3]/[4] on one GPU); overrides --steps")
     ap.add_argument("--stream-frames", type=int, default=100000)
+    ap.add_argument("--strong", action="store_true",
+                    help="BASELINE configs[3] (with --ba-window: configs[4]) STRONG-scaled over the --gpus ranks: the ONE --stream-frames stream is sharded by "
+                         "frame (rank r runs shard_range(stream, N, r, window)), one packed gather, Procrustes over the whole sequence on rank 0 -- all inside "
+                         "the timed region; --steps is derived (the largest shard's batches)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: create a 1-rank process group (RCCL) and execute the packed gather anyway")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -234,9 +243,13 @@ class Job:
     """One workload on one engine: frames streamed from the resident pool through the pipeline in steps, optional bundle
     adjustment per window on a worker thread, optional packed gather -- timed as the contract asks."""
 
-    def __init__(self, a, engine, frames, calib, dev, rank, world, total_frames, steps, ba_window, collective, force_collective):
+    def __init__(self, a, engine, frames, calib, dev, rank, world, total_frames, steps, ba_window, collective, force_collective, global_frames=None):
         from deepfly3d_amd.pipeline import FramePipeline
 
+        # global_frames: strong scaling -- the length of the ONE sequence the ranks share (this rank holds total_frames of it, its
+        # shard_range); None: weak scaling, every rank holds total_frames of a world x total_frames sequence
+        self.global_frames = global_frames
+        self.tail_ms = {}
         self.a, self.engine, self.frames, self.calib, self.dev = a, engine, frames, calib, dev
         self.rank, self.world, self.total_frames, self.steps, self.ba_window = rank, world, total_frames, steps, ba_window
         self.collective, self.force_collective = collective, force_collective
@@ -314,14 +327,25 @@ class Job:
         cams = None
         if self.ba_window > 0:
             cams = torch.from_numpy(np.stack(self.ba_cams) if self.ba_cams else np.zeros((0, 7, 12))).to(self.dev)
-        return dd.gather_results(*self.outs, num_frames=self.total_frames * self.world, rank=self.rank, world_size=self.world, align=self.align, cameras=cams,
+        num = self.global_frames if self.global_frames is not None else self.total_frames * self.world
+        return dd.gather_results(*self.outs, num_frames=num, rank=self.rank, world_size=self.world, align=self.align, cameras=cams,
                                  force_collective=self.force_collective)
+
+    def sequence_tail(self, gathered):
+        """Strong scaling: what only rank 0 can do once the whole sequence is there -- Procrustes is sequence-global (medians over
+        all frames, reference df3d/procrustes.py:123-135) -- on the device, inside the timed region."""
+        from deepfly3d_amd.procrustes import procrustes_separate
+
+        if self.global_frames is None or self.rank != 0:
+            return None
+        p3 = gathered[2] if gathered is not None else self.outs[2]
+        return procrustes_separate(p3, device=self.dev, return_tensor=True)
 
     def run(self, warmup):
         """W untimed steps, then exactly `steps` timed steps (+ joins + gather) between barrier + synchronize on both sides."""
         dist = torch.distributed
-        for w in range(warmup):
-            self.step(w % self.steps, record=False, solve=False)
+        for w in range(warmup if self.total_frames > 0 else 0):
+            self.step(w % max(1, -(-self.total_frames // self.fps_step)), record=False, solve=False)
         if self.ba_px is not None:
             # the re-calibration has one-time costs of its own (allocator growth on its stream, the LSMR chunk's graph: ~0.7 s per
             # call until buffers and graph settle) and no window closes inside the W warm-up steps: warm it on its worker thread,
@@ -342,14 +366,18 @@ class Job:
             tl["ev0"] = torch.cuda.Event(enable_timing=True)
             tl["ev0"].record()
         for i in range(self.steps):
-            self.step(i)
+            if i * self.fps_step < self.total_frames:   # (strong scaling: a shorter shard has fewer batches)
+                self.step(i)
         marks = [time.perf_counter()]
         self.join_recalibrations()
         marks.append(time.perf_counter())
         gathered = self.gather()
         marks.append(time.perf_counter())
+        self.aligned = self.sequence_tail(gathered)
         torch.cuda.synchronize()
         marks.append(time.perf_counter())
+        self.tail_ms = {"steps_enqueued": 1e3 * (marks[0] - t_start), "recalibrations_joined": 1e3 * (marks[1] - marks[0]),
+                        "gather": 1e3 * (marks[2] - marks[1]), "procrustes_and_drain": 1e3 * (marks[3] - marks[2])}
         if self.world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t_start
@@ -443,6 +471,16 @@ def share_leg(a, sd, dtype, frames, calib, dev):
     return out
 
 
+def strong_plan(stream_frames, world, align, frames_per_step):
+    """Strong scaling: per rank (first frame, last frame + 1, batches) of the ONE stream, and the batches of the largest shard
+    (the `steps` every rank loops over; a shorter shard skips its missing batches).  Pure: the CPU tests walk it for 8 ranks."""
+    from deepfly3d_amd import distributed as dd
+
+    ranges = dd.all_ranges(stream_frames, world, align)
+    per_rank = [(t0, t1, -(-(t1 - t0) // frames_per_step)) for t0, t1 in ranges]
+    return per_rank, max(b for _, _, b in per_rank)
+
+
 def main(argv=None):
     a = parse(argv)
     from deepfly3d_amd import _native
@@ -464,13 +502,20 @@ def main(argv=None):
 
     fps_step = a.frames_per_step
     align = a.ba_window if a.ba_window > 0 else 1
-    if a.rank_share > 0:
+    global_frames = shards = None
+    if a.strong:
+        if a.rank_share > 0:
+            raise SystemExit("--strong shards the stream over the real ranks; --rank-share emulates one rank of a larger run: pick one")
+        shards, a.steps = strong_plan(a.stream_frames, world, align, fps_step)
+        t0, t1, _ = shards[rank]
+        total_frames, global_frames = t1 - t0, a.stream_frames
+    elif a.rank_share > 0:
         t0, t1 = dd.shard_range(a.stream_frames, a.rank_share, 0, align)
         total_frames = t1 - t0
         a.steps = -(-total_frames // fps_step)
     else:
         total_frames = a.steps * fps_step
-    if a.ba_window > 0 and total_frames % a.ba_window and world > 1:
+    if a.ba_window > 0 and total_frames % a.ba_window and world > 1 and not a.strong:
         # every rank sees the same arguments: all of them stop here, in front of any collective
         raise SystemExit("per-GPU frames must be a multiple of --ba-window when N > 1")
     sd = synthetic_state_dict(0)
@@ -478,14 +523,14 @@ def main(argv=None):
     cal = load_calibration()
     calib = {k: np.stack([cal[c][k] for c in range(7)]) for k in ("R", "tvec", "intr", "distort")}
 
-    pool = a.pool_frames or min(a.steps * fps_step, 1024)
+    pool = a.pool_frames or min(max(a.steps, 1) * fps_step, 1024)
     pool = max(fps_step, (pool // fps_step) * fps_step)
     gen = torch.Generator(device=dev).manual_seed(rank)
     frames = torch.empty((pool, 7, 256, 512, 3), dtype=torch.float32, device=dev)
     for i in range(0, pool, 64):  # bounded temporary memory
         frames[i : i + 64].uniform_(0.0, 1.0, generator=gen)
 
-    job = Job(a, engine, frames, calib, dev, rank, world, total_frames, a.steps, a.ba_window, collective, a.force_collective)
+    job = Job(a, engine, frames, calib, dev, rank, world, total_frames, a.steps, a.ba_window, collective, a.force_collective, global_frames)
     elapsed, gather_ok = job.run(a.warmup)
 
     roof = None
@@ -494,7 +539,7 @@ def main(argv=None):
 
     # the attached legs (N = 1, plain configs[1] run only): same process, same driver clock
     legs = {}
-    if a.dtype == "f32" and world == 1 and not a.no_legs and a.rank_share == 0 and a.ba_window == 0:
+    if a.dtype == "f32" and world == 1 and not a.no_legs and a.rank_share == 0 and a.ba_window == 0 and not a.strong:
         legs["config2_bf16"] = hourglass_leg(a, sd, "bf16", frames, calib, dev, total_frames, "BASELINE configs[2]")
         legs["config2_f16"] = hourglass_leg(a, sd, "f16", frames, calib, dev, total_frames,
                                             "BASELINE configs[2] on IEEE half (the 16-bit engine inside the reference's 2e-3 confidence tolerance)")
@@ -506,9 +551,16 @@ def main(argv=None):
     if rank == 0:
         ms_step = 1e3 * elapsed / a.steps
         fl, by = engine.work(fps_step * 7)
-        per_step = total_frames / a.steps / fps_step  # < 1 when the last batch of a rank share is short
+        per_step = total_frames / max(a.steps, 1) / fps_step  # < 1 when the last batch of a rank share is short
         words = DTYPE_WORDS[a.dtype]
-        if a.rank_share:
+        if a.strong:
+            cfg = 4 if a.ba_window else 3
+            workload = (f"BASELINE configs[{cfg}], strong-scaled: ONE {a.stream_frames}-frame 7-view stream sharded by frame over {world} rank(s) "
+                        f"(rank r runs shard_range(stream, {world}, r, {align}): {[t1 - t0 for t0, t1, _ in shards]} frames) through a {pool}-frame resident pool each, "
+                        f"2-stack hourglass {words}, arg-max + 38-joint layout + fp64 DLT"
+                        + (f", bundle-adjustment re-calibration every {a.ba_window} frames" if a.ba_window else "")
+                        + ", ONE packed gather to rank 0" + ("" if collective else " (N = 1: nothing to gather)") + ", Procrustes over the whole sequence on rank 0 -- all inside the timed region")
+        elif a.rank_share:
             cfg = 4 if a.ba_window else 3
             workload = (f"BASELINE configs[{cfg}], ONE rank's share on one GPU: rank 0 of {a.rank_share} ranks of a {a.stream_frames}-frame 7-view stream = "
                         f"{total_frames} frames streamed through a {pool}-frame resident pool, 2-stack hourglass {words}, arg-max + 38-joint layout + fp64 DLT"
@@ -523,21 +575,23 @@ def main(argv=None):
         sec = ms_step * 1e-3
         line = {
             "metric": "frames/sec (7-view 2D->3D)",
-            "value": world * total_frames / elapsed,
+            "value": (a.stream_frames if a.strong else world * total_frames) / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if a.strong else "weak",
             "vs_baseline": None,
             "dtype": a.dtype,
             "data": "synthetic (seeded uniform frames resident in HBM, seeded synthetic hourglass weights, data/calib.pkl cameras)",
             "config": {
                 "workload": workload,
                 "frames_per_step": fps_step,
-                "frames_per_gpu": total_frames,
+                "frames_per_gpu": total_frames if not a.strong else [t1 - t0 for t0, t1, _ in shards],
+                "stream_frames": a.stream_frames if a.strong else None,
+                "rank0_tail_ms": job.tail_ms if a.strong else None,   # host marks on rank 0: batches enqueued / recalibrations joined / gather / Procrustes + drain
                 "parallelism": f"frame-sharded x{world}, one packed gather" + (" (executed: RCCL, 1 rank)" if collective and world == 1 else ""),
                 "collective_executed": bool(collective),
                 "collective_backend": torch.distributed.get_backend() if collective else None,
@@ -556,7 +610,7 @@ def main(argv=None):
         if roof is not None:
             line["roofline"] = roof
         line.update(legs)
-        if not a.no_cpu_baseline and world == 1 and a.rank_share == 0:
+        if not a.no_cpu_baseline and world == 1 and a.rank_share == 0 and not a.strong:
             try:
                 line["cpu_baseline"] = cpu_baseline(sd, frames[:16].cpu(), calib, a.cpu_seconds)
             except Exception as e:  # the baseline is reporting only; never hide the GPU number

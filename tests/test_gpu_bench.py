@@ -70,3 +70,26 @@ def test_two_ranks_over_gloo_share_the_gpu(native_lib, cuda):
     assert abs(d2["value"] - 2 * 96 / (3 * d2["ms_per_step"] * 1e-3)) < 1e-6 * d2["value"]
     # two ranks on ONE device: the aggregate is the device's rate, less the gloo gather through host memory and the interleaving
     assert 0.4 * d1["value"] < d2["value"] < 1.3 * d1["value"], (d1["value"], d2["value"])
+
+
+def test_strong_scaled_stream_one_rank_and_two_ranks_over_gloo(native_lib, cuda):
+    """`--strong`: BASELINE configs[3]/[4] as ONE stream sharded over the ranks, gather + sequence-global Procrustes inside the timed
+    region.  N = 1 must agree with the plain single-GPU rate (same pipeline, plus the Procrustes launch); N = 2 (two ranks sharing the
+    one GPU, gloo standing in for RCCL) splits the stream by the bundle-adjustment window and reports the stream's rate once."""
+    env = dict(os.environ, DF3D_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    common = ["--warmup", "1", "--frames-per-step", "32", "--dtype", "f16", "--no-cpu-baseline", "--no-roofline"]
+    plain = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "12"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert plain.returncode == 0, plain.stdout[-2000:] + plain.stderr[-4000:]
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--strong", "--stream-frames", "384"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29643",
+                          "bench.py", "--gpus", "2", "--strong", "--stream-frames", "360", "--ba-window", "120"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    d0, d1, d2 = _line(plain.stdout), _line(one.stdout), _line(two.stdout)
+    assert d1["scaling"] == "strong" and d1["n_gpus"] == 1 and d1["steps"] == 12 and d1["config"]["frames_per_gpu"] == [384] and "configs[3]" in d1["config"]["workload"]
+    assert abs(d1["value"] - 384 / (12 * d1["ms_per_step"] * 1e-3)) < 1e-6 * d1["value"]
+    assert 0.85 * d0["value"] < d1["value"] < 1.1 * d0["value"], (d0["value"], d1["value"])   # the plain rate, less the sequence tail
+    assert d2["scaling"] == "strong" and d2["n_gpus"] == 2 and d2["config"]["frames_per_gpu"] == [240, 120] and d2["steps"] == 8   # windows 2 + 1
+    assert "configs[4]" in d2["config"]["workload"] and d2["config"]["collective_executed"] is True and d2["config"]["bundle_adjust_runs_rank0"] == 2
+    assert abs(d2["value"] - 360 / (8 * d2["ms_per_step"] * 1e-3)) < 1e-6 * d2["value"]
+    assert set(d2["config"]["rank0_tail_ms"]) == {"steps_enqueued", "recalibrations_joined", "gather", "procrustes_and_drain"}

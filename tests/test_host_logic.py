@@ -159,6 +159,22 @@ def test_checkpoint_packing_is_strict(native_lib):
     native_lib.df3d_hg_destroy(h4)
 
 
+def test_bench_strong_plan_covers_the_stream_for_every_world_size():
+    """bench.py --strong: the shards of the ONE stream (BASELINE configs[3]/[4]: 100 000 frames, window 1 000) tile it exactly for
+    1, 2, 4 and 8 ranks, whole windows per rank, and `steps` is the largest shard's batch count."""
+    import bench
+
+    for world in (1, 2, 4, 8):
+        for stream, align in ((100000, 1000), (100000, 1), (2560, 1000), (7, 1)):
+            per_rank, steps = bench.strong_plan(stream, world, align, 128)
+            assert len(per_rank) == world and per_rank[0][0] == 0 and per_rank[-1][1] == stream
+            assert all(a[1] == b[0] for a, b in zip(per_rank, per_rank[1:]))
+            assert all(t0 % align == 0 for t0, t1, _ in per_rank if t1 > t0)   # (an empty shard sits at the stream's end)
+            assert steps == max(-(-(t1 - t0) // 128) for t0, t1, _ in per_rank)
+    per_rank, steps = bench.strong_plan(100000, 8, 1000, 128)
+    assert [t1 - t0 for t0, t1, _ in per_rank] == [13000] * 4 + [12000] * 4 and steps == 102
+
+
 def test_synthetic_state_dict_matches_oracle_module_shapes():
     from deepfly3d_amd.synthetic import synthetic_state_dict
     from oracle import hourglass_torch as oh
