@@ -85,6 +85,7 @@ PROTOTYPES = {
          c_void_p, c_void_p, POINTER(c_double), c_void_p],
     ),
     "df3d_vec_dot": (c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_double), c_void_p, c_void_p]),
+    "df3d_vec_dots": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_size_t), POINTER(c_double), c_void_p, c_void_p]),
     "df3d_vec_pairnorm_sum": (c_int, [c_void_p, c_size_t, POINTER(c_double), c_void_p, c_void_p]),
     "df3d_vec_axpby": (c_int, [c_double, c_void_p, c_double, c_void_p, c_void_p, c_size_t, c_void_p]),
     "df3d_vec_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

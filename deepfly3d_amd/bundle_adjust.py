@@ -62,43 +62,63 @@ def _visible_pairs(points2d_px):
 
 
 class BAProblemDevice:
-    """Observation tables on the device (built once per calibration window) + work buffers."""
+    """Observation tables on the device (built once per calibration window) + work buffers.
+
+    Round 4: the tables are BUILT on the device too (torch index operations on the uploaded detections: visibility mask, the
+    (frame, joint, camera) observation order, the per-point and per-camera groupings) -- on a 1 000-frame window the numpy version of
+    this constructor cost 3 ms of host time, a quarter of the whole adjustment."""
 
     def __init__(self, points2d_px, intr, device):
-        p = np.asarray(points2d_px, np.float64)
-        ncam, T, J, _ = p.shape
-        vis = (p[..., 0] != 0) & (p[..., 1] != 0)
-        ok = vis.sum(axis=0) >= 2  # (T, J)
-        slot = np.full((T, J), -1, dtype=np.int64)
-        slot[ok] = np.arange(int(ok.sum()))
-        # observations in (frame, joint, camera) order: move the camera axis last and flatten
-        vis_tjc = np.moveaxis(vis, 0, 2) & ok[..., None]
-        t_i, j_i, c_i = np.nonzero(vis_tjc)
-        self.slot = slot
-        self.ncam, self.npts, self.nobs = ncam, int(ok.sum()), int(t_i.size)
-        if self.nobs == 0:
-            raise ValueError("bundle adjustment needs at least one joint seen by two cameras")
-        cam_idx = c_i.astype(np.int32)
-        pt_idx = slot[t_i, j_i].astype(np.int32)
-        obs_xy = np.stack([p[c_i, t_i, j_i, 1], p[c_i, t_i, j_i, 0]], axis=1)  # x = col_px, y = row_px
-        counts = np.bincount(pt_idx, minlength=self.npts)
-        pt_start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-        cam_perm = np.argsort(cam_idx, kind="stable").astype(np.int32)
-        cam_start = np.concatenate([[0], np.cumsum(np.bincount(cam_idx, minlength=ncam))]).astype(np.int32)
-        intr = np.asarray(intr, np.float64)
-        intr4 = np.stack([intr[:, 0, 0], intr[:, 1, 1], intr[:, 0, 2], intr[:, 1, 2]], axis=1)
-
         dev = torch.device(device)
         self.device = dev
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-        self.t = dict(intr4=up(intr4), obs_xy=up(obs_xy), cam_idx=up(cam_idx), pt_idx=up(pt_idx), pt_start=up(pt_start),
-                      cam_perm=up(cam_perm), cam_start=up(cam_start))
+        if isinstance(points2d_px, torch.Tensor):
+            p = points2d_px.to(device=dev, dtype=torch.float64)
+        else:
+            p = torch.from_numpy(np.ascontiguousarray(points2d_px, dtype=np.float64)).to(dev)
+        ncam, T, J, _ = p.shape
+        vis = (p[..., 0] != 0) & (p[..., 1] != 0)                 # (ncam, T, J)
+        ok = vis.sum(dim=0) >= 2                                  # (T, J): the joints seen by at least two cameras = the 3-D points
+        self.ok_dev = ok.reshape(-1)
+        slot = torch.cumsum(self.ok_dev.to(torch.int64), 0) - 1   # point index of (t, j) where ok
+        # observations in (frame, joint, camera) order: move the camera axis last; nonzero() lists them in that order
+        vis_tjc = vis.permute(1, 2, 0) & ok[..., None]
+        idx = torch.nonzero(vis_tjc)
+        t_i, j_i, c_i = idx[:, 0], idx[:, 1], idx[:, 2]
+        self.ncam, self.nobs = ncam, int(idx.shape[0])
+        if self.nobs == 0:
+            raise ValueError("bundle adjustment needs at least one joint seen by two cameras")
+        cam_idx = c_i.to(torch.int32)
+        pt_long = slot[t_i * J + j_i]
+        self.npts = int(slot[-1].item()) + 1
+        pt_idx = pt_long.to(torch.int32)
+        obs = p[c_i, t_i, j_i]                                    # (nobs, 2) (row_px, col_px)
+        obs_xy = torch.stack([obs[:, 1], obs[:, 0]], dim=1).contiguous()  # x = col_px, y = row_px
+        zero = torch.zeros(1, dtype=torch.int64, device=dev)
+        pt_start = torch.cat([zero, torch.cumsum(torch.bincount(pt_long, minlength=self.npts), 0)]).to(torch.int32)
+        cam_perm = torch.argsort(c_i, stable=True).to(torch.int32)
+        cam_start = torch.cat([zero, torch.cumsum(torch.bincount(c_i, minlength=ncam), 0)]).to(torch.int32)
+        intr = np.asarray(intr, np.float64)
+        intr4 = torch.from_numpy(np.stack([intr[:, 0, 0], intr[:, 1, 1], intr[:, 0, 2], intr[:, 1, 2]], axis=1)).to(dev)
+        self._TJ = (T, J)
+        self._slot = None
+        self.t = dict(intr4=intr4, obs_xy=obs_xy, cam_idx=cam_idx.contiguous(), pt_idx=pt_idx.contiguous(), pt_start=pt_start.contiguous(),
+                      cam_perm=cam_perm.contiguous(), cam_start=cam_start.contiguous())
         self.c = _native.BAProblem(
             ncam, self.nobs, self.npts, self.t["intr4"].data_ptr(), self.t["obs_xy"].data_ptr(), self.t["cam_idx"].data_ptr(),
             self.t["pt_idx"].data_ptr(), self.t["pt_start"].data_ptr(), self.t["cam_perm"].data_ptr(), self.t["cam_start"].data_ptr(),
         )
         self.m = 2 * self.nobs
         self.n = 6 * ncam + 3 * self.npts
+
+    @property
+    def slot(self):
+        """(T, J) int64: index of the 3-D point of (frame, joint), -1 where fewer than two cameras see the joint (host copy, on demand)."""
+        if self._slot is None:
+            ok = self.ok_dev.cpu().numpy()
+            s = np.full(ok.shape, -1, dtype=np.int64)
+            s[ok] = np.arange(int(ok.sum()))
+            self._slot = s.reshape(self._TJ)
+        return self._slot
 
 
 class _Dev:
@@ -120,6 +140,16 @@ class _Dev:
     def dot(self, a, b):
         _native.check(self.lib.df3d_vec_dot(a.data_ptr(), b.data_ptr(), a.numel(), ctypes.byref(self._res), self.scratch.data_ptr(), self.stream()), "df3d_vec_dot")
         return self._res.value
+
+    def dots(self, *pairs):
+        """Several dot products in one launch and ONE synchronising read-back; each is summed exactly as `dot` sums it."""
+        k = len(pairs)
+        a = (ctypes.c_void_p * k)(*[x.data_ptr() for x, _ in pairs])
+        b = (ctypes.c_void_p * k)(*[y.data_ptr() for _, y in pairs])
+        n = (ctypes.c_size_t * k)(*[x.numel() for x, _ in pairs])
+        out = (ctypes.c_double * k)()
+        _native.check(self.lib.df3d_vec_dots(k, a, b, n, out, self.scratch.data_ptr(), self.stream()), "df3d_vec_dots")
+        return list(out)
 
     def absmax(self, a):
         _native.check(self.lib.df3d_vec_absmax(a.data_ptr(), a.numel(), ctypes.byref(self._res), self.scratch.data_ptr(), self.stream()), "df3d_vec_absmax")
@@ -237,8 +267,8 @@ def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None):
         dv.mul(d, g, g_h)
         # Tikhonov term from the 1-D Cauchy model along -g_h
         dv.matvec(Jc, Jp, d, g_h, tmp_m)
-        a = 0.5 * dv.dot(tmp_m, tmp_m)
-        gh2 = dv.dot(g_h, g_h)
+        jg2, gh2 = dv.dots((tmp_m, tmp_m), (g_h, g_h))   # (round 4: the driver's scalars come back in groups, one read-back each)
+        a = 0.5 * jg2
         b = -gh2
         to_tr = Delta / np.sqrt(gh2)
         cand = [0.0, to_tr]
@@ -261,9 +291,9 @@ def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None):
         dv.axpby(-1.0 / n1, s1, 0.0, None, s1)
         dv.matvec(Jc, Jp, d, s0, Js0)
         dv.matvec(Jc, Jp, d, s1, Js1)
-        b00, b01, b11 = dv.dot(Js0, Js0), dv.dot(Js0, Js1), dv.dot(Js1, Js1)
+        b00, b01, b11, gs0, gs1 = dv.dots((Js0, Js0), (Js0, Js1), (Js1, Js1), (s0, g_h), (s1, g_h))
         B_S = np.array([[b00, b01], [b01, b11]])
-        g_S = np.array([dv.dot(s0, g_h), dv.dot(s1, g_h)])
+        g_S = np.array([gs0, gs1])
         actual_reduction = -1.0
         cost_new = cost
         while actual_reduction <= 0 and nfev < max_nfev:
@@ -271,13 +301,14 @@ def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None):
             dv.axpby(float(p_S[0]), s0, float(p_S[1]), s1, step_h)
             # predicted reduction = -(0.5 |J_h step|^2 + step . g_h), with J_h step = p0 Js0 + p1 Js1
             dv.axpby(float(p_S[0]), Js0, float(p_S[1]), Js1, tmp_m)
-            predicted_reduction = -(0.5 * dv.dot(tmp_m, tmp_m) + dv.dot(step_h, g_h))
             dv.mul(d, step_h, tmp_n2)  # step
             dv.axpby(1.0, x, 1.0, tmp_n2, x_new)
             dv.eval(x_new, f_new, None, None)
             nfev += 1
-            step_h_norm = dv.norm(step_h)
-            cost_new = 0.5 * dv.dot(f_new, f_new)
+            jp2, sg, sh2, ff, st2, xx = dv.dots((tmp_m, tmp_m), (step_h, g_h), (step_h, step_h), (f_new, f_new), (tmp_n2, tmp_n2), (x, x))
+            predicted_reduction = -(0.5 * jp2 + sg)
+            step_h_norm = float(np.sqrt(sh2))
+            cost_new = 0.5 * ff
             if not np.isfinite(cost_new):
                 Delta = 0.25 * step_h_norm
                 continue
@@ -293,9 +324,9 @@ def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None):
                 Delta_new = 0.25 * step_h_norm
             elif ratio > 0.75 and step_h_norm > 0.95 * Delta:
                 Delta_new = 2.0 * Delta
-            step_norm = dv.norm(tmp_n2)
+            step_norm = float(np.sqrt(st2))
             ftol_ok = actual_reduction < ftol * cost and ratio > 0.25
-            xtol_ok = step_norm < xtol * (xtol + dv.norm(x))
+            xtol_ok = step_norm < xtol * (xtol + float(np.sqrt(xx)))
             if ftol_ok and xtol_ok:
                 status = 4
             elif ftol_ok:
@@ -336,8 +367,7 @@ def reprojection_error(points2d_px, points3d, R, tvec, intr, device="cuda:0"):
         dv = _Dev(prob)
         ncam = prob.ncam
         cams = np.concatenate([np.stack([_rotvec_from_matrix(np.asarray(R[c], np.float64)) for c in range(ncam)]), np.asarray(tvec, np.float64)], axis=1).ravel()
-        sel = torch.from_numpy((prob.slot.ravel() >= 0)).to(dev)
-        X = torch.from_numpy(np.ascontiguousarray(points3d, dtype=np.float64)).to(dev).reshape(-1, 3)[sel].reshape(-1)
+        X = torch.from_numpy(np.ascontiguousarray(points3d, dtype=np.float64)).to(dev).reshape(-1, 3)[prob.ok_dev].reshape(-1)
         x = torch.cat([torch.from_numpy(cams).to(dev), X])
         r = dv.new(prob.m)
         dv.eval(x, r, None, None)
@@ -377,14 +407,13 @@ def _bundle_adjust(points2d_px, R, tvec, intr, device, return_info):
     intr = np.asarray(intr, np.float64)
     ncam = R.shape[0]
     dev = torch.device(device)
-    prob = BAProblemDevice(points2d_px, intr, dev)
+    px_dev = torch.from_numpy(np.ascontiguousarray(points2d_px, dtype=np.float64)).to(dev)
+    prob = BAProblemDevice(px_dev, intr, dev)
     # initial points: DLT with the initial calibration (HIP kernel)
     P = np.einsum("cij,cjk->cik", intr, np.concatenate([R, tvec[..., None]], axis=-1))
-    px_dev = torch.from_numpy(np.ascontiguousarray(points2d_px, dtype=np.float64)).to(dev)
     X0 = ops.triangulate(P, px_dev)
     cams = np.concatenate([np.stack([_rotvec_from_matrix(R[c]) for c in range(ncam)]), tvec], axis=1).ravel()
-    sel = torch.from_numpy((prob.slot.ravel() >= 0)).to(dev)
-    x0 = torch.cat([torch.from_numpy(cams).to(dev), X0.reshape(-1, 3)[sel].reshape(-1)])
+    x0 = torch.cat([torch.from_numpy(cams).to(dev), X0.reshape(-1, 3)[prob.ok_dev].reshape(-1)])
     res = solve_trf(prob, x0)
     cams_new = res["x"][: 6 * ncam].cpu().numpy().reshape(ncam, 6)
     R_new = np.stack([_matrix_from_rotvec(cams_new[c, :3]) for c in range(ncam)])

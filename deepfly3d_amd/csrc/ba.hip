@@ -265,6 +265,35 @@ __global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ a, 
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// up to 8 dot products in one launch (blockIdx.y = product), each with dot_kernel's grid and summation order
+struct DotBatch {
+    const double* a[8];
+    const double* b[8];
+    unsigned long long n[8];
+    int g[8];
+};
+__global__ __launch_bounds__(256) void dots_kernel(DotBatch q, double* __restrict__ partial) {
+    __shared__ double lds4[4];
+    const int j = blockIdx.y;
+    const int g = q.g[j];
+    if ((int)blockIdx.x >= g) return;
+    const double* __restrict__ a = q.a[j];
+    const double* __restrict__ b = q.b[j];
+    const size_t n = (size_t)q.n[j];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)g * 256) acc += a[i] * b[i];
+    const double tot = block_reduce_256(acc, lds4);
+    if (threadIdx.x == 0) partial[(size_t)j * RED_BLOCKS + blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void dots_final_kernel(DotBatch q, const double* __restrict__ partial, double* __restrict__ result) {
+    __shared__ double lds4[4];
+    const int j = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < q.g[j]; i += 256) acc += partial[(size_t)j * RED_BLOCKS + i];
+    const double tot = block_reduce_256(acc, lds4);
+    if (threadIdx.x == 0) result[j] = tot;
+}
+
 // partial sums of the Euclidean norms of n (x, y) pairs (reprojection error: mean pixel distance)
 __global__ __launch_bounds__(256) void pairnorm_kernel(const double* __restrict__ r, size_t n, double* __restrict__ partial) {
     __shared__ double lds4[4];
@@ -502,6 +531,29 @@ int df3d_vec_dot(const double* a_dev, const double* b_dev, size_t n, double* res
     return read_back(scratch_dev + RED_BLOCKS, result_host, s);
 }
 
+int df3d_vec_dots(int count, const double* const* a_dev, const double* const* b_dev, const size_t* n, double* results_host, double* scratch_dev,
+                  void* stream) {
+    DF3D_CHECK_ARG(count >= 1 && count <= 8 && a_dev && b_dev && n && results_host && scratch_dev, "1..8 products, no null pointer");
+    hipStream_t s = df3d::as_stream(stream);
+    DotBatch q{};
+    int gmax = 1;
+    for (int j = 0; j < count; ++j) {
+        DF3D_CHECK_ARG(a_dev[j] && b_dev[j], "null vector");
+        q.a[j] = a_dev[j];
+        q.b[j] = b_dev[j];
+        q.n[j] = n[j];
+        q.g[j] = grid_for(n[j]);
+        gmax = q.g[j] > gmax ? q.g[j] : gmax;
+    }
+    double* const result = scratch_dev + 8 * RED_BLOCKS;
+    hipLaunchKernelGGL(dots_kernel, dim3(gmax, count), dim3(256), 0, s, q, scratch_dev);
+    hipLaunchKernelGGL(dots_final_kernel, dim3(count), dim3(256), 0, s, q, scratch_dev, result);
+    DF3D_LAUNCH_CHECK();
+    DF3D_HIP(hipMemcpyAsync(results_host, result, count * sizeof(double), hipMemcpyDeviceToHost, s));
+    DF3D_HIP(hipStreamSynchronize(s));
+    return DF3D_OK;
+}
+
 int df3d_vec_pairnorm_sum(const double* r_dev, size_t npairs, double* result_host, double* scratch_dev, void* stream) {
     DF3D_CHECK_ARG(r_dev && result_host && scratch_dev, "null pointer");
     hipStream_t s = df3d::as_stream(stream);
@@ -550,8 +602,8 @@ int df3d_ba_update_scale(const double* colsq_dev, double* scale_inv_dev, double*
 size_t df3d_ba_lsmr_work_doubles(const df3d_ba_problem* p) {
     if (!p) return 0;
     const size_t m = 2 * (size_t)p->nobs, n = 6 * (size_t)p->ncam + 3 * (size_t)p->npts;
-    // u, tmp_m (m each); v, h, hbar, tmp_n (n each); scratch
-    return 2 * m + 4 * n + DF3D_BA_SCRATCH_DOUBLES + 64;
+    // u, tmp_m (m each); v, h, hbar, tmp_n (n each); scratch; round 4 (fused iteration): two state slots, |u|^2 / |x|^2 partials, |v|^2 partials
+    return 2 * m + 4 * n + DF3D_BA_SCRATCH_DOUBLES + 64 + 2 * df3d_lsmr::FUSED_DOUBLES + 3 * df3d_lsmr::FUSED_RED;
 }
 
 int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, const double* d_dev,
@@ -649,30 +701,65 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
         DF3D_HIP(hipStreamSynchronize(s));
         return finish(init);
     }
+    // round 4: the iteration is THREE kernels (ba_lsmr.hip: fused_k1 / k2 / k3; the scalar steps run in every workgroup's prologue, the
+    // state alternates between two slots, u and v stay un-normalised with 1 / beta, 1 / alpha in the state) instead of eleven
+    double* const fbase = work_dev + (2 * m + 4 * n + DF3D_BA_SCRATCH_DOUBLES + 64);
+    df3d_lsmr::FusedArgs fa{};
+    fa.Jc = Jc; fa.Jp = Jp; fa.d = d_dev;
+    fa.u = u; fa.v = v; fa.h = h; fa.hbar = hbar; fa.x = x_dev;
+    fa.cam_partial = scratch;
+    fa.st = fbase;
+    fa.red1 = fbase + 2 * df3d_lsmr::FUSED_DOUBLES;
+    fa.red3 = fa.red1 + df3d_lsmr::FUSED_RED;
+    fa.red2 = fa.red3 + df3d_lsmr::FUSED_RED;
+    fa.nchunk = NCHUNK;
+    fa.g1 = gm;    // round 3's grids: the grouping of the sums of squares is part of the arithmetic
+    fa.g2p = gn;
+    fa.g3 = gn;
+    df3d_lsmr::Fused finit{};
+    finit.s = init;
+    finit.pending_c = 0;
+    DF3D_HIP(hipMemcpyAsync(fa.st, &finit, sizeof(finit), hipMemcpyHostToDevice, s));
+    DF3D_HIP(hipMemcpyAsync(reinterpret_cast<unsigned char*>(fa.st) + offsetof(df3d_lsmr::Fused, vcam), v, 6 * (size_t)p->ncam * sizeof(double),
+                            hipMemcpyDeviceToDevice, s));
+    DF3D_HIP(hipStreamSynchronize(s));  // `finit` is on the stack
+
+    // round 3's form (eleven kernels per iteration, one state, u and v normalised in place) stays selectable for A/B runs and as the
+    // arithmetic reference: DF3D_LSMR_KERNELS=11 in the environment
+    static const bool r3_form = [] { const char* e = getenv("DF3D_LSMR_KERNELS"); return e && atoi(e) == 11; }();
     static_assert(sizeof(df3d_lsmr::State) <= 64 * sizeof(double), "state must fit behind the reduction scratch");
     df3d_lsmr::State* st = reinterpret_cast<df3d_lsmr::State*>(result + 8);
-    DF3D_HIP(hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, s));
-    DF3D_HIP(hipStreamSynchronize(s));  // `init` is on the stack
+    if (r3_form) {
+        DF3D_HIP(hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, s));
+        DF3D_HIP(hipStreamSynchronize(s));
+    }
 
-    constexpr int CHUNK = 16;
+    constexpr int CHUNK = 16;           // (even: a chunk leaves the state in the slot it found it in)
     df3d_lsmr::State now = init;
+    int slot = 0;
     auto enqueue_iteration = [&]() -> int {
-        // u = A v - alpha u ; beta = |u| ; u /= beta
-        if (int rc = launch_matvec(p, Jc, Jp, d_dev, v, tmp_m, s)) return rc;
-        hipLaunchKernelGGL(lsmr_bidiag_kernel<0>, dim3(gm), dim3(256), 0, s, st, tmp_m, u, m, red);
-        df3d_lsmr::launch_step_a(st, red, gm, s);
-        hipLaunchKernelGGL(lsmr_scale_kernel<0>, dim3(gm), dim3(256), 0, s, st, u, m);
-        // v = A^T u - beta v ; alpha = |v| ; rotations ; v /= alpha
-        if (int rc = launch_rmatvec(p, Jc, Jp, d_dev, u, tmp_n, scratch, s)) return rc;
-        hipLaunchKernelGGL(lsmr_bidiag_kernel<1>, dim3(gn), dim3(256), 0, s, st, tmp_n, v, n, red);
-        df3d_lsmr::launch_step_b(st, red, gn, s);
-        hipLaunchKernelGGL(lsmr_scale_kernel<1>, dim3(gn), dim3(256), 0, s, st, v, n);
-        // hbar, x, h ; |x| ; stopping tests
-        hipLaunchKernelGGL(lsmr_update_dev_kernel, dim3(gn), dim3(256), 0, s, st, hbar, h, x_dev, v, n, red);
-        df3d_lsmr::launch_step_c(st, red, gn, s);
+        if (r3_form) {
+            // u = A v - alpha u ; beta = |u| ; u /= beta
+            if (int rc = launch_matvec(p, Jc, Jp, d_dev, v, tmp_m, s)) return rc;
+            hipLaunchKernelGGL(lsmr_bidiag_kernel<0>, dim3(gm), dim3(256), 0, s, st, tmp_m, u, m, red);
+            df3d_lsmr::launch_step_a(st, red, gm, s);
+            hipLaunchKernelGGL(lsmr_scale_kernel<0>, dim3(gm), dim3(256), 0, s, st, u, m);
+            // v = A^T u - beta v ; alpha = |v| ; rotations ; v /= alpha
+            if (int rc = launch_rmatvec(p, Jc, Jp, d_dev, u, tmp_n, scratch, s)) return rc;
+            hipLaunchKernelGGL(lsmr_bidiag_kernel<1>, dim3(gn), dim3(256), 0, s, st, tmp_n, v, n, red);
+            df3d_lsmr::launch_step_b(st, red, gn, s);
+            hipLaunchKernelGGL(lsmr_scale_kernel<1>, dim3(gn), dim3(256), 0, s, st, v, n);
+            // hbar, x, h ; |x| ; stopping tests
+            hipLaunchKernelGGL(lsmr_update_dev_kernel, dim3(gn), dim3(256), 0, s, st, hbar, h, x_dev, v, n, red);
+            df3d_lsmr::launch_step_c(st, red, gn, s);
+            return DF3D_OK;
+        }
+        df3d_lsmr::launch_fused_iteration(*p, fa, slot, s);
+        slot ^= 1;
+        DF3D_LAUNCH_CHECK();
         return DF3D_OK;
     };
-    // One chunk of CHUNK iterations = 12 x CHUNK small dependent kernels: launch-bound when enqueued one by one.  On a
+    // One chunk of CHUNK iterations = 3 x CHUNK small dependent kernels (round 3: 11 x CHUNK): launch-bound when enqueued one by one.  On a
     // capturable stream (not the legacy default stream) the chunk is recorded once into a HIP graph and replayed -- every
     // scalar the kernels need lives in `st`, so the recording is valid for every chunk of every LSMR run on the same problem
     // and buffers (the three or four runs of one trust-region solve); otherwise the kernels are enqueued directly.
@@ -722,7 +809,16 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
                 if (int rc = enqueue_iteration()) return rc;
             DF3D_LAUNCH_CHECK();
         }
-        DF3D_HIP(hipMemcpyAsync(&now, st, sizeof(now), hipMemcpyDeviceToHost, s));
+        DF3D_HIP(hipMemcpyAsync(&now, r3_form ? reinterpret_cast<const double*>(st) : fa.st + (size_t)slot * df3d_lsmr::FUSED_DOUBLES, sizeof(now),
+                                hipMemcpyDeviceToHost, s));   // (State leads Fused)
+        DF3D_HIP(hipStreamSynchronize(s));
+    }
+    if (now.istop == 0 && !r3_form) {
+        // maxiter reached: the last iteration's stopping test (step C) is still pending -- the NEXT k1's prologue takes it (k1 touches
+        // u and the state only, not x); a run that stopped earlier was settled by the k1 behind its last iteration
+        df3d_lsmr::launch_fused_flush(*p, fa, slot, s);
+        slot ^= 1;
+        DF3D_HIP(hipMemcpyAsync(&now, fa.st + (size_t)slot * df3d_lsmr::FUSED_DOUBLES, sizeof(now), hipMemcpyDeviceToHost, s));
         DF3D_HIP(hipStreamSynchronize(s));
     }
     return finish(now);

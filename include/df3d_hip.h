@@ -219,7 +219,13 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc_dev, const double* J
 
 /* small device-vector helpers used by the host TRF driver (all float64, asynchronous except dot) */
 int df3d_vec_dot(const double* a_dev, const double* b_dev, size_t n, double* result_host, double* scratch_dev,
-                 void* stream); /* synchronous; scratch_dev >= 1024 doubles */
+                 void* stream);
+/* `count` (1..8) dot products a_dev[j] . b_dev[j] of lengths n[j] in ONE launch and ONE synchronising read-back (results_host[count]); every
+ * product is summed exactly as df3d_vec_dot sums it (same grid, same order: the same bits).  The trust-region driver of a7 needs its
+ * scalars in groups (the 2 x 2 subspace system: five products) -- round 4, reference call site df3d/core.py:249.
+ * scratch_dev: DF3D_BA_SCRATCH_DOUBLES doubles. */
+int df3d_vec_dots(int count, const double* const* a_dev, const double* const* b_dev, const size_t* n, double* results_host,
+                  double* scratch_dev, void* stream); /* synchronous; scratch_dev >= 1024 doubles */
 int df3d_vec_axpby(double a, const double* x_dev, double b, const double* y_dev, double* out_dev, size_t n,
                    void* stream); /* out = a*x + b*y (y may be NULL)        */
 int df3d_vec_mul(const double* x_dev, const double* y_dev, double* out_dev, size_t n, void* stream);
