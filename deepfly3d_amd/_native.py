@@ -109,6 +109,9 @@ PROTOTYPES = {
     "df3d_hg_profile_read": (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int)]),
     "df3d_hg_step_m1_bytes": (c_double, [c_void_p, c_int, c_int]),
     "df3d_hg_num_steps": (c_int, [c_void_p]),
+    "df3d_render_pose2d_grid": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, POINTER(c_int), c_int, POINTER(ctypes.c_ubyte), c_double, c_double, c_void_p, c_void_p]),
+    "df3d_render_pose3d_panels": (c_int, [c_void_p, c_int, POINTER(c_int), c_int, POINTER(ctypes.c_ubyte), POINTER(c_double), c_double, c_double, c_int, c_double, c_void_p, c_void_p]),
+    "df3d_resize_rgb": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "df3d_hg_step_desc": (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_int)]),
     "df3d_hg_forward_upto": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
 }

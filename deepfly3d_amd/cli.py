@@ -71,8 +71,15 @@ def run(args):
         core.save()
     core.calibrate_calc(0, core.max_img_id)
     core.save()
-    if args.video_2d or args.video_3d:
-        logger.warning("--video-2d/--video-3d: video rendering is not part of the MI355X hot-path build; skipped.")
+    if (args.video_2d or args.video_3d) and core.is_primary:
+        # f4 (reference cli.py:305-321): frames drawn on the GPU (csrc/render.hip), encoded by ffmpeg when present
+        from . import video
+
+        fps = args.output_fps if args.output_fps is not None else core.fps
+        if args.video_2d:
+            video.make_pose2d_video(core, fps=fps)
+        if args.video_3d:
+            video.make_pose3d_video(core, fps=fps)
     if args.delete_images:
         core.delete_images()
     return 0

@@ -335,6 +335,27 @@ int df3d_hg_step_desc(const df3d_hg* h, int step, char* name_buf, int buflen, in
 int df3d_hg_forward_upto(df3d_hg* h, const float* images_dev, int n, int upto, float* out_dev, void* workspace_dev,
                          size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * f4  frames of the pose videos (reference df3d/video.py:21-108, called from df3d/cli.py:308-321).  One launch draws one frame:
+ *     every output pixel tests itself against the joints and bones of its camera (rule restated in oracle/render.py).
+ * df3d_render_pose2d_grid: luma_dev [6, height, width] uint8 = the images of cameras (0, 1, 2 / 4, 5, 6) in that order;
+ *     points_px_dev [6, num_joints, 2] float64 (row_px, col_px), a joint with a 0 coordinate is unseen; bones_host [num_bones, 2] and
+ *     joint_rgb_host [num_joints, 3] (colour of a joint; a bone takes its first joint's) are HOST tables (<= 64 joints, <= 96 bones);
+ *     out_rgb_dev [2 height, 3 width, 3] uint8: grey image, bone segments of thickness line_width, joint discs of `radius` on top.
+ * df3d_render_pose3d_panels: points3d_dev [num_joints, 3] float64 (the pose Core.get_points3d returns for one image), three square
+ *     panels [size, 3 size, 3] uint8, orthographic views from azimuth_deg3[k] / elevation_deg (matplotlib's view_init angles,
+ *     reference df3d/plot_util.py:48-51), +-lim mapped onto the panel, black background.
+ * df3d_resize_rgb: bilinear, pixel centres at half integers (cv2.INTER_LINEAR's geometry); pitches in pixels.
+ * All asynchronous on `stream`. */
+int df3d_render_pose2d_grid(const unsigned char* luma_dev, int height, int width, const double* points_px_dev, int num_joints,
+                            const int* bones_host, int num_bones, const unsigned char* joint_rgb_host, double radius, double line_width,
+                            unsigned char* out_rgb_dev, void* stream);
+int df3d_render_pose3d_panels(const double* points3d_dev, int num_joints, const int* bones_host, int num_bones,
+                              const unsigned char* joint_rgb_host, const double* azimuth_deg3, double elevation_deg, double lim, int size,
+                              double line_width, unsigned char* out_rgb_dev, void* stream);
+int df3d_resize_rgb(const unsigned char* in_dev, int in_h, int in_w, int in_pitch_px, unsigned char* out_dev, int out_h, int out_w,
+                    int out_pitch_px, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
