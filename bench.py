@@ -75,6 +75,9 @@ def parse(argv=None):
                          "the timed region; --steps is derived (the largest shard's batches)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: create a 1-rank process group (RCCL) and execute the packed gather anyway")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the multi-rank control flow (no GPU, gloo): the pipeline is a stub that stamps every frame with its global index, "
+                         "everything else -- shards, batches per rank, window bookkeeping, the packed gather -- is the real code; rank 0 checks the gathered sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-bf16-leg", "--no-legs", dest="no_legs", action="store_true",
@@ -471,6 +474,81 @@ def share_leg(a, sd, dtype, frames, calib, dev):
     return out
 
 
+class _StubPipeline:
+    """--dry-run: stands in for FramePipeline on the CPU.  Every frame's points3d[t, 0, 0] (and points2d / confidence) carry the frame's
+    GLOBAL index, so rank 0 can check that the gather put every shard where it belongs."""
+
+    def __init__(self, frame0):
+        self.frame0 = frame0
+
+    def allocate_outputs(self, T):
+        return (torch.zeros((7, T, 38, 2), dtype=torch.float64), torch.zeros((7, T, 19), dtype=torch.float32), torch.zeros((T, 38, 3), dtype=torch.float64))
+
+    def run_batch(self, frames, p2, cf, p3, t0):
+        n = frames.shape[0]
+        idx = torch.arange(self.frame0 + t0, self.frame0 + t0 + n, dtype=torch.float64)
+        p3[t0:t0 + n] = idx[:, None, None]
+        p2[:, t0:t0 + n] = idx[None, :, None, None]
+        cf[:, t0:t0 + n] = (idx % 1024).to(torch.float32)[None, :, None]
+
+
+def dry_run(a):
+    """The N-rank control flow of `--strong` / the weak default on CPU tensors over gloo: what an 8-GPU box will execute around the kernels."""
+    from deepfly3d_amd import distributed as dd
+
+    rank, world, _ = dd.init_from_env(backend="gloo")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    fps_step = a.frames_per_step
+    align = a.ba_window if a.ba_window > 0 else 1
+    if a.strong:
+        shards, a.steps = strong_plan(a.stream_frames, world, align, fps_step)
+        t0, t1, _ = shards[rank]
+        total, global_frames = t1 - t0, a.stream_frames
+    else:
+        shards = None
+        total, global_frames, t0 = a.steps * fps_step, None, rank * a.steps * fps_step
+    job = Job.__new__(Job)
+    job.a, job.rank, job.world, job.total_frames, job.steps, job.ba_window = a, rank, world, total, a.steps, a.ba_window
+    job.collective, job.force_collective, job.global_frames, job.align = world > 1, False, global_frames, align
+    job.fps_step, job.pool, job.dev = fps_step, fps_step, torch.device("cpu")
+    job.frames = torch.zeros((fps_step, 1))
+    job.pipe = _StubPipeline(t0)
+    job.outs = job.pipe.allocate_outputs(total)
+    job.timeline = None
+    nwin = -(-total // a.ba_window) if a.ba_window > 0 else 0
+    job.ba_px = None
+    job.ba_cams = [np.full((7, 12), float(t0 // a.ba_window + w)) for w in range(nwin)] if nwin else []   # window w of the stream, stamped
+    job.ba_runs, job.ba_ms, job.ba_futures, job.ba_pool = [0] * nwin, [], [], None
+    if world > 1:
+        torch.distributed.barrier()
+    t_start = time.perf_counter()
+    for i in range(a.steps):
+        if i * fps_step < total:
+            job.step(i, record=False, solve=False)
+    cams = torch.from_numpy(np.stack(job.ba_cams)) if nwin or a.ba_window else None
+    if a.ba_window and cams is None:
+        cams = torch.zeros((0, 7, 12), dtype=torch.float64)
+    num = global_frames if global_frames is not None else total * world
+    got = dd.gather_results(*job.outs, num_frames=num, rank=rank, world_size=world, align=align, cameras=cams)
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t_start
+    if rank == 0:
+        p2, cf, p3 = got[:3]
+        seq = torch.arange(num, dtype=torch.float64)
+        ok = bool(torch.equal(p3[:, 0, 0], seq) and torch.equal(p2[3, :, 7, 1], seq) and torch.equal(cf[0, :, 0], (seq % 1024).to(torch.float32)))
+        if a.ba_window:
+            ok = ok and got[3].shape[0] == -(-num // a.ba_window) and bool(torch.equal(got[3][:, 0, 0], torch.arange(got[3].shape[0], dtype=torch.float64)))
+        print(json.dumps({"metric": "frames/sec (7-view 2D->3D)", "dry_run": True, "value": num / elapsed, "unit": "frames/s (CPU stub: control flow only)", "n_gpus": world,
+                          "steps": a.steps, "scaling": "strong" if a.strong else "weak", "frames_per_gpu": [b - c for c, b, _ in shards] if shards else total,
+                          "collective_backend": torch.distributed.get_backend() if world > 1 else None, "gather_check": ok,
+                          "windows_gathered": int(got[3].shape[0]) if a.ba_window else None}), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def strong_plan(stream_frames, world, align, frames_per_step):
     """Strong scaling: per rank (first frame, last frame + 1, batches) of the ONE stream, and the batches of the largest shard
     (the `steps` every rank loops over; a shorter shard skips its missing batches).  Pure: the CPU tests walk it for 8 ranks."""
@@ -483,6 +561,8 @@ def strong_plan(stream_frames, world, align, frames_per_step):
 
 def main(argv=None):
     a = parse(argv)
+    if a.dry_run:
+        return dry_run(a)
     from deepfly3d_amd import _native
     from deepfly3d_amd import distributed as dd
     from deepfly3d_amd.config import load_calibration

@@ -228,3 +228,23 @@ def test_single_rank_is_a_no_op():
     p2, cf, p3 = _full_sequence(5)
     out = dd.gather_results(p2, cf, p3, 5, 0, 1)
     assert out[0] is p2 and out[1] is cf and out[2] is p3
+
+
+def test_bench_eight_rank_dry_run_of_the_strong_scaled_stream():
+    """`bench.py --dry-run`: the launch line the driver will use on an 8-GPU box (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8
+    --strong --stream-frames 100000 --ba-window 1000`), executed here on CPU tensors over gloo with a stub in the pipeline's place: BASELINE
+    configs[4]'s own split (13 000 x 4 + 12 000 x 4 frames, 102 batches on the largest shard), per-rank window records, ONE packed gather
+    of 570 MB; rank 0 finds every frame and every window where it belongs."""
+    import json
+    import subprocess
+
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--strong", "--stream-frames", "100000", "--ba-window", "1000", "--dry-run"],
+                       cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(rows) == 1, r.stdout[-2000:]
+    d = json.loads(rows[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["scaling"] == "strong" and d["steps"] == 102
+    assert d["frames_per_gpu"] == [13000] * 4 + [12000] * 4 and d["collective_backend"] == "gloo"
+    assert d["gather_check"] is True and d["windows_gathered"] == 100
