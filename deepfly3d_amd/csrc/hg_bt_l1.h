@@ -361,7 +361,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck_l1_kernel(BtL1Args p) {
                     const int pw = 8 * c + (lanev >> 3);
                     fin[c] = *reinterpret_cast<const u32x4*>(slice + pw * L1_OP + (lanev & 7) * 16);
                     if (outs)
-                        *reinterpret_cast<u32x4*>(outs + ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CO + 64 * hc + (lanev & 7) * 8) = fin[c];
+                        hg_store16(outs + ((size_t)(ty0 + 2 * wave + (pw >> 4)) * p.W + (tx0 + (pw & 15))) * CO + 64 * hc + (lanev & 7) * 8, fin[c]);
                 }
                 if (pp) {
 #pragma unroll
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck_l1_kernel(BtL1Args p) {
                         for (int e = 0; e < 4; ++e) o[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m[e], 0x128 /* row_ror:8 */, 0xf, 0xf, false);
                         m = bf16_key_chunk(bf16_key_max_chunk(m, o));
                         if (((lanev >> 3) & 1) == 0)
-                            *reinterpret_cast<u32x4*>(pp + ((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + 4 * c + (lanev >> 4))) * CO + 64 * hc + (lanev & 7) * 8) = m;
+                            hg_store16(pp + ((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + 4 * c + (lanev >> 4))) * CO + 64 * hc + (lanev & 7) * 8, m);
                     }
                 }
             }

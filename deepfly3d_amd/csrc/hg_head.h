@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                         for (int c = 0; c < 4; ++c) {
                             const long long m = m0 + wave * 32 + 8 * c + (lane >> 3);
                             const u32x4 v = *reinterpret_cast<const u32x4*>(slice + (8 * c + (lane >> 3)) * SP + (lane & 7) * 16);
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)m * 256 + nh * 128 + 64 * hc + (lane & 7) * 8) = v;
+                            hg_store16(reinterpret_cast<unsigned short*>(p.out) + (size_t)m * 256 + nh * 128 + 64 * hc + (lane & 7) * 8, v);
                         }
                     }
                 }
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                     for (int c = 0; c < 4; ++c) {
                         const long long m = m0 + wave * 32 + 8 * c + (lane >> 3);
                         const u32x4 v = *reinterpret_cast<const u32x4*>(slice + (8 * c + (lane >> 3)) * SP + (lane & 7) * 16);
-                        if (m < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)m * 256 + nh * CH + 64 * hc + (lane & 7) * 8) = v;
+                        if (m < p.M) hg_store16(reinterpret_cast<unsigned short*>(p.out) + (size_t)m * 256 + nh * CH + 64 * hc + (lane & 7) * 8, v);
                     }
                 }
             }

@@ -86,6 +86,20 @@ struct Lp<_Float16> {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
     }
 };
+// 16-byte global store of an activation chunk; HG_NT_STORES (development switch, default 0) makes it a streaming (nt) store in the stack
+// heads and the 16-bit layer1 kernel, as the ring bottleneck's MODE 2 does (hg_bt_ring.h: -1.2 % there)
+#ifndef HG_NT_STORES
+#define HG_NT_STORES 0
+#endif
+using hg_u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+__device__ __forceinline__ void hg_store16(void* dst, hg_u32x4 v) {
+#if HG_NT_STORES
+    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
+#else
+    *reinterpret_cast<hg_u32x4*>(dst) = v;
+#endif
+}
+
 // eight consecutive floats -> one 16-byte MFMA operand chunk
 template <typename T>
 __device__ __forceinline__ u32x4 lp_pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
