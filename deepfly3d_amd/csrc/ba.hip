@@ -701,7 +701,7 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
         DF3D_HIP(hipStreamSynchronize(s));
         return finish(init);
     }
-    // round 4: the iteration is THREE kernels (ba_lsmr.hip: fused_k1 / k2 / k3; the scalar steps run in every workgroup's prologue, the
+    // round 4: the iteration is TWO kernels (ba_lsmr.hip: fused_ka / fused_kb; the scalar steps run in every workgroup's prologue, the
     // state alternates between two slots, u and v stay un-normalised with 1 / beta, 1 / alpha in the state) instead of eleven
     double* const fbase = work_dev + (2 * m + 4 * n + DF3D_BA_SCRATCH_DOUBLES + 64);
     df3d_lsmr::FusedArgs fa{};
@@ -719,6 +719,7 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
     df3d_lsmr::Fused finit{};
     finit.s = init;
     finit.pending_c = 0;
+    finit.pending_b = 0;
     DF3D_HIP(hipMemcpyAsync(fa.st, &finit, sizeof(finit), hipMemcpyHostToDevice, s));
     DF3D_HIP(hipMemcpyAsync(reinterpret_cast<unsigned char*>(fa.st) + offsetof(df3d_lsmr::Fused, vcam), v, 6 * (size_t)p->ncam * sizeof(double),
                             hipMemcpyDeviceToDevice, s));
@@ -734,7 +735,7 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
         DF3D_HIP(hipStreamSynchronize(s));
     }
 
-    constexpr int CHUNK = 16;           // (even: a chunk leaves the state in the slot it found it in)
+    constexpr int CHUNK = 16;
     df3d_lsmr::State now = init;
     int slot = 0;
     auto enqueue_iteration = [&]() -> int {
@@ -754,12 +755,11 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
             df3d_lsmr::launch_step_c(st, red, gn, s);
             return DF3D_OK;
         }
-        df3d_lsmr::launch_fused_iteration(*p, fa, slot, s);
-        slot ^= 1;
+        df3d_lsmr::launch_fused_iteration(*p, fa, s);   // (ka: state slot 0 -> 1, kb: 1 -> 0)
         DF3D_LAUNCH_CHECK();
         return DF3D_OK;
     };
-    // One chunk of CHUNK iterations = 3 x CHUNK small dependent kernels (round 3: 11 x CHUNK): launch-bound when enqueued one by one.  On a
+    // One chunk of CHUNK iterations = 2 x CHUNK small dependent kernels (round 3: 11 x CHUNK): launch-bound when enqueued one by one.  On a
     // capturable stream (not the legacy default stream) the chunk is recorded once into a HIP graph and replayed -- every
     // scalar the kernels need lives in `st`, so the recording is valid for every chunk of every LSMR run on the same problem
     // and buffers (the three or four runs of one trust-region solve); otherwise the kernels are enqueued directly.
@@ -814,10 +814,9 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
         DF3D_HIP(hipStreamSynchronize(s));
     }
     if (now.istop == 0 && !r3_form) {
-        // maxiter reached: the last iteration's stopping test (step C) is still pending -- the NEXT k1's prologue takes it (k1 touches
-        // u and the state only, not x); a run that stopped earlier was settled by the k1 behind its last iteration
-        df3d_lsmr::launch_fused_flush(*p, fa, slot, s);
-        slot ^= 1;
+        // maxiter reached: the last iteration's steps B and C (and its update of x) are still pending -- one more ka and the scalar half of
+        // kb take them; a run that stopped earlier was settled by the kernels behind its last iteration
+        df3d_lsmr::launch_fused_flush(*p, fa, s);
         DF3D_HIP(hipMemcpyAsync(&now, fa.st + (size_t)slot * df3d_lsmr::FUSED_DOUBLES, sizeof(now), hipMemcpyDeviceToHost, s));
         DF3D_HIP(hipStreamSynchronize(s));
     }

@@ -35,19 +35,22 @@ __device__ __forceinline__ double block_reduce_256(double v, double* lds4) {
     return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
-// ---- round 4: the iteration as THREE kernels (ba_lsmr.hip: fused_k1 / k2 / k3) instead of eleven -------------------------------------
-// Each vector kernel starts by doing, in every workgroup, the scalar step that used to be a kernel of its own: it sums the
-// previous kernel's per-workgroup partials in the fixed order of the single-workgroup kernels and runs the same scalar code, so all
-// workgroups hold the same scalars without a grid-wide hand-off; workgroup 0 writes the state for the next kernel into the OTHER of two
-// state slots (a workgroup that starts late must still find the state its kernel was launched against).  u and v are kept
-// UN-normalised with 1 / beta, 1 / alpha in the state (the normalised element is formed where it is used, rounded like the stored one
-// was), which removes the two scaling kernels; the 6 x ncam camera entries of v live in the state (`vcam`), because their J^T u sums
-// are finished by the kernel AFTER the one that forms the partial sums.
+// ---- round 4: the iteration as TWO kernels (ba_lsmr.hip: fused_ka / fused_kb) instead of eleven -----------------------------------------
+// Each kernel starts by doing, in every workgroup, the scalar steps that used to be kernels of their own: it sums the previous kernel's
+// per-workgroup partials in the fixed order of the single-workgroup kernels and runs the same scalar code, so all workgroups hold the same
+// scalars without a grid-wide hand-off; workgroup 0 writes the state for the next kernel into the OTHER of two state slots (a workgroup
+// that starts late must still find the state its kernel was launched against).  u and v are kept UN-normalised with 1 / beta, 1 / alpha
+// in the state (the normalised element is formed where it is used, rounded like the stored one was), which removes the two scaling
+// kernels; the 6 x ncam camera entries of v live in the state (`vcam`), because their J^T u sums are finished by the kernel AFTER the one
+// that forms the partial sums.  The kernel boundaries sit where a grid-wide sum is needed and nowhere else:
+//     ka_i = [step B of i - 1 (alpha, rotations); hbar, x, h of i - 1 -> partial |x|^2] + [u <- A v - alpha u of i -> partial |u|^2]
+//     kb_i = [step C of i - 1 (stopping tests; a stopped run ends here); step A of i (beta)] + [v <- A^T u - beta v of i -> partial |v|^2]
+// (a run's last matrix-vector product is computed in vain: it touches u only).
 struct Fused {
     State s;
     double vcam[48];   // camera entries of v (un-normalised), 6 per camera
     int pending_c;     // step C of the previous iteration is still to be taken (0 in front of the first iteration)
-    int pad;
+    int pending_b;     // step B and the vector update of the previous iteration are still to be taken (likewise)
 };
 constexpr int FUSED_DOUBLES = 128;        // one state slot, in doubles (sizeof(Fused) rounded up)
 constexpr int FUSED_RED = 256;            // partial sums per reduction array (= RED_BLOCKS of ba.hip)
@@ -59,13 +62,12 @@ struct FusedArgs {
     double *red1, *red2, *red3;           // FUSED_RED partials each: |u|^2, |v|^2 (point entries), |x|^2
     double* st;                           // two state slots, FUSED_DOUBLES doubles apart
     int nchunk;                           // chunks per camera of the J^T u partial sums
-    int g1, g2p, g3;                      // workgroups of k1, point workgroups of k2, workgroups of k3 (= partials in red1 / red2 / red3)
+    int g1, g2p, g3;                      // round 3's grids of the |u|^2, |v|^2, |x|^2 sums (= partials in red1 / red2 / red3): part of the arithmetic
 };
-// one iteration = k1, k2, k3 with `slot` = the state slot k1 reads (k1: slot -> slot ^ 1, k2: slot ^ 1 -> slot, k3: slot -> slot ^ 1):
-// after an iteration the state is in slot ^ 1
-void launch_fused_iteration(const df3d_ba_problem& p, const FusedArgs& a, int slot, hipStream_t s);
-// k1 alone: takes a pending step C (slot -> slot ^ 1)
-void launch_fused_flush(const df3d_ba_problem& p, const FusedArgs& a, int slot, hipStream_t s);
+// one iteration = ka (state slot 0 -> 1), kb (1 -> 0)
+void launch_fused_iteration(const df3d_ba_problem& p, const FusedArgs& a, hipStream_t s);
+// ka + the scalar half of kb: takes the pending steps B and C of the last iteration of a run that ends on maxiter
+void launch_fused_flush(const df3d_ba_problem& p, const FusedArgs& a, hipStream_t s);
 
 // step A: beta = |u| from `count` partials;  step B: alpha = |v| and the rotations;  step C: |x| and the stopping tests.
 // One workgroup each; no-ops once st->istop != 0.

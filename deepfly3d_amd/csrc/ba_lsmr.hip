@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void step_c_kernel(State* st, const double* __
     *st = S;
 }
 
-// ---- round 4: the iteration as three kernels (ba_lsmr.h) --------------------------------------------------------------------------
+// ---- round 4: the iteration as two kernels (ba_lsmr.h) --------------------------------------------------------------------------
 constexpr int FWORDS = (int)(sizeof(Fused) / sizeof(double));
 static_assert(sizeof(Fused) % sizeof(double) == 0, "the state is copied as doubles");
 
@@ -205,34 +205,6 @@ __device__ double k1_rows(const df3d_ba_problem& p, const FusedArgs& a, const Fu
     return acc;
 }
 
-// k1: [step C of the previous iteration] ; u <- A (D v) - alpha u ; partial |u|^2
-__global__ __launch_bounds__(256) void fused_k1(df3d_ba_problem p, FusedArgs a, int slot) {
-    __shared__ double lds4[4];
-    __shared__ Fused F;
-    load_state(F, a.st + (size_t)slot * FUSED_DOUBLES);
-    double* const out = a.st + (size_t)(slot ^ 1) * FUSED_DOUBLES;
-    if (F.s.istop) {
-        store_state(out, F);
-        return;
-    }
-    if (F.pending_c) {
-        const double ss = sum_partials(a.red3, a.g3, lds4);
-        if (threadIdx.x == 0) {
-            apply_step_c(F.s, ss);
-            F.pending_c = 0;
-        }
-        __syncthreads();
-        if (F.s.istop) {
-            store_state(out, F);
-            return;
-        }
-    }
-    const double acc = k1_rows(p, a, F, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
-    const double tot = block_reduce_256(acc, lds4);
-    if (threadIdx.x == 0) a.red1[blockIdx.x] = tot;
-    store_state(out, F);
-}
-
 __device__ void k2_cam_block(const df3d_ba_problem& p, const FusedArgs& a, double inv_beta, int c, int chunk, double* lds4) {
 #pragma clang fp contract(fast)
     const size_t n = (size_t)p.nobs;
@@ -286,19 +258,39 @@ __device__ double k2_points(const df3d_ba_problem& p, const FusedArgs& a, const 
     return acc2;
 }
 
-// k2: step A (beta) ; camera workgroups: partial sums of J_c^T u ; the others: the point entries of v, partial |v|^2 in round 3's grouping
-__global__ __launch_bounds__(256) void fused_k2(df3d_ba_problem p, FusedArgs a, int slot) {
+// kb: [step C of the previous iteration: a stopped run ends here] ; step A (beta) ; camera workgroups: partial sums of J_c^T u ; the others:
+// the point entries of v, partial |v|^2 in round 3's grouping.  flush: the scalar half only.
+__global__ __launch_bounds__(256) void fused_kb(df3d_ba_problem p, FusedArgs a, int flush) {
     __shared__ double lds4[4];
     __shared__ Fused F;
-    load_state(F, a.st + (size_t)slot * FUSED_DOUBLES);
-    double* const out = a.st + (size_t)(slot ^ 1) * FUSED_DOUBLES;
+    load_state(F, a.st + FUSED_DOUBLES);
+    double* const out = a.st;
     if (F.s.istop) {
+        store_state(out, F);
+        return;
+    }
+    if (F.pending_c) {
+        const double ss = sum_partials(a.red3, a.g3, lds4);
+        if (threadIdx.x == 0) {
+            apply_step_c(F.s, ss);
+            F.pending_c = 0;
+        }
+        __syncthreads();
+        if (F.s.istop) {
+            store_state(out, F);
+            return;
+        }
+    }
+    if (flush) {
         store_state(out, F);
         return;
     }
     {
         const double ss = sum_partials(a.red1, a.g1, lds4);
-        if (threadIdx.x == 0) apply_step_a(F.s, ss);
+        if (threadIdx.x == 0) {
+            apply_step_a(F.s, ss);
+            F.pending_b = 1;
+        }
         __syncthreads();
     }
     const int ncamblk = p.ncam * a.nchunk;
@@ -358,21 +350,22 @@ __device__ double k3_cam_entry(const FusedArgs& a, const Fused& F, int k) {
     return v;
 }
 
-// k3: the camera entries of v from k2's partial sums ; step B (alpha, rotations) ; hbar, x, h ; partial |x|^2
-__global__ __launch_bounds__(256) void fused_k3(df3d_ba_problem p, FusedArgs a, int slot) {
+// ka: [the camera entries of v from kb's partial sums ; step B (alpha, rotations) ; hbar, x, h ; partial |x|^2] of the previous iteration, then
+// u <- A (D v) - alpha u ; partial |u|^2 of this one
+__global__ __launch_bounds__(256) void fused_ka(df3d_ba_problem p, FusedArgs a) {
     __shared__ double lds4[4];
     __shared__ double vnew[48];
     __shared__ Fused F;
-    load_state(F, a.st + (size_t)slot * FUSED_DOUBLES);
-    double* const out = a.st + (size_t)(slot ^ 1) * FUSED_DOUBLES;
+    load_state(F, a.st);
+    double* const out = a.st + FUSED_DOUBLES;
     if (F.s.istop) {
         store_state(out, F);
         return;
     }
-    const int ncc = 6 * p.ncam;
-    if ((int)threadIdx.x < ncc) vnew[threadIdx.x] = F.s.beta_pos ? k3_cam_entry(a, F, threadIdx.x) : F.vcam[threadIdx.x];
-    __syncthreads();
-    {
+    if (F.pending_b) {
+        const int ncc = 6 * p.ncam;
+        if ((int)threadIdx.x < ncc) vnew[threadIdx.x] = F.s.beta_pos ? k3_cam_entry(a, F, threadIdx.x) : F.vcam[threadIdx.x];
+        __syncthreads();
         double ss = 0.0;
         if (F.s.beta_pos) {   // (step B ignores the sum otherwise, as round 3's skipped kernels left it stale)
             const double p0 = block_reduce_256(k3_partial0(p, a, vnew, (size_t)a.g2p * 256), lds4);
@@ -383,27 +376,35 @@ __global__ __launch_bounds__(256) void fused_k3(df3d_ba_problem p, FusedArgs a, 
         if (threadIdx.x == 0) {
             apply_step_b(F.s, ss);
             F.pending_c = 1;
+            F.pending_b = 0;
         }
         __syncthreads();
         if ((int)threadIdx.x < ncc) F.vcam[threadIdx.x] = vnew[threadIdx.x];
         __syncthreads();
+        if ((int)blockIdx.x < a.g3) {
+            const double acc = k3_update(p, a, F, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)a.g3 * 256);
+            const double tot = block_reduce_256(acc, lds4);
+            if (threadIdx.x == 0) a.red3[blockIdx.x] = tot;
+        }
     }
-    const double acc = k3_update(p, a, F, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
-    const double tot = block_reduce_256(acc, lds4);
-    if (threadIdx.x == 0) a.red3[blockIdx.x] = tot;
+    if ((int)blockIdx.x < a.g1) {
+        const double acc = k1_rows(p, a, F, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)a.g1 * 256);
+        const double tot = block_reduce_256(acc, lds4);
+        if (threadIdx.x == 0) a.red1[blockIdx.x] = tot;
+    }
     store_state(out, F);
 }
 
 }  // namespace
 
-void launch_fused_iteration(const df3d_ba_problem& p, const FusedArgs& a, int slot, hipStream_t s) {
-    hipLaunchKernelGGL(fused_k1, dim3(a.g1), dim3(256), 0, s, p, a, slot);
-    hipLaunchKernelGGL(fused_k2, dim3(p.ncam * a.nchunk + a.g2p), dim3(256), 0, s, p, a, slot ^ 1);
-    hipLaunchKernelGGL(fused_k3, dim3(a.g3), dim3(256), 0, s, p, a, slot);
+void launch_fused_iteration(const df3d_ba_problem& p, const FusedArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(fused_ka, dim3(a.g1 > a.g3 ? a.g1 : a.g3), dim3(256), 0, s, p, a);
+    hipLaunchKernelGGL(fused_kb, dim3(p.ncam * a.nchunk + a.g2p), dim3(256), 0, s, p, a, 0);
 }
 
-void launch_fused_flush(const df3d_ba_problem& p, const FusedArgs& a, int slot, hipStream_t s) {
-    hipLaunchKernelGGL(fused_k1, dim3(a.g1), dim3(256), 0, s, p, a, slot);
+void launch_fused_flush(const df3d_ba_problem& p, const FusedArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(fused_ka, dim3(a.g1 > a.g3 ? a.g1 : a.g3), dim3(256), 0, s, p, a);
+    hipLaunchKernelGGL(fused_kb, dim3(1), dim3(256), 0, s, p, a, 1);
 }
 
 void launch_step_a(State* st, const double* partial, int count, hipStream_t s) {
