@@ -8,7 +8,13 @@
 #   -DDF3D_BT_TIMING        per-phase s_memtime sums of wave 0 of the ring kernels (scripts/probe_ring.py, probe_l1.py); the atomics cost ~17 %
 #   -DBR_ABL=n              16-bit ring kernel: 1 no phase-2 MFMAs | 3 no phase-2 weight DMA | 4 phase 2 without waits / barriers |
 #                           5 no x loads | 6 no bn1 arithmetic | 7, 8 phases 2(-3) without barriers | 9 no MFMAs at all
-#   -DBR_ABLM=mask          16-bit ring kernel, combinable: 1 no MFMAs, 2 no weight DMA, 4 no x loads, 8 no residual loads, 16 no output stores
+#   -DBR_ABL=10             16-bit ring kernel WITHOUT phase 1 (the t1 tile keeps whatever the LDS holds): what phases 2-3 cost alone
+#   -DBR_ABLM=mask          16-bit ring kernel, combinable: 1 no MFMAs (phases 1 and 3; W2D's phase 2 keeps its own), 2 no weight DMA, 4 no x loads,
+#                           8 no residual loads, 16 no output stores, 32 no W2 fragment reloads, 64 no t1 fragment reads, 128 empty workgroups
+#                           (dispatch cost), 256 prologue only
+#   -DBR_RET=n              the workgroup returns at checkpoint n (1 before phase 2's barrier .. 6 after the second half's K loop): wall-clock decomposition
+#   -DBR_P2_DEPTH=n         t1 fragment groups requested n ahead in phase 2 (default 1);  -DBR_ST_POLICY=0..3  output stores plain / sc1 / nt / sc0 sc1
+#   -DHG_NT_STORES=1        streaming stores in the stack heads and the 16-bit layer1 kernel too (measured: no change)
 #   -DBR_FORCE_LDS=90000    ring kernels at ONE workgroup per CU
 #   -DBR_SETPRIO            s_setprio around the phase-2 MFMAs
 #   -DC1_ABLM=mask          fp32 conv1 kernel: 1 no MFMAs, 2 no weight DMA, 4 no x loads, 8 no t1 stores
