@@ -173,8 +173,8 @@ def pack_state_dict(engine_handle, state_dict, strict=True):
                 wrong.append(f"{_input_bn(name)}: {st[0].shape[0]} channels, engine {d.cin}")
                 continue
             view[: d.cin] = (st[0] if d.kind == 2 else st[1]).astype(np.float32)
-    if strict:
-        left = {k for k in state_dict if k not in consumed and not k.endswith(_IGNORED_SUFFIXES)}
+    left = {k for k in state_dict if k not in consumed and not k.endswith(_IGNORED_SUFFIXES)} if strict else set()
+    if strict or missing or wrong:   # (non-strict tolerates LEFT-OVER keys only: a parameter the engine needs is never optional)
         if missing or left or wrong:
             desc = describe_state_dict(state_dict)
             why = []
@@ -192,7 +192,8 @@ def pack_state_dict(engine_handle, state_dict, strict=True):
                 msg += f" Missing keys: {_listing(missing)}."
             if left:
                 msg += f" Unconsumed keys: {_listing(left)}."
-            msg += f" (checkpoint describes {desc})"
+            msg += (f" (checkpoint describes {desc}).  If the reference is known to load this file non-strictly -- e.g. the first "
+                    "config['num_stacks'] stacks of a network trained with more -- pass strict=False / set DF3D_CHECKPOINT_STRICT=0: missing keys still raise.")
             raise CheckpointMismatch(msg)
     return blob
 
@@ -201,7 +202,7 @@ class HourglassEngine:
     """The device engine: `forward(images_nhwc) -> heat-maps (n, 19, H/4, W/4)` on the current torch stream."""
 
     def __init__(self, state_dict, dtype="f32", num_stacks=2, device=None, height=256, width=512, row_bytes=0, fuse=True, fuse_upadd=None, ring=None, l1=None,
-                 chain_views=None, split1=None, w2d=None, ring2=None):
+                 chain_views=None, split1=None, w2d=None, ring2=None, strict=None):
         _native.require_gpu()
         self.lib = _native.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -240,7 +241,9 @@ class HourglassEngine:
             chain_views = int(os.environ["DF3D_CHAIN_VIEWS"])
         if chain_views is not None:  # chains of full-resolution steps in chunks of this many views (0 = whole batch per launch)
             _native.check(self.lib.df3d_hg_set_option(self.h, b"chain_views", int(chain_views)), "df3d_hg_set_option")
-        blob = pack_state_dict(self.h, state_dict)
+        if strict is None:   # DF3D_CHECKPOINT_STRICT=0: the non-strict load (e.g. the first N stacks of a checkpoint trained with more)
+            strict = os.environ.get("DF3D_CHECKPOINT_STRICT", "1") not in ("0", "false", "no")
+        blob = pack_state_dict(self.h, state_dict, strict=strict)
         self.blob = torch.from_numpy(blob).to(self.device)
         lowp_bytes = self.lib.df3d_hg_lowp_bytes(self.h)
         self.lowp = torch.empty(max(lowp_bytes, 16), dtype=torch.uint8, device=self.device) if lowp_bytes else None

@@ -139,6 +139,10 @@ def test_checkpoint_packing_is_strict(native_lib):
     with pytest.raises(CheckpointMismatch) as e:
         pack_state_dict(h2, four)
     assert "4 stacks" in str(e.value) and "built for 2" in str(e.value) and "fc.2.0.weight" in str(e.value) or "hg.2." in str(e.value)
+    first_two = pack_state_dict(h2, four, strict=False)   # on request: the first two stacks of the 4-stack checkpoint (left-over keys tolerated)
+    assert first_two.shape == pack_state_dict(h2, sd).shape
+    with pytest.raises(CheckpointMismatch):
+        pack_state_dict(h2, {k: v for k, v in four.items() if k != "bn1.weight"}, strict=False)   # ... a MISSING key never is
     h4 = handle(4)
     assert pack_state_dict(h4, four).size > pack_state_dict(h2, sd).size
     with pytest.raises(CheckpointMismatch) as e:
