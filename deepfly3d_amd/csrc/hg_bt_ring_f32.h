@@ -410,7 +410,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
             for (int r = 0; r < 16; ++r) {
                 const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n;
+#ifdef BRF_NT_STORES   // development switch: streaming stores of the block output (measured in round 4: see DESIGN.md 8)
+                __builtin_nontemporal_store(acc[i][r], reinterpret_cast<float*>(outp) + po);
+#else
                 reinterpret_cast<float*>(outp)[po] = acc[i][r];
+#endif
             }
             if constexpr (!UP) if (p.pool_in) {   // 2x2 max-pool of the block's INPUT (the skip values just added), same in-lane geometry as below (the engine asks for it on plain blocks only)
                 float* const pp = reinterpret_cast<float*>(p.pool_in) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN;
