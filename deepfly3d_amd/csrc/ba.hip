@@ -737,7 +737,6 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
 
     constexpr int CHUNK = 16;
     df3d_lsmr::State now = init;
-    int slot = 0;
     auto enqueue_iteration = [&]() -> int {
         if (r3_form) {
             // u = A v - alpha u ; beta = |u| ; u /= beta
@@ -809,15 +808,15 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
                 if (int rc = enqueue_iteration()) return rc;
             DF3D_LAUNCH_CHECK();
         }
-        DF3D_HIP(hipMemcpyAsync(&now, r3_form ? reinterpret_cast<const double*>(st) : fa.st + (size_t)slot * df3d_lsmr::FUSED_DOUBLES, sizeof(now),
-                                hipMemcpyDeviceToHost, s));   // (State leads Fused)
+        DF3D_HIP(hipMemcpyAsync(&now, r3_form ? reinterpret_cast<const double*>(st) : fa.st, sizeof(now), hipMemcpyDeviceToHost,
+                                s));   // (two-kernel form: an iteration leaves the state in slot 0; State leads Fused)
         DF3D_HIP(hipStreamSynchronize(s));
     }
     if (now.istop == 0 && !r3_form) {
         // maxiter reached: the last iteration's steps B and C (and its update of x) are still pending -- one more ka and the scalar half of
         // kb take them; a run that stopped earlier was settled by the kernels behind its last iteration
         df3d_lsmr::launch_fused_flush(*p, fa, s);
-        DF3D_HIP(hipMemcpyAsync(&now, fa.st + (size_t)slot * df3d_lsmr::FUSED_DOUBLES, sizeof(now), hipMemcpyDeviceToHost, s));
+        DF3D_HIP(hipMemcpyAsync(&now, fa.st, sizeof(now), hipMemcpyDeviceToHost, s));
         DF3D_HIP(hipStreamSynchronize(s));
     }
     return finish(now);
