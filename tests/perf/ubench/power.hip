@@ -3,7 +3,8 @@
 // is energy per operation, not cycles.
 //   hipcc -O2 --offload-arch=gfx950 power.hip -o power && ./power <mode> <seconds>
 //   modes: mfma_rand (v_mfma_f32_32x32x16_f16 on random operands, 2 waves / SIMD), mfma_zero (the same on zeros), hbm (16-byte streaming
-//   reads of a 4 GB buffer), lds (ds_read_b128 from a 64 KB tile, 2 waves / SIMD), mix (mfma_rand + lds in one loop)
+//   reads of a 4 GB buffer), l2 (every workgroup re-reads the same 2 MB: L2 -> CU traffic), lds (ds_read_b128 from a 64 KB tile, 2 waves / SIMD),
+//   mix (mfma_rand + lds in one loop)
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -55,6 +56,21 @@ __global__ __launch_bounds__(256) void hbm_kernel(const u32x4* __restrict__ buf,
     if ((v.x ^ v.y ^ v.z ^ v.w) == 0x12345u) sink[0] = 1.0f;
 }
 
+// every workgroup walks the same small buffer: L2 hits (the weight-stream pattern of the ring kernels), 8 x 16 bytes per lane and round
+__global__ __launch_bounds__(256) void l2_kernel(const u32x4* __restrict__ buf, size_t n, int rounds, float* sink) {
+    u32x4 v = {0, 0, 0, 0};
+    size_t i = ((size_t)blockIdx.x * 977 + threadIdx.x) % n;
+    for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v ^= buf[i];
+            i += 256;
+            if (i >= n) i -= n;
+        }
+    }
+    if ((v.x ^ v.y ^ v.z ^ v.w) == 0x12345u) sink[0] = 1.0f;
+}
+
 int main(int argc, char** argv) {
     const char* mode = argc > 1 ? argv[1] : "mfma_rand";
     const double seconds = argc > 2 ? atof(argv[2]) : 3.0;
@@ -73,7 +89,9 @@ int main(int argc, char** argv) {
     hipMemcpy(seed, h, sizeof(h), hipMemcpyHostToDevice);
     u32x4* big = nullptr;
     const size_t nbig = (size_t)4 << 30 >> 4;
-    if (!strcmp(mode, "hbm")) {
+    const bool l2mode = !strcmp(mode, "l2");
+    const size_t nsmall = (size_t)2 << 20 >> 4;   // l2: every workgroup streams the same 2 MB (resident in every XCD's 4 MB L2) again and again
+    if (!strcmp(mode, "hbm") || l2mode) {
         hipMalloc(&big, nbig * 16);
         hipMemset(big, 1, nbig * 16);
     }
@@ -88,6 +106,9 @@ int main(int argc, char** argv) {
         } else if (!strcmp(mode, "lds") || !strcmp(mode, "mix")) {
             hipLaunchKernelGGL(lds_kernel, dim3(512), dim3(256), 0, 0, sink, 20000, !strcmp(mode, "mix"), seed);
             work += 512.0 * 4 * 20000 * 4 * 1024;    // LDS bytes
+        } else if (l2mode) {
+            hipLaunchKernelGGL(l2_kernel, dim3(2048), dim3(256), 0, 0, big, nsmall, 64, sink);
+            work += 2048.0 * 64 * 256 * 16 * 8;      // bytes through L2 -> CU
         } else {
             hipLaunchKernelGGL(hbm_kernel, dim3(2048), dim3(256), 0, 0, big, nbig, sink);
             work += (double)nbig * 16;               // bytes

@@ -2,7 +2,7 @@
 # watts and clock of each steady-state loop of power.hip (run on the GPU box): bash tests/perf/ubench/power.sh
 cd "$(dirname "$0")"
 hipcc -O2 --offload-arch=gfx950 power.hip -o /tmp/power_ubench || exit 1
-for mode in mfma_rand mfma_zero lds mix hbm; do
+for mode in mfma_rand mfma_zero lds mix hbm l2; do
   ( while true; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Socket Graphics Package Power|sclk clock level"; sleep 0.1; done ) > /tmp/power_$mode.txt &
   S=$!
   /tmp/power_ubench $mode 4
