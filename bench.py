@@ -253,6 +253,7 @@ class Job:
         # shard_range); None: weak scaling, every rank holds total_frames of a world x total_frames sequence
         self.global_frames = global_frames
         self.tail_ms = {}
+        self.settled = None
         self.a, self.engine, self.frames, self.calib, self.dev = a, engine, frames, calib, dev
         self.rank, self.world, self.total_frames, self.steps, self.ba_window = rank, world, total_frames, steps, ba_window
         self.collective, self.force_collective = collective, force_collective
@@ -344,11 +345,33 @@ class Job:
         p3 = gathered[2] if gathered is not None else self.outs[2]
         return procrustes_separate(p3, device=self.dev, return_tensor=True)
 
+    def settle(self, min_ms=300.0, agree=0.05, max_steps=64, max_ms=5000.0):
+        """After the W warm-up steps: keep stepping (untimed) until the DEVICE is warm, not merely the code -- at least `min_ms` of GPU work
+        has run and two consecutive steps agree within `agree`.  An idle MI355X sits at ~150 MHz and takes several 50-ms samples to reach
+        its working clocks (profiles/r04_power_f16_samples.txt): a short run (--steps 3 of 32 frames = 30 ms of work) whose warm-up is a
+        step COUNT measures that ramp, a third of the device's rate on a fresh box (GPUTEST_r04).  Bounded by `max_steps` / `max_ms`."""
+        full = max(1, self.total_frames // self.fps_step)   # full batches only: a short last batch is not comparable
+        total, prev, n = 0.0, None, 0
+        torch.cuda.synchronize()
+        while n < max_steps and total < max_ms:
+            t0 = time.perf_counter()
+            self.step(n % full, record=False, solve=False)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0)
+            total += ms
+            n += 1
+            if total >= min_ms and prev is not None and abs(ms - prev) <= agree * max(ms, prev):
+                break
+            prev = ms
+        self.settled = {"steps": n, "ms": round(total, 1), "last_step_ms": round(ms, 3)}
+
     def run(self, warmup):
         """W untimed steps, then exactly `steps` timed steps (+ joins + gather) between barrier + synchronize on both sides."""
         dist = torch.distributed
         for w in range(warmup if self.total_frames > 0 else 0):
             self.step(w % max(1, -(-self.total_frames // self.fps_step)), record=False, solve=False)
+        if self.total_frames > 0:
+            self.settle()
         if self.ba_px is not None:
             # the re-calibration has one-time costs of its own (allocator growth on its stream, the LSMR chunk's graph: ~0.7 s per
             # call until buffers and graph settle) and no window closes inside the W warm-up steps: warm it on its worker thread,
@@ -660,6 +683,7 @@ def main(argv=None):
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
+            "warmup_settle": job.settled,   # untimed steps after the W warm-up steps, until the clocks are up: >= 300 ms of GPU work and two steps within 5 %
             "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "strong" if a.strong else "weak",

@@ -71,15 +71,22 @@ def run(args):
         core.save()
     core.calibrate_calc(0, core.max_img_id)
     core.save()
-    if (args.video_2d or args.video_3d) and core.is_primary:
-        # f4 (reference cli.py:305-321): frames drawn on the GPU (csrc/render.hip), encoded by ffmpeg when present
+    if args.video_2d or args.video_3d:
+        # f4 (reference cli.py:305-321): frames drawn on the GPU (csrc/render.hip), encoded by ffmpeg when present.  Rank 0 draws and
+        # encodes; the peers wait for its outcome with a heartbeat (distributed.primary_section), so that an encoder failure moves
+        # every rank on to the next folder together and a long encode never holds a peer in one collective
+        from . import distributed as dd
         from . import video
 
         fps = args.output_fps if args.output_fps is not None else core.fps
-        if args.video_2d:
-            video.make_pose2d_video(core, fps=fps)
-        if args.video_3d:
-            video.make_pose3d_video(core, fps=fps)
+
+        def videos(beat):
+            if args.video_2d:
+                video.make_pose2d_video(core, fps=fps, progress=beat)
+            if args.video_3d:
+                video.make_pose3d_video(core, fps=fps, progress=beat)
+
+        dd.primary_section(videos, "video")
     if args.delete_images:
         core.delete_images()
     return 0

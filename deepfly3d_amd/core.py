@@ -265,6 +265,27 @@ class Core:
             bad = ValueError(f"rank {rank}: {0 if px is None else px.shape[1]} frames of 2-D points for the frame range [{t0}, {t1}) of {self.num_images}")
             px = torch.zeros((7, t1 - t0, config["num_joints"], 2), dtype=torch.float64, device=dev)
         px = px.contiguous()
+        # Manual corrections live in rank 0's camera network only (written in place by corrected_points2d_matrix()); the other
+        # ranks triangulate from their raw inference shard.  Rank 0 therefore broadcasts the rows its correction store names, with
+        # the values ITS table holds for them -- [cam, frame, J x 2 pixels] per row, two small broadcasts -- and every rank writes
+        # the rows of its own frame range over its shard: the sharded result is then CameraNetwork.triangulate()'s, corrections
+        # included, whichever rank owns the frame (round-4 advisor finding).
+        J = config["num_joints"]
+        rows = np.zeros((0, 2 + 2 * J))
+        if rank == 0 and self.camNet is not None and self.camNet.points2d is not None and self.camNet.points2d.shape[1] == self.num_images:
+            listed = [(c, i) for c, per_image in self.db.manual_corrections().items() for i in per_image if c < config["num_cameras"] and i < self.num_images]
+            if listed:
+                rows = np.stack([np.concatenate([[c, i], self.camNet.points2d[c, i].reshape(-1)]) for c, i in listed])
+        count = dd._wire_tensor(torch.tensor([rows.shape[0]], dtype=torch.int64).to(dev), None)
+        dist.broadcast(count, src=0)
+        if int(count.cpu()[0]):
+            wire = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float64)) if rank == 0 else torch.zeros((int(count.cpu()[0]), 2 + 2 * J), dtype=torch.float64)
+            wire = dd._wire_tensor(wire.to(dev), None)
+            dist.broadcast(wire, src=0)
+            for row in wire.cpu().numpy():
+                c, i = int(row[0]), int(row[1])
+                if t0 <= i < t1:
+                    px[c, i - t0] = torch.from_numpy(row[2:].reshape(J, 2)).to(px.device)
         X = ops.triangulate(rec[1:].reshape(7, 3, 4).numpy(), px) if t1 > t0 else torch.zeros((0, config["num_joints"], 3), dtype=torch.float64, device=dev)
         logger.debug(f"rank {rank} of {world}: triangulated frames [{t0}, {t1}) on {dev}")
         full = dd.gather_frames(X, 0, self.num_images)

@@ -122,6 +122,7 @@ struct df3d_hg {
     int split1 = 1;       // fp32: 1 (default) = plain 256 -> 128 -> 128 -> 256 blocks run as conv1 (every pixel once) + tail (hg_c1_f32.h), bit-identical
     bool uses_zero_page = false;
     size_t zero_off = 0;  // byte offset of 256 zero bytes behind the weight streams (split form: the 3x3 padding of the tail's LDS-DMA)
+    int no_reuse = 0;     // 1 = the alias-free workspace plan: no tensor ever takes a released tensor's memory (tests: the default plan must match it bit for bit)
     int chain_views = 0;  // > 0: chains of full-resolution steps run in chunks of this many views (Infinity Cache residency); 0 = off
     std::vector<int> chain_end;   // step i starts a chain [i, chain_end[i]) (chain_end[i] = i + 1: no chain)
     size_t stream_bytes = 0;  // weight streams of all ring bottlenecks (behind the bf16 copy of the blob)
@@ -191,6 +192,7 @@ struct df3d_hg {
             return;
         }
         const TensorDesc& t = tensors[id];
+        if (no_reuse) return;
         if (t.off != VIRTUAL_OFF) alloc.release(t.off, (size_t)t.h * t.w * t.pitch);
     }
     void end_chain() {
@@ -1216,6 +1218,13 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
         DF3D_CHECK_ARG(value == 0 || value == 1, "split1 must be 0 or 1");
         DF3D_CHECK_ARG(h->blob == nullptr, "set 'split1' before df3d_hg_set_weights (it changes the plan and the weight streams)");
         h->split1 = value;
+        h->build();
+        return DF3D_OK;
+    }
+    if (!strcmp(key, "no_reuse")) {
+        DF3D_CHECK_ARG(value == 0 || value == 1, "no_reuse must be 0 or 1");
+        DF3D_CHECK_ARG(h->blob == nullptr, "set 'no_reuse' before df3d_hg_set_weights (it changes the workspace plan)");
+        h->no_reuse = value;
         h->build();
         return DF3D_OK;
     }

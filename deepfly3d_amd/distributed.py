@@ -100,6 +100,48 @@ def agree(error=None, what="", group=None):
         raise RemoteRankError(f"rank {worst - 1} failed{' in ' + what if what else ''}; this rank (rank {rank}) abandons the step with it")
 
 
+def primary_section(fn, what="", heartbeat_s=60.0, group=None):
+    """Run `fn(beat)` on rank 0 only while the peers WAIT for its outcome -- for work that only the primary does but every rank has
+    to leave together (the video stage of cli.run: files rank 0 writes; the next collective belongs to the next step / folder).
+    One small MAX all-reduce per signal: 0 = still working, 1 = done, r + 2 = rank r failed.  Rank 0 calls `beat()` from inside its
+    loop; at most every `heartbeat_s` seconds that sends a 0, so no peer ever sits in one collective longer than a heartbeat and
+    the back-end's watchdog (10 min by default) cannot fire on a long encode.  A failure on rank 0 is re-raised there and raised
+    as RemoteRankError on the peers (round-4 advisor finding: rank 0 moving on alone left the peers in delete_images' barrier).
+    Returns fn's value on rank 0, None elsewhere.  Without a process group it simply runs fn."""
+    import time
+
+    rank, world = current()
+    if world <= 1:
+        return fn(lambda: None)
+
+    def signal(code):
+        wire = _wire_tensor(torch.tensor([code], dtype=torch.int32), group)
+        dist.all_reduce(wire, op=dist.ReduceOp.MAX, group=group)
+        return int(wire.cpu()[0])
+
+    if rank == 0:
+        last = [time.monotonic()]
+
+        def beat():
+            if time.monotonic() - last[0] >= heartbeat_s:
+                signal(0)
+                last[0] = time.monotonic()
+
+        try:
+            out = fn(beat)
+        except BaseException:
+            signal(2)
+            raise
+        signal(1)
+        return out
+    while True:
+        code = signal(0)
+        if code == 1:
+            return None
+        if code >= 2:
+            raise RemoteRankError(f"rank {code - 2} failed{' in ' + what if what else ''}; this rank (rank {rank}) abandons the step with it")
+
+
 def _gather_rows(rows, counts, rank, world_size, group=None, force_collective=False):
     """ONE `dist.gather` of a [n_r, width] uint8 record table per rank (n_r = counts[rank]) to rank 0, which
     returns the concatenation in rank order; other ranks return None.  Shards are padded to the longest one.

@@ -202,7 +202,7 @@ class HourglassEngine:
     """The device engine: `forward(images_nhwc) -> heat-maps (n, 19, H/4, W/4)` on the current torch stream."""
 
     def __init__(self, state_dict, dtype="f32", num_stacks=2, device=None, height=256, width=512, row_bytes=0, fuse=True, fuse_upadd=None, ring=None, l1=None,
-                 chain_views=None, split1=None, w2d=None, ring2=None, strict=None):
+                 chain_views=None, split1=None, w2d=None, ring2=None, strict=None, no_reuse=False):
         _native.require_gpu()
         self.lib = _native.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -241,6 +241,8 @@ class HourglassEngine:
             chain_views = int(os.environ["DF3D_CHAIN_VIEWS"])
         if chain_views is not None:  # chains of full-resolution steps in chunks of this many views (0 = whole batch per launch)
             _native.check(self.lib.df3d_hg_set_option(self.h, b"chain_views", int(chain_views)), "df3d_hg_set_option")
+        if no_reuse:  # tests: the alias-free workspace plan (every tensor keeps memory of its own)
+            _native.check(self.lib.df3d_hg_set_option(self.h, b"no_reuse", 1), "df3d_hg_set_option")
         if strict is None:   # DF3D_CHECKPOINT_STRICT=0: the non-strict load (e.g. the first N stacks of a checkpoint trained with more)
             strict = os.environ.get("DF3D_CHECKPOINT_STRICT", "1") not in ("0", "false", "no")
         blob = pack_state_dict(self.h, state_dict, strict=strict)

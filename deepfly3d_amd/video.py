@@ -19,6 +19,7 @@ import os
 import shutil
 import struct
 import subprocess
+import sys
 
 import numpy as np
 import torch
@@ -105,18 +106,38 @@ class FfmpegWriter:
     """Raw RGB frames into an ffmpeg child process (mpeg4 in .mp4, like the reference's cv2 'mp4v')."""
 
     def __init__(self, path, width, height, fps):
+        import tempfile
+
         self.path = path
+        self.log = tempfile.TemporaryFile()   # ffmpeg's stderr: a file, so a chatty child can never block on a full pipe
         self.proc = subprocess.Popen(
             ["ffmpeg", "-y", "-loglevel", "error", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{width}x{height}", "-r", str(fps), "-i", "-",
-             "-c:v", "mpeg4", "-q:v", "3", "-pix_fmt", "yuv420p", path], stdin=subprocess.PIPE)
+             "-c:v", "mpeg4", "-q:v", "3", "-pix_fmt", "yuv420p", path], stdin=subprocess.PIPE, stderr=self.log)
+
+    def _reason(self):
+        self.log.seek(0)
+        return self.log.read()[-2000:].decode(errors="replace").strip()
 
     def write(self, frame):
-        self.proc.stdin.write(frame.tobytes())
+        try:
+            self.proc.stdin.write(frame.tobytes())
+        except BrokenPipeError:
+            self.proc.wait()
+            raise RuntimeError(f"ffmpeg exited (code {self.proc.returncode}) while writing {self.path}: {self._reason()}") from None
 
     def close(self):
-        self.proc.stdin.close()
-        if self.proc.wait() != 0:
-            raise RuntimeError(f"ffmpeg failed writing {self.path}")
+        """Always reaps the child; raises for a failed encode only when no other exception is already in flight (a `finally:
+        writer.close()` must not mask the error that got us here)."""
+        in_flight = sys.exc_info()[1] is not None
+        try:
+            self.proc.stdin.close()
+        except (BrokenPipeError, OSError):
+            pass
+        code = self.proc.wait()
+        reason = self._reason()
+        self.log.close()
+        if code != 0 and not in_flight:
+            raise RuntimeError(f"ffmpeg failed (code {code}) writing {self.path}: {reason}")
 
 
 class MjpegAviWriter:
@@ -126,6 +147,7 @@ class MjpegAviWriter:
         self.path, self.w, self.h, self.fps, self.q = path, width, height, float(fps), quality
         self.f = open(path, "wb")
         self.index = []
+        self.limit = (1 << 32) - (1 << 24)   # a plain RIFF/AVI carries 32-bit sizes and idx1 offsets: stop 16 MiB short of 4 GiB
         self.f.write(b"\0" * 224)   # RIFF + hdrl, patched in close()
         self.movi_at = self.f.tell()
         self.f.write(b"LIST\0\0\0\0movi")
@@ -139,6 +161,9 @@ class MjpegAviWriter:
         Image.fromarray(frame).save(buf, format="JPEG", quality=self.q)
         data = buf.getvalue()
         pad = len(data) & 1
+        if self.f.tell() + 8 + len(data) + pad + 16 * (len(self.index) + 1) + 8 > self.limit:
+            raise RuntimeError(f"{self.path}: the Motion-JPEG fallback writes a plain RIFF/AVI, which ends at 4 GiB ({len(self.index)} frames written so far); "
+                               "install ffmpeg for the .mp4 path, or render fewer frames (-n)")
         self.index.append((self.f.tell() - self.movi_at - 8, len(data)))
         self.f.write(b"00dc" + struct.pack("<I", len(data)) + data + b"\0" * pad)
 
@@ -225,7 +250,7 @@ def _video_stem(core, kind):
     return os.path.join(core.output_folder, f"video_{kind}_" + core.input_folder.replace("/", "_"))
 
 
-def make_pose2d_video(core, fps=None):
+def make_pose2d_video(core, fps=None, progress=None):
     """video_pose2d_<folder>: per image the 2 x 3 camera grid with the 2-D pose drawn on it (reference video.py:21-49).  Returns the path."""
     fps = fps or DEFAULT_FPS
     W, H = core.image_shape
@@ -236,13 +261,15 @@ def make_pose2d_video(core, fps=None):
         for _, frame in _grid_frames(core, renderer):
             host.copy_(frame)
             writer.write(host.numpy())
+            if progress is not None:
+                progress()   # (multi-rank: rank 0's heartbeat to the waiting peers, distributed.primary_section)
     finally:
         writer.close()
     logger.info(f"Video created at {path}\n")
     return path
 
 
-def make_pose3d_video(core, fps=None):
+def make_pose3d_video(core, fps=None, progress=None):
     """video_pose3d_<folder>: two rows of the six camera images with their 2-D pose (200 x 100 each) over a row of three 3-D views of
     the pose `Core.get_points3d` returns (reference video.py:52-82).  Returns the path."""
     fps = fps or DEFAULT_FPS
@@ -260,6 +287,8 @@ def make_pose3d_video(core, fps=None):
             renderer.panels3d(pose[i].contiguous(), out=frame[2 * sh:])
             host.copy_(frame)
             writer.write(host.numpy())
+            if progress is not None:
+                progress()   # (multi-rank: rank 0's heartbeat to the waiting peers, distributed.primary_section)
     finally:
         writer.close()
     logger.info(f"Video created at {path}\n")

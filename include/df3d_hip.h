@@ -219,13 +219,13 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc_dev, const double* J
 
 /* small device-vector helpers used by the host TRF driver (all float64, asynchronous except dot) */
 int df3d_vec_dot(const double* a_dev, const double* b_dev, size_t n, double* result_host, double* scratch_dev,
-                 void* stream);
+                 void* stream); /* synchronous; scratch_dev >= 1024 doubles */
 /* `count` (1..8) dot products a_dev[j] . b_dev[j] of lengths n[j] in ONE launch and ONE synchronising read-back (results_host[count]); every
  * product is summed exactly as df3d_vec_dot sums it (same grid, same order: the same bits).  The trust-region driver of a7 needs its
  * scalars in groups (the 2 x 2 subspace system: five products) -- round 4, reference call site df3d/core.py:249.
  * scratch_dev: DF3D_BA_SCRATCH_DOUBLES doubles. */
 int df3d_vec_dots(int count, const double* const* a_dev, const double* const* b_dev, const size_t* n, double* results_host,
-                  double* scratch_dev, void* stream); /* synchronous; scratch_dev >= 1024 doubles */
+                  double* scratch_dev, void* stream); /* synchronous; scratch_dev >= DF3D_BA_SCRATCH_DOUBLES (uses 8*256+8) */
 int df3d_vec_axpby(double a, const double* x_dev, double b, const double* y_dev, double* out_dev, size_t n,
                    void* stream); /* out = a*x + b*y (y may be NULL)        */
 int df3d_vec_mul(const double* x_dev, const double* y_dev, double* out_dev, size_t n, void* stream);
@@ -298,7 +298,9 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
  * weights, both bit-identical to their 0 form;  "split1" = 1 (default) | 0 (fp32): conv1 of every bottleneck (layer1 / layer2 included) once per
  * pixel in a kernel of its own, the rest in tail kernels (17 MB more workspace per view: query df3d_hg_workspace_bytes);  "w2d" = 1 (default) | 0 (16-bit): the 3x3's weights of the ring bottlenecks as per-wave MFMA
  * fragments loaded straight from global memory (288 KB more stream space per bottleneck) -- both before the weights, both
- * bit-identical to their 0 form;  "chain_views" = 0 (default) | n: chains of full-resolution steps in chunks of n views */
+ * bit-identical to their 0 form;  "chain_views" = 0 (default) | n: chains of full-resolution steps in chunks of n views;
+ * "no_reuse" = 0 (default) | 1: the alias-free workspace plan (no tensor is ever given memory another tensor has released: ~5x the workspace) --
+ * the reference form the aliasing tests compare the default plan with, bit for bit; before the weights */
 int df3d_hg_set_option(df3d_hg* h, const char* key, int value);
 size_t df3d_hg_workspace_bytes(const df3d_hg* h, int n);
 int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_dev, void* workspace_dev,

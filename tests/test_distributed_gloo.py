@@ -197,6 +197,50 @@ def test_a_failure_on_rank0_between_the_saves_is_raised_on_every_rank(tmp_path, 
     assert os.path.exists(os.path.join(tmp_path, "df3d_result_" + str(tmp_path).replace("/", "_") + ".pkl"))
 
 
+def _primary_section_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import datetime
+
+    from deepfly3d_amd import distributed as dd
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    outcomes, ran = [], []
+
+    def encode(beat):   # "the video stage": only rank 0 runs it, beating from inside its loop
+        for k in range(5):
+            ran.append(k)
+            beat()
+        return "video.mp4"
+
+    def broken(beat):
+        beat()
+        raise RuntimeError("ffmpeg died")
+
+    for fn in (encode, broken, encode):
+        try:
+            outcomes.append(repr(dd.primary_section(fn, "video", heartbeat_s=0.0)))
+        except Exception as e:  # noqa: BLE001
+            outcomes.append(f"{type(e).__name__}: {e}")
+    dist.barrier()   # still in step: the next collective matches
+    with open(os.path.join(outdir, f"outcome{rank}.txt"), "w") as f:
+        f.write("\n".join(outcomes + [str(len(ran))]))
+    dist.destroy_process_group()
+
+
+def test_primary_section_releases_the_peers_with_rank0s_outcome(tmp_path):
+    """Round-4 advisor finding: the video stage ran on rank 0 only and was not collective -- an encoder failure moved rank 0 on to the
+    next folder while the peers sat in delete_images' barrier.  `distributed.primary_section`: rank 0 works (heart-beating, so no peer
+    sits in one collective for the whole encode), every rank leaves with rank 0's outcome."""
+    port = _free_port()
+    mp.spawn(_primary_section_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    out = [open(os.path.join(tmp_path, f"outcome{r}.txt")).read().split("\n") for r in range(3)]
+    assert out[0] == ["'video.mp4'", "RuntimeError: ffmpeg died", "'video.mp4'", "10"]
+    for r in (1, 2):
+        assert out[r][0] == "None" and out[r][2] == "None" and out[r][3] == "0"
+        assert out[r][1].startswith("RemoteRankError: rank 0 failed in video")
+
+
 def test_one_rank_group_executes_the_collective():
     """A 1-rank process group with force_collective runs the real `dist.gather` (what the GPU box does on RCCL with
     its single GPU) and returns the same tensors."""

@@ -60,6 +60,7 @@ def test_fp32_every_step_matches_oracle(native_lib, cuda, oracle_net, images, tr
     img = images.to(cuda)
     worst = (0.0, None)
     for k, (name, hwc) in enumerate(steps, start=1):
+        eng._workspace(img.shape[0]).fill_(0xFF)   # NaN-poisoned workspace: a step reading memory this forward has not written shows it
         got = eng.forward_upto(img, k).cpu()
         ref = traced[name]
         assert tuple(got.shape) == tuple(ref.shape), (name, got.shape, ref.shape)
@@ -502,3 +503,122 @@ def test_fp32_split_conv1_is_bit_identical(native_lib, cuda, oracle_net, height,
     assert torch.equal(first, off.forward(img))
     for _ in range(3):
         assert torch.equal(on.forward(img), first)
+
+
+def _poison(eng, n):
+    """All-ones bytes = NaN in fp32, f16 and bf16: a step that reads workspace memory nobody wrote in THIS forward shows it."""
+    eng._workspace(n).fill_(0xFF)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+def test_workspace_plan_aliasing_every_step_bit_identical_to_the_alias_free_plan(native_lib, cuda, dtype):
+    """The default workspace plan lets a tensor take the memory of one whose last consumer has run (round 4, 89aba4d: frees are no
+    longer postponed; 37.7 MB per view in fp32 instead of 65).  That is only right if every release sits behind the LAST reader in
+    launch order.  Proof by comparison: `no_reuse=1` plans the same steps with memory of its own for every tensor -- no aliasing
+    possible -- and `chain_views` >= the batch plans round 3's postponed frees; with the workspace NaN-poisoned before every
+    forward, EVERY plan step and the heat-maps of the default plan must equal both bit for bit, at batch sizes 1, 7 and 8."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    sd = synthetic_state_dict(0)
+    dflt = HourglassEngine(sd, dtype=dtype, device=cuda)
+    free = HourglassEngine(sd, dtype=dtype, device=cuda, no_reuse=True)
+    r3 = HourglassEngine(sd, dtype=dtype, device=cuda, chain_views=1 << 20)
+    b = [e.lib.df3d_hg_workspace_bytes(e.h, 1) for e in (dflt, r3, free)]
+    assert b[0] < b[1] < b[2], b
+    assert dflt.steps() == free.steps() == r3.steps()
+    nsteps = len(dflt.steps())
+    for n in (1, 7, 8):
+        img = torch.rand((n, 256, 512, 3), generator=torch.Generator().manual_seed(100 + n), dtype=torch.float32).to(cuda)
+        for e in (dflt, free, r3):
+            _poison(e, n)
+        ref = free.forward(img).clone()
+        assert bool(torch.isfinite(ref).all())
+        assert torch.equal(dflt.forward(img), ref) and torch.equal(r3.forward(img), ref)
+        for k in range(1, nsteps + 1):
+            for e in (dflt, free):
+                _poison(e, n)
+            a, c = dflt.forward_upto(img, k), free.forward_upto(img, k)
+            assert bool(torch.isfinite(c).all()), (n, k, dflt.steps()[k - 1])
+            assert torch.equal(a, c), (n, k, dflt.steps()[k - 1])
+    print(f"{dtype}: workspace per view default {b[0] / 1e6:.1f} MB, postponed frees {b[1] / 1e6:.1f} MB, alias-free {b[2] / 1e6:.1f} MB; {nsteps} steps x 3 batch sizes identical")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,n", [("f32", 896), ("f16", 896), ("f32", 131), ("f16", 61)])
+def test_workspace_plan_aliasing_at_bench_batch_size(native_lib, cuda, dtype, n):
+    """The same comparison at the bench's step size (128 frames x 7 views: tensor address = offset x n_views, the plan's one
+    size-dependent term) and at odd view counts: heat-maps and three plan steps of the default plan == the alias-free plan."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    sd = synthetic_state_dict(0)
+    torch.cuda.empty_cache()   # (fp32 at 896 views: 34 GB + 137 GB of workspace for the two plans)
+    img = torch.rand((n, 256, 512, 3), generator=torch.Generator(device=cuda).manual_seed(n), dtype=torch.float32, device=cuda)
+    dflt = HourglassEngine(sd, dtype=dtype, device=cuda)
+    free = HourglassEngine(sd, dtype=dtype, device=cuda, no_reuse=True)
+    _poison(dflt, n)
+    _poison(free, n)
+    ref = free.forward(img).clone()
+    assert bool(torch.isfinite(ref).all()) and torch.equal(dflt.forward(img), ref)
+    nsteps = len(dflt.steps())
+    for k in (nsteps // 3, nsteps // 2, nsteps - 2):
+        _poison(dflt, n)
+        a = dflt.forward_upto(img, k).clone()
+        _poison(free, n)
+        assert torch.equal(a, free.forward_upto(img, k)), (k, dflt.steps()[k - 1])
+    del free, dflt
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("height,width,n", [(64, 64, 3), (192, 320, 2), (128, 64, 5), (64, 512, 1)])
+def test_workspace_plan_aliasing_on_odd_shapes(native_lib, cuda, dtype, height, width, n):
+    """Other image sizes take other kernels (levels too small for the fused tiles): default plan == alias-free plan there too,
+    and both against the oracle in fp32."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    net = oh.build(seed=0)
+    img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(height * 7 + width), dtype=torch.float32)
+    dflt = HourglassEngine(net.state_dict(), dtype=dtype, device=cuda, height=height, width=width)
+    free = HourglassEngine(net.state_dict(), dtype=dtype, device=cuda, height=height, width=width, no_reuse=True)
+    _poison(dflt, n)
+    _poison(free, n)
+    a, c = dflt.forward(img.to(cuda)), free.forward(img.to(cuda))
+    assert bool(torch.isfinite(c).all()) and torch.equal(a, c)
+    for k in range(1, len(dflt.steps()) + 1, 3):
+        _poison(dflt, n)
+        _poison(free, n)
+        assert torch.equal(dflt.forward_upto(img.to(cuda), k), free.forward_upto(img.to(cuda), k)), (k, dflt.steps()[k - 1])
+    assert _rel_err(a.cpu(), oh.forward_nhwc(net, img)) < (FP32_TOL if dtype == "f32" else F16_TOL)
+
+
+@pytest.mark.gpu
+def test_two_engines_interleaved_on_two_streams_keep_their_workspaces_apart(native_lib, cuda):
+    """Two engines (fp32 and f16), each with its own workspace, launched alternately on two streams without synchronising in
+    between: each must reproduce what it computes alone, poisoned workspaces included."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    sd = synthetic_state_dict(0)
+    e32, e16 = HourglassEngine(sd, dtype="f32", device=cuda), HourglassEngine(sd, dtype="f16", device=cuda)
+    imgs = [torch.rand((n, 256, 512, 3), generator=torch.Generator().manual_seed(40 + n), dtype=torch.float32).to(cuda) for n in (7, 3, 8)]
+    alone = [(e32.forward(x).clone(), e16.forward(x).clone()) for x in imgs]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    got = []
+    for rep in range(3):
+        for x in imgs:
+            _poison(e32, x.shape[0])
+            _poison(e16, x.shape[0])
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s1):
+                a = e32.forward(x)
+            with torch.cuda.stream(s2):
+                b = e16.forward(x)
+            torch.cuda.synchronize()
+            got.append((a.clone(), b.clone()))
+    for i, (a, b) in enumerate(got):
+        assert torch.equal(a, alone[i % 3][0]) and torch.equal(b, alone[i % 3][1]), i
