@@ -11,7 +11,9 @@
 //                        trust-region-reflective step (oracle/trf_lsmr.py:lsmr).  Vectors stay on the device;
 //                        three scalars (beta, alpha, |x|) come back to the host per iteration.
 // All kernels are latency/launch-bound at the reference's sizes (1e5 observations): ~15 MB per Jacobian pass.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 #include "ba_lsmr.h"
@@ -603,12 +605,17 @@ size_t df3d_ba_lsmr_work_doubles(const df3d_ba_problem* p) {
     if (!p) return 0;
     const size_t m = 2 * (size_t)p->nobs, n = 6 * (size_t)p->ncam + 3 * (size_t)p->npts;
     // u, tmp_m (m each); v, h, hbar, tmp_n (n each); scratch; round 4 (fused iteration): two state slots, |u|^2 / |x|^2 partials, |v|^2 partials
-    return 2 * m + 4 * n + DF3D_BA_SCRATCH_DOUBLES + 64 + 2 * df3d_lsmr::FUSED_DOUBLES + 3 * df3d_lsmr::FUSED_RED;
+    // round 5 (persistent run): 8 doubles for the grid barrier's two words
+    return 2 * m + 4 * n + DF3D_BA_SCRATCH_DOUBLES + 64 + 2 * df3d_lsmr::FUSED_DOUBLES + 3 * df3d_lsmr::FUSED_RED + 8;
 }
 
-int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, const double* d_dev,
-                 const double* b_dev, double damp, double atol, double btol, double conlim, int maxiter,
-                 double* x_dev, double* work_dev, double* info_host, void* stream) {
+}  // extern "C"
+
+namespace {
+// form: 0 = one persistent kernel per run (round 5, the default), 2 = two kernels per iteration (round 4), 11 = round 3's eleven
+int lsmr_run(const df3d_ba_problem* p, const double* Jc, const double* Jp, const double* d_dev,
+             const double* b_dev, double damp, double atol, double btol, double conlim, int maxiter,
+             double* x_dev, double* work_dev, double* info_host, void* stream, int form) {
     if (int rc = check_problem(p)) return rc;
     DF3D_CHECK_ARG(Jc && Jp && b_dev && x_dev && work_dev && info_host, "null pointer");
     hipStream_t s = df3d::as_stream(stream);
@@ -727,12 +734,30 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
 
     // round 3's form (eleven kernels per iteration, one state, u and v normalised in place) stays selectable for A/B runs and as the
     // arithmetic reference: DF3D_LSMR_KERNELS=11 in the environment
-    static const bool r3_form = [] { const char* e = getenv("DF3D_LSMR_KERNELS"); return e && atoi(e) == 11; }();
+    const bool r3_form = form == 11;
     static_assert(sizeof(df3d_lsmr::State) <= 64 * sizeof(double), "state must fit behind the reduction scratch");
     df3d_lsmr::State* st = reinterpret_cast<df3d_lsmr::State*>(result + 8);
     if (r3_form) {
         DF3D_HIP(hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, s));
         DF3D_HIP(hipStreamSynchronize(s));
+    }
+
+    if (form == 0) {
+        // round 5: the whole run in ONE launch (ba_lsmr.hip: fused_persistent) -- grid-wide barriers where the two-kernel form has kernel
+        // boundaries, ONE read-back.  Grid: a quarter of the largest phase's virtual workgroups, 8..128 (DF3D_LSMR_GRID overrides): the
+        // barrier's price grows with the arrivals, the phases' time shrinks with them; measured in profiles/r05_ba_timings.txt
+        const char* const ge = getenv("DF3D_LSMR_GRID");
+        const int grid_env = ge ? atoi(ge) : 0;
+        const int vmax = std::max(std::max(fa.g1, fa.g3), p->ncam * fa.nchunk + fa.g2p);
+        int grid = grid_env > 0 ? grid_env : std::min(128, std::max(8, (vmax + 3) / 4));
+        grid = std::min(grid, 256);
+        unsigned* const bar = reinterpret_cast<unsigned*>(fa.red2 + df3d_lsmr::FUSED_RED);
+        df3d_lsmr::launch_fused_persistent(*p, fa, bar, maxiter, grid, s);
+        DF3D_LAUNCH_CHECK();
+        df3d_lsmr::State now = init;
+        DF3D_HIP(hipMemcpyAsync(&now, fa.st, sizeof(now), hipMemcpyDeviceToHost, s));
+        DF3D_HIP(hipStreamSynchronize(s));
+        return finish(now);
     }
 
     constexpr int CHUNK = 16;
@@ -820,6 +845,27 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
         DF3D_HIP(hipStreamSynchronize(s));
     }
     return finish(now);
+}
+}  // namespace
+
+extern "C" {
+
+int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, const double* d_dev,
+                 const double* b_dev, double damp, double atol, double btol, double conlim, int maxiter,
+                 double* x_dev, double* work_dev, double* info_host, void* stream) {
+    // DF3D_LSMR_KERNELS = 1 (default: one persistent kernel per run) | 2 (round 4: two kernels per iteration) | 11 (round 3) -- A/B runs and
+    // the arithmetic references of tests/test_gpu_ba.py (all three: the same bits)
+    const char* e = getenv("DF3D_LSMR_KERNELS");
+    const int k = e ? atoi(e) : 1;
+    const int form = k == 11 ? 11 : k == 2 ? 2 : 0;
+    int rc = lsmr_run(p, Jc, Jp, d_dev, b_dev, damp, atol, btol, conlim, maxiter, x_dev, work_dev, info_host, stream, form);
+    if (rc == DF3D_OK && form == 0 && info_host[0] < 0) {
+        // the persistent kernel's grid barrier timed out (its workgroups were not all resident: a device full of other persistent
+        // work): the run is repeated from its inputs in the two-kernel form, which needs no co-residency
+        rc = lsmr_run(p, Jc, Jp, d_dev, b_dev, damp, atol, btol, conlim, maxiter, x_dev, work_dev, info_host, stream, 2);
+        if (rc == DF3D_OK) info_host[7] = 1;   // (reported: the fallback was taken)
+    }
+    return rc;
 }
 
 }  // extern "C"

@@ -69,6 +69,11 @@ void launch_fused_iteration(const df3d_ba_problem& p, const FusedArgs& a, hipStr
 // ka + the scalar half of kb: takes the pending steps B and C of the last iteration of a run that ends on maxiter
 void launch_fused_flush(const df3d_ba_problem& p, const FusedArgs& a, hipStream_t s);
 
+// round 5: the whole run (up to `maxiter` iterations + the flush) as ONE persistent kernel of `grid` workgroups with grid-wide barriers in
+// the kernel boundaries' places; state in and out through slot 0; `bar`: two 32-bit words (arrival counter, failure flag), zeroed by the
+// launch.  Bit-identical to launch_fused_iteration x maxiter (+ launch_fused_flush).  A run whose barrier timed out leaves istop = -1.
+void launch_fused_persistent(const df3d_ba_problem& p, const FusedArgs& a, unsigned* bar, int maxiter, int grid, hipStream_t s);
+
 // step A: beta = |u| from `count` partials;  step B: alpha = |v| and the rotations;  step C: |x| and the stopping tests.
 // One workgroup each; no-ops once st->istop != 0.
 void launch_step_a(State* st, const double* partial, int count, hipStream_t s);

@@ -395,7 +395,146 @@ __global__ __launch_bounds__(256) void fused_ka(df3d_ba_problem p, FusedArgs a) 
     store_state(out, F);
 }
 
+// ---- round 5: the whole LSMR run as ONE persistent kernel ------------------------------------------------------------------------------
+// The two kernels of an iteration become the two phases of a loop inside one launch; the kernel boundary -- which sat exactly where a
+// grid-wide sum is needed -- becomes a grid-wide barrier.  Everything else is unchanged ON PURPOSE: the same leaf functions run over the
+// same VIRTUAL workgroups (round 3's grids g1 / g2p / g3 and the ncam x nchunk camera blocks are part of the arithmetic: they fix how the
+// sums of squares are grouped), workgroup w of the G resident ones taking virtual blocks w, w + G, ...; every workgroup keeps the
+// state in its LDS and runs the scalar steps itself on the same partial sums, so no state is handed from workgroup to workgroup.  Same
+// products, same sums, same order: the iterates, alpha, beta, |x| and the iteration counts are bit for bit those of the two-kernel form
+// (tests/test_gpu_ba.py), at 2 barriers instead of 2 launches per iteration and ONE host synchronisation per solve instead of one per
+// 16 iterations.
+//
+// The barrier (guide: cdna_hip_programming.md Guideline 16, MI355X_MICROARCH.md "barrier-counter"): every wave drains its stores,
+// __syncthreads, ONE lane: agent-scope release (writes back this XCD's L2) -> s_waitcnt vmcnt(0) (in asm: the compiler may drop its own)
+// -> relaxed agent-scope add on a monotonic counter -> relaxed polling with s_sleep until the counter reaches G x epoch -> ONE agent-scope
+// acquire (drops this CU's stale L1 lines) -> __syncthreads.  The counter is zeroed by a memset in front of every launch; the spin is bounded
+// (a workgroup that never becomes resident -- the device full of somebody else's persistent kernels -- ends the run with istop = -1, and
+// the host falls back to the two-kernel form); G <= 128 workgroups of 256 threads and ~2 KB of LDS are resident on an idle device by
+// construction.
+constexpr unsigned BAR_SPIN_LIMIT = 1u << 21;   // x (poll + s_sleep) ~ 1 us each: seconds
+
+__device__ __forceinline__ bool grid_barrier(unsigned* __restrict__ bar, unsigned target, int* ok_lds) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (gridDim.x == 1) return true;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > BAR_SPIN_LIMIT || __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everybody else leaves with us
+                ok = 0;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *ok_lds = ok;
+    }
+    __syncthreads();
+    return *ok_lds != 0;
+}
+
+__global__ __launch_bounds__(256) void fused_persistent(df3d_ba_problem p, FusedArgs a, unsigned* bar, int maxiter) {
+    __shared__ double lds4[4];
+    __shared__ double vnew[48];
+    __shared__ Fused F;
+    __shared__ int bar_ok;
+    const int G = (int)gridDim.x, wg = (int)blockIdx.x;
+    unsigned epoch = 0;
+    bool failed = false;
+    load_state(F, a.st);
+    for (int it = 0; it <= maxiter; ++it) {
+        const bool flush = it == maxiter;   // maxiter reached: the last iteration's steps B and C are still to be taken (launch_fused_flush)
+        if (F.s.istop) break;
+        // ---- phase A (fused_ka)
+        if (F.pending_b) {
+            const int ncc = 6 * p.ncam;
+            if ((int)threadIdx.x < ncc) vnew[threadIdx.x] = F.s.beta_pos ? k3_cam_entry(a, F, threadIdx.x) : F.vcam[threadIdx.x];
+            __syncthreads();
+            double ss = 0.0;
+            if (F.s.beta_pos) {
+                const double p0 = block_reduce_256(k3_partial0(p, a, vnew, (size_t)a.g2p * 256), lds4);
+                double acc = 0.0;
+                for (int i = threadIdx.x; i < a.g2p; i += 256) acc += i == 0 ? p0 : a.red2[i];
+                ss = block_reduce_256(acc, lds4);
+            }
+            if (threadIdx.x == 0) {
+                apply_step_b(F.s, ss);
+                F.pending_c = 1;
+                F.pending_b = 0;
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < ncc) F.vcam[threadIdx.x] = vnew[threadIdx.x];
+            __syncthreads();
+            for (int vb = wg; vb < a.g3; vb += G) {
+                const double acc = k3_update(p, a, F, (size_t)vb * 256 + threadIdx.x, (size_t)a.g3 * 256);
+                const double tot = block_reduce_256(acc, lds4);
+                if (threadIdx.x == 0) a.red3[vb] = tot;
+            }
+        }
+        for (int vb = wg; vb < a.g1; vb += G) {
+            const double acc = k1_rows(p, a, F, (size_t)vb * 256 + threadIdx.x, (size_t)a.g1 * 256);
+            const double tot = block_reduce_256(acc, lds4);
+            if (threadIdx.x == 0) a.red1[vb] = tot;
+        }
+        ++epoch;
+        if (!grid_barrier(bar, epoch * (unsigned)G, &bar_ok)) {
+            failed = true;
+            break;
+        }
+        // ---- phase B (fused_kb)
+        if (F.pending_c) {
+            const double ss = sum_partials(a.red3, a.g3, lds4);
+            if (threadIdx.x == 0) {
+                apply_step_c(F.s, ss);
+                F.pending_c = 0;
+            }
+            __syncthreads();
+            if (F.s.istop) break;
+        }
+        if (flush) break;
+        {
+            const double ss = sum_partials(a.red1, a.g1, lds4);
+            if (threadIdx.x == 0) {
+                apply_step_a(F.s, ss);
+                F.pending_b = 1;
+            }
+            __syncthreads();
+        }
+        const int ncamblk = p.ncam * a.nchunk;
+        for (int vb = wg; vb < ncamblk + a.g2p; vb += G) {
+            if (vb < ncamblk) {
+                k2_cam_block(p, a, F.s.inv_beta, vb / a.nchunk, vb % a.nchunk, lds4);
+            } else if (F.s.beta_pos) {
+                const int pb = vb - ncamblk;
+                const double acc = k2_points(p, a, F, (size_t)pb * 256 + threadIdx.x, (size_t)a.g2p * 256);
+                const double tot = block_reduce_256(acc, lds4);
+                if (threadIdx.x == 0) a.red2[pb] = tot;
+            }
+        }
+        ++epoch;
+        if (!grid_barrier(bar, epoch * (unsigned)G, &bar_ok)) {
+            failed = true;
+            break;
+        }
+    }
+    __syncthreads();
+    if (failed && threadIdx.x == 0) F.s.istop = -1;
+    __syncthreads();
+    store_state(a.st, F);
+}
+
 }  // namespace
+
+void launch_fused_persistent(const df3d_ba_problem& p, const FusedArgs& a, unsigned* bar, int maxiter, int grid, hipStream_t s) {
+    (void)hipMemsetAsync(bar, 0, 2 * sizeof(unsigned), s);
+    hipLaunchKernelGGL(fused_persistent, dim3(grid), dim3(256), 0, s, p, a, bar, maxiter);
+}
 
 void launch_fused_iteration(const df3d_ba_problem& p, const FusedArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(fused_ka, dim3(a.g1 > a.g3 ? a.g1 : a.g3), dim3(256), 0, s, p, a);

@@ -12,7 +12,7 @@ cd "$R"
   echo "libdf3d_hip.so sha256 $(sha256sum deepfly3d_amd/libdf3d_hip.so | cut -c1-16)"
   echo "\$ python -m pytest tests -m gpu -x -q ${PYTEST_EXTRA:-}"
 } > "$OUT/pytest.log"
-timeout ${PYTEST_TIMEOUT:-2000} python -m pytest tests -m gpu -x -q -rs --durations=15 ${PYTEST_EXTRA:-} >> "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest.log"
+timeout ${PYTEST_TIMEOUT:-2000} python -m pytest tests -m gpu ${PYTEST_X--x} -q -rs --durations=15 ${PYTEST_EXTRA:-} >> "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest.log"
 tail -25 "$OUT/pytest.log"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log"
 timeout 600 python bench.py > "$OUT/bench_default.log" 2>&1

@@ -1,5 +1,5 @@
 """Dump the LSMR solution and its info after 16 ... 1000 iterations on the reference sample problem: python tests/perf/lsmr_dump.py OUT.npz
-(tests/test_gpu_ba.py runs it twice -- DF3D_LSMR_KERNELS=11, round 3s eleven kernels per iteration, and the default three -- and compares the bits)"""
+(tests/test_gpu_ba.py runs it once per LSMR form -- DF3D_LSMR_KERNELS = 11 | 2 | 1, the last at several DF3D_LSMR_GRID -- and compares the bits)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

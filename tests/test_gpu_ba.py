@@ -142,29 +142,62 @@ def test_bundle_adjust_window_1000_frames(native_lib, cuda, golden_dir):
     assert np.abs(R - Ro).max() < 5e-6 and np.abs(t - to).max() < 5e-5
 
 
-def test_two_kernel_lsmr_iteration_equals_the_eleven_kernel_one_bit_for_bit(native_lib, cuda, tmp_path):
+def test_every_lsmr_form_gives_the_same_bits(native_lib, cuda, tmp_path):
     """Round 4: an LSMR iteration is two kernels (csrc/ba_lsmr.hip: the scalar steps run in every workgroup's prologue, u and v stay
-    un-normalised, the camera entries of v live in the state) instead of eleven.  The iterate sequence is the parity requirement of a7
-    (the reference's solver stops after 3-4 outer iterations on a problem with a free gauge), so the fused form must
-    reproduce round 3's arithmetic exactly: same solution vector and same (istop, itn, |r|, |A^T r|, |A|, cond, |x|) after 16, 17, 18,
-    32, 33, 48 iterations and at convergence, on the reference's own sample problem."""
+    un-normalised, the camera entries of v live in the state) instead of round 3's eleven.  Round 5: the whole run is ONE persistent
+    kernel, the two kernel boundaries of an iteration replaced by grid-wide barriers (the default).  The iterate sequence is the
+    parity requirement of a7 (the reference's solver stops after 3-4 outer iterations on a problem with a free gauge),
+    so every form must reproduce round 3's arithmetic exactly: same solution vector and same (istop, itn, |r|, |A^T r|, |A|, cond, |x|)
+    after 16, 17, 18, 32, 33, 48 iterations and at convergence, on the reference's own sample problem -- the persistent form at several
+    grid sizes (1 workgroup: no grid barrier at all; 37: an odd count that divides no phase's virtual grid; 200), never through its fallback."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for form in ("11", "2"):
-        out = tmp_path / f"lsmr_{form}.npz"
-        env = dict(os.environ, PYTHONPATH=root)
-        env.pop("DF3D_LSMR_KERNELS", None)
-        if form == "11":
-            env["DF3D_LSMR_KERNELS"] = "11"
+    forms = [("11", None), ("2", None), ("1", None), ("1", "1"), ("1", "37"), ("1", "200")]
+    for form, grid in forms:
+        out = tmp_path / f"lsmr_{form}_{grid}.npz"
+        env = dict(os.environ, PYTHONPATH=root, DF3D_LSMR_KERNELS=form)
+        env.pop("DF3D_LSMR_GRID", None)
+        if grid:
+            env["DF3D_LSMR_GRID"] = grid
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "perf", "lsmr_dump.py"), str(out)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         outs.append(np.load(out))
-    a, b = outs
-    assert set(a.files) == set(b.files) and len(a.files) == 14
-    for k in a.files:
-        assert np.array_equal(a[k], b[k]), f"{k}: max |diff| {np.abs(a[k] - b[k]).max():.3e}"
+    a = outs[0]
+    assert len(a.files) == 14
+    for (form, grid), b in zip(forms[1:], outs[1:]):
+        assert set(a.files) == set(b.files)
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), f"form {form} grid {grid}: {k}: max |diff| {np.abs(a[k] - b[k]).max():.3e}"
+            if k.startswith("i"):
+                assert b[k][7] == 0.0, "the persistent run fell back to the two-kernel form"
     assert a["i1000"][0] in (1.0, 2.0) and a["i1000"][1] < 200   # converged (atol / btol), not maxiter
+
+
+def test_persistent_lsmr_on_the_1000_frame_window_equals_the_two_kernel_form(native_lib, cuda, golden_dir, monkeypatch):
+    """The same comparison on BASELINE configs[4]'s window (106 k observations: every phase has more virtual workgroups than the
+    persistent grid has real ones, so each workgroup walks several): the whole adjustment -- cameras, cost, evaluation and LSMR
+    iteration counts -- bit for bit, default grid and a small one."""
+    from deepfly3d_amd.bundle_adjust import bundle_adjust
+    from deepfly3d_amd.synthetic import synthetic_points2d
+
+    g3 = np.load(f"{golden_dir}/golden_3d.npz")
+    c = np.load(f"{golden_dir}/calib.npz")
+    rng = np.random.default_rng(0)
+    X = np.tile(g3["points3d_wo_procrustes"], (67, 1, 1))[:1000] + rng.normal(0, 0.05, size=(1000, 38, 3))
+    px = og.pixels_from_normalised(synthetic_points2d(X, g3["R"], g3["tvec"], g3["intr"]), [960, 480])
+    got = []
+    for form, grid in (("2", None), ("1", None), ("1", "16")):
+        monkeypatch.setenv("DF3D_LSMR_KERNELS", form)
+        if grid:
+            monkeypatch.setenv("DF3D_LSMR_GRID", grid)
+        else:
+            monkeypatch.delenv("DF3D_LSMR_GRID", raising=False)
+        R, t, info = bundle_adjust(px, c["R"], c["tvec"], c["intr"], device=cuda, return_info=True)
+        got.append((R, t, info["cost"], info["nfev"], info["lsmr_iters"]))
+    for other in got[1:]:
+        assert np.array_equal(got[0][0], other[0]) and np.array_equal(got[0][1], other[1])
+        assert got[0][2:] == other[2:]
