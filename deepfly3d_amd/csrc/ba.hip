@@ -606,7 +606,8 @@ size_t df3d_ba_lsmr_work_doubles(const df3d_ba_problem* p) {
     const size_t m = 2 * (size_t)p->nobs, n = 6 * (size_t)p->ncam + 3 * (size_t)p->npts;
     // u, tmp_m (m each); v, h, hbar, tmp_n (n each); scratch; round 4 (fused iteration): two state slots, |u|^2 / |x|^2 partials, |v|^2 partials
     // round 5 (persistent run): 8 doubles for the grid barrier's two words
-    return 2 * m + 4 * n + DF3D_BA_SCRATCH_DOUBLES + 64 + 2 * df3d_lsmr::FUSED_DOUBLES + 3 * df3d_lsmr::FUSED_RED + 8;
+    //          + the data-local form's ranges, granules and state
+    return 2 * m + 4 * n + DF3D_BA_SCRATCH_DOUBLES + 64 + 2 * df3d_lsmr::FUSED_DOUBLES + 3 * df3d_lsmr::FUSED_RED + 8 + (df3d_lsmr::local_scratch_bytes() + 7) / 8 + 64;
 }
 
 }  // extern "C"
@@ -621,6 +622,29 @@ int lsmr_run(const df3d_ba_problem* p, const double* Jc, const double* Jp, const
     hipStream_t s = df3d::as_stream(stream);
     const size_t m = 2 * (size_t)p->nobs, n = 6 * (size_t)p->ncam + 3 * (size_t)p->npts;
     if (maxiter <= 0) maxiter = (int)(m < n ? m : n);
+    if (form == 3) {
+        // round 5: the data-local run (ba_lsmr.hip: lsmr_local_kernel) -- the whole solve, its set-up included, in ONE launch and ONE read-back
+        double* const lscratch = work_dev + (2 * m + 4 * n + DF3D_BA_SCRATCH_DOUBLES + 64 + 2 * df3d_lsmr::FUSED_DOUBLES + 3 * df3d_lsmr::FUSED_RED + 8);
+        double* const lstate = lscratch + (df3d_lsmr::local_scratch_bytes() + 7) / 8;
+        const int rc = df3d_lsmr::launch_local(*p, Jc, Jp, d_dev, b_dev, x_dev, damp, atol, btol, conlim > 0 ? 1.0 / conlim : 0.0, maxiter, lscratch, lstate, s);
+        if (rc < 0) {
+            info_host[0] = -2;   // does not fit this form: the caller takes another
+            return DF3D_OK;
+        }
+        DF3D_LAUNCH_CHECK();
+        df3d_lsmr::State now{};
+        DF3D_HIP(hipMemcpyAsync(&now, lstate, sizeof(now), hipMemcpyDeviceToHost, s));
+        DF3D_HIP(hipStreamSynchronize(s));
+        info_host[0] = now.istop;
+        info_host[1] = now.itn;
+        info_host[2] = now.normr;
+        info_host[3] = now.normar;
+        info_host[4] = now.normA;
+        info_host[5] = now.condA;
+        info_host[6] = now.normx;
+        info_host[7] = 0;
+        return DF3D_OK;
+    }
     double* u = work_dev;
     double* tmp_m = u + m;
     double* v = tmp_m + m;
@@ -853,17 +877,22 @@ extern "C" {
 int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, const double* d_dev,
                  const double* b_dev, double damp, double atol, double btol, double conlim, int maxiter,
                  double* x_dev, double* work_dev, double* info_host, void* stream) {
-    // DF3D_LSMR_KERNELS = 1 (default: one persistent kernel per run) | 2 (round 4: two kernels per iteration) | 11 (round 3) -- A/B runs and
-    // the arithmetic references of tests/test_gpu_ba.py (all three: the same bits)
+    // DF3D_LSMR_KERNELS selects the form of the run (A/B runs and the arithmetic references of tests/test_gpu_ba.py):
+    //   0 (default)  the data-local persistent kernel (round 5) where the problem fits it (<= 64 ranges of 2 048 observations: every
+    //                window of <= 1 000 frames), else 2;  its sums are grouped per range: last-bit differences from the other forms
+    //   1            the launch-based arithmetic inside one persistent kernel with grid barriers (round 5; measured slower than 2)
+    //   2            two kernels per iteration (round 4)          11   round 3's eleven kernels -- 1, 2 and 11 give the same bits
     const char* e = getenv("DF3D_LSMR_KERNELS");
-    const int k = e ? atoi(e) : 1;
-    const int form = k == 11 ? 11 : k == 2 ? 2 : 0;
+    const int k = e ? atoi(e) : 0;
+    const int form = k == 11 ? 11 : k == 2 ? 2 : k == 1 ? 0 : 3;
     int rc = lsmr_run(p, Jc, Jp, d_dev, b_dev, damp, atol, btol, conlim, maxiter, x_dev, work_dev, info_host, stream, form);
-    if (rc == DF3D_OK && form == 0 && info_host[0] < 0) {
-        // the persistent kernel's grid barrier timed out (its workgroups were not all resident: a device full of other persistent
-        // work): the run is repeated from its inputs in the two-kernel form, which needs no co-residency
+    if (rc == DF3D_OK && (form == 0 || form == 3) && info_host[0] < 0) {
+        // the problem does not fit the data-local form, or a persistent kernel timed out waiting for its peers (its workgroups were not
+        // all resident: a device full of other persistent work): the run is repeated from its inputs in the two-kernel form, which
+        // needs no co-residency
+        const bool timeout = info_host[0] == -1;
         rc = lsmr_run(p, Jc, Jp, d_dev, b_dev, damp, atol, btol, conlim, maxiter, x_dev, work_dev, info_host, stream, 2);
-        if (rc == DF3D_OK) info_host[7] = 1;   // (reported: the fallback was taken)
+        if (rc == DF3D_OK) info_host[7] = timeout ? 1 : 2;   // (reported: the fallback was taken, and why)
     }
     return rc;
 }

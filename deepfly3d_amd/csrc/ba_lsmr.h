@@ -74,6 +74,15 @@ void launch_fused_flush(const df3d_ba_problem& p, const FusedArgs& a, hipStream_
 // launch.  Bit-identical to launch_fused_iteration x maxiter (+ launch_fused_flush).  A run whose barrier timed out leaves istop = -1.
 void launch_fused_persistent(const df3d_ba_problem& p, const FusedArgs& a, unsigned* bar, int maxiter, int grid, hipStream_t s);
 
+// round 5: the DATA-LOCAL run (ba_lsmr.hip: lsmr_local_kernel): every workgroup owns a range of points with their observations for the
+// whole run, Jacobian slice and vectors in registers, two small all-reduces per iteration.  Returns 0, or < 0 when the problem does not
+// fit (more than local_max_workgroups() ranges: the caller takes another form).  The final State lands in state_out (istop = -1: timeout).
+int local_workgroups_for(int nobs);
+int local_max_workgroups();
+size_t local_scratch_bytes();
+int launch_local(const df3d_ba_problem& p, const double* Jc, const double* Jp, const double* d, const double* b, double* x, double damp, double atol,
+                 double btol, double ctol, int maxiter, void* scratch, double* state_out, hipStream_t s);
+
 // step A: beta = |u| from `count` partials;  step B: alpha = |v| and the rotations;  step C: |x| and the stopping tests.
 // One workgroup each; no-ops once st->istop != 0.
 void launch_step_a(State* st, const double* partial, int count, hipStream_t s);

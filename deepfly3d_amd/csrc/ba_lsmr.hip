@@ -3,6 +3,9 @@
 // statement, as restated in oracle/trf_lsmr.py:lsmr; this file is compiled with -ffp-contract=off (build.py), so every
 // product and sum rounds on its own, exactly as the CPython / numpy float arithmetic of the oracle does.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #include "ba_lsmr.h"
 
@@ -529,7 +532,522 @@ __global__ __launch_bounds__(256) void fused_persistent(df3d_ba_problem p, Fused
     store_state(a.st, F);
 }
 
+// ---- round 5: the DATA-LOCAL run ------------------------------------------------------------------------------------------------------
+// What the persistent form above shows (profiles/r05_ba_timings.txt): replacing the launches by barriers is not enough -- an iteration is
+// two latency chains (index loads -> Jacobian loads -> gathers through L2, block reductions, partial sums re-read by every workgroup),
+// and a grid barrier with its release / acquire fences costs more than the launch boundary it replaces.  This form removes the chains:
+//
+//   * the observations are cut into G contiguous ranges at POINT boundaries (<= 1 024 observations, hence <= 512 points each); a
+//     workgroup of 512 threads owns one range for the whole run and keeps its slice of the Jacobian (18 doubles per observation), of u
+//     (2) and of the point entries of v, h, hbar, x (12 per point) in REGISTERS, read once; J v and J^T u for the point block touch only
+//     the workgroup's own data (a point's observations are consecutive), through LDS;
+//   * what is global is small: |u|^2 (+ the previous iteration's |x|^2) after the first half, the 6 x ncam camera sums of J^T u and
+//     |v|^2 after the second -- two ALL-REDUCES of 2 and 43 doubles per iteration, done with the guide's tagged granules (cdna_hip_programming.md
+//     Guideline 16 R2: 8-byte {epoch, 32-bit value} agent-scope atomic stores, every workgroup sweeps all G x N x 2 granules until the
+//     tags match, no counter, no fence) and summed by every workgroup in the same fixed order, so all of them hold the same scalars and
+//     run the scalar steps themselves (the step functions are the ones of the other forms);
+//   * the camera entries (6 x ncam of every vector) are kept by every workgroup redundantly in LDS.
+// The sums are grouped differently from the launch-based forms (per workgroup range instead of grid-strided), so the iterates differ
+// from theirs in the last bits; every reduction has a fixed order, so a run reproduces itself bit for bit.  Parity: the oracle's
+// iteration counts, stop reasons and solution (tests/test_gpu_ba.py).
+constexpr int LT = 512;             // threads per workgroup: 8 waves per CU = 256 registers per thread (1 024 threads x 1 observation: 128
+                                    // registers, 49-65 of them spilled beside the inlined scalar steps)
+#ifndef DF3D_LSMR_LK
+#define DF3D_LSMR_LK 2
+#endif
+constexpr int LK = DF3D_LSMR_LK;    // observations per thread
+constexpr int LOBS = LT * LK;       // observations per workgroup
+constexpr int LNAR = 43;            // doubles of the larger all-reduce: |v_points|^2 + 6 x 7 camera sums (MAX_CAM = 8 -> 49 would be needed: checked by the host)
+constexpr int LMAXG = 128;          // workgroups (<= 130 000 observations: every window of 1 000 frames)
+constexpr int LRED = 16;            // partial sums per (camera, column) of the camera reduction (8 cameras x 3 columns x 16 <= LT threads)
+constexpr unsigned LSWEEP_LIMIT = 1u << 20;
+
+struct LocalLds {
+    double contrib[3][LOBS];        // J^T u contributions of the observations, one column triple at a time
+    double dv[3 * LT];              // d * v of the workgroup's points
+    int camlist[LOBS];              // local observation indices grouped by camera (ascending inside a camera)
+    double part[8 * 3 * LRED];      // partial camera sums
+    double gathered[LMAXG * 49];    // an all-reduce's values of every workgroup
+    double own[49], res[49];
+    double dcam[48], vcam[48], hcam[48], hbarcam[48], xcam[48], dvcam[48];
+    double wred[16];
+    int camstart[9];
+    int flag;
+    State S;
+    int pending_c;
+};
+
+__device__ __forceinline__ double block_reduce_wg(double v, double* wred) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < LT / 64; ++w) t += wred[w];
+    return t;
+}
+
+// all-reduce of L.own[0 .. n) over the G workgroups -> L.res[0 .. n): publish as 2 n granules, sweep everybody's until the tags match,
+// sum in workgroup order.  Returns false on a timeout (a workgroup that never became resident).
+__device__ double* g_lsmr_dbg = nullptr;   // development: see LocalArgs::dbg
+__device__ int g_lsmr_dbg_call = 0;
+typedef __attribute__((address_space(1))) unsigned long long gu64;   // every shared word: a GLOBAL agent-scope access, never flat (Guideline 16)
+constexpr int LDBG_CALLS_FWD = 64;
+__device__ bool all_reduce(LocalLds& L, unsigned long long* gran_, int n, unsigned epoch, double* dbg = nullptr, int call = 0) {
+    constexpr int LDBG_CALLS = LDBG_CALLS_FWD;
+    gu64* const gran = (gu64*)gran_;
+    const int G = (int)gridDim.x, wg = (int)blockIdx.x, tid = (int)threadIdx.x;
+    __syncthreads();   // L.own is complete
+    if (G == 1) {
+        if (tid < n) L.res[tid] = L.own[tid];
+        __syncthreads();
+        return true;
+    }
+    if (tid < 2 * n) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(L.own[tid >> 1]);
+        const unsigned half = (unsigned)(tid & 1 ? bits >> 32 : bits & 0xffffffffull);
+        __hip_atomic_store(gran + (size_t)wg * 2 * n + tid, ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int total = G * 2 * n;
+    unsigned* const words = reinterpret_cast<unsigned*>(L.gathered);
+    unsigned spins = 0;
+    for (;;) {
+        int ok = 1;
+        for (int idx = tid; idx < total; idx += LT) {
+            const unsigned long long g = __hip_atomic_load(gran + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok &= (unsigned)(g >> 32) == epoch;
+            words[idx] = (unsigned)g;
+        }
+        if (__syncthreads_and(ok)) break;
+        if (++spins > LSWEEP_LIMIT) return false;   // (uniform: every thread counts the same sweeps)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (tid < n) {
+        double t = 0.0;
+        for (int w = 0; w < G; ++w) t += L.gathered[w * n + tid];
+        L.res[tid] = t;
+    }
+    __syncthreads();
+    if (dbg != nullptr && call < LDBG_CALLS && tid < n) {
+        double* const row = dbg + ((size_t)call * G + wg) * 98;
+        row[tid] = L.own[tid];
+        row[49 + tid] = L.res[tid];
+    }
+    return true;
+}
+
+// the scalar steps on the state in LDS
+__device__ __forceinline__ void local_step_a(State* S, double ss) { apply_step_a(*S, ss); }
+__device__ __forceinline__ void local_step_b(State* S, double ss) { apply_step_b(*S, ss); }
+__device__ __forceinline__ void local_step_c(State* S, double ss) { apply_step_c(*S, ss); }
+__device__ __forceinline__ void local_init_state(State* S, double alpha, double beta, double normb, double damp, double atol, double btol, double ctol, int maxiter) {
+    S->alpha = alpha;
+    S->beta = beta;
+    S->rho = S->rhobar = S->cbar = 1;
+    S->sbar = 0;
+    S->zeta = 0;
+    S->zetabar = alpha * beta;
+    S->alphabar = alpha;
+    S->betadd = beta;
+    S->betad = 0;
+    S->rhodold = 1;
+    S->tautildeold = S->thetatilde = S->dd = 0;
+    S->normA2 = alpha * alpha;
+    S->maxrbar = 0;
+    S->minrbar = 1e100;
+    S->normA = sqrt(S->normA2);
+    S->condA = 1;
+    S->normx = 0;
+    S->normr = beta;
+    S->normar = alpha * beta;
+    S->normb = normb;
+    S->damp = damp;
+    S->atol = atol;
+    S->btol = btol;
+    S->ctol = ctol;
+    S->rhobarold = S->zetaold = S->thetabar = S->rhotemp = S->chat = S->shat = S->c = S->sn = 0;
+    S->c1 = S->c2 = S->c3 = 0;
+    S->inv_beta = S->inv_alpha = 1.0;
+    S->itn = 0;
+    S->istop = 0;
+    S->maxiter = maxiter;
+    S->beta_pos = 1;
+}
+
+struct LocalArgs {
+    const double *Jc, *Jp, *d, *b;
+    double* x;                         // [n] out
+    const int* wg_obs;                 // [G + 1] observation ranges, cut at point boundaries
+    unsigned long long *gr1, *gr2;     // granules of the two all-reduces: G x 4, G x 2 (1 + 6 ncam); zeroed in front of the launch
+    double* state_out;                 // the final State (workgroup 0)
+    double damp, atol, btol, ctol;
+    int maxiter;
+    double* dbg;                       // development (DF3D_LSMR_DEBUG=1): per all-reduce call [call][workgroup][own 49 | res 49], or nullptr
+};
+constexpr int LDBG_CALLS = 64;
+
+__global__ __launch_bounds__(LT, 2) void lsmr_local_kernel(df3d_ba_problem p, LocalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    LocalLds& L = *reinterpret_cast<LocalLds*>(lds_raw);
+    const int tid = (int)threadIdx.x, wg = (int)blockIdx.x;
+    const int ncc = 6 * p.ncam, nar2 = 1 + ncc;
+    const size_t nobs = (size_t)p.nobs;
+    const int o0 = a.wg_obs[wg], o1 = a.wg_obs[wg + 1], nob = o1 - o0;
+    const int q0 = nob > 0 ? p.pt_idx[o0] : 0, npt = nob > 0 ? p.pt_idx[o1 - 1] + 1 - q0 : 0;
+
+    // ---- this thread's observations (local index tid + k LT) and point (local index tid)
+    double Jc[LK][12], Jp[LK][6], u[LK][2];
+    int cam[LK], ql[LK];
+    bool have[LK];
+#pragma unroll
+    for (int k = 0; k < LK; ++k) {
+        const int jl = tid + k * LT;
+        have[k] = jl < nob;
+        const size_t i = have[k] ? (size_t)(o0 + jl) : 0;
+        cam[k] = p.cam_idx[i];
+        ql[k] = p.pt_idx[i] - q0;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) Jc[k][e] = have[k] ? a.Jc[(size_t)e * nobs + i] : 0.0;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) Jp[k][e] = have[k] ? a.Jp[(size_t)e * nobs + i] : 0.0;
+        u[k][0] = have[k] ? a.b[2 * i] : 0.0;
+        u[k][1] = have[k] ? a.b[2 * i + 1] : 0.0;
+    }
+    const bool owner = tid < npt;
+    const size_t col0 = (size_t)ncc + 3 * (size_t)(q0 + (owner ? tid : 0));
+    double dp[3], v[3] = {0, 0, 0}, h[3], hbar[3] = {0, 0, 0}, x[3] = {0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 3; ++e) dp[e] = owner ? a.d[col0 + e] : 0.0;
+    const int ps = owner ? p.pt_start[q0 + tid] - o0 : 0, pe = owner ? p.pt_start[q0 + tid + 1] - o0 : 0;
+    if (tid < 48) {
+        L.dcam[tid] = tid < ncc ? a.d[tid] : 0.0;
+        L.vcam[tid] = L.hcam[tid] = L.hbarcam[tid] = L.xcam[tid] = L.dvcam[tid] = 0.0;
+    }
+    // the workgroup's observations grouped by camera: its part of camera c's (ascending) list in cam_perm is contiguous
+    if (tid <= p.ncam) {
+        int pos = 0;
+        for (int c = 0; c < tid; ++c) {   // (entries of the cameras in front of camera tid that fall into [o0, o1))
+            int lo = p.cam_start[c], hi = p.cam_start[c + 1];
+            auto lower = [&](int key) {
+                int l = lo, r = hi;
+                while (l < r) {
+                    const int mid = (l + r) >> 1;
+                    if (p.cam_perm[mid] < key) l = mid + 1;
+                    else r = mid;
+                }
+                return l;
+            };
+            pos += lower(o1) - lower(o0);
+        }
+        L.camstart[tid] = pos;
+    }
+    if (tid == 0) L.pending_c = 0;
+    __syncthreads();
+    for (int c = 0; c < p.ncam; ++c) {
+        const int cnt = L.camstart[c + 1] - L.camstart[c];
+        if (cnt > 0) {
+            int l = p.cam_start[c], r = p.cam_start[c + 1];   // first entry of camera c >= o0
+            while (l < r) {
+                const int mid = (l + r) >> 1;
+                if (p.cam_perm[mid] < o0) l = mid + 1;
+                else r = mid;
+            }
+            for (int j = tid; j < cnt; j += LT) L.camlist[L.camstart[c] + j] = p.cam_perm[l + j] - o0;
+        }
+    }
+    __syncthreads();
+
+    unsigned e1 = 0, e2 = 0;
+    bool failed = false;
+
+    // u <- u * s (this thread's rows)
+    auto scale_u = [&](double sc) {
+#pragma unroll
+        for (int k = 0; k < LK; ++k) {
+            u[k][0] *= sc;
+            u[k][1] *= sc;
+        }
+    };
+    // second half of a bidiagonalisation step: v <- D J^T u - beta v for the workgroup's points, the camera sums and |v_points|^2 into
+    // L.own, all-reduce, the camera entries of v and |v|^2 (returned) in every workgroup
+    auto half_b = [&](double beta, double& ss_v) -> bool {
+        double accv = 0.0;
+        for (int pass = 0; pass < 3; ++pass) {   // 0: point columns; 1, 2: camera columns 0..2, 3..5
+#pragma unroll
+            for (int k = 0; k < LK; ++k) {
+                const int jl = tid + k * LT;
+                if (have[k]) {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        const double j0 = pass == 0 ? Jp[k][e] : Jc[k][3 * (pass - 1) + e];
+                        const double j1 = pass == 0 ? Jp[k][3 + e] : Jc[k][6 + 3 * (pass - 1) + e];
+                        L.contrib[e][jl] = j0 * u[k][0] + j1 * u[k][1];
+                    }
+                }
+            }
+            __syncthreads();
+            if (pass == 0) {
+                if (owner) {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        double w = 0.0;
+                        for (int j = ps; j < pe; ++j) w += L.contrib[e][j];
+                        const double vn = dp[e] * w - beta * v[e];
+                        v[e] = vn;
+                        accv += vn * vn;
+                    }
+                }
+            } else {
+                if (tid < p.ncam * 3 * LRED) {
+                    const int c = tid / (3 * LRED), e = (tid / LRED) % 3, r = tid % LRED;
+                    double t = 0.0;
+                    for (int j = L.camstart[c] + r; j < L.camstart[c + 1]; j += LRED) t += L.contrib[e][L.camlist[j]];
+                    L.part[tid] = t;
+                }
+                __syncthreads();
+                if (tid < p.ncam * 3) {
+                    const int c = tid / 3, e = tid % 3;
+                    double t = 0.0;
+                    for (int r = 0; r < LRED; ++r) t += L.part[(c * 3 + e) * LRED + r];
+                    L.own[1 + c * 6 + 3 * (pass - 1) + e] = t;
+                }
+            }
+            __syncthreads();
+        }
+        const double tot = block_reduce_wg(accv, L.wred);
+        if (tid == 0) L.own[0] = tot;
+        if (!all_reduce(L, a.gr2, nar2, ++e2, a.dbg, (int)(e1 + e2) - 1)) return false;
+        if (tid < ncc) L.vcam[tid] = L.dcam[tid] * L.res[1 + tid] - beta * L.vcam[tid];
+        __syncthreads();
+        double t = L.res[0];
+        for (int j = 0; j < ncc; ++j) t += L.vcam[j] * L.vcam[j];   // (every thread: the same sum in the same order)
+        ss_v = t;
+        __syncthreads();   // every thread has read L.vcam: the caller rescales it next (without this barrier a fast wave's scaling reached a slow
+                           // wave's sum: 1e-8 off in 18 % of the runs at 105 workgroups -- found with DF3D_LSMR_DEBUG and tests/perf/lsmr_stress.py)
+        return true;
+    };
+    auto scale_v = [&](double sc) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) v[e] *= sc;
+        if (tid < ncc) L.vcam[tid] *= sc;
+        __syncthreads();
+    };
+
+    // ---- u = b, beta = |b|; v = D J^T u, alpha = |v| (scipy's lsmr, restated in oracle/trf_lsmr.py:lsmr)
+    double normb, alpha = 0.0, beta;
+    {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < LK; ++k) acc += u[k][0] * u[k][0] + u[k][1] * u[k][1];
+        const double tot = block_reduce_wg(acc, L.wred);
+        if (tid == 0) {
+            L.own[0] = tot;
+            L.own[1] = 0.0;
+        }
+        if (!all_reduce(L, a.gr1, 2, ++e1, a.dbg, (int)(e1 + e2) - 1)) failed = true;
+        normb = beta = failed ? 0.0 : sqrt(L.res[0]);
+    }
+    if (!failed && beta > 0) {
+        scale_u(1.0 / beta);
+        double ss;
+        if (!half_b(0.0, ss)) failed = true;
+        else {
+            alpha = sqrt(ss);
+            if (alpha > 0) scale_v(1.0 / alpha);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) h[e] = v[e];
+    if (tid < 48) L.hcam[tid] = L.vcam[tid];
+    if (tid == 0) local_init_state(&L.S, alpha, beta, normb, a.damp, a.atol, a.btol, a.ctol, a.maxiter);
+    __syncthreads();
+    const bool trivial = L.S.normar == 0 || L.S.normb == 0;
+
+    // ---- iterations
+    double ssx_points = 0.0;
+    while (!failed && !trivial) {
+        const bool last = L.S.itn >= a.maxiter;   // maxiter reached: only the pending stopping tests are left
+        double acc = 0.0;
+        if (!last) {
+            // u <- J (D v) - alpha u
+            if (owner) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) L.dv[3 * tid + e] = dp[e] * v[e];
+            }
+            if (tid < ncc) L.dvcam[tid] = L.dcam[tid] * L.vcam[tid];
+            __syncthreads();
+            const double al = L.S.alpha;
+#pragma unroll
+            for (int k = 0; k < LK; ++k) {
+                if (have[k]) {
+#pragma unroll
+                    for (int row = 0; row < 2; ++row) {
+                        double y = 0.0;
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) y += Jc[k][row * 6 + e] * L.dvcam[cam[k] * 6 + e];
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) y += Jp[k][row * 3 + e] * L.dv[3 * ql[k] + e];
+                        const double un = y - al * u[k][row];
+                        u[k][row] = un;
+                        acc += un * un;
+                    }
+                }
+            }
+        }
+        const double tot = block_reduce_wg(acc, L.wred);
+        if (tid == 0) {
+            L.own[0] = tot;
+            L.own[1] = ssx_points;
+        }
+        if (!all_reduce(L, a.gr1, 2, ++e1, a.dbg, (int)(e1 + e2) - 1)) {
+            failed = true;
+            break;
+        }
+        if (tid == 0) {
+            if (L.pending_c) {
+                double ssx = L.res[1];
+                for (int j = 0; j < ncc; ++j) ssx += L.xcam[j] * L.xcam[j];
+                local_step_c(&L.S, ssx);
+                L.pending_c = 0;
+            }
+            if (!L.S.istop && !last) local_step_a(&L.S, L.res[0]);
+        }
+        __syncthreads();
+        if (L.S.istop || last) break;
+        if (L.S.beta_pos) {
+            scale_u(L.S.inv_beta);
+            double ss;
+            if (!half_b(L.S.beta, ss)) {
+                failed = true;
+                break;
+            }
+            if (tid == 0) local_step_b(&L.S, ss);
+            __syncthreads();
+            scale_v(L.S.inv_alpha);
+        } else {
+            if (tid == 0) local_step_b(&L.S, 0.0);
+            __syncthreads();
+        }
+        // hbar, x, h
+        const double c1 = L.S.c1, c2 = L.S.c2, c3 = L.S.c3;
+        double accx = 0.0;
+        if (owner) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const double hb = h[e] - c1 * hbar[e];
+                x[e] += c2 * hb;
+                hbar[e] = hb;
+                h[e] = v[e] - c3 * h[e];
+                accx += x[e] * x[e];
+            }
+        }
+        if (tid < ncc) {
+            const double hb = L.hcam[tid] - c1 * L.hbarcam[tid];
+            L.xcam[tid] += c2 * hb;
+            L.hbarcam[tid] = hb;
+            L.hcam[tid] = L.vcam[tid] - c3 * L.hcam[tid];
+        }
+        ssx_points = block_reduce_wg(accx, L.wred);
+        if (tid == 0) L.pending_c = 1;
+        __syncthreads();
+    }
+    if (owner) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) a.x[col0 + e] = x[e];
+    }
+    if (wg == 0) {
+        if (tid < ncc) a.x[tid] = L.xcam[tid];
+        if (tid == 0) {
+            if (failed) L.S.istop = -1;
+            *reinterpret_cast<State*>(a.state_out) = L.S;
+        }
+    }
+}
+
+// observation ranges of the data-local form: greedy, as many whole points as fit into LOBS observations; one thread (G <= 64 steps of a binary search)
+__global__ void lsmr_local_partition_kernel(const int* __restrict__ pt_start, int npts, int nobs, int gmax, int* __restrict__ wg_obs) {
+    if (threadIdx.x || blockIdx.x) return;
+    int start = 0, q = 0;
+    wg_obs[0] = 0;
+    for (int w = 0; w < gmax; ++w) {
+        if (start < nobs) {
+            int lo = q, hi = npts;   // the largest point boundary <= start + LOBS
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (pt_start[mid] <= start + LOBS) lo = mid;
+                else hi = mid - 1;
+            }
+            q = lo;
+            start = pt_start[q];
+        }
+        wg_obs[w + 1] = start;
+    }
+}
+
 }  // namespace
+
+int local_max_workgroups() { return LMAXG; }
+int local_workgroups_for(int nobs) { return (nobs + (LOBS - 8) - 1) / (LOBS - 8); }   // a range holds at least LOBS - 7 observations (a point has <= 8)
+size_t local_scratch_bytes() { return (size_t)(LMAXG + 1) * sizeof(int) + 64 + (size_t)LMAXG * (4 + 2 * 49) * sizeof(unsigned long long); }
+
+// the whole run in one launch; `scratch`: local_scratch_bytes() bytes of device memory (zeroed here); state_out: >= sizeof(State)
+int launch_local(const df3d_ba_problem& p, const double* Jc, const double* Jp, const double* d, const double* b, double* x, double damp, double atol,
+                 double btol, double ctol, int maxiter, void* scratch, double* state_out, hipStream_t s) {
+    const int G = local_workgroups_for(p.nobs);
+    if (G > LMAXG || 1 + 6 * p.ncam > 49) return -1;
+    if (hipMemsetAsync(scratch, 0, local_scratch_bytes(), s) != hipSuccess) return -2;
+    int* const wg_obs = reinterpret_cast<int*>(scratch);
+    unsigned long long* const gr1 = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(scratch) + (((size_t)(LMAXG + 1) * sizeof(int) + 63) & ~size_t(63)));
+    unsigned long long* const gr2 = gr1 + (size_t)LMAXG * 4;
+    hipLaunchKernelGGL(lsmr_local_partition_kernel, dim3(1), dim3(64), 0, s, p.pt_start, p.npts, p.nobs, G, wg_obs);
+    static double* dbg = nullptr;
+    static const bool want_dbg = getenv("DF3D_LSMR_DEBUG") != nullptr;
+    if (want_dbg && !dbg && hipMalloc(&dbg, (size_t)LDBG_CALLS * LMAXG * 98 * sizeof(double)) != hipSuccess) return -4;
+    if (want_dbg) (void)hipMemsetAsync(dbg, 0, (size_t)LDBG_CALLS * LMAXG * 98 * sizeof(double), s);
+    LocalArgs a{Jc, Jp, d, b, x, wg_obs, gr1, gr2, state_out, damp, atol, btol, ctol, maxiter, want_dbg ? dbg : nullptr};
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lsmr_local_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LocalLds)) != hipSuccess) return -3;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lsmr_local_kernel, dim3(G), dim3(LT), sizeof(LocalLds), s, p, a);
+    if (want_dbg) {   // development: every all-reduce's inputs and outputs of every workgroup, checked on the host
+        std::vector<double> hbuf((size_t)LDBG_CALLS * G * 98);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(hbuf.data(), dbg, hbuf.size() * sizeof(double), hipMemcpyDeviceToHost);
+        static std::vector<double> first;
+        int bad_sum = 0, bad_agree = 0, bad_repro = 0, calls = 0;
+        for (int c = 0; c < LDBG_CALLS; ++c) {
+            const double* base = hbuf.data() + (size_t)c * G * 98;
+            bool any = false;
+            for (int k = 0; k < 49 && !any; ++k) any = base[49 + k] != 0.0;
+            if (!any) continue;
+            ++calls;
+            for (int k = 0; k < 49; ++k) {
+                double t = 0.0;
+                for (int w = 0; w < G; ++w) t += base[(size_t)w * 98 + k];
+                for (int w = 0; w < G; ++w) {
+                    bad_agree += base[(size_t)w * 98 + 49 + k] != base[49 + k];
+                    bad_sum += base[(size_t)w * 98 + 49 + k] != t;
+                }
+            }
+        }
+        if (first.empty()) first = hbuf;
+        else {
+            for (size_t i = 0; i < hbuf.size() && i < first.size(); ++i)
+                if (hbuf[i] != first[i]) {
+                    if (bad_repro < 6) fprintf(stderr, "lsmr dbg: first difference from run 0: call %zu wg %zu slot %zu (%s): %.17g vs %.17g\n", i / ((size_t)G * 98), (i / 98) % G, i % 98,
+                                               (i % 98) < 49 ? "own" : "res", hbuf[i], first[i]);
+                    ++bad_repro;
+                }
+        }
+        fprintf(stderr, "lsmr dbg: G %d, %d all-reduces logged: results != ordered sum of inputs: %d, workgroups disagreeing: %d, values differing from the first run: %d\n", G, calls, bad_sum,
+                bad_agree, bad_repro);
+    }
+    return 0;
+}
 
 void launch_fused_persistent(const df3d_ba_problem& p, const FusedArgs& a, unsigned* bar, int maxiter, int grid, hipStream_t s) {
     (void)hipMemsetAsync(bar, 0, 2 * sizeof(unsigned), s);
