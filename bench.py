@@ -288,7 +288,8 @@ class Job:
 
         t_ba = time.perf_counter()
         with torch.cuda.device(self.dev), torch.cuda.stream(self.ba_stream):
-            Rn, tn, info = bundle_adjust(window_px, self.calib["R"], self.calib["tvec"], self.calib["intr"], device=self.dev, return_info=True)
+            Rn, tn, info = bundle_adjust(window_px, self.calib["R"], self.calib["tvec"], self.calib["intr"], device=self.dev, return_info=True,
+                                         concurrent=True)   # beside the frame pipeline: the launch-based LSMR (no co-resident workgroups needed)
         self.ba_ms.append(round(1e3 * (time.perf_counter() - t_ba), 1))   # wall time of the solve (beside the pipeline when threaded)
         if self.timeline is not None:
             self.timeline["ba"].append((t_ba, time.perf_counter()))

@@ -185,12 +185,12 @@ class _Dev:
         _native.check(self.lib.df3d_ba_rmatvec(ctypes.byref(self.p.c), Jc.data_ptr(), Jp.data_ptr(), d.data_ptr() if d is not None else None, u.data_ptr(), out.data_ptr(), self.scratch.data_ptr(), self.stream()), "df3d_ba_rmatvec")
         return out
 
-    def lsmr(self, Jc, Jp, d, b, damp, x_out, work, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=0):
+    def lsmr(self, Jc, Jp, d, b, damp, x_out, work, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=0, form=_native.LSMR_AUTO):
         info = (ctypes.c_double * 8)()
         _native.check(
-            self.lib.df3d_ba_lsmr(ctypes.byref(self.p.c), Jc.data_ptr(), Jp.data_ptr(), d.data_ptr(), b.data_ptr(), damp, atol, btol, conlim, maxiter,
-                                  x_out.data_ptr(), work.data_ptr(), info, self.stream()),
-            "df3d_ba_lsmr",
+            self.lib.df3d_ba_lsmr_form(ctypes.byref(self.p.c), Jc.data_ptr(), Jp.data_ptr(), d.data_ptr(), b.data_ptr(), damp, atol, btol, conlim, maxiter,
+                                       x_out.data_ptr(), work.data_ptr(), info, self.stream(), form),
+            "df3d_ba_lsmr_form",
         )
         return list(info)
 
@@ -213,9 +213,11 @@ def _solve_trust_region_2d(B, g, Delta):
     return p[:, np.argmin(value)]
 
 
-def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None):
+def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, lsmr_form=_native.LSMR_AUTO):
     """Trust-region-reflective least squares without bounds, LSMR subspace step, x_scale='jac'.
-    x0: device float64 [n].  Returns dict(x=device tensor, cost, nfev, njev, status, lsmr_iters, optimality)."""
+    x0: device float64 [n].  Returns dict(x=device tensor, cost, nfev, njev, status, lsmr_iters, optimality).
+    lsmr_form: DF3D_LSMR_* of include/df3d_hip.h (AUTO: one persistent data-local kernel per inner solve; LAUNCHES when the adjustment
+    runs beside other work on the device)."""
     dv = _Dev(prob)
     m, n, nobs = prob.m, prob.n, prob.nobs
     x = x0.clone()
@@ -256,6 +258,7 @@ def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None):
         max_nfev = n * 100
     status = None
     lsmr_iters = []
+    lsmr_fallbacks = 0
     g_norm = None
     while True:
         g_norm = dv.absmax(g)
@@ -280,8 +283,9 @@ def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None):
         ag_value = np.min(cand * (a * cand + b))
         reg_term = -ag_value / Delta**2
         damp = float(np.sqrt(reg_term))
-        info = dv.lsmr(Jc, Jp, d, f, damp, gn_h, work)
+        info = dv.lsmr(Jc, Jp, d, f, damp, gn_h, work, form=lsmr_form)
         lsmr_iters.append(int(info[1]))
+        lsmr_fallbacks += int(info[7]) != 0
         # orthonormal basis S = qr([g_h, gn_h]) (Householder sign convention of LAPACK: R diagonal < 0)
         n0 = np.sqrt(gh2)
         dv.axpby(-1.0 / n0, g_h, 0.0, None, s0)
@@ -346,7 +350,7 @@ def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None):
             refresh_scale(False)
     if status is None:
         status = 0
-    return dict(x=x, cost=cost, nfev=nfev, njev=njev, status=status, lsmr_iters=lsmr_iters, optimality=g_norm)
+    return dict(x=x, cost=cost, nfev=nfev, njev=njev, status=status, lsmr_iters=lsmr_iters, optimality=g_norm, lsmr_fallbacks=lsmr_fallbacks)
 
 
 def reprojection_error(points2d_px, points3d, R, tvec, intr, device="cuda:0"):
@@ -378,8 +382,11 @@ def reprojection_error(points2d_px, points3d, R, tvec, intr, device="cuda:0"):
 _side_streams = {}
 
 
-def bundle_adjust(points2d_px, R, tvec, intr, device="cuda:0", return_info=False):
-    """See _bundle_adjust; runs with `device` as the current HIP device (kernels launch on the current device).  When the
+def bundle_adjust(points2d_px, R, tvec, intr, device="cuda:0", return_info=False, concurrent=False):
+    """See _bundle_adjust; runs with `device` as the current HIP device (kernels launch on the current device).
+    concurrent=True: the adjustment shares the device with other work (a window's re-calibration beside the frame pipeline): its inner
+    solves take the launch-based LSMR form, which needs no co-resident workgroups; the default -- the CLI's one adjustment per folder
+    (reference df3d/core.py:249) -- takes one persistent kernel per solve.  When the
     caller's current stream is the legacy default stream the solve runs on a private stream ordered behind it: the LSMR
     chunks are replayed from a HIP graph, and a graph cannot be recorded on the default stream."""
     _native.require_gpu()
@@ -387,18 +394,18 @@ def bundle_adjust(points2d_px, R, tvec, intr, device="cuda:0", return_info=False
     with torch.cuda.device(dev):
         cur = torch.cuda.current_stream(dev)
         if cur.cuda_stream != 0:
-            return _bundle_adjust(points2d_px, R, tvec, intr, device, return_info)
+            return _bundle_adjust(points2d_px, R, tvec, intr, device, return_info, concurrent)
         side = _side_streams.get(str(dev))
         if side is None:
             side = _side_streams[str(dev)] = torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            out = _bundle_adjust(points2d_px, R, tvec, intr, device, return_info)
+            out = _bundle_adjust(points2d_px, R, tvec, intr, device, return_info, concurrent)
         cur.wait_stream(side)
         return out
 
 
-def _bundle_adjust(points2d_px, R, tvec, intr, device, return_info):
+def _bundle_adjust(points2d_px, R, tvec, intr, device, return_info, concurrent=False):
     """points2d_px (ncam, T, J, 2) float64 (row_px, col_px); R (ncam,3,3), tvec (ncam,3), intr (ncam,3,3).
     Returns adjusted (R, tvec) as float64 numpy arrays (+ solver info)."""
     _native.require_gpu()
@@ -414,7 +421,7 @@ def _bundle_adjust(points2d_px, R, tvec, intr, device, return_info):
     X0 = ops.triangulate(P, px_dev)
     cams = np.concatenate([np.stack([_rotvec_from_matrix(R[c]) for c in range(ncam)]), tvec], axis=1).ravel()
     x0 = torch.cat([torch.from_numpy(cams).to(dev), X0.reshape(-1, 3)[prob.ok_dev].reshape(-1)])
-    res = solve_trf(prob, x0)
+    res = solve_trf(prob, x0, lsmr_form=_native.LSMR_LAUNCHES if concurrent else _native.LSMR_AUTO)
     cams_new = res["x"][: 6 * ncam].cpu().numpy().reshape(ncam, 6)
     R_new = np.stack([_matrix_from_rotvec(cams_new[c, :3]) for c in range(ncam)])
     t_new = cams_new[:, 3:].copy()

@@ -874,17 +874,19 @@ int lsmr_run(const df3d_ba_problem* p, const double* Jc, const double* Jp, const
 
 extern "C" {
 
-int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, const double* d_dev,
-                 const double* b_dev, double damp, double atol, double btol, double conlim, int maxiter,
-                 double* x_dev, double* work_dev, double* info_host, void* stream) {
-    // DF3D_LSMR_KERNELS selects the form of the run (A/B runs and the arithmetic references of tests/test_gpu_ba.py):
-    //   0 (default)  the data-local persistent kernel (round 5) where the problem fits it (<= 64 ranges of 2 048 observations: every
-    //                window of <= 1 000 frames), else 2;  its sums are grouped per range: last-bit differences from the other forms
-    //   1            the launch-based arithmetic inside one persistent kernel with grid barriers (round 5; measured slower than 2)
-    //   2            two kernels per iteration (round 4)          11   round 3's eleven kernels -- 1, 2 and 11 give the same bits
-    const char* e = getenv("DF3D_LSMR_KERNELS");
-    const int k = e ? atoi(e) : 0;
-    const int form = k == 11 ? 11 : k == 2 ? 2 : k == 1 ? 0 : 3;
+int df3d_ba_lsmr_form(const df3d_ba_problem* p, const double* Jc, const double* Jp, const double* d_dev,
+                      const double* b_dev, double damp, double atol, double btol, double conlim, int maxiter,
+                      double* x_dev, double* work_dev, double* info_host, void* stream, int form_arg) {
+    DF3D_CHECK_ARG(form_arg == DF3D_LSMR_AUTO || form_arg == DF3D_LSMR_BARRIERS || form_arg == DF3D_LSMR_LAUNCHES || form_arg == DF3D_LSMR_LOCAL ||
+                       form_arg == DF3D_LSMR_ELEVEN, "unknown LSMR form");
+    // AUTO: the environment may name a form (A/B runs; tests/test_gpu_ba.py compares them): DF3D_LSMR_KERNELS = 0 (AUTO) | 1 | 2 | 11
+    int want = form_arg;
+    if (want == DF3D_LSMR_AUTO) {
+        const char* e = getenv("DF3D_LSMR_KERNELS");
+        const int k = e ? atoi(e) : 0;
+        want = k == 11 ? DF3D_LSMR_ELEVEN : k == 2 ? DF3D_LSMR_LAUNCHES : k == 1 ? DF3D_LSMR_BARRIERS : DF3D_LSMR_LOCAL;
+    }
+    const int form = want == DF3D_LSMR_ELEVEN ? 11 : want == DF3D_LSMR_LAUNCHES ? 2 : want == DF3D_LSMR_BARRIERS ? 0 : 3;   // (lsmr_run's numbering)
     int rc = lsmr_run(p, Jc, Jp, d_dev, b_dev, damp, atol, btol, conlim, maxiter, x_dev, work_dev, info_host, stream, form);
     if (rc == DF3D_OK && (form == 0 || form == 3) && info_host[0] < 0) {
         // the problem does not fit the data-local form, or a persistent kernel timed out waiting for its peers (its workgroups were not
@@ -895,6 +897,12 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
         if (rc == DF3D_OK) info_host[7] = timeout ? 1 : 2;   // (reported: the fallback was taken, and why)
     }
     return rc;
+}
+
+int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, const double* d_dev,
+                 const double* b_dev, double damp, double atol, double btol, double conlim, int maxiter,
+                 double* x_dev, double* work_dev, double* info_host, void* stream) {
+    return df3d_ba_lsmr_form(p, Jc, Jp, d_dev, b_dev, damp, atol, btol, conlim, maxiter, x_dev, work_dev, info_host, stream, DF3D_LSMR_AUTO);
 }
 
 }  // extern "C"

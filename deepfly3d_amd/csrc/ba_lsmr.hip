@@ -575,6 +575,7 @@ struct LocalLds {
     int flag;
     State S;
     int pending_c;
+    unsigned long long tacc[10];    // development (DF3D_LSMR_DEBUG): cycles per segment, summed over the iterations (workgroup 0, thread 0)
 };
 
 __device__ __forceinline__ double block_reduce_wg(double v, double* wred) {
@@ -589,11 +590,14 @@ __device__ __forceinline__ double block_reduce_wg(double v, double* wred) {
     return t;
 }
 
-// all-reduce of L.own[0 .. n) over the G workgroups -> L.res[0 .. n): publish as 2 n granules, sweep everybody's until the tags match,
-// sum in workgroup order.  Returns false on a timeout (a workgroup that never became resident).
-__device__ double* g_lsmr_dbg = nullptr;   // development: see LocalArgs::dbg
-__device__ int g_lsmr_dbg_call = 0;
 typedef __attribute__((address_space(1))) unsigned long long gu64;   // every shared word: a GLOBAL agent-scope access, never flat (Guideline 16)
+// all-reduce of L.own[0 .. n) over the G workgroups -> L.res[0 .. n), every workgroup summing everybody's values in workgroup order.
+// Two transports (cdna_hip_programming.md Guideline 16):
+//   n <= 2 (R2, the data is the flag): 2 n tagged granules per workgroup, every workgroup sweeps all of them until the tags match;
+//   larger (R1): the payload as 8-byte write-through (sc1) stores from ONE wave, that wave's s_waitcnt vmcnt(0), then ONE tagged flag per
+//     workgroup; readers poll the G flags, then read the payload once with sc1 loads.  With 105 workgroups the granule form of the
+//     43-double reduction had every workgroup re-reading 72 KB per sweep: 12.6 us per call; flags: G x 8 bytes per sweep.
+// Returns false on a timeout (a workgroup that never became resident).
 constexpr int LDBG_CALLS_FWD = 64;
 __device__ bool all_reduce(LocalLds& L, unsigned long long* gran_, int n, unsigned epoch, double* dbg = nullptr, int call = 0) {
     constexpr int LDBG_CALLS = LDBG_CALLS_FWD;
@@ -605,24 +609,45 @@ __device__ bool all_reduce(LocalLds& L, unsigned long long* gran_, int n, unsign
         __syncthreads();
         return true;
     }
-    if (tid < 2 * n) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(L.own[tid >> 1]);
-        const unsigned half = (unsigned)(tid & 1 ? bits >> 32 : bits & 0xffffffffull);
-        __hip_atomic_store(gran + (size_t)wg * 2 * n + tid, ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const int total = G * 2 * n;
-    unsigned* const words = reinterpret_cast<unsigned*>(L.gathered);
     unsigned spins = 0;
-    for (;;) {
-        int ok = 1;
-        for (int idx = tid; idx < total; idx += LT) {
-            const unsigned long long g = __hip_atomic_load(gran + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok &= (unsigned)(g >> 32) == epoch;
-            words[idx] = (unsigned)g;
+    if (n <= 2) {
+        if (tid < 2 * n) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(L.own[tid >> 1]);
+            const unsigned half = (unsigned)(tid & 1 ? bits >> 32 : bits & 0xffffffffull);
+            __hip_atomic_store(gran + (size_t)wg * 2 * n + tid, ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (__syncthreads_and(ok)) break;
-        if (++spins > LSWEEP_LIMIT) return false;   // (uniform: every thread counts the same sweeps)
-        __builtin_amdgcn_s_sleep(1);
+        const int total = G * 2 * n;
+        unsigned* const words = reinterpret_cast<unsigned*>(L.gathered);
+        for (;;) {
+            int ok = 1;
+            for (int idx = tid; idx < total; idx += LT) {
+                const unsigned long long g = __hip_atomic_load(gran + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok &= (unsigned)(g >> 32) == epoch;
+                words[idx] = (unsigned)g;
+            }
+            if (__syncthreads_and(ok)) break;
+            if (++spins > LSWEEP_LIMIT) return false;   // (uniform: every thread counts the same sweeps)
+            __builtin_amdgcn_s_sleep(1);
+        }
+    } else {
+        // layout: [G flags, one per 128-byte line][G x n payload doubles]
+        gu64* const flags = gran;
+        gu64* const payload = gran + (size_t)gridDim.x * 16;
+        if (tid < 64) {   // wave 0 alone publishes (n <= 49 < 64 lanes), so its own vmcnt(0) orders payload before flag
+            if (tid < n) __hip_atomic_store(payload + (size_t)wg * n + tid, (unsigned long long)__double_as_longlong(L.own[tid]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) __hip_atomic_store(flags + (size_t)wg * 16, (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (;;) {
+            int ok = 1;
+            for (int w = tid; w < G; w += LT) ok &= (unsigned)__hip_atomic_load(flags + (size_t)w * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+            if (__syncthreads_and(ok)) break;
+            if (++spins > LSWEEP_LIMIT) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        unsigned long long* const q = reinterpret_cast<unsigned long long*>(L.gathered);
+        for (int idx = tid; idx < G * n; idx += LT) q[idx] = __hip_atomic_load(payload + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
     }
     if (tid < n) {
         double t = 0.0;
@@ -761,6 +786,16 @@ __global__ __launch_bounds__(LT, 2) void lsmr_local_kernel(df3d_ba_problem p, Lo
 
     unsigned e1 = 0, e2 = 0;
     bool failed = false;
+    unsigned long long tlast = 0;
+    const bool timing = a.dbg != nullptr && tid == 0;
+    if (tid < 10) L.tacc[tid] = 0;
+    auto stamp = [&](int k) {   // (development builds of the run only: a.dbg set)
+        if (timing) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            L.tacc[k] += now - tlast;
+            tlast = now;
+        }
+    };
 
     // u <- u * s (this thread's rows)
     auto scale_u = [&](double sc) {
@@ -818,7 +853,10 @@ __global__ __launch_bounds__(LT, 2) void lsmr_local_kernel(df3d_ba_problem p, Lo
         }
         const double tot = block_reduce_wg(accv, L.wred);
         if (tid == 0) L.own[0] = tot;
-        if (!all_reduce(L, a.gr2, nar2, ++e2, a.dbg, (int)(e1 + e2) - 1)) return false;
+        stamp(3);
+        if (!all_reduce(L, a.gr2, nar2, e2 + 1, a.dbg, (int)(e1 + e2))) return false;
+        ++e2;
+        stamp(4);
         if (tid < ncc) L.vcam[tid] = L.dcam[tid] * L.res[1 + tid] - beta * L.vcam[tid];
         __syncthreads();
         double t = L.res[0];
@@ -846,7 +884,8 @@ __global__ __launch_bounds__(LT, 2) void lsmr_local_kernel(df3d_ba_problem p, Lo
             L.own[0] = tot;
             L.own[1] = 0.0;
         }
-        if (!all_reduce(L, a.gr1, 2, ++e1, a.dbg, (int)(e1 + e2) - 1)) failed = true;
+        if (!all_reduce(L, a.gr1, 2, e1 + 1, a.dbg, (int)(e1 + e2))) failed = true;
+        ++e1;
         normb = beta = failed ? 0.0 : sqrt(L.res[0]);
     }
     if (!failed && beta > 0) {
@@ -867,6 +906,7 @@ __global__ __launch_bounds__(LT, 2) void lsmr_local_kernel(df3d_ba_problem p, Lo
 
     // ---- iterations
     double ssx_points = 0.0;
+    if (timing) tlast = __builtin_amdgcn_s_memtime();
     while (!failed && !trivial) {
         const bool last = L.S.itn >= a.maxiter;   // maxiter reached: only the pending stopping tests are left
         double acc = 0.0;
@@ -901,10 +941,13 @@ __global__ __launch_bounds__(LT, 2) void lsmr_local_kernel(df3d_ba_problem p, Lo
             L.own[0] = tot;
             L.own[1] = ssx_points;
         }
-        if (!all_reduce(L, a.gr1, 2, ++e1, a.dbg, (int)(e1 + e2) - 1)) {
+        stamp(0);
+        if (!all_reduce(L, a.gr1, 2, e1 + 1, a.dbg, (int)(e1 + e2))) {
             failed = true;
             break;
         }
+        ++e1;
+        stamp(1);
         if (tid == 0) {
             if (L.pending_c) {
                 double ssx = L.res[1];
@@ -915,6 +958,7 @@ __global__ __launch_bounds__(LT, 2) void lsmr_local_kernel(df3d_ba_problem p, Lo
             if (!L.S.istop && !last) local_step_a(&L.S, L.res[0]);
         }
         __syncthreads();
+        stamp(2);
         if (L.S.istop || last) break;
         if (L.S.beta_pos) {
             scale_u(L.S.inv_beta);
@@ -925,6 +969,7 @@ __global__ __launch_bounds__(LT, 2) void lsmr_local_kernel(df3d_ba_problem p, Lo
             }
             if (tid == 0) local_step_b(&L.S, ss);
             __syncthreads();
+            stamp(5);
             scale_v(L.S.inv_alpha);
         } else {
             if (tid == 0) local_step_b(&L.S, 0.0);
@@ -952,7 +997,9 @@ __global__ __launch_bounds__(LT, 2) void lsmr_local_kernel(df3d_ba_problem p, Lo
         ssx_points = block_reduce_wg(accx, L.wred);
         if (tid == 0) L.pending_c = 1;
         __syncthreads();
+        stamp(6);
     }
+    if (a.dbg != nullptr && wg == 0 && tid < 10) a.dbg[(size_t)LDBG_CALLS * gridDim.x * 98 + tid] = (double)L.tacc[tid];
     if (owner) {
 #pragma unroll
         for (int e = 0; e < 3; ++e) a.x[col0 + e] = x[e];
@@ -990,7 +1037,7 @@ __global__ void lsmr_local_partition_kernel(const int* __restrict__ pt_start, in
 
 int local_max_workgroups() { return LMAXG; }
 int local_workgroups_for(int nobs) { return (nobs + (LOBS - 8) - 1) / (LOBS - 8); }   // a range holds at least LOBS - 7 observations (a point has <= 8)
-size_t local_scratch_bytes() { return (size_t)(LMAXG + 1) * sizeof(int) + 64 + (size_t)LMAXG * (4 + 2 * 49) * sizeof(unsigned long long); }
+size_t local_scratch_bytes() { return (size_t)(LMAXG + 1) * sizeof(int) + 64 + (size_t)LMAXG * (4 + 16 + 49) * sizeof(unsigned long long); }
 
 // the whole run in one launch; `scratch`: local_scratch_bytes() bytes of device memory (zeroed here); state_out: >= sizeof(State)
 int launch_local(const df3d_ba_problem& p, const double* Jc, const double* Jp, const double* d, const double* b, double* x, double damp, double atol,
@@ -1004,7 +1051,7 @@ int launch_local(const df3d_ba_problem& p, const double* Jc, const double* Jp, c
     hipLaunchKernelGGL(lsmr_local_partition_kernel, dim3(1), dim3(64), 0, s, p.pt_start, p.npts, p.nobs, G, wg_obs);
     static double* dbg = nullptr;
     static const bool want_dbg = getenv("DF3D_LSMR_DEBUG") != nullptr;
-    if (want_dbg && !dbg && hipMalloc(&dbg, (size_t)LDBG_CALLS * LMAXG * 98 * sizeof(double)) != hipSuccess) return -4;
+    if (want_dbg && !dbg && hipMalloc(&dbg, ((size_t)LDBG_CALLS * LMAXG * 98 + 16) * sizeof(double)) != hipSuccess) return -4;
     if (want_dbg) (void)hipMemsetAsync(dbg, 0, (size_t)LDBG_CALLS * LMAXG * 98 * sizeof(double), s);
     LocalArgs a{Jc, Jp, d, b, x, wg_obs, gr1, gr2, state_out, damp, atol, btol, ctol, maxiter, want_dbg ? dbg : nullptr};
     static bool attr_set = false;
@@ -1017,6 +1064,10 @@ int launch_local(const df3d_ba_problem& p, const double* Jc, const double* Jp, c
         std::vector<double> hbuf((size_t)LDBG_CALLS * G * 98);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(hbuf.data(), dbg, hbuf.size() * sizeof(double), hipMemcpyDeviceToHost);
+        double tacc[10];
+        (void)hipMemcpy(tacc, dbg + (size_t)LDBG_CALLS * G * 98, sizeof(tacc), hipMemcpyDeviceToHost);
+        fprintf(stderr, "lsmr dbg: cycles of workgroup 0 summed over the run (100 MHz s_memtime ticks?): A+reduce %.0f | AR1 %.0f | steps C,A %.0f | scale u + J^T u passes %.0f | AR2 %.0f | vcam + step B %.0f | scale v + update %.0f\n",
+                tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6]);
         static std::vector<double> first;
         int bad_sum = 0, bad_agree = 0, bad_repro = 0, calls = 0;
         for (int c = 0; c < LDBG_CALLS; ++c) {

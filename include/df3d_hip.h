@@ -38,9 +38,9 @@ extern "C" {
 const char* df3d_last_error(void);
 /* ABI revision of the library: DF3D_ABI_VERSION of the header it was built from.  It changes whenever an entry point's signature or
  * a struct layout does (round 3 inserted `resize` into df3d_preprocess_u8 / df3d_hg_forward_u8 and `bytes_m1` into
- * df3d_hg_profile_read: 300; round 4: 400); a caller compares it with the header it compiled against before its first call
+ * df3d_hg_profile_read: 300; round 4: 400; round 5 added df3d_ba_lsmr_form and grew df3d_ba_lsmr_work_doubles: 500); a caller compares it with the header it compiled against before its first call
  * (deepfly3d_amd/_native.py:load does). */
-#define DF3D_ABI_VERSION 400
+#define DF3D_ABI_VERSION 500
 int df3d_version(void);
 /* number of visible HIP devices (<0 on error); name of device `dev` copied to buf */
 int df3d_device_count(void);
@@ -207,15 +207,33 @@ int df3d_ba_rmatvec(const df3d_ba_problem* p, const double* Jc_dev, const double
                     const double* u_dev, double* w_dev, double* scratch_dev, void* stream);
 
 /* LSMR on A = J*diag(d) with Tikhonov `damp`, the inner solve of scipy's TRF (tr_solver='lsmr').
- * Synchronous: returns when the solve has stopped.  The scalar recurrence is kept on the device; the host enqueues 16
- * iterations at a time and then reads the stop flag (kernels of iterations past the stop are no-ops).  x_dev[n]
- * receives the solution.
+ * Synchronous: returns when the solve has stopped; x_dev[n] receives the solution.  Every scalar of the recurrence lives on the device.
  * work_dev: at least df3d_ba_lsmr_work_doubles(p) doubles (includes the scratch).  info_host[8] =
- * {istop, itn, normr, normar, normA, condA, normx, 0}. */
+ * {istop, itn, normr, normar, normA, condA, normx, fallback} (fallback: 0, or why a persistent form handed the run to the launch-based
+ * one: 1 its workgroups never became co-resident, 2 the problem does not fit it).
+ * Forms (df3d_ba_lsmr_form; df3d_ba_lsmr = DF3D_LSMR_AUTO, the environment variable DF3D_LSMR_KERNELS = 0 | 1 | 2 | 11 overrides AUTO):
+ *   DF3D_LSMR_LOCAL     ONE persistent kernel per solve: every workgroup owns a range of points with their observations, Jacobian slice and
+ *                       vectors in registers, two small all-reduces per iteration, one read-back per solve (round 5).  Up to 128 ranges of
+ *                       1 024 observations (every window of <= 1 000 frames); wants the device to itself: up to 128 workgroups of 512
+ *                       threads and 96 KB of LDS have to be resident at once.  Sums grouped per range: last-bit differences from the others.
+ *   DF3D_LSMR_LAUNCHES  two kernels per iteration, 16 iterations per host read-back (round 4): needs no co-residency -- the form to use
+ *                       when the solve runs BESIDE other work on the device (a re-calibration next to the frame pipeline).
+ *   DF3D_LSMR_BARRIERS  the launch-based arithmetic in one persistent kernel with grid-wide barriers (round 5; measured slower than
+ *                       LAUNCHES: profiles/r05_ba_timings.txt);  DF3D_LSMR_ELEVEN  round 3's eleven kernels per iteration.
+ *                       LAUNCHES, BARRIERS and ELEVEN produce the same bits.
+ *   DF3D_LSMR_AUTO      LOCAL where the problem fits, else LAUNCHES. */
+#define DF3D_LSMR_AUTO 0
+#define DF3D_LSMR_BARRIERS 1
+#define DF3D_LSMR_LAUNCHES 2
+#define DF3D_LSMR_LOCAL 3
+#define DF3D_LSMR_ELEVEN 11
 size_t df3d_ba_lsmr_work_doubles(const df3d_ba_problem* p);
 int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc_dev, const double* Jp_dev, const double* d_dev,
                  const double* b_dev, double damp, double atol, double btol, double conlim, int maxiter,
                  double* x_dev, double* work_dev, double* info_host, void* stream);
+int df3d_ba_lsmr_form(const df3d_ba_problem* p, const double* Jc_dev, const double* Jp_dev, const double* d_dev,
+                      const double* b_dev, double damp, double atol, double btol, double conlim, int maxiter,
+                      double* x_dev, double* work_dev, double* info_host, void* stream, int form);
 
 /* small device-vector helpers used by the host TRF driver (all float64, asynchronous except dot) */
 int df3d_vec_dot(const double* a_dev, const double* b_dev, size_t n, double* result_host, double* scratch_dev,

@@ -1,9 +1,10 @@
 #!/bin/bash
-# run-to-run reproducibility of the default LSMR form (and of the two-kernel form), then the timings
+# run-to-run reproducibility of the default LSMR form, its per-segment cycles (DF3D_LSMR_DEBUG), then tests + timings
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}; cd "$R"
-DF3D_LSMR_DEBUG=1 timeout 300 python tests/perf/lsmr_stress.py 1000 20 7 2>&1 | grep -v "results != ordered sum of inputs: 0, workgroups disagreeing: 0, values differing from the first run: 0" | tail -8
+for T in 1000 15; do DF3D_LSMR_DEBUG=1 timeout 300 python tests/perf/lsmr_stress.py $T 3 0 2>&1 | grep "cycles\|runs" | tail -2; done
 for T in 1000 15 300 700; do
   timeout 300 python tests/perf/lsmr_stress.py $T 300 0 2>&1 | tail -1
   timeout 300 python tests/perf/lsmr_stress.py $T 300 9 2>&1 | tail -1
 done
+bash scripts/gpu_ba_check.sh 2>&1 | grep -v "subnormal\|RESULT"
