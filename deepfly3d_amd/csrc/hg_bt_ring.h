@@ -34,7 +34,7 @@
 
 #include "hg_kernels.h"
 #ifndef BR_ABLM
-#define BR_ABLM 0   // development builds: ablation mask (1 no MFMAs, 2 no weight DMA, 4 no x loads, 8 no residual loads, 16 no output stores)
+#define BR_ABLM 0   // development builds: ablation mask (1 no MFMAs, 2 no weight DMA, 4 no x loads, 8 no residual loads, 16 no output stores, 512 no phase-2 MFMAs of the W2D form)
 #endif
 
 namespace hgk {
@@ -524,7 +524,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_kernel(BtRingArgs p) {
             if (g + BR_P2_DEPTH < NG && !((BR_ABLM & 64) && g >= 2)) load_t(g + BR_P2_DEPTH, (g + BR_P2_DEPTH) % TD);   // (ablation mask 64: no t1 fragment reads after the first groups)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < NT; ++m) mfma_chunk<T>(wq[g % D], tfr[g % TD][m], t2[m]);
+            for (int m = 0; m < NT; ++m) {
+                if (BR_ABLM & 512) asm volatile("" ::"v"(wq[g % D]), "v"(tfr[g % TD][m]));   // (ablation mask 512: no phase-2 MFMAs in the W2D form)
+                else mfma_chunk<T>(wq[g % D], tfr[g % TD][m], t2[m]);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #if !(BR_ABLM & 32)   // (ablation mask 32: the W2 fragments are loaded once, the first BR_W2D_DEPTH of them, and re-used)
             if (g + D < NG) wq[g % D] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)(g + D) * 4096);

@@ -60,10 +60,9 @@ __device__ __forceinline__ float br_relu(float x) {
 // conv1_ring_f32_kernel and its 10 x 18 halo tile arrives by LDS-DMA, one 64-channel half at a time (lane -> (halo pixel,
 // 16-byte slot), fetching the chunk that belongs in that slot of the swizzled tile; halo pixels outside the image fetch from a
 // page of zeros = the 3x3 convolution's padding).  The W1 stages of the stream are skipped: the tail walks 88 of the 104.
-template <bool UP, bool ADD2 = false, bool TAIL = false>
+template <bool UP, bool ADD2 = false, bool TAIL = false, typename T = float>   // T: float (exact-fp32 MFMA) or F32S (the same kernel, split products)
 __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs p) {
     static_assert(!(UP && ADD2), "the fused up-path sum is written by plain blocks");
-    using T = float;
     constexpr int CIN = 256, CO = 256, NT = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;
@@ -359,9 +358,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(t2[tile][8 * q2 + 4 * jj + e], wf[e], acc[i], 0, 0, 0);
+                        mfma_quad<T>(t2[tile][8 * q2 + 4 * jj], t2[tile][8 * q2 + 4 * jj + 1], t2[tile][8 * q2 + 4 * jj + 2], t2[tile][8 * q2 + 4 * jj + 3], wf, acc[i]);
                     }
             }
         }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void bt_c1_pack_f32_kernel(const float* __rest
 // keeps the counted waits valid; the kernel drains the queue before it ends.
 // CIN / COUT: 256 -> 128 (the identity-skip bottlenecks) or 64 -> 64 (layer1: four K steps, one channel tile per wave, and only
 // the lower half of every stage image travels)
-template <bool UP, int CIN = 256, int COUT = 128>
+template <bool UP, int CIN = 256, int COUT = 128, typename T = float>   // T: float or F32S (split products)
 __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
     static_assert((CIN == 256 && COUT == 128) || (CIN == 128 && COUT == 128 && !UP) || (CIN == 64 && COUT == 64 && !UP), "instantiated shapes");
     constexpr int NST = CIN / 16;       // K steps = weight stages
@@ -68,7 +68,6 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
     // fragments requested right behind the barrier, the previous step's second half multiplied first and the next step's x staged
     // under the MFMAs (1 051-1 057; UP form 4 410 -> 4 200); transposed accumulators with sixteen 16-byte stores per lane
     // instead of 64 four-byte ones (1 071).
-    using T = float;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;
     unsigned char* const xr = smem + BR_RING_BYTES;

@@ -327,8 +327,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         const f32x4 wf = *reinterpret_cast<const f32x4*>(wrow + (32 * m) * 4 + (4 * q2 + 2 * jj + half) * 16);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[e], y[m][8 * q2 + 4 * jj + e], sc, 0, 0, 0);
+                        mfma_quad<T, false>(y[m][8 * q2 + 4 * jj], y[m][8 * q2 + 4 * jj + 1], y[m][8 * q2 + 4 * jj + 2], y[m][8 * q2 + 4 * jj + 3], wf, sc);
                     }
             } else {
 #pragma unroll
@@ -535,11 +534,8 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
 #pragma unroll
                             for (int i = 0; i < NI; ++i) {
                                 const f32x4 wf = *reinterpret_cast<const f32x4*>(sw + (i * 32 + l31) * PITCH + (4 * q2 + 2 * jj + half) * 16);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const float a = s < YSTEPS ? y[s < YSTEPS ? s : 0][8 * q2 + 4 * jj + e] : sc[8 * q2 + 4 * jj + e];
-                                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wf[e], acc[i], 0, 0, 0);
-                                }
+                                const f32x16& src = s < YSTEPS ? y[s < YSTEPS ? s : 0] : sc;
+                                mfma_quad<T>(src[8 * q2 + 4 * jj], src[8 * q2 + 4 * jj + 1], src[8 * q2 + 4 * jj + 2], src[8 * q2 + 4 * jj + 3], wf, acc[i]);
                             }
                 } else {
                     // y steps: KE channels = tiles s*(KE/32) .. +KE/32-1; score step: one 32-channel group

@@ -113,6 +113,17 @@ struct Elem<float> {
     static constexpr int BYTES = 4;
     static constexpr int PER16 = 4;  // elements per 16-byte chunk
 };
+// "f32s" (round 5): float32 STORAGE everywhere -- the fp32 engine's tensors, weights, streams, LDS images and kernels, bit for bit --
+// with every product formed on the 16-bit matrix pipe as a two-way IEEE-half split (mfma_chunk<F32S>).  A tag type: sizeof == 4 sends it
+// down the float32 path of every helper and kernel; only the MFMA differs.
+struct F32S {
+    float v;
+};
+template <>
+struct Elem<F32S> {
+    static constexpr int BYTES = 4;
+    static constexpr int PER16 = 4;
+};
 template <>
 struct Elem<__hip_bfloat16> {
     static constexpr int BYTES = 2;
@@ -161,16 +172,57 @@ __device__ __forceinline__ u32x4 preact_apply(u32x4 raw, const PreactCoef<T>& k)
     }
 }
 
+// float32 x -> IEEE-half (hi, lo) with x = hi + lo to 2^-22 |x|: hi = rn(x), lo = rn(x - hi) (the difference is exact in float32).  gfx950's
+// v_mfma_f32_32x32x16_f16 keeps subnormal inputs (tests/perf/ubench/mfma_f16_denorm.hip), so lo needs no scaling for small |x|; |x| up to the
+// half range 65 504 (the hourglass' batch-normalised activations and O(1) weights are nowhere near it).  Two floats per call: packed converters.
+__device__ __forceinline__ void f32s_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {x0, x1};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 r = {x0 - (float)h[0], x1 - (float)h[1]};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
 // one 16-byte A fragment x one 16-byte B fragment -> accumulate into a 32x32 tile
 template <typename T>
 __device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x16& acc) {
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (std::is_same<T, F32S>::value) {
+        // The chunk's K = 8 (four floats per lane and operand, lane half h = K parity) as ONE K = 16 step of the half-precision MFMA, taken
+        // twice: A = [a_hi(4) | a_lo(4)] against B = [b_hi | b_hi], then against [b_lo | b_lo] -- all four terms of (a_hi + a_lo)(b_hi + b_lo),
+        // float32 accumulation: 2 x 32 matrix-pipe cycles where the exact-fp32 v_mfma_f32_32x32x2_f32 takes 4 x 64.  Per-product error 2^-22.
+        const f32x4 af = __builtin_bit_cast(f32x4, a);
+        const f32x4 bf = __builtin_bit_cast(f32x4, b);
+        u32x4 A, B1, B2;
+        f32s_split2(af[0], af[1], A[0], A[2]);
+        f32s_split2(af[2], af[3], A[1], A[3]);
+        f32s_split2(bf[0], bf[1], B1[0], B2[0]);
+        f32s_split2(bf[2], bf[3], B1[1], B2[1]);
+        B1[2] = B1[0], B1[3] = B1[1];
+        B2[2] = B2[0], B2[3] = B2[1];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B1), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B2), acc, 0, 0, 0);
+    } else if constexpr (sizeof(T) == 4) {
         const f32x4 af = __builtin_bit_cast(f32x4, a);
         const f32x4 bf = __builtin_bit_cast(f32x4, b);
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
     } else {
         acc = Lp<T>::mfma(a, b, acc);
+    }
+}
+
+// four K = 2 steps of the float32 engines whose operands sit in registers as scalars (an accumulator row used as the next product's operand):
+// acc += sum_e a_e x w[e] with the a's as the MFMA's A operand (A_FIRST) or its B operand.  float: the four exact-fp32 MFMAs in that order
+// (what these sites did before round 5); F32S: one split chunk product.
+template <typename T, bool A_FIRST = true>
+__device__ __forceinline__ void mfma_quad(float a0, float a1, float a2, float a3, const f32x4& w, f32x16& acc) {
+    const f32x4 a = {a0, a1, a2, a3};
+    if constexpr (std::is_same<T, F32S>::value) {
+        if constexpr (A_FIRST) mfma_chunk<T>(__builtin_bit_cast(u32x4, a), __builtin_bit_cast(u32x4, w), acc);
+        else mfma_chunk<T>(__builtin_bit_cast(u32x4, w), __builtin_bit_cast(u32x4, a), acc);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = A_FIRST ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], w[e], acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], a[e], acc, 0, 0, 0);
     }
 }
 
@@ -1203,9 +1255,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const f32x4 wf = *reinterpret_cast<const f32x4*>(sw + (i * 32 + l31) * PITCH + mm * 128 + (4 * q2 + 2 * jj + half) * 16);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(t2[s * (KE / 32) + mm][8 * q2 + 4 * jj + e], wf[e], acc[i], 0, 0, 0);
+                                const f32x16& tt = t2[s * (KE / 32) + mm];
+                                mfma_quad<T>(tt[8 * q2 + 4 * jj], tt[8 * q2 + 4 * jj + 1], tt[8 * q2 + 4 * jj + 2], tt[8 * q2 + 4 * jj + 3], wf, acc[i]);
                             }
                         }
             } else {

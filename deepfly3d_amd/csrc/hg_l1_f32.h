@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void bt_l1f_pack_kernel(const float* __restric
 
 // BtRingArgs: in = x [V, H, W, 64], t1in = [V, H, W, 64] (conv1's output), zeros, out = [V, H, W, 128], pool (optional) = [V, H/2, W/2, 128],
 // wstream, b2 [64], b3 [128], bd [128].
+template <typename T = float>   // float or F32S (split products)
 __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
-    using T = float;
     constexpr int CIN = 64, CO = 128, NT = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;
@@ -192,13 +192,13 @@ __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             const int u = g >> 1, jj = g & 1, k = (2 * dd + u) & 3;   // 16-float K slice of t2's (dd < 2) or x's 64 channels
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                // t2 tile k >> 1, registers 8 (k & 1) + 4 jj + e <-> channels 16 k + 8 jj + 4 half + e: chunk 2 jj + half of the slice
+                float av[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // t2 tile k >> 1, registers 8 (k & 1) + 4 jj + e <-> channels 16 k + 8 jj + 4 half + e: chunk 2 jj + half of the slice
-                    const float a = dd < 2 ? t2[k >> 1][8 * (k & 1) + 4 * jj + e] : xfr[k][jj][e];
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w3v[g & 1][i][e], acc[i], 0, 0, 0);
-                }
+                for (int e = 0; e < 4; ++e) av[e] = dd < 2 ? t2[k >> 1][8 * (k & 1) + 4 * jj + e] : xfr[k][jj][e];
+                mfma_quad<T>(av[0], av[1], av[2], av[3], w3v[g & 1][i], acc[i]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(256) void bt_l2f_pack_kernel(const float* __restric
 }
 
 // BtRingArgs: in = x [V, H, W, 128], t1in = [V, H, W, 128], zeros, out = [V, H, W, 256], wstream, b2 [128], b3 [256], bd [256].
+template <typename T = float>   // float or F32S (split products)
 __global__ __launch_bounds__(256, 2) void layer2_tail_f32_kernel(BtRingArgs p) {
-    using T = float;
     constexpr int CIN = 128, CO = 256, NT = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;
@@ -409,11 +409,10 @@ __global__ __launch_bounds__(256, 2) void layer2_tail_f32_kernel(BtRingArgs p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
+                        float av[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float a = dd < 4 ? t2[k >> 1][8 * (k & 1) + 4 * jj + e] : xcur[u][jj][e];
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wf[e], acc[i], 0, 0, 0);
-                        }
+                        for (int e = 0; e < 4; ++e) av[e] = dd < 4 ? t2[k >> 1][8 * (k & 1) + 4 * jj + e] : xcur[u][jj][e];
+                        mfma_quad<T>(av[0], av[1], av[2], av[3], wf, acc[i]);
                     }
             }
         }

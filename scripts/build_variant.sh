@@ -10,7 +10,7 @@
 #                           5 no x loads | 6 no bn1 arithmetic | 7, 8 phases 2(-3) without barriers | 9 no MFMAs at all
 #   -DBR_ABL=10             16-bit ring kernel WITHOUT phase 1 (the t1 tile keeps whatever the LDS holds): what phases 2-3 cost alone
 #   -DBR_ABLM=mask          16-bit ring kernel, combinable: 1 no MFMAs (phases 1 and 3; W2D's phase 2 keeps its own), 2 no weight DMA, 4 no x loads,
-#                           8 no residual loads, 16 no output stores, 32 no W2 fragment reloads, 64 no t1 fragment reads, 128 empty workgroups
+#                           8 no residual loads, 16 no output stores, 32 no W2 fragment reloads, 64 no t1 fragment reads, 512 no phase-2 MFMAs (W2D form), 128 empty workgroups
 #                           (dispatch cost), 256 prologue only
 #   -DBR_RET=n              the workgroup returns at checkpoint n (1 before phase 2's barrier .. 6 after the second half's K loop): wall-clock decomposition
 #   -DBR_P2_DEPTH=n         t1 fragment groups requested n ahead in phase 2 (default 1);  -DBR_ST_POLICY=0..3  output stores plain / sc1 / nt / sc0 sc1

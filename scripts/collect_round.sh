@@ -5,7 +5,7 @@
 #   bash scripts/collect_round.sh r04
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$R"

@@ -106,6 +106,31 @@ class Sim:
         return score
 
 
+class SimSplit(Sim):
+    """Every convolution as THREE half-precision products with float32 accumulation (verdict r4 item 5, "f32s"): x = xh + xl, w = wh + wl
+    (each part IEEE half; gfx950's v_mfma_f32_32x32x16_f16 keeps subnormal inputs -- tests/perf/ubench/mfma_f16_denorm.hip -- so the low parts
+    need no scaling), y = xh wh + xl wh + xh wl; the dropped xl wl term is 2^-22 of the product.  Activations stay float32 everywhere.
+    `wscale`: weights multiplied by a power of two first so that their low parts are normal halves (exact to undo)."""
+
+    def __init__(self, net, wscale=False):
+        super().__init__(net, ident, ident, ident, ident)
+        self.wscale = wscale
+
+    def conv(self, x, conv, bn, op, **kw):
+        w, b = fold(conv, bn)
+        w = w.float()
+        k = 1.0
+        if self.wscale:
+            k = 2.0 ** np.floor(np.log2(16384.0 / float(w.abs().max())))
+            w = w * k
+        xh = f16(x)
+        xl = f16(x - xh)
+        wh = f16(w)
+        wl = f16(w - wh)
+        y = F.conv2d(xh.double(), wh.double(), None, **kw) + F.conv2d(xl.double(), wh.double(), None, **kw) + F.conv2d(xh.double(), wl.double(), None, **kw)
+        return (y / k + b[None, :, None, None]).float()
+
+
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "peaked_input.npz")
     torch.set_num_threads(os.cpu_count() or 1)
@@ -125,7 +150,12 @@ def main():
         "trunk_f32 + small tensors f32": Sim(net, ident, small=ident),
         "all_f16 (the f16 engine)": Sim(net, f16, op=f16, small=f16),
         "f16 operands, trunk_f32": Sim(net, ident, op=f16, small=f16),
+        "f16 2-way split, 3 products (f32s)": SimSplit(net),
+        "f16 2-way split, weights pre-scaled": SimSplit(net, wscale=True),
     }
+    only = os.environ.get("SIM_ONLY")
+    if only:
+        variants = {k: v for k, v in variants.items() if only in k or "sanity" in k}
     for name, sim in variants.items():
         hm = sim.forward(x)
         p, c = og.heatmap_argmax(hm.numpy())
