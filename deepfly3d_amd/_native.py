@@ -17,6 +17,7 @@ DF3D_EIO = -6
 DF3D_DTYPE_F32 = 0
 DF3D_DTYPE_BF16 = 1
 DF3D_DTYPE_F16 = 2
+DF3D_DTYPE_F32S = 3   # float32 storage, products as two-way IEEE-half splits on the 16-bit matrix pipe (include/df3d_hip.h)
 # df3d_preprocess_u8 / df3d_hg_forward_u8: the resize rule (DF3D_RESIZE_* of include/df3d_hip.h)
 RESIZE_MODES = {"bilinear": 0, "bilinear_align_corners": 1, "area": 2}
 

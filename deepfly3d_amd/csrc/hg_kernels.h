@@ -192,13 +192,12 @@ __device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x1
         // float32 accumulation: 2 x 32 matrix-pipe cycles where the exact-fp32 v_mfma_f32_32x32x2_f32 takes 4 x 64.  Per-product error 2^-22.
         const f32x4 af = __builtin_bit_cast(f32x4, a);
         const f32x4 bf = __builtin_bit_cast(f32x4, b);
-        u32x4 A, B1, B2;
-        f32s_split2(af[0], af[1], A[0], A[2]);
-        f32s_split2(af[2], af[3], A[1], A[3]);
-        f32s_split2(bf[0], bf[1], B1[0], B2[0]);
-        f32s_split2(bf[2], bf[3], B1[1], B2[1]);
-        B1[2] = B1[0], B1[3] = B1[1];
-        B2[2] = B2[0], B2[3] = B2[1];
+        unsigned ah0, al0, ah1, al1, bh0, bl0, bh1, bl1;
+        f32s_split2(af[0], af[1], ah0, al0);
+        f32s_split2(af[2], af[3], ah1, al1);
+        f32s_split2(bf[0], bf[1], bh0, bl0);
+        f32s_split2(bf[2], bf[3], bh1, bl1);
+        const u32x4 A = {ah0, ah1, al0, al1}, B1 = {bh0, bh1, bh0, bh1}, B2 = {bl0, bl1, bl0, bl1};
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B1), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B2), acc, 0, 0, 0);
     } else if constexpr (sizeof(T) == 4) {

@@ -153,7 +153,7 @@ struct df3d_hg {
     std::vector<Timed> timed;
     std::vector<hipEvent_t> event_pool;
 
-    bool lp() const { return dtype != DF3D_DTYPE_F32; }   // a 16-bit engine (bf16 or f16: same plan, same kernels, other element type)
+    bool lp() const { return dtype == DF3D_DTYPE_BF16 || dtype == DF3D_DTYPE_F16; }   // a 16-bit engine (bf16 or f16: same plan, same kernels, other element type)
     int elem_bytes() const { return lp() ? 2 : 4; }
     // byte offset of the weight streams in the caller's "lowp" buffer: behind the 16-bit copy of the blob (bf16 / f16), at its start (f32)
     size_t stream_base() const { return lp() ? (blob_floats * 2 + 255) & ~size_t(255) : 0; }
@@ -719,6 +719,9 @@ template <typename T> struct TypeName;
 template <> struct TypeName<float> { static constexpr const char* value = "float"; };
 template <> struct TypeName<__hip_bfloat16> { static constexpr const char* value = "__hip_bfloat16"; };
 template <> struct TypeName<_Float16> { static constexpr const char* value = "_Float16"; };
+template <> struct TypeName<F32S> { static constexpr const char* value = "hgk::F32S"; };
+// the element type of the kernels that only move or compare float32 data (pools, upsample-add, export): F32S tensors ARE float32 tensors
+template <typename T> using StorageT = std::conditional_t<std::is_same<T, F32S>::value, float, T>;
 
 // one launcher per 16-bit element type (hipFuncSetAttribute is per instantiation and per device)
 template <typename T, bool UP, int CIN, bool ADD2, int MODE>
@@ -739,12 +742,12 @@ int launch_ring_lp(const BtRingArgs& r, int ring2, int blocks, int lds_bytes, hi
            : mode    ? launch_ring_lp_<T, UP, CIN, ADD2, 1>(r, blocks, lds_bytes, s)
                      : launch_ring_lp_<T, UP, CIN, ADD2, 0>(r, blocks, lds_bytes, s);
 }
-template <bool UP, bool ADD2 = false, bool TAIL = false>
+template <typename T, bool UP, bool ADD2 = false, bool TAIL = false>
 int launch_ring_f32(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t s) {
     static unsigned attr_done = 0;
     if (first_use_on_this_device(attr_done))
-        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<UP, ADD2, TAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL((bottleneck_ring_f32_kernel<UP, ADD2, TAIL>), dim3(blocks), dim3(256), lds_bytes, s, r);
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<UP, ADD2, TAIL, T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL((bottleneck_ring_f32_kernel<UP, ADD2, TAIL, T>), dim3(blocks), dim3(256), lds_bytes, s, r);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }
@@ -782,11 +785,11 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                 }
                 const int blocks = n * (h->H / 2 / 8) * (h->W / 2 / 16);
                 const double opx = (double)n * (h->H / 2) * (h->W / 2);
-                ScopedTimer tm(h, s, std::string(eb == 2 ? "stem_lp_kernel<" : "stem_kernel<") + tname + ">", 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb), st.m1_elems * n * eb);
+                ScopedTimer tm(h, s, std::string(eb == 2 ? "stem_lp_kernel<" : "stem_kernel<") + TypeName<StorageT<T>>::value + ">", 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb), st.m1_elems * n * eb);
                 if constexpr (sizeof(T) == 2)
                     hipLaunchKernelGGL((stem_lp_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
                 else
-                    hipLaunchKernelGGL((stem_kernel<T>), dim3(std::min(blocks, 3 * cu_count())), dim3(256), 0, s, a);   // persistent: weights once per workgroup
+                    hipLaunchKernelGGL((stem_kernel<StorageT<T>>), dim3(std::min(blocks, 3 * cu_count())), dim3(256), 0, s, a);   // persistent: weights once per workgroup
                 DF3D_LAUNCH_CHECK();
                 break;
             }
@@ -880,12 +883,12 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                         c.b1 = a.b1; c.s1 = a.s1; c.t1c = a.t1;
                         c.M = (long long)n * ti.h * ti.w;
                         {
-                            ScopedTimer tc(h, s, "conv1_ring_f32_kernel<false, 128, 128>", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);
+                            ScopedTimer tc(h, s, std::string("conv1_ring_f32_kernel<false, 128, 128, ") + tname + ">", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);
                             static unsigned attr_c1 = 0;
                             if (first_use_on_this_device(attr_c1))
-                                DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_ring_f32_kernel<false, 128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+                                DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_ring_f32_kernel<false, 128, 128, T>), hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
                             const unsigned c1_grid = (unsigned)std::min<long long>(c.M / 128, 2LL * cu_count());
-                            hipLaunchKernelGGL((conv1_ring_f32_kernel<false, 128, 128>), dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
+                            hipLaunchKernelGGL((conv1_ring_f32_kernel<false, 128, 128, T>), dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
                             DF3D_LAUNCH_CHECK();
                         }
                         BtRingArgs r{};
@@ -895,11 +898,11 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                         r.wstream = sb + st.wstream;
                         r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd;
                         r.V = n; r.H = ti.h; r.W = ti.w;
-                        ScopedTimer tm(h, s, "layer2_tail_f32_kernel", 2.0 * px * (9.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl), px * 4.0 * (cin + pl + 2.0 * pl), st.m1_elems * n * eb);
+                        ScopedTimer tm(h, s, std::string("layer2_tail_f32_kernel<") + tname + ">", 2.0 * px * (9.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl), px * 4.0 * (cin + pl + 2.0 * pl), st.m1_elems * n * eb);
                         static unsigned attr_t = 0;
                         if (first_use_on_this_device(attr_t))
-                            DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer2_tail_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L2F_LDS_BYTES));
-                        hipLaunchKernelGGL(layer2_tail_f32_kernel, dim3(n * (ti.h / BT_TH) * (ti.w / BT_TW)), dim3(256), L2F_LDS_BYTES, s, r);
+                            DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer2_tail_f32_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, L2F_LDS_BYTES));
+                        hipLaunchKernelGGL(layer2_tail_f32_kernel<T>, dim3(n * (ti.h / BT_TH) * (ti.w / BT_TW)), dim3(256), L2F_LDS_BYTES, s, r);
                         DF3D_LAUNCH_CHECK();
                     }
                     break;
@@ -917,12 +920,12 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                         c.b1 = a.b1; c.s1 = a.s1; c.t1c = a.t1;
                         c.M = (long long)n * ti.h * ti.w;
                         {
-                            ScopedTimer tc(h, s, "conv1_ring_f32_kernel<false, 64, 64>", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);
+                            ScopedTimer tc(h, s, std::string("conv1_ring_f32_kernel<false, 64, 64, ") + tname + ">", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);
                             static unsigned attr_c1 = 0;
                             if (first_use_on_this_device(attr_c1))
-                                DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_ring_f32_kernel<false, 64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
+                                DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_ring_f32_kernel<false, 64, 64, T>), hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
                             const unsigned c1_grid = (unsigned)std::min<long long>(c.M / 128, 2LL * cu_count());
-                            hipLaunchKernelGGL((conv1_ring_f32_kernel<false, 64, 64>), dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
+                            hipLaunchKernelGGL((conv1_ring_f32_kernel<false, 64, 64, T>), dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
                             DF3D_LAUNCH_CHECK();
                         }
                         BtRingArgs r{};
@@ -932,11 +935,11 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                         r.wstream = sb + st.wstream;
                         r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd;
                         r.V = n; r.H = ti.h; r.W = ti.w;
-                        ScopedTimer tm(h, s, "layer1_tail_f32_kernel", 2.0 * px * (9.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl), px * 4.0 * (cin + pl + 2.0 * pl), st.m1_elems * n * eb);
+                        ScopedTimer tm(h, s, std::string("layer1_tail_f32_kernel<") + tname + ">", 2.0 * px * (9.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl), px * 4.0 * (cin + pl + 2.0 * pl), st.m1_elems * n * eb);
                         static unsigned attr_t = 0;
                         if (first_use_on_this_device(attr_t))
-                            DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer1_tail_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L1F_LDS_BYTES));
-                        hipLaunchKernelGGL(layer1_tail_f32_kernel, dim3(n * (ti.h / BT_TH) * (ti.w / BT_TW)), dim3(256), L1F_LDS_BYTES, s, r);
+                            DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer1_tail_f32_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, L1F_LDS_BYTES));
+                        hipLaunchKernelGGL(layer1_tail_f32_kernel<T>, dim3(n * (ti.h / BT_TH) * (ti.w / BT_TW)), dim3(256), L1F_LDS_BYTES, s, r);
                         DF3D_LAUNCH_CHECK();
                     }
                     break;
@@ -970,9 +973,9 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                             c.M = (long long)n * ti.h * ti.w;
                             r.t1in = c.t1;
                             r.zeros = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + h->zero_off;
-                            ScopedTimer tc(h, s, a.in2 ? "conv1_ring_f32_kernel<true, 256, 128>" : "conv1_ring_f32_kernel<false, 256, 128>", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);   // (as rocprofv3 prints them)
+                            ScopedTimer tc(h, s, std::string(a.in2 ? "conv1_ring_f32_kernel<true, 256, 128, " : "conv1_ring_f32_kernel<false, 256, 128, ") + tname + ">", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);   // (as rocprofv3 prints them)
                             static unsigned attr_c1[2] = {0, 0};
-                            const void* const fn = a.in2 ? reinterpret_cast<const void*>(conv1_ring_f32_kernel<true>) : reinterpret_cast<const void*>(conv1_ring_f32_kernel<false>);
+                            const void* const fn = a.in2 ? reinterpret_cast<const void*>(conv1_ring_f32_kernel<true, 256, 128, T>) : reinterpret_cast<const void*>(conv1_ring_f32_kernel<false, 256, 128, T>);
                             if (first_use_on_this_device(attr_c1[a.in2 ? 1 : 0]))
                                 DF3D_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS_BYTES));
                             if (c.M % 128) {
@@ -981,16 +984,16 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                             }
                             const unsigned c1_grid = (unsigned)std::min<long long>(c.M / 128, 2LL * cu_count());   // persistent: two workgroups per CU
                             if (a.in2)
-                                hipLaunchKernelGGL(conv1_ring_f32_kernel<true>, dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
+                                hipLaunchKernelGGL((conv1_ring_f32_kernel<true, 256, 128, T>), dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
                             else
-                                hipLaunchKernelGGL(conv1_ring_f32_kernel<false>, dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
+                                hipLaunchKernelGGL((conv1_ring_f32_kernel<false, 256, 128, T>), dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
                             DF3D_LAUNCH_CHECK();
                         }
                     }
-                    const char* const flags2 = split ? (a.in2 ? "true, false, true>" : a.add2 ? "false, true, true>" : "false, false, true>")
-                                                     : a.in2 ? "true, false, false>" : a.add2 ? "false, true, false>" : "false, false, false>";
+                    const char* const flags2 = split ? (a.in2 ? "true, false, true, " : a.add2 ? "false, true, true, " : "false, false, true, ")
+                                                     : a.in2 ? "true, false, false, " : a.add2 ? "false, true, false, " : "false, false, false, ";
                     ScopedTimer tm(h, s, eb == 2 ? std::string("bottleneck_ring_kernel<") + tname + (a.in2 ? ", true, 256, false, " : a.add2 ? ", false, 256, true, " : ", false, 256, false, ") + std::to_string(ring_mode(r, h->ring2)) + ">"
-                                                 : std::string("bottleneck_ring_f32_kernel<") + flags2,   // as rocprofv3 prints them
+                                                 : std::string("bottleneck_ring_f32_kernel<") + flags2 + tname + ">",   // as rocprofv3 prints them
                                    2.0 * px * ((split ? 0.0 : (double)cin * pl) + 9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl + (split ? pl : 0)), st.m1_elems * n * eb);
                     const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
                     int lds_bytes = BR_LDS_BYTES;
@@ -1005,11 +1008,11 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                         rc = a.in2 ? launch_ring_lp<T, true, 256>(r, h->ring2, blocks, lds_bytes, s) : a.add2 ? launch_ring_lp<T, false, 256, true>(r, h->ring2, blocks, lds_bytes, s)
                                                                                            : launch_ring_lp<T, false, 256>(r, h->ring2, blocks, lds_bytes, s);
                     else
-                        rc = split ? (a.in2 ? launch_ring_f32<true, false, true>(r, blocks, lds_bytes, s)
-                                      : a.add2 ? launch_ring_f32<false, true, true>(r, blocks, lds_bytes, s) : launch_ring_f32<false, false, true>(r, blocks, lds_bytes, s))
-                             : a.in2 ? launch_ring_f32<true>(r, blocks, lds_bytes, s)
-                             : a.add2 ? launch_ring_f32<false, true>(r, blocks, lds_bytes, s)
-                                      : launch_ring_f32<false>(r, blocks, lds_bytes, s);
+                        rc = split ? (a.in2 ? launch_ring_f32<T, true, false, true>(r, blocks, lds_bytes, s)
+                                      : a.add2 ? launch_ring_f32<T, false, true, true>(r, blocks, lds_bytes, s) : launch_ring_f32<T, false, false, true>(r, blocks, lds_bytes, s))
+                             : a.in2 ? launch_ring_f32<T, true>(r, blocks, lds_bytes, s)
+                             : a.add2 ? launch_ring_f32<T, false, true>(r, blocks, lds_bytes, s)
+                                      : launch_ring_f32<T, false>(r, blocks, lds_bytes, s);
                     if (rc) return rc;
                     break;
                 }
@@ -1061,8 +1064,8 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                 const TensorDesc& to = h->tensors[st.out];
                 const int chunks = to.pitch * eb / 16;
                 const long long total = (long long)n * to.h * to.w * chunks;
-                ScopedTimer tm(h, s, std::string("pool2_kernel<") + tname + ">", 0.0, (double)total * 16 * 5, st.m1_elems * n * eb);
-                hipLaunchKernelGGL((pool2_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                ScopedTimer tm(h, s, std::string("pool2_kernel<") + TypeName<StorageT<T>>::value + ">", 0.0, (double)total * 16 * 5, st.m1_elems * n * eb);
+                hipLaunchKernelGGL((pool2_kernel<StorageT<T>>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                                    reinterpret_cast<const u32x4*>(tptr(st.in)), reinterpret_cast<u32x4*>(tptr(st.out)),
                                    total, to.h, to.w, chunks);
                 DF3D_LAUNCH_CHECK();
@@ -1072,8 +1075,8 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                 const TensorDesc& to = h->tensors[st.out];
                 const int chunks = to.pitch * eb / 16;
                 const long long total = (long long)n * to.h * to.w * chunks;
-                ScopedTimer tm(h, s, std::string("upadd_kernel<") + tname + ">", 0.0, (double)total * 16 * 2.25, st.m1_elems * n * eb);
-                hipLaunchKernelGGL((upadd_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                ScopedTimer tm(h, s, std::string("upadd_kernel<") + TypeName<StorageT<T>>::value + ">", 0.0, (double)total * 16 * 2.25, st.m1_elems * n * eb);
+                hipLaunchKernelGGL((upadd_kernel<StorageT<T>>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                                    reinterpret_cast<const u32x4*>(tptr(st.in)), reinterpret_cast<const u32x4*>(tptr(st.res)),
                                    reinterpret_cast<u32x4*>(tptr(st.out)), total, to.h, to.w, chunks);
                 DF3D_LAUNCH_CHECK();
@@ -1104,6 +1107,7 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
 int run_steps_dtype(df3d_hg* h, const float* images, int n, int upto, float* heatmaps, unsigned char* act, hipStream_t s) {
     switch (h->dtype) {
         case DF3D_DTYPE_F32: return run_steps<float>(h, images, n, upto, heatmaps, act, s);
+        case DF3D_DTYPE_F32S: return run_steps<F32S>(h, images, n, upto, heatmaps, act, s);
         case DF3D_DTYPE_F16: return run_steps<_Float16>(h, images, n, upto, heatmaps, act, s);
         default: return run_steps<__hip_bfloat16>(h, images, n, upto, heatmaps, act, s);
     }
@@ -1138,7 +1142,7 @@ int df3d_dbg_ring_cycles(unsigned long long* out8) {
 
 int df3d_hg_create(int dtype, int num_stacks, df3d_hg** out) {
     DF3D_CHECK_ARG(out != nullptr, "null out");
-    DF3D_CHECK_ARG(dtype == DF3D_DTYPE_F32 || dtype == DF3D_DTYPE_BF16 || dtype == DF3D_DTYPE_F16, "dtype must be DF3D_DTYPE_F32, DF3D_DTYPE_BF16 or DF3D_DTYPE_F16");
+    DF3D_CHECK_ARG(dtype == DF3D_DTYPE_F32 || dtype == DF3D_DTYPE_BF16 || dtype == DF3D_DTYPE_F16 || dtype == DF3D_DTYPE_F32S, "dtype must be DF3D_DTYPE_F32, DF3D_DTYPE_BF16, DF3D_DTYPE_F16 or DF3D_DTYPE_F32S");
     DF3D_CHECK_ARG(num_stacks >= 1 && num_stacks <= 8, "num_stacks must be in [1, 8]");
     df3d_hg* h = new df3d_hg();
     h->dtype = dtype;
@@ -1475,7 +1479,7 @@ int df3d_hg_forward_upto(df3d_hg* h, const float* images_dev, int n, int upto, f
     const long long pixels = (long long)n * t.h * t.w;
     const long long total = pixels * t.c;
     const void* src = act + t.off * (size_t)n * h->elem_bytes();
-    if (h->dtype == DF3D_DTYPE_F32)
+    if (!h->lp())
         hipLaunchKernelGGL((export_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, out_dev, pixels, t.c, t.pitch);
     else if (h->dtype == DF3D_DTYPE_F16)
         hipLaunchKernelGGL((export_kernel<_Float16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, out_dev, pixels, t.c, t.pitch);

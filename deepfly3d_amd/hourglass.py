@@ -207,7 +207,8 @@ class HourglassEngine:
         self.lib = _native.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.dtype = dtype
-        code = {"f32": _native.DF3D_DTYPE_F32, "bf16": _native.DF3D_DTYPE_BF16, "f16": _native.DF3D_DTYPE_F16}[dtype]
+        code = {"f32": _native.DF3D_DTYPE_F32, "bf16": _native.DF3D_DTYPE_BF16, "f16": _native.DF3D_DTYPE_F16, "f32s": _native.DF3D_DTYPE_F32S}[dtype]
+        fp32_storage = dtype in ("f32", "f32s")   # f32s: the f32 engine's plan, buffers and kernels with split products (include/df3d_hip.h)
         h = ctypes.c_void_p()
         _native.check(self.lib.df3d_hg_create(code, num_stacks, ctypes.byref(h)), "df3d_hg_create")
         self.h = h
@@ -227,15 +228,15 @@ class HourglassEngine:
             _native.check(self.lib.df3d_hg_set_option(self.h, b"row_bytes", row_bytes), "df3d_hg_set_option")
         if split1 is None and os.environ.get("DF3D_SPLIT1"):
             split1 = int(os.environ["DF3D_SPLIT1"])
-        if split1 is not None and dtype == "f32":  # fp32: conv1 of the identity-skip bottlenecks as a launch of its own (csrc/hg_c1_f32.h), bit-identical
+        if split1 is not None and fp32_storage:  # fp32: conv1 of the identity-skip bottlenecks as a launch of its own (csrc/hg_c1_f32.h), bit-identical
             _native.check(self.lib.df3d_hg_set_option(self.h, b"split1", 1 if split1 else 0), "df3d_hg_set_option")
         if w2d is None and os.environ.get("DF3D_W2D"):
             w2d = int(os.environ["DF3D_W2D"])
-        if w2d is not None and dtype != "f32":  # 16-bit: the 3x3's weights of the ring bottlenecks as direct per-wave fragment loads (csrc/hg_bt_ring.h), bit-identical
+        if w2d is not None and not fp32_storage:  # 16-bit: the 3x3's weights of the ring bottlenecks as direct per-wave fragment loads (csrc/hg_bt_ring.h), bit-identical
             _native.check(self.lib.df3d_hg_set_option(self.h, b"w2d", 1 if w2d else 0), "df3d_hg_set_option")
         if ring2 is None and os.environ.get("DF3D_RING2"):
             ring2 = int(os.environ["DF3D_RING2"])
-        if ring2 is not None and dtype != "f32":  # 16-bit: 1 (default) = round 4's ring bottleneck (csrc/hg_bt_ring.h MODE 2), 0 = round 3's; bit-identical
+        if ring2 is not None and not fp32_storage:  # 16-bit: 1 (default) = round 4's ring bottleneck (csrc/hg_bt_ring.h MODE 2), 0 = round 3's; bit-identical
             _native.check(self.lib.df3d_hg_set_option(self.h, b"ring2", 1 if ring2 else 0), "df3d_hg_set_option")
         if chain_views is None and os.environ.get("DF3D_CHAIN_VIEWS"):
             chain_views = int(os.environ["DF3D_CHAIN_VIEWS"])

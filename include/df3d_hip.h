@@ -34,6 +34,9 @@ extern "C" {
 #define DF3D_DTYPE_F32 0
 #define DF3D_DTYPE_BF16 1
 #define DF3D_DTYPE_F16 2  /* IEEE half activations + weights, fp32 accumulate: the bf16 engine's kernels on the other 16-bit format */
+#define DF3D_DTYPE_F32S 3 /* float32 tensors, weights and accumulation -- the F32 engine's plan, buffers and kernels -- with every product formed on the
+                             half-precision matrix pipe from a two-way IEEE-half split of both operands (x = hi + lo to 2^-22 |x|); operands must lie
+                             inside the half range (|x| < 65 504), which batch-normalised activations do.  Not bit-identical to F32: a few 1e-6 relative */
 
 const char* df3d_last_error(void);
 /* ABI revision of the library: DF3D_ABI_VERSION of the header it was built from.  It changes whenever an entry point's signature or

@@ -47,12 +47,15 @@ def _rel_err(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("fuse,row_bytes,fuse_upadd", [(True, 0, True), (True, 0, False), (False, 0, False), (False, 64, False)])
-def test_fp32_every_step_matches_oracle(native_lib, cuda, oracle_net, images, traced, fuse, row_bytes, fuse_upadd):
+# f32s (round 5): the f32 engine's plan and float32 tensors with every product formed from two-way IEEE-half splits on the 16-bit matrix
+# pipe (include/df3d_hip.h DF3D_DTYPE_F32S) -- held to the SAME tolerance as the exact-fp32 engine, step by step.
+@pytest.mark.parametrize("dtype,fuse,row_bytes,fuse_upadd", [("f32", True, 0, True), ("f32", True, 0, False), ("f32", False, 0, False), ("f32", False, 64, False),
+                                                             ("f32s", True, 0, True), ("f32s", False, 0, False)])
+def test_fp32_every_step_matches_oracle(native_lib, cuda, oracle_net, images, traced, dtype, fuse, row_bytes, fuse_upadd):
     """Every plan step (fused bottlenecks: the block output; unfused: every convolution) against the oracle."""
     from deepfly3d_amd.hourglass import HourglassEngine
 
-    eng = HourglassEngine(oracle_net.state_dict(), dtype="f32", device=cuda, row_bytes=row_bytes, fuse=fuse, fuse_upadd=fuse_upadd)
+    eng = HourglassEngine(oracle_net.state_dict(), dtype=dtype, device=cuda, row_bytes=row_bytes, fuse=fuse, fuse_upadd=fuse_upadd)
     steps = eng.steps()
     # fused: 23 bottlenecks + 2 heads in one launch each, 8 + 1 max-pools written by a neighbouring kernel, 8 upsample-adds folded
     expect = len(traced) if not fuse else len(traced) - 2 * 23 - 6 - 4 - 8 - 1 - (8 if fuse_upadd else 0)
@@ -68,14 +71,15 @@ def test_fp32_every_step_matches_oracle(native_lib, cuda, oracle_net, images, tr
         if err > worst[0]:
             worst = (err, name)
         assert err < FP32_TOL, f"step {k} {name}: rel err {err:.3e}"
-    print(f"fp32 worst step error {worst}")
+    print(f"{dtype} worst step error {worst}")
 
 
-def test_fp32_forward_heatmaps_and_argmax(native_lib, cuda, oracle_net, images, traced):
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
+def test_fp32_forward_heatmaps_and_argmax(native_lib, cuda, oracle_net, images, traced, dtype):
     from deepfly3d_amd import ops
     from deepfly3d_amd.hourglass import HourglassEngine
 
-    eng = HourglassEngine(oracle_net.state_dict(), dtype="f32", device=cuda)
+    eng = HourglassEngine(oracle_net.state_dict(), dtype=dtype, device=cuda)
     hm = eng.forward(images.to(cuda))
     ref = traced["score.1"]
     assert _rel_err(hm.cpu(), ref) < FP32_TOL
@@ -121,7 +125,8 @@ def peaked(oracle_net, golden_dir):
     return dict(x=x, ref=ref, pts=rp, conf=rc, margin=margin)
 
 
-def test_peaked_heatmaps_fp32_identical_cells(native_lib, cuda, oracle_net, peaked):
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
+def test_peaked_heatmaps_fp32_identical_cells(native_lib, cuda, oracle_net, peaked, dtype):
     """north_star's 2-D bar (points2d within 1e-4 px = the same heat-map cell) on peaked heat-maps: the fp32 engine
     returns the oracle's cell for 100 % of the joints, the peak value within 2e-3 (the reference's confidence bar,
     reference tests/test_df3d.py:167-178) -- in heat-map units, although these peaks are O(10), not O(1)."""
@@ -130,13 +135,13 @@ def test_peaked_heatmaps_fp32_identical_cells(native_lib, cuda, oracle_net, peak
 
     assert peaked["margin"].min() > 100 * FP32_TOL, peaked["margin"].min()
     assert peaked["pts"].shape[0] >= 16 and peaked["pts"].shape[0] * 19 >= 300, "the enlarged fixture: >= 16 images, >= 300 maps"
-    eng = HourglassEngine(oracle_net.state_dict(), dtype="f32", device=cuda)
+    eng = HourglassEngine(oracle_net.state_dict(), dtype=dtype, device=cuda)
     hm = eng.forward(peaked["x"].to(cuda))
     assert _rel_err(hm.cpu(), peaked["ref"]) < FP32_TOL
     pts, conf = ops.heatmap_argmax(hm)
-    assert np.array_equal(pts.cpu().numpy(), peaked["pts"]), "fp32: identical arg-max cell for every joint"
+    assert np.array_equal(pts.cpu().numpy(), peaked["pts"]), f"{dtype}: identical arg-max cell for every joint"
     np.testing.assert_allclose(conf.cpu().numpy(), peaked["conf"], rtol=0, atol=2e-3)
-    print(f"peaked fp32: {peaked['pts'].shape[0] * 19} maps, all identical cells, max |conf diff| {np.abs(conf.cpu().numpy() - peaked['conf']).max():.2e} "
+    print(f"peaked {dtype}: {peaked['pts'].shape[0] * 19} maps, all identical cells, max |conf diff| {np.abs(conf.cpu().numpy() - peaked['conf']).max():.2e} "
           f"(peaks {peaked['conf'].min():.1f}..{peaked['conf'].max():.1f}, smallest relative margin {peaked['margin'].min():.3f})")
 
 
@@ -215,13 +220,14 @@ def test_f16_every_step_close_to_oracle(native_lib, cuda, oracle_net, images, tr
     print(f"f16 worst step error {worst}")
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
 @pytest.mark.parametrize("height,width,n", [(128, 256, 3), (64, 128, 2), (64, 64, 1), (192, 320, 1)])
-def test_fp32_other_input_sizes(native_lib, cuda, oracle_net, height, width, n):
+def test_fp32_other_input_sizes(native_lib, cuda, oracle_net, height, width, n, dtype):
     """Tile-edge logic of the fused kernels: inputs whose levels are partly too small for the 8 x 16 tile (those fall
     back to the single-convolution kernels) and non-power-of-two tile counts, against the size-agnostic oracle."""
     from deepfly3d_amd.hourglass import HourglassEngine
 
-    eng = HourglassEngine(oracle_net.state_dict(), dtype="f32", device=cuda, height=height, width=width)
+    eng = HourglassEngine(oracle_net.state_dict(), dtype=dtype, device=cuda, height=height, width=width)
     img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(height + width), dtype=torch.float32)
     ref = oh.forward_nhwc(oracle_net, img)
     got = eng.forward(img.to(cuda)).cpu()
@@ -239,7 +245,7 @@ def test_batch_composition_does_not_change_results(native_lib, cuda, oracle_net)
     full = eng.forward(img).clone()
     parts = torch.cat([eng.forward(img[:2].contiguous()).clone(), eng.forward(img[2:].contiguous()).clone()])
     assert torch.equal(full, parts)
-    for dt in ("bf16", "f16"):
+    for dt in ("bf16", "f16", "f32s"):
         e2 = HourglassEngine(oracle_net.state_dict(), dtype=dt, device=cuda)
         a = e2.forward(img).clone()
         b = torch.cat([e2.forward(img[:1].contiguous()).clone(), e2.forward(img[1:].contiguous()).clone()])
@@ -573,7 +579,7 @@ def test_workspace_plan_aliasing_at_bench_batch_size(native_lib, cuda, dtype, n)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f32s"])
 @pytest.mark.parametrize("height,width,n", [(64, 64, 3), (192, 320, 2), (128, 64, 5), (64, 512, 1)])
 def test_workspace_plan_aliasing_on_odd_shapes(native_lib, cuda, dtype, height, width, n):
     """Other image sizes take other kernels (levels too small for the fused tiles): default plan == alias-free plan there too,
@@ -592,7 +598,7 @@ def test_workspace_plan_aliasing_on_odd_shapes(native_lib, cuda, dtype, height, 
         _poison(dflt, n)
         _poison(free, n)
         assert torch.equal(dflt.forward_upto(img.to(cuda), k), free.forward_upto(img.to(cuda), k)), (k, dflt.steps()[k - 1])
-    assert _rel_err(a.cpu(), oh.forward_nhwc(net, img)) < (FP32_TOL if dtype == "f32" else F16_TOL)
+    assert _rel_err(a.cpu(), oh.forward_nhwc(net, img)) < (FP32_TOL if dtype in ("f32", "f32s") else F16_TOL)
 
 
 @pytest.mark.gpu
