@@ -13,6 +13,9 @@ N > 1: every rank owns its own frame range (weak scaling) and the per-frame resu
 (RCCL, one packed `dist.gather`), inside the timed region.  Rank 0 prints ONE JSON line.
 
 The line's headline is configs[1] (fp32).  At N = 1 the same process then times, under the same driver clock,
+  config1_f32_split  configs[1] through the f32s engine: float32 tensors, weights and accumulation, the products as two-way IEEE-half splits on
+                 the 16-bit matrix pipe (gfx950's exact-fp32 MFMA runs at 1/16 of the half-precision rate); NOT the headline -- its heat-maps differ
+                 from the exact-fp32 engine's by the `max_rel_diff_vs_f32_engine` printed beside it (same 5e-5 test tolerance, tests/test_gpu_hourglass.py)
   config2_bf16   configs[2]: the same frames through the bf16 hourglass (all convolutions on MFMA, fp32 accumulate)
   config2_f16    the same kernels on IEEE half: the 16-bit engine whose heat-map confidences stay inside the reference's
                  own test tolerance (2e-3; bf16's are ~5e-3 off: tests/test_gpu_hourglass.py)
@@ -50,9 +53,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}  # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+# /opt/skills/guides/MI355X_MICROARCH.md (dense).  f32s forms every float32 product from FOUR half-precision products (two-way split of both
+# operands): its matrix-pipe roof in float32 FLOPs is the half-precision peak / 4
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "f32s": 625.0}
 PEAK_HBM_GBS = 8000.0
-DTYPE_WORDS = {"f32": "fp32", "bf16": "bf16 (all convolutions on MFMA, fp32 accumulate)", "f16": "IEEE-half f16 (all convolutions on MFMA, fp32 accumulate)"}
+DTYPE_WORDS = {"f32": "fp32", "bf16": "bf16 (all convolutions on MFMA, fp32 accumulate)", "f16": "IEEE-half f16 (all convolutions on MFMA, fp32 accumulate)",
+               "f32s": "fp32 tensors and weights, every product as a two-way IEEE-half split of both operands on the 16-bit matrix pipe (fp32 accumulate)"}
 
 
 def parse(argv=None):
@@ -61,7 +67,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-step", type=int, default=128)
-    ap.add_argument("--dtype", choices=["f32", "bf16", "f16"], default="f32")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f16", "f32s"], default="f32")
     ap.add_argument("--pool-frames", type=int, default=0, help="distinct frames resident in HBM (0 = steps*frames_per_step, capped at 1024)")
     ap.add_argument("--ba-window", type=int, default=0,
                     help="BASELINE configs[4]: run one bundle adjustment (HIP kernels + TRF/LSMR driver) per this many frames on "
@@ -468,6 +474,11 @@ def hourglass_leg(a, sd, dtype, frames, calib, dev, total_frames, config_words):
     }
     if not a.no_roofline:
         leg["roofline"] = job.roofline(dtype)
+    if dtype == "f32s":   # the leg's price: what it differs by from the exact-fp32 engine, measured here on 2 frames of the run's own input
+        ref = HourglassEngine(sd, dtype="f32", device=dev).forward(frames[:2].reshape(14, 256, 512, 3))
+        got = eng.forward(frames[:2].reshape(14, 256, 512, 3))
+        leg["max_rel_diff_vs_f32_engine"] = float((got - ref).abs().max() / ref.abs().max())
+        leg["argmax_cells_identical_to_f32_engine"] = bool(torch.equal(got.flatten(2).argmax(-1), ref.flatten(2).argmax(-1)))
     del job, eng
     return leg
 
@@ -644,6 +655,7 @@ def main(argv=None):
     # the attached legs (N = 1, plain configs[1] run only): same process, same driver clock
     legs = {}
     if a.dtype == "f32" and world == 1 and not a.no_legs and a.rank_share == 0 and a.ba_window == 0 and not a.strong:
+        legs["config1_f32_split"] = hourglass_leg(a, sd, "f32s", frames, calib, dev, total_frames, "BASELINE configs[1] with split products")
         legs["config2_bf16"] = hourglass_leg(a, sd, "bf16", frames, calib, dev, total_frames, "BASELINE configs[2]")
         legs["config2_f16"] = hourglass_leg(a, sd, "f16", frames, calib, dev, total_frames,
                                             "BASELINE configs[2] on IEEE half (the 16-bit engine inside the reference's 2e-3 confidence tolerance)")
@@ -674,7 +686,7 @@ def main(argv=None):
             workload = (f"BASELINE configs[4] (per-GPU share): {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {words}, "
                         f"arg-max + 38-joint layout + fp64 DLT, bundle-adjustment re-calibration every {a.ba_window} frames")
         else:
-            workload = (f"BASELINE configs[{1 if a.dtype == 'f32' else 2}]: {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {words}, "
+            workload = (f"BASELINE configs[{1 if a.dtype in ('f32', 'f32s') else 2}]: {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {words}, "
                         "arg-max + 38-joint layout + fp64 DLT with fixed calib.pkl")
         sec = ms_step * 1e-3
         line = {

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
 #pragma unroll
                     for (int j = 0; j < NCT; ++j) {
                         if (C1_ABLM & 1) asm volatile("" ::"v"(xf[i]), "v"(wf[j]));
-                        else mfma_chunk<T>(xf[i], wf[j], acc[i][j]);
+                        else mfma_chunk<T, false>(xf[i], wf[j], acc[i][j]);
                     }
             }
         }

@@ -183,28 +183,47 @@ __device__ __forceinline__ void f32s_split2(float x0, float x1, unsigned& hi, un
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
-// one 16-byte A fragment x one 16-byte B fragment -> accumulate into a 32x32 tile
-template <typename T>
+// F32S engines keep their WEIGHTS pre-split (f32s_presplit_kernel at df3d_hg_set_weights: the blob copy the kernels read and every stream / LDS
+// image made from it): the 16-byte chunk of four consecutive-K floats w0..w3 is stored as {hi(w0, w1), hi(w2, w3), lo(w0, w1), lo(w2, w3)} --
+// eight halves, i.e. ONE operand of the K = 16 half-precision MFMA holding [w_hi(4) | w_lo(4)].  Chunk granularity, so every packer (which
+// moves whole chunks) and every fragment read stays what it is.
+__global__ __launch_bounds__(256) void f32s_presplit_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t nchunks) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+        const f32x4 w = __builtin_bit_cast(f32x4, src[i]);
+        unsigned h0, l0, h1, l1;
+        f32s_split2(w[0], w[1], h0, l0);
+        f32s_split2(w[2], w[3], h1, l1);
+        dst[i] = u32x4{h0, h1, l0, l1};
+    }
+}
+
+// one 16-byte A fragment x one 16-byte B fragment -> accumulate into a 32x32 tile.  W_FIRST (F32S only): which of the two is the weight chunk.
+template <typename T, bool W_FIRST = true>
 __device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x16& acc) {
     if constexpr (std::is_same<T, F32S>::value) {
         // The chunk's K = 8 (four floats per lane and operand, lane half h = K parity) as ONE K = 16 step of the half-precision MFMA, taken
-        // twice: A = [a_hi(4) | a_lo(4)] against B = [b_hi | b_hi], then against [b_lo | b_lo] -- all four terms of (a_hi + a_lo)(b_hi + b_lo),
-        // float32 accumulation: 2 x 32 matrix-pipe cycles where the exact-fp32 v_mfma_f32_32x32x2_f32 takes 4 x 64.  Per-product error 2^-22.
-        const f32x4 af = __builtin_bit_cast(f32x4, a);
-        const f32x4 bf = __builtin_bit_cast(f32x4, b);
-        unsigned ah0, al0, ah1, al1, bh0, bl0, bh1, bl1;
-        f32s_split2(af[0], af[1], ah0, al0);
-        f32s_split2(af[2], af[3], ah1, al1);
-        f32s_split2(bf[0], bf[1], bh0, bl0);
-        f32s_split2(bf[2], bf[3], bh1, bl1);
-        const u32x4 A = {ah0, ah1, al0, al1}, B1 = {bh0, bh1, bh0, bh1}, B2 = {bl0, bl1, bl0, bl1};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B1), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B2), acc, 0, 0, 0);
+        // twice: the weight operand is [w_hi(4) | w_lo(4)] as stored, the activation x is split here (hi = rn(x), lo = rn(x - hi)) and goes in as
+        // [x_hi | x_hi], then as [x_lo | x_lo] -- all four terms of (w_hi + w_lo)(x_hi + x_lo), float32 accumulation: 2 x 32 matrix-pipe cycles
+        // where the exact-fp32 v_mfma_f32_32x32x2_f32 takes 4 x 64.  Per-product error 2^-22.  An activation fragment that meets several weight
+        // fragments in an unrolled loop is split once (common subexpressions).
+        const u32x4& w = W_FIRST ? a : b;
+        const f32x4 xf = __builtin_bit_cast(f32x4, W_FIRST ? b : a);
+        unsigned h0, l0, h1, l1;
+        f32s_split2(xf[0], xf[1], h0, l0);
+        f32s_split2(xf[2], xf[3], h1, l1);
+        const f16x8 W = __builtin_bit_cast(f16x8, w), XH = __builtin_bit_cast(f16x8, u32x4{h0, h1, h0, h1}), XL = __builtin_bit_cast(f16x8, u32x4{l0, l1, l0, l1});
+        if constexpr (W_FIRST) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, XH, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, XL, acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(XH, W, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(XL, W, acc, 0, 0, 0);
+        }
     } else if constexpr (sizeof(T) == 4) {
         const f32x4 af = __builtin_bit_cast(f32x4, a);
         const f32x4 bf = __builtin_bit_cast(f32x4, b);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[i], acc, 0, 0, 0);
     } else {
         acc = Lp<T>::mfma(a, b, acc);
     }
@@ -217,8 +236,8 @@ template <typename T, bool A_FIRST = true>
 __device__ __forceinline__ void mfma_quad(float a0, float a1, float a2, float a3, const f32x4& w, f32x16& acc) {
     const f32x4 a = {a0, a1, a2, a3};
     if constexpr (std::is_same<T, F32S>::value) {
-        if constexpr (A_FIRST) mfma_chunk<T>(__builtin_bit_cast(u32x4, a), __builtin_bit_cast(u32x4, w), acc);
-        else mfma_chunk<T>(__builtin_bit_cast(u32x4, w), __builtin_bit_cast(u32x4, a), acc);
+        if constexpr (A_FIRST) mfma_chunk<T, false>(__builtin_bit_cast(u32x4, a), __builtin_bit_cast(u32x4, w), acc);
+        else mfma_chunk<T, true>(__builtin_bit_cast(u32x4, w), __builtin_bit_cast(u32x4, a), acc);
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = A_FIRST ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], w[e], acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], a[e], acc, 0, 0, 0);
@@ -371,7 +390,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
             for (int i = 0; i < G::TM; ++i)
 #pragma unroll
-                for (int k = 0; k < G::TN; ++k) mfma_chunk<T>(af[i], bf[k], acc[i][k]);
+                for (int k = 0; k < G::TN; ++k) mfma_chunk<T, false>(af[i], bf[k], acc[i][k]);
         }
         if (s + 1 < nsteps) store_step(buf ^ 1);
         __syncthreads();
@@ -1108,7 +1127,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
 #pragma unroll
                 for (int i = 0; i < RT; ++i) {
                     const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * PITCH + j * 32 + half * 16);
-                    mfma_chunk<T>(xf, wf, acc[i]);
+                    mfma_chunk<T, false>(xf, wf, acc[i]);
                 }
             }
             if (s + 1 < NSTEPS) __syncthreads();  // every wave is done reading the only buffer
@@ -1317,7 +1336,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (i * 32 + l31) * PITCHd + j * 32 + half * 16);
-                        mfma_chunk<T>(xf, wf, acc[i]);
+                        mfma_chunk<T, false>(xf, wf, acc[i]);
                     }
                 }
                 if (s + 1 < NSTEPSd) __syncthreads();

@@ -156,7 +156,8 @@ struct df3d_hg {
     bool lp() const { return dtype == DF3D_DTYPE_BF16 || dtype == DF3D_DTYPE_F16; }   // a 16-bit engine (bf16 or f16: same plan, same kernels, other element type)
     int elem_bytes() const { return lp() ? 2 : 4; }
     // byte offset of the weight streams in the caller's "lowp" buffer: behind the 16-bit copy of the blob (bf16 / f16), at its start (f32)
-    size_t stream_base() const { return lp() ? (blob_floats * 2 + 255) & ~size_t(255) : 0; }
+    // (f32s: behind the pre-split float32 copy of the blob, hg_kernels.h f32s_presplit_kernel)
+    size_t stream_base() const { return lp() ? (blob_floats * 2 + 255) & ~size_t(255) : dtype == DF3D_DTYPE_F32S ? (blob_floats * 4 + 255) & ~size_t(255) : 0; }
 
     // every step-creating site brackets its accounting: m1_open() before the first elems_per_view update that belongs to the
     // step, push_step(), m1_close() after the last one -> Step::m1_elems
@@ -756,7 +757,9 @@ template <typename T>
 int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* heatmaps_all, unsigned char* act, hipStream_t s) {
     const int eb = sizeof(T);
     const char* const tname = TypeName<T>::value;   // as rocprofv3 prints the template argument
-    const unsigned char* wb = reinterpret_cast<const unsigned char*>(eb == 4 ? (const void*)h->blob : h->lowp);
+    // the weights the kernels read: the caller's float32 blob (f32), its 16-bit copy (bf16 / f16), its pre-split copy (f32s); biases and
+    // BatchNorm coefficients always come from the blob
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(std::is_same<T, float>::value ? (const void*)h->blob : h->lowp);
     // one plan step on the views [v0, v0 + n) of the batch: every tensor is [views][h][w][pitch], so a view range is a
     // contiguous slice of each (the whole batch: v0 = 0, n = n_all)
     auto launch = [&](int i, int v0, int n) -> int {
@@ -1316,6 +1319,9 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
         }
         DF3D_LAUNCH_CHECK();
         h->lowp = lowp_dev;
+    } else if (h->dtype == DF3D_DTYPE_F32S && lowp_dev == nullptr) {
+        df3d::set_error("an f32s engine needs a df3d_hg_lowp_bytes() device buffer (the pre-split copy of the weights)");
+        return DF3D_EINVAL;
     } else if (h->stream_bytes && lowp_dev == nullptr) {
         // round 1's contract for f32 engines (no scratch buffer): honoured by falling back to the register-staged kernels, which
         // need no weight streams and give bit-identical results.  The parameter manifest does not depend on the option, so the
@@ -1352,6 +1358,19 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
         }
         if (h->uses_zero_page)
             DF3D_HIP(hipMemsetAsync(reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + h->zero_off, 0, 256, df3d::as_stream(stream)));
+        DF3D_LAUNCH_CHECK();
+        h->lowp = lowp_dev;
+    }
+    if (h->dtype == DF3D_DTYPE_F32S) {
+        // every weight chunk (4 consecutive-K floats) pre-split into [hi(4) | lo(4)] halves: the blob's copy, and -- in place -- the streams
+        // just packed from the float32 blob (chunk movers; the zero page stays zero)
+        DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(lowp_dev) & 255) == 0, "lowp buffer must be 256-byte aligned");
+        unsigned char* const lo = reinterpret_cast<unsigned char*>(lowp_dev);
+        hipLaunchKernelGGL(f32s_presplit_kernel, dim3(1024), dim3(256), 0, df3d::as_stream(stream), reinterpret_cast<const u32x4*>(blob_dev),
+                           reinterpret_cast<u32x4*>(lo), h->blob_floats / 4);
+        if (h->stream_bytes)
+            hipLaunchKernelGGL(f32s_presplit_kernel, dim3(1024), dim3(256), 0, df3d::as_stream(stream), reinterpret_cast<const u32x4*>(lo + h->stream_base()),
+                               reinterpret_cast<u32x4*>(lo + h->stream_base()), h->stream_bytes / 16);
         DF3D_LAUNCH_CHECK();
         h->lowp = lowp_dev;
     }

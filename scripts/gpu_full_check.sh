@@ -22,7 +22,7 @@ l=[x for x in open("$OUT/bench_default.log") if x.startswith("{")]
 if l:
     d=json.loads(l[-1])
     print("f32 frames/s", round(d["value"],1), "ms/step", round(d["ms_per_step"],2), "settle", d.get("warmup_settle"), "frac", round(d["roofline"]["frac"],4))
-    for k in ("config2_bf16","config2_f16","config4_share"):
+    for k in ("config1_f32_split","config2_bf16","config2_f16","config4_share"):
         if k in d: print(k, round(d[k].get("value",0),1), d[k].get("error",""))
     print("cpu", d.get("cpu_baseline"))
     for k in d["roofline"]["kernels"][:8]: print("  ", k["kernel"], k["launches"], round(k["avg_us"],1), round(k["tflops"],1))

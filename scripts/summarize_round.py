@@ -41,7 +41,7 @@ def main():
         name = f"{tag}_{base}.json" if base.endswith("_bench") else f"{tag}_{base.split('_cfg')[0]}.json"
         with open(os.path.join(ROOT, "profiles", name), "w") as f:
             json.dump(d, f, indent=1)
-        legs = {k: round(d[k]["value"], 1) for k in ("config2_bf16", "config2_f16", "config4_share") if k in d and "value" in d[k]}
+        legs = {k: round(d[k]["value"], 1) for k in ("config1_f32_split", "config2_bf16", "config2_f16", "config4_share") if k in d and "value" in d[k]}
         print(f"{name}: {d['value']:.1f} frames/s {legs if legs else ''}")
     meta = json.load(open(tj))["_meta"]
     sys.path.insert(0, ROOT)

@@ -41,16 +41,18 @@ def test_default_line_has_every_leg_and_every_fraction(native_lib, cuda):
     assert "configs[1]" in d["config"]["workload"]
     _check_roofline(d["roofline"], "f32")
     assert d["roofline"]["bound"] == "mfma" and "bottleneck_ring_f32_kernel" in d["roofline"]["kernel"]
-    for key, dt in (("config2_bf16", "bf16"), ("config2_f16", "f16")):
+    for key, dt in (("config1_f32_split", "f32s"), ("config2_bf16", "bf16"), ("config2_f16", "f16")):
         leg = d[key]
-        assert leg["dtype"] == dt and leg["value"] > 0 and "configs[2]" in leg["workload"]
+        assert leg["dtype"] == dt and leg["value"] > 0 and ("configs[1]" if dt == "f32s" else "configs[2]") in leg["workload"]
         assert abs(leg["value"] - 64 / (leg["steps"] * leg["ms_per_step"] * 1e-3)) < 1e-6 * leg["value"]
         _check_roofline(leg["roofline"], dt)
+    # the split-product leg carries its price: its heat-maps against the exact-fp32 engine's, inside the fp32 test tolerance, same cells
+    assert d["config1_f32_split"]["max_rel_diff_vs_f32_engine"] < 5e-5
     sh = d["config4_share"]
     assert "error" not in sh, sh
     assert sh["frames"] == 2000 and sh["bundle_adjust_runs"] == 2 and sh["gather_roundtrip_exact"] is True and sh["collective_backend"] == "nccl"
     assert sh["value"] > 0   # (rates are printed, never compared: a fresh box's clocks are still ramping in a run this short)
-    print("rates (frames/s): f32", round(d["value"], 1), "bf16", round(d["config2_bf16"]["value"], 1), "f16", round(d["config2_f16"]["value"], 1),
+    print("rates (frames/s): f32", round(d["value"], 1), "f32 split", round(d["config1_f32_split"]["value"], 1), "bf16", round(d["config2_bf16"]["value"], 1), "f16", round(d["config2_f16"]["value"], 1),
           "configs[4] share", round(sh["value"], 1), "cpu port", round(d["cpu_baseline"]["value"], 3))
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
