@@ -17,6 +17,10 @@
 #pragma once
 #include "hg_bt_ring.h"
 
+#ifndef BRF_ABLM
+#define BRF_ABLM 0   // development builds (scripts/build_variant.sh): ablation mask of the fp32 / f32s ring kernels, see the uses below
+#endif
+
 namespace hgk {
 
 constexpr int BRF_W1_STAGES = 8, BRF_W2_STAGES = 36, BRF_KH_STAGES = BRF_W1_STAGES + BRF_W2_STAGES, BRF_W3_STAGES = 16;
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
     constexpr int NQ = TAIL ? BRF_NSTAGE - 2 * BRF_W1_STAGES : BRF_NSTAGE;
     auto stream_index = [](int q) { return !TAIL ? q : q < BRF_W2_STAGES ? BRF_W1_STAGES + q : q < 2 * BRF_W2_STAGES ? 2 * BRF_W1_STAGES + q : 2 * BRF_W1_STAGES + q; };
     auto ring_issue = [&](int q) {   // this wave copies pieces 2 wave, 2 wave + 1
+        if ((BRF_ABLM & 2) && q >= 3) return;   // (ablation mask 2: no weight DMA after the prologue's stages)
         if (q < NQ) {
             const unsigned dst = ring_addr + (unsigned)(q % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048;
             br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)stream_index(q) * BR_STAGE_BYTES, wvoff, dst);
@@ -306,7 +311,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
 #pragma unroll
                     for (int m = 0; m < NT; ++m) {
                         const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + m * 2048);
-                        mfma_chunk<T>(wf, tf, t2[m]);
+                        if (BRF_ABLM & 1) asm volatile("" ::"v"(wf), "v"(tf));   // (ablation mask 1: no phase-2 MFMAs)
+                        else if ((BRF_ABLM & 4) && m > 0) continue;              // (ablation mask 4: a quarter of the phase-2 MFMAs and weight fragment reads)
+                        else mfma_chunk<T>(wf, tf, t2[m]);
                     }
                 }
             }

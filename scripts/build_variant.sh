@@ -18,6 +18,7 @@
 #   -DBR_FORCE_LDS=90000    ring kernels at ONE workgroup per CU
 #   -DBR_SETPRIO            s_setprio around the phase-2 MFMAs
 #   -DC1_ABLM=mask          fp32 conv1 kernel: 1 no MFMAs, 2 no weight DMA, 4 no x loads, 8 no t1 stores
+#   -DBRF_ABLM=mask         fp32 / f32s ring (tail) kernel: 1 no phase-2 MFMAs, 2 no weight DMA after the prologue, 4 a quarter of phase 2's MFMAs and fragment reads
 #   -DBRF_NO_T1DMA          fp32 tail kernels without their t1 halo DMA;  -DBRF_NO_LATE_RES  without the residual tiles requested in the epilogue
 set -e
 cd "$(dirname "$0")/.."
