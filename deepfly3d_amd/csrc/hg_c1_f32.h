@@ -190,20 +190,36 @@ __global__ __launch_bounds__(256, 2) void conv1_ring_f32_kernel(Conv1Args p) {
             if (s + DX < NST) loadx(false, s + DX, s % DX);
             else loadx(true, s + DX - NST, s % DX);
             const unsigned char* const sx = xr + (s % C1_XSLOTS) * C1_XSTAGE;
+            if constexpr (std::is_same<T, F32S>::value) {   // the K step as a whole: two split pixel-row pairs against NCT weight fragment pairs
+                XPair<T> xp2[2];
 #pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2) {   // the K step's two 8-float halves
-                u32x4 wf[NCT], xf[2];
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned char* const row = sx + ((rt0 + i) * 32 + l31) * C1_XPITCH;
+                    xp2[i] = make_xpair<T>(*reinterpret_cast<const u32x4*>(row + br_xslot(l31, half)), *reinterpret_cast<const u32x4*>(row + br_xslot(l31, 2 + half)));
+                }
 #pragma unroll
-                for (int j = 0; j < NCT; ++j) wf[j] = *reinterpret_cast<const u32x4*>((j2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + (ct0 + j) * 2048);
+                for (int j = 0; j < NCT; ++j) {
+                    const u32x4 w0 = *reinterpret_cast<const u32x4*>(wf0 + (s % BR_RING) * BR_STAGE_BYTES + (ct0 + j) * 2048);
+                    const u32x4 w1 = *reinterpret_cast<const u32x4*>(wf1 + (s % BR_RING) * BR_STAGE_BYTES + (ct0 + j) * 2048);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * C1_XPITCH + br_xslot(l31, 2 * j2 + half));
+                    for (int i = 0; i < 2; ++i) mfma_pair<T, false>(w0, w1, xp2[i], acc[i][j]);
+                }
+            } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int j2 = 0; j2 < 2; ++j2) {   // the K step's two 8-float halves
+                    u32x4 wf[NCT], xf[2];
 #pragma unroll
-                    for (int j = 0; j < NCT; ++j) {
-                        if (C1_ABLM & 1) asm volatile("" ::"v"(xf[i]), "v"(wf[j]));
-                        else mfma_chunk<T, false>(xf[i], wf[j], acc[i][j]);
-                    }
+                    for (int j = 0; j < NCT; ++j) wf[j] = *reinterpret_cast<const u32x4*>((j2 ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + (ct0 + j) * 2048);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * C1_XPITCH + br_xslot(l31, 2 * j2 + half));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < NCT; ++j) {
+                            if (C1_ABLM & 1) asm volatile("" ::"v"(xf[i]), "v"(wf[j]));
+                            else mfma_chunk<T>(xf[i], wf[j], acc[i][j]);
+                        }
+                }
             }
         }
         // epilogue: ReLU, 4-byte stores of 128 contiguous bytes per (pixel, channel tile): 64 per lane, unconditional (M is a multiple

@@ -193,6 +193,16 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                 u32x4 rf[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) rf[j] = *reinterpret_cast<const u32x4*>(rfrag + (s % RSLOT) * BR_STAGE_BYTES + ((((unsigned)(2 * j + half)) ^ rsw) << 4));
+                if constexpr (std::is_same<T, F32S>::value) {   // the K step as a whole: the r pair split once, eight row tiles of three MFMAs
+                    const XPair<T> rp = make_xpair<T>(rf[0], rf[1]);
+#pragma unroll
+                    for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            mfma_pair<T, true>(*reinterpret_cast<const u32x4*>(wf0 + ((2 * s + rh) % NSLOT) * BR_STAGE_BYTES + m * 2048),
+                                               *reinterpret_cast<const u32x4*>(wf1 + ((2 * s + rh) % NSLOT) * BR_STAGE_BYTES + m * 2048), rp, y[4 * rh + m]);
+                    continue;
+                }
                 // four groups of four MFMAs (K half j, row half of the stage pair), the four weight fragments of group g + 1 requested
                 // BEFORE the MFMAs of group g (hipcc otherwise serialises ds_read -> wait -> MFMA on one register quad: hg_bt_ring.h)
                 u32x4 wfr[2][4];
@@ -208,7 +218,9 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                     if (g < 3) load_group(g + 1, (g + 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) mfma_chunk<T>(wfr[g & 1][m], rf[g >> 1], y[4 * (g & 1) + m]);
+                    for (int m = 0; m < 4; ++m) {
+                        if constexpr (!std::is_same<T, F32S>::value) mfma_chunk<T>(wfr[g & 1][m], rf[g >> 1], y[4 * (g & 1) + m]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -264,12 +276,13 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
             if (s + 1 < NSTEPS) loadA(s + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < RB / 32; ++j) {
-                const u32x4 rf = *reinterpret_cast<const u32x4*>(sr + (wave * 32 + l31) * PITCH + j * 32 + half * 16);
+            for (int j = 0; j < RB / 32; j += 2) {   // fragment pairs (j, j + 1): one 64-byte K step (mfma_pair)
+                const unsigned char* const rrow = sr + (wave * 32 + l31) * PITCH + half * 16;
+                const XPair<T> rp = make_xpair<T>(*reinterpret_cast<const u32x4*>(rrow + j * 32), *reinterpret_cast<const u32x4*>(rrow + (j + 1) * 32));
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
-                    const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (m * 32 + l31) * PITCH + j * 32 + half * 16);
-                    mfma_chunk<T>(wf, rf, y[m]);
+                    const unsigned char* const wrowa = sw + (m * 32 + l31) * PITCH + half * 16;
+                    mfma_pair<T, true>(*reinterpret_cast<const u32x4*>(wrowa + j * 32), *reinterpret_cast<const u32x4*>(wrowa + (j + 1) * 32), rp, y[m]);
                 }
             }
             if (s + 1 < NSTEPS) storeA((s & 1) ^ 1);
@@ -285,6 +298,15 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[m][4 * q + e] = fmaxf(y[m][4 * q + e] + bb[e], 0.0f);
         }
+    // F32S: y is the activation operand of the score convolution and of phase C: split once per 16-channel K step
+    XPair<T> ysp[std::is_same<T, F32S>::value ? 8 : 1][2];
+    if constexpr (std::is_same<T, F32S>::value) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+                ysp[m][q2] = make_xpair<T>(y[m][8 * q2], y[m][8 * q2 + 1], y[m][8 * q2 + 2], y[m][8 * q2 + 3], y[m][8 * q2 + 4], y[m][8 * q2 + 5], y[m][8 * q2 + 6], y[m][8 * q2 + 7]);
+    }
     // 16-bit engines: pack y once (slot e of group q2 <-> register 8*q2 + e)
     u32x4 ypk[EB == 2 ? 8 : 1][2];
     if constexpr (EB == 2) {
@@ -323,12 +345,18 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
         for (int m = 0; m < 8; ++m) {
             if constexpr (EB == 4) {
 #pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2)
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    if constexpr (std::is_same<T, F32S>::value) {
+                        const unsigned char* const w2p = wrow + (32 * m) * 4 + (4 * q2 + half) * 16;
+                        mfma_pair<T, true>(*reinterpret_cast<const u32x4*>(w2p), *reinterpret_cast<const u32x4*>(w2p + 32), ysp[m][q2], sc);
+                    } else {
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const f32x4 wf = *reinterpret_cast<const f32x4*>(wrow + (32 * m) * 4 + (4 * q2 + 2 * jj + half) * 16);
-                        mfma_quad<T, false>(y[m][8 * q2 + 4 * jj], y[m][8 * q2 + 4 * jj + 1], y[m][8 * q2 + 4 * jj + 2], y[m][8 * q2 + 4 * jj + 3], wf, sc);
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const f32x4 wf = *reinterpret_cast<const f32x4*>(wrow + (32 * m) * 4 + (4 * q2 + 2 * jj + half) * 16);
+                            mfma_quad<T, false>(y[m][8 * q2 + 4 * jj], y[m][8 * q2 + 4 * jj + 1], y[m][8 * q2 + 4 * jj + 2], y[m][8 * q2 + 4 * jj + 3], wf, sc);
+                        }
                     }
+                }
             } else {
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2) {
@@ -389,6 +417,12 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
 #pragma unroll
             for (int i = 0; i < WPASS; ++i) *reinterpret_cast<u32x4*>(sw + (srow + i * RPP) * PITCH + chunk * 16) = rw[i];
         };
+        XPair<T> scsp[2];   // F32S: the 32 (padded) score channels as phase C's last K steps, split once
+        if constexpr (std::is_same<T, F32S>::value) {
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+                scsp[q2] = make_xpair<T>(sc[8 * q2], sc[8 * q2 + 1], sc[8 * q2 + 2], sc[8 * q2 + 3], sc[8 * q2 + 4], sc[8 * q2 + 5], sc[8 * q2 + 6], sc[8 * q2 + 7]);
+        }
         u32x4 scpk[2];
         if constexpr (EB == 2) {
 #pragma unroll
@@ -528,15 +562,25 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                 if constexpr (EB == 4) {
                     // y steps: KE = 32 channels = tile s; score step: the 32 score channels
 #pragma unroll
-                    for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj)
+                    for (int q2 = 0; q2 < 2; ++q2) {
+                        if constexpr (std::is_same<T, F32S>::value) {
+                            const XPair<T> ap = s < YSTEPS ? ysp[s < YSTEPS ? s : 0][q2] : scsp[q2];
 #pragma unroll
                             for (int i = 0; i < NI; ++i) {
-                                const f32x4 wf = *reinterpret_cast<const f32x4*>(sw + (i * 32 + l31) * PITCH + (4 * q2 + 2 * jj + half) * 16);
-                                const f32x16& src = s < YSTEPS ? y[s < YSTEPS ? s : 0] : sc;
-                                mfma_quad<T>(src[8 * q2 + 4 * jj], src[8 * q2 + 4 * jj + 1], src[8 * q2 + 4 * jj + 2], src[8 * q2 + 4 * jj + 3], wf, acc[i]);
+                                const unsigned char* const wcp = sw + (i * 32 + l31) * PITCH + (4 * q2 + half) * 16;
+                                mfma_pair<T, false>(*reinterpret_cast<const u32x4*>(wcp), *reinterpret_cast<const u32x4*>(wcp + 32), ap, acc[i]);
                             }
+                        } else {
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                                for (int i = 0; i < NI; ++i) {
+                                    const f32x4 wf = *reinterpret_cast<const f32x4*>(sw + (i * 32 + l31) * PITCH + (4 * q2 + 2 * jj + half) * 16);
+                                    const f32x16& src = s < YSTEPS ? y[s < YSTEPS ? s : 0] : sc;
+                                    mfma_quad<T>(src[8 * q2 + 4 * jj], src[8 * q2 + 4 * jj + 1], src[8 * q2 + 4 * jj + 2], src[8 * q2 + 4 * jj + 3], wf, acc[i]);
+                                }
+                        }
+                    }
                 } else {
                     // y steps: KE channels = tiles s*(KE/32) .. +KE/32-1; score step: one 32-channel group
 #pragma unroll

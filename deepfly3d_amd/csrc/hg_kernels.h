@@ -183,43 +183,63 @@ __device__ __forceinline__ void f32s_split2(float x0, float x1, unsigned& hi, un
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
-// F32S engines keep their WEIGHTS pre-split (f32s_presplit_kernel at df3d_hg_set_weights: the blob copy the kernels read and every stream / LDS
-// image made from it): the 16-byte chunk of four consecutive-K floats w0..w3 is stored as {hi(w0, w1), hi(w2, w3), lo(w0, w1), lo(w2, w3)} --
-// eight halves, i.e. ONE operand of the K = 16 half-precision MFMA holding [w_hi(4) | w_lo(4)].  Chunk granularity, so every packer (which
-// moves whole chunks) and every fragment read stays what it is.
-__global__ __launch_bounds__(256) void f32s_presplit_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t nchunks) {
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
-        const f32x4 w = __builtin_bit_cast(f32x4, src[i]);
-        unsigned h0, l0, h1, l1;
-        f32s_split2(w[0], w[1], h0, l0);
-        f32s_split2(w[2], w[3], h1, l1);
-        dst[i] = u32x4{h0, h1, l0, l1};
+// ---- F32S: float32 products on the half-precision matrix pipe (round 5) ---------------------------------------------------------------
+// A lane's share of one 16-float K step is EIGHT floats: the step's 16-byte chunks `half` and `2 + half` (every float32 kernel reads them as
+// fragment j = 0 and j = 1 of the step).  With x = hi + lo (f32s_split2: two IEEE halves, x to 2^-22 |x|) the step's product is three K = 16
+// half-precision MFMAs -- w_hi x_hi + w_lo x_hi + w_hi x_lo, float32 accumulation; the w_lo x_lo term (2^-22 of the product) is dropped --
+// where the exact-fp32 v_mfma_f32_32x32x2_f32 takes eight: 96 matrix-pipe cycles instead of 512.
+//   * WEIGHTS are stored pre-split (f32s_presplit_kernel at df3d_hg_set_weights: the blob's copy, from which every stream / LDS image is then
+//     packed -- the packers move whole chunks and keep a chunk's index inside its step): per 64-byte step of a row, chunk 0 = hi(f0..3, f8..11),
+//     chunk 1 = hi(f4..7, f12..15), chunk 2 = lo(f0..3, f8..11), chunk 3 = lo(f4..7, f12..15) -- so the fragment a lane reads at j = 0 IS the
+//     MFMA operand w_hi of its eight K values and the one at j = 1 is w_lo: no arithmetic, no register moves.
+//   * ACTIVATIONS are split where they are used, once per fragment pair (make_xpair), however many weight fragments the pair then meets.
+__global__ __launch_bounds__(256) void f32s_presplit_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t nsteps) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nsteps; i += (size_t)gridDim.x * 256) {
+        f32x4 f[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) f[c] = __builtin_bit_cast(f32x4, src[4 * i + c]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // lane half h owns floats 4 h .. 4 h + 3 and 8 + 4 h .. 8 + 4 h + 3 of the step
+            unsigned hi[4], lo[4];
+            f32s_split2(f[h][0], f[h][1], hi[0], lo[0]);
+            f32s_split2(f[h][2], f[h][3], hi[1], lo[1]);
+            f32s_split2(f[2 + h][0], f[2 + h][1], hi[2], lo[2]);
+            f32s_split2(f[2 + h][2], f[2 + h][3], hi[3], lo[3]);
+            dst[4 * i + h] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            dst[4 * i + 2 + h] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
     }
 }
 
-// one 16-byte A fragment x one 16-byte B fragment -> accumulate into a 32x32 tile.  W_FIRST (F32S only): which of the two is the weight chunk.
-template <typename T, bool W_FIRST = true>
-__device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x16& acc) {
+// the activation operand of one K step: float / 16-bit kernels keep the two chunks as loaded; F32S holds a = the hi halves, b = the lo halves
+template <typename T>
+struct XPair {
+    u32x4 a, b;
+};
+template <typename T>
+__device__ __forceinline__ XPair<T> make_xpair(const u32x4& x0, const u32x4& x1) {
     if constexpr (std::is_same<T, F32S>::value) {
-        // The chunk's K = 8 (four floats per lane and operand, lane half h = K parity) as ONE K = 16 step of the half-precision MFMA, taken
-        // twice: the weight operand is [w_hi(4) | w_lo(4)] as stored, the activation x is split here (hi = rn(x), lo = rn(x - hi)) and goes in as
-        // [x_hi | x_hi], then as [x_lo | x_lo] -- all four terms of (w_hi + w_lo)(x_hi + x_lo), float32 accumulation: 2 x 32 matrix-pipe cycles
-        // where the exact-fp32 v_mfma_f32_32x32x2_f32 takes 4 x 64.  Per-product error 2^-22.  An activation fragment that meets several weight
-        // fragments in an unrolled loop is split once (common subexpressions).
-        const u32x4& w = W_FIRST ? a : b;
-        const f32x4 xf = __builtin_bit_cast(f32x4, W_FIRST ? b : a);
-        unsigned h0, l0, h1, l1;
-        f32s_split2(xf[0], xf[1], h0, l0);
-        f32s_split2(xf[2], xf[3], h1, l1);
-        const f16x8 W = __builtin_bit_cast(f16x8, w), XH = __builtin_bit_cast(f16x8, u32x4{h0, h1, h0, h1}), XL = __builtin_bit_cast(f16x8, u32x4{l0, l1, l0, l1});
-        if constexpr (W_FIRST) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, XH, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, XL, acc, 0, 0, 0);
-        } else {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(XH, W, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(XL, W, acc, 0, 0, 0);
-        }
-    } else if constexpr (sizeof(T) == 4) {
+        const f32x4 f0 = __builtin_bit_cast(f32x4, x0), f1 = __builtin_bit_cast(f32x4, x1);
+        unsigned hi[4], lo[4];
+        f32s_split2(f0[0], f0[1], hi[0], lo[0]);
+        f32s_split2(f0[2], f0[3], hi[1], lo[1]);
+        f32s_split2(f1[0], f1[1], hi[2], lo[2]);
+        f32s_split2(f1[2], f1[3], hi[3], lo[3]);
+        return XPair<T>{u32x4{hi[0], hi[1], hi[2], hi[3]}, u32x4{lo[0], lo[1], lo[2], lo[3]}};
+    } else {
+        return XPair<T>{x0, x1};
+    }
+}
+template <typename T>
+__device__ __forceinline__ XPair<T> make_xpair(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    return make_xpair<T>(__builtin_bit_cast(u32x4, f32x4{a0, a1, a2, a3}), __builtin_bit_cast(u32x4, f32x4{a4, a5, a6, a7}));
+}
+
+// one 16-byte A fragment x one 16-byte B fragment -> accumulate into a 32x32 tile (float32: K = 8, 16-bit: K = 16)
+template <typename T>
+__device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x16& acc) {
+    static_assert(!std::is_same<T, F32S>::value, "F32S kernels multiply whole K steps (mfma_pair): a single pre-split weight chunk is half an operand");
+    if constexpr (sizeof(T) == 4) {
         const f32x4 af = __builtin_bit_cast(f32x4, a);
         const f32x4 bf = __builtin_bit_cast(f32x4, b);
 #pragma unroll
@@ -229,19 +249,39 @@ __device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x1
     }
 }
 
-// four K = 2 steps of the float32 engines whose operands sit in registers as scalars (an accumulator row used as the next product's operand):
-// acc += sum_e a_e x w[e] with the a's as the MFMA's A operand (A_FIRST) or its B operand.  float: the four exact-fp32 MFMAs in that order
-// (what these sites did before round 5); F32S: one split chunk product.
+// one K step: the weight fragments w0 (j = 0), w1 (j = 1) against the activation pair.  W_FIRST: the weights are the MFMA's first operand
+// (rows of the result = weight rows).  float / 16-bit: chunk 0 then chunk 1, as the kernels did before round 5.
+template <typename T, bool W_FIRST = true>
+__device__ __forceinline__ void mfma_pair(const u32x4& w0, const u32x4& w1, const XPair<T>& x, f32x16& acc) {
+    if constexpr (std::is_same<T, F32S>::value) {
+        const f16x8 WH = __builtin_bit_cast(f16x8, w0), WL = __builtin_bit_cast(f16x8, w1), XH = __builtin_bit_cast(f16x8, x.a), XL = __builtin_bit_cast(f16x8, x.b);
+        if constexpr (W_FIRST) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH, XH, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(WL, XH, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH, XL, acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(XH, WH, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(XH, WL, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(XL, WH, acc, 0, 0, 0);
+        }
+    } else if constexpr (W_FIRST) {
+        mfma_chunk<T>(w0, x.a, acc);
+        mfma_chunk<T>(w1, x.b, acc);
+    } else {
+        mfma_chunk<T>(x.a, w0, acc);
+        mfma_chunk<T>(x.b, w1, acc);
+    }
+}
+
+// four K = 2 steps of the exact-fp32 engine whose operands sit in registers as scalars (an accumulator row used as the next product's operand):
+// acc += sum_e a_e x w[e] with the a's as the MFMA's A operand (A_FIRST) or its B operand.  (F32S sites build an XPair from the eight registers
+// of a K step and call mfma_pair.)
 template <typename T, bool A_FIRST = true>
 __device__ __forceinline__ void mfma_quad(float a0, float a1, float a2, float a3, const f32x4& w, f32x16& acc) {
+    static_assert(std::is_same<T, float>::value, "exact-fp32 form");
     const f32x4 a = {a0, a1, a2, a3};
-    if constexpr (std::is_same<T, F32S>::value) {
-        if constexpr (A_FIRST) mfma_chunk<T, false>(__builtin_bit_cast(u32x4, a), __builtin_bit_cast(u32x4, w), acc);
-        else mfma_chunk<T, true>(__builtin_bit_cast(u32x4, w), __builtin_bit_cast(u32x4, a), acc);
-    } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = A_FIRST ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], w[e], acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], a[e], acc, 0, 0, 0);
-    }
+    for (int e = 0; e < 4; ++e) acc = A_FIRST ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], w[e], acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], a[e], acc, 0, 0, 0);
 }
 
 // Tile geometry for a given BN
@@ -379,18 +419,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         if (s + 1 < nsteps) load_step(s + 1);
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads ABOVE the MFMA block (hipcc sinks them otherwise)
 #pragma unroll
-        for (int j = 0; j < RB / 32; ++j) {
-            u32x4 af[G::TM], bf[G::TN];
+        for (int j = 0; j < RB / 32; j += 2) {   // fragment pairs (j, j + 1) = one 64-byte step of K (float32: 16 values) per lane pair, see mfma_pair
+            XPair<T> af[G::TM];
+            u32x4 bf[G::TN][2];
 #pragma unroll
             for (int i = 0; i < G::TM; ++i)
-                af[i] = *reinterpret_cast<const u32x4*>(sa + a_off + i * 32 * PITCH + j * 32);
+                af[i] = make_xpair<T>(*reinterpret_cast<const u32x4*>(sa + a_off + i * 32 * PITCH + j * 32), *reinterpret_cast<const u32x4*>(sa + a_off + i * 32 * PITCH + (j + 1) * 32));
 #pragma unroll
             for (int i = 0; i < G::TN; ++i)
-                bf[i] = *reinterpret_cast<const u32x4*>(sb + b_off + i * 32 * PITCH + j * 32);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) bf[i][jj] = *reinterpret_cast<const u32x4*>(sb + b_off + i * 32 * PITCH + (j + jj) * 32);
 #pragma unroll
             for (int i = 0; i < G::TM; ++i)
 #pragma unroll
-                for (int k = 0; k < G::TN; ++k) mfma_chunk<T, false>(af[i], bf[k], acc[i][k]);
+                for (int k = 0; k < G::TN; ++k) mfma_pair<T, false>(bf[k][0], bf[k][1], af[i], acc[i][k]);
         }
         if (s + 1 < nsteps) store_step(buf ^ 1);
         __syncthreads();
@@ -1122,12 +1164,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
             if (s + 1 < NSTEPS) load1(s + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < RB / 32; ++j) {
-                const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (ct * 32 + l31) * PITCH + j * 32 + half * 16);
+            for (int j = 0; j < RB / 32; j += 2) {   // fragment pairs (j, j + 1): one 64-byte K step (mfma_pair)
+                const u32x4 w0 = *reinterpret_cast<const u32x4*>(sw + (ct * 32 + l31) * PITCH + j * 32 + half * 16);
+                const u32x4 w1 = *reinterpret_cast<const u32x4*>(sw + (ct * 32 + l31) * PITCH + (j + 1) * 32 + half * 16);
 #pragma unroll
                 for (int i = 0; i < RT; ++i) {
-                    const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + ((rt0 + i) * 32 + l31) * PITCH + j * 32 + half * 16);
-                    mfma_chunk<T, false>(xf, wf, acc[i]);
+                    const unsigned char* const xrow = sx + ((rt0 + i) * 32 + l31) * PITCH + half * 16;
+                    mfma_pair<T, false>(w0, w1, make_xpair<T>(*reinterpret_cast<const u32x4*>(xrow + j * 32), *reinterpret_cast<const u32x4*>(xrow + (j + 1) * 32)), acc[i]);
                 }
             }
             if (s + 1 < NSTEPS) __syncthreads();  // every wave is done reading the only buffer
@@ -1192,13 +1235,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
                 // (requesting the fragments of two K chunks before their eight MFMA groups, pinned with sched_barrier, made the fp32
                 // layer1 form 2-3 % SLOWER -- at three workgroups per CU hipcc's own interleaving is the better one)
 #pragma unroll
-                for (int j = 0; j < RB / 32; ++j) {
-                    const u32x4 tf = *reinterpret_cast<const u32x4*>(tb + j * 32);
+                for (int j = 0; j < RB / 32; j += 2) {   // fragment pairs (j, j + 1): one 64-byte K step (mfma_pair)
+                    const XPair<T> tp = make_xpair<T>(*reinterpret_cast<const u32x4*>(tb + j * 32), *reinterpret_cast<const u32x4*>(tb + (j + 1) * 32));
 #pragma unroll
-                    for (int m = 0; m < NT; ++m) {
-                        const u32x4 wf = *reinterpret_cast<const u32x4*>(wrow + m * 32 * PITCH + j * 32);
-                        mfma_chunk<T>(wf, tf, t2[m]);
-                    }
+                    for (int m = 0; m < NT; ++m)
+                        mfma_pair<T, true>(*reinterpret_cast<const u32x4*>(wrow + m * 32 * PITCH + j * 32), *reinterpret_cast<const u32x4*>(wrow + m * 32 * PITCH + (j + 1) * 32), tp, t2[m]);
                 }
                 if (s + 1 < NSTEPS) __syncthreads();
                 if (s + 1 < NSTEPS) store_w(0, PL);
@@ -1267,16 +1308,16 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
                 for (int mm = 0; mm < KE / 32; ++mm)
 #pragma unroll
                     for (int q2 = 0; q2 < 2; ++q2)
+                    {
+                        // registers 8*q2 + 4*jj + e hold channels 16*q2 + 8*jj + 4*half + e  -> 16-byte chunk (4*q2 + 2*jj + half): jj = 0, 1 = one K step
+                        const f32x16& tt = t2[s * (KE / 32) + mm];
+                        const XPair<T> tp = make_xpair<T>(tt[8 * q2], tt[8 * q2 + 1], tt[8 * q2 + 2], tt[8 * q2 + 3], tt[8 * q2 + 4], tt[8 * q2 + 5], tt[8 * q2 + 6], tt[8 * q2 + 7]);
 #pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            // registers 8*q2 + 4*jj + e hold channels 16*q2 + 8*jj + 4*half + e  -> 16-byte chunk (4*q2 + 2*jj + half)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const f32x4 wf = *reinterpret_cast<const f32x4*>(sw + (i * 32 + l31) * PITCH + mm * 128 + (4 * q2 + 2 * jj + half) * 16);
-                                const f32x16& tt = t2[s * (KE / 32) + mm];
-                                mfma_quad<T>(tt[8 * q2 + 4 * jj], tt[8 * q2 + 4 * jj + 1], tt[8 * q2 + 4 * jj + 2], tt[8 * q2 + 4 * jj + 3], wf, acc[i]);
-                            }
+                        for (int i = 0; i < 4; ++i) {
+                            const unsigned char* const wrow3 = sw + (i * 32 + l31) * PITCH + mm * 128 + (4 * q2 + half) * 16;
+                            mfma_pair<T, false>(*reinterpret_cast<const u32x4*>(wrow3), *reinterpret_cast<const u32x4*>(wrow3 + 32), tp, acc[i]);
                         }
+                    }
             } else {
                 // per 32-channel tile two MFMAs (registers 0-7 and 8-15).  Packed W3 K order (host): position
                 // 8*(2*q + half) + e  <->  channel 16*q + 8*(e>>2) + 4*half + (e&3) within the tile
@@ -1331,12 +1372,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(BottleneckArgs p) {
                 if (s + 1 < NSTEPSd) loadd(s + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < RBd / 32; ++j) {
-                    const u32x4 xf = *reinterpret_cast<const u32x4*>(sx + (wave * 32 + l31) * PITCHd + j * 32 + half * 16);
+                for (int j = 0; j < RBd / 32; j += 2) {   // fragment pairs (j, j + 1): one 64-byte K step (mfma_pair)
+                    const unsigned char* const xrow = sx + (wave * 32 + l31) * PITCHd + half * 16;
+                    const XPair<T> xp2 = make_xpair<T>(*reinterpret_cast<const u32x4*>(xrow + j * 32), *reinterpret_cast<const u32x4*>(xrow + (j + 1) * 32));
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const u32x4 wf = *reinterpret_cast<const u32x4*>(sw + (i * 32 + l31) * PITCHd + j * 32 + half * 16);
-                        mfma_chunk<T, false>(xf, wf, acc[i]);
+                        const unsigned char* const wrowd = sw + (i * 32 + l31) * PITCHd + half * 16;
+                        mfma_pair<T, false>(*reinterpret_cast<const u32x4*>(wrowd + j * 32), *reinterpret_cast<const u32x4*>(wrowd + (j + 1) * 32), xp2, acc[i]);
                     }
                 }
                 if (s + 1 < NSTEPSd) __syncthreads();

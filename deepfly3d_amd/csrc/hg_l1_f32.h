@@ -138,6 +138,22 @@ __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
         // the three fragments of group g + 1 are requested before the MFMAs of group g (hipcc on its own requests them one MFMA
         // ahead and then waits: 24.1 -> 23.4 ms.  With SIXTEEN MFMAs per group -- layer2's tail, the identity-skip tails -- the same
         // hand-pipelining made the kernels 1-4 % slower: there hipcc's own order is the better one)
+        if constexpr (std::is_same<T, F32S>::value) {   // whole K steps: the t1 pair split once, then NT tiles of three MFMAs
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    const int kc = 2 * u + sub;
+                    const unsigned char* const trow = t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH;
+                    const XPair<T> tp = make_xpair<T>(*reinterpret_cast<const u32x4*>(trow + (tsw[kx] ^ (unsigned)((4 * kc) << 4))),
+                                                      *reinterpret_cast<const u32x4*>(trow + (tsw[kx] ^ (unsigned)((4 * kc + 2) << 4))));
+#pragma unroll
+                    for (int m = 0; m < NT; ++m)
+                        mfma_pair<T, true>(*reinterpret_cast<const u32x4*>(wf0 + ((s0 + u) % BR_RING) * BR_STAGE_BYTES + (2 * sub + m) * 2048),
+                                           *reinterpret_cast<const u32x4*>(wf1 + ((s0 + u) % BR_RING) * BR_STAGE_BYTES + (2 * sub + m) * 2048), tp, t2[m]);
+                }
+            continue;
+        }
         u32x4 tfv[2], wfv[2][NT];
         auto load_group = [&](int g, int buf) {
             const int u = g >> 2, sub = (g >> 1) & 1, j = g & 1, kc = 2 * u + sub;
@@ -152,7 +168,9 @@ __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
             if (g + 1 < 8) load_group(g + 1, (g + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < NT; ++m) mfma_chunk<T>(wfv[g & 1][m], tfv[g & 1], t2[m]);
+            for (int m = 0; m < NT; ++m) {
+                if constexpr (!std::is_same<T, F32S>::value) mfma_chunk<T>(wfv[g & 1][m], tfv[g & 1], t2[m]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -160,6 +178,14 @@ __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
     for (int m = 0; m < NT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) t2[m][r] = br_relu(t2[m][r]);
+    XPair<T> t2p[NT][2];   // F32S: relu(t2) split once per 16-channel K step (registers 8 q .. 8 q + 7 of a tile)
+    if constexpr (std::is_same<T, F32S>::value) {
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                t2p[m][q] = make_xpair<T>(t2[m][8 * q], t2[m][8 * q + 1], t2[m][8 * q + 2], t2[m][8 * q + 3], t2[m][8 * q + 4], t2[m][8 * q + 5], t2[m][8 * q + 6], t2[m][8 * q + 7]);
+    }
 
     // ---- phase 3: out = W3 relu(t2) + Wd x + (b3 + bd): rows = the wave's pixels, columns = channels -------------------------
     f32x16 acc[4];
@@ -177,6 +203,20 @@ __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = bias;
             }
+        }
+        if constexpr (std::is_same<T, F32S>::value) {   // whole K steps: two per double-step, four output tiles of three MFMAs each
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = (2 * dd + u) & 3;
+                XPair<T> ap;
+                if (dd < 2) ap = t2p[k >> 1][k & 1];
+                else ap = make_xpair<T>(__builtin_bit_cast(u32x4, xfr[k][0]), __builtin_bit_cast(u32x4, xfr[k][1]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    mfma_pair<T, false>(*reinterpret_cast<const u32x4*>(wf0 + ((s0 + u) % BR_RING) * BR_STAGE_BYTES + i * 2048),
+                                        *reinterpret_cast<const u32x4*>(wf1 + ((s0 + u) % BR_RING) * BR_STAGE_BYTES + i * 2048), ap, acc[i]);
+            }
+            continue;
         }
         // four groups (stage u, chunk jj) of four weight fragments and sixteen MFMAs, the fragments one group ahead
         f32x4 w3v[2][4];
@@ -197,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
                 float av[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) av[e] = dd < 2 ? t2[k >> 1][8 * (k & 1) + 4 * jj + e] : xfr[k][jj][e];
-                mfma_quad<T>(av[0], av[1], av[2], av[3], w3v[g & 1][i], acc[i]);
+                if constexpr (!std::is_same<T, F32S>::value) mfma_quad<T>(av[0], av[1], av[2], av[3], w3v[g & 1][i], acc[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -350,13 +390,23 @@ __global__ __launch_bounds__(256, 2) void layer2_tail_f32_kernel(BtRingArgs p) {
             for (int u = 0; u < 2; ++u) {
                 const int q = 2 * d + u, tap = q >> 2, kc = q & 3;
                 const int ky = tap / 3, kx = tap - 3 * ky;
+                if constexpr (std::is_same<T, F32S>::value) {   // the K step as a whole: the t1 pair split once, then four tiles of three MFMAs
+                    const unsigned char* const trow = t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH;
+                    const XPair<T> tp = make_xpair<T>(*reinterpret_cast<const u32x4*>(trow + (tsw[kx] ^ (unsigned)((4 * kc) << 4))),
+                                                      *reinterpret_cast<const u32x4*>(trow + (tsw[kx] ^ (unsigned)((4 * kc + 2) << 4))));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const u32x4 tf = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
+                    for (int m = 0; m < NT; ++m)
+                        mfma_pair<T, true>(*reinterpret_cast<const u32x4*>(wf0 + ((s0 + u) % BR_RING) * BR_STAGE_BYTES + m * 2048),
+                                           *reinterpret_cast<const u32x4*>(wf1 + ((s0 + u) % BR_RING) * BR_STAGE_BYTES + m * 2048), tp, t2[m]);
+                } else {
 #pragma unroll
-                    for (int m = 0; m < NT; ++m) {
-                        const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + ((s0 + u) % BR_RING) * BR_STAGE_BYTES + m * 2048);
-                        mfma_chunk<T>(wf, tf, t2[m]);
+                    for (int j = 0; j < 2; ++j) {
+                        const u32x4 tf = *reinterpret_cast<const u32x4*>(t1_lane + (ky * BT_HW + kx) * BR_T1_PITCH + (tsw[kx] ^ (unsigned)((4 * kc + 2 * j) << 4)));
+#pragma unroll
+                        for (int m = 0; m < NT; ++m) {
+                            const u32x4 wf = *reinterpret_cast<const u32x4*>((j ? wf1 : wf0) + ((s0 + u) % BR_RING) * BR_STAGE_BYTES + m * 2048);
+                            mfma_chunk<T>(wf, tf, t2[m]);
+                        }
                     }
                 }
             }
@@ -366,6 +416,14 @@ __global__ __launch_bounds__(256, 2) void layer2_tail_f32_kernel(BtRingArgs p) {
     for (int m = 0; m < NT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) t2[m][r] = br_relu(t2[m][r]);
+    XPair<T> t2p[NT][2];   // F32S: relu(t2) split once per 16-channel K step (registers 8 q .. 8 q + 7 of a tile)
+    if constexpr (std::is_same<T, F32S>::value) {
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                t2p[m][q] = make_xpair<T>(t2[m][8 * q], t2[m][8 * q + 1], t2[m][8 * q + 2], t2[m][8 * q + 3], t2[m][8 * q + 4], t2[m][8 * q + 5], t2[m][8 * q + 6], t2[m][8 * q + 7]);
+    }
 
     // ---- phase 3, per output half: out = W3 relu(t2) + Wd x + (b3 + bd) ----------------------------------------------------------
     float* const outp = reinterpret_cast<float*>(p.out) + (size_t)view * p.H * p.W * CO;
@@ -404,16 +462,26 @@ __global__ __launch_bounds__(256, 2) void layer2_tail_f32_kernel(BtRingArgs p) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int s = s0 + u, k = (2 * dd + u) & 7;   // 16-float K slice of t2's (dd < 4) or x's 128 channels
+                if constexpr (std::is_same<T, F32S>::value) {
+                    XPair<T> ap;
+                    if (dd < 4) ap = t2p[k >> 1][k & 1];
+                    else ap = make_xpair<T>(__builtin_bit_cast(u32x4, xcur[u][0]), __builtin_bit_cast(u32x4, xcur[u][1]));
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
+                    for (int i = 0; i < 4; ++i)
+                        mfma_pair<T, false>(*reinterpret_cast<const u32x4*>(wf0 + (s % BR_RING) * BR_STAGE_BYTES + i * 2048),
+                                            *reinterpret_cast<const u32x4*>(wf1 + (s % BR_RING) * BR_STAGE_BYTES + i * 2048), ap, acc[i]);
+                } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
-                        float av[4];
+                    for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) av[e] = dd < 4 ? t2[k >> 1][8 * (k & 1) + 4 * jj + e] : xcur[u][jj][e];
-                        mfma_quad<T>(av[0], av[1], av[2], av[3], wf, acc[i]);
-                    }
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
+                            float av[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) av[e] = dd < 4 ? t2[k >> 1][8 * (k & 1) + 4 * jj + e] : xcur[u][jj][e];
+                            mfma_quad<T>(av[0], av[1], av[2], av[3], wf, acc[i]);
+                        }
+                }
             }
         }
 #pragma unroll

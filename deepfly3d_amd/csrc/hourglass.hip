@@ -1271,6 +1271,7 @@ size_t df3d_hg_lowp_bytes(const df3d_hg* h) {
 
 int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void* stream) {
     DF3D_CHECK_ARG(h && blob_dev, "null argument");
+    const float* const blob_caller = blob_dev;
     DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(blob_dev) & 255) == 0, "blob must be 256-byte aligned");
     if (h->lp()) {
         DF3D_CHECK_ARG(lowp_dev != nullptr, "a 16-bit engine needs a df3d_hg_lowp_bytes() device buffer");
@@ -1328,8 +1329,16 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
         // caller's blob stays valid.
         h->ring = 0;
         h->build();
-    } else if (h->stream_bytes) {
+    } else if (h->stream_bytes || h->dtype == DF3D_DTYPE_F32S) {
         DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(lowp_dev) & 255) == 0, "lowp buffer must be 256-byte aligned");
+        if (h->dtype == DF3D_DTYPE_F32S) {
+            // f32s: the weights pre-split per 16-float K step (hg_kernels.h f32s_presplit_kernel) -- a float32-sized copy of the blob in front of
+            // the streams; the packers below then read THAT copy (they move whole 16-byte chunks and keep a chunk's index inside its step).
+            // Biases and BatchNorm vectors are transformed along with the rest and never read from the copy.
+            hipLaunchKernelGGL(f32s_presplit_kernel, dim3(1024), dim3(256), 0, df3d::as_stream(stream), reinterpret_cast<const u32x4*>(blob_dev),
+                               reinterpret_cast<u32x4*>(lowp_dev), h->blob_floats / 16);
+            blob_dev = reinterpret_cast<const float*>(lowp_dev);   // (restored below: h->blob stays the caller's float32 blob)
+        }
         for (const Step& st : h->steps) {
             if (st.kind == ST_HEAD && st.wstream >= 0)
                 hipLaunchKernelGGL(bt_fc_pack_f32_kernel, dim3((HD_FC_STAGES_F32 * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
@@ -1361,20 +1370,7 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
         DF3D_LAUNCH_CHECK();
         h->lowp = lowp_dev;
     }
-    if (h->dtype == DF3D_DTYPE_F32S) {
-        // every weight chunk (4 consecutive-K floats) pre-split into [hi(4) | lo(4)] halves: the blob's copy, and -- in place -- the streams
-        // just packed from the float32 blob (chunk movers; the zero page stays zero)
-        DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(lowp_dev) & 255) == 0, "lowp buffer must be 256-byte aligned");
-        unsigned char* const lo = reinterpret_cast<unsigned char*>(lowp_dev);
-        hipLaunchKernelGGL(f32s_presplit_kernel, dim3(1024), dim3(256), 0, df3d::as_stream(stream), reinterpret_cast<const u32x4*>(blob_dev),
-                           reinterpret_cast<u32x4*>(lo), h->blob_floats / 4);
-        if (h->stream_bytes)
-            hipLaunchKernelGGL(f32s_presplit_kernel, dim3(1024), dim3(256), 0, df3d::as_stream(stream), reinterpret_cast<const u32x4*>(lo + h->stream_base()),
-                               reinterpret_cast<u32x4*>(lo + h->stream_base()), h->stream_bytes / 16);
-        DF3D_LAUNCH_CHECK();
-        h->lowp = lowp_dev;
-    }
-    h->blob = blob_dev;
+    h->blob = blob_caller;
     return DF3D_OK;
 }
 

@@ -17,7 +17,7 @@ steps = eng.steps()
 names = [n for n, _ in steps]
 buf = (ctypes.c_ulonglong * 12)()
 labels = ["prologue", "phase1 K loop", "t1 epilogue", "t2 crossing (W2D) / phase2", "phase3a K", "epilogue a", "phase3b K", "epilogue b", "phase2 loop (W2D)", "-", "-", "-"]
-if dtype == "f32":  # both t1 halves are summed into the phase-1 / phase-2 slots ("phase2" = second-half entry barrier + both phase 2)
+if dtype in ("f32", "f32s"):  # both t1 halves are summed into the phase-1 / phase-2 slots ("phase2" = second-half entry barrier + both phase 2)
     labels = ["prologue", "phase1 K loops (2)", "t1 epilogues (2)", "phase2 (2) + entry", "phase3a K", "epilogue a", "phase3b K", "epilogue b", "-", "-", "-", "-"]
 eng.forward(img); torch.cuda.synchronize()
 lib.df3d_dbg_ring_cycles.argtypes = [ctypes.c_void_p]
