@@ -358,110 +358,229 @@ __global__ __launch_bounds__(256, 2) void bottleneck_ring_f32_kernel(BtRingArgs 
                 t2p[m][q] = make_xpair<T>(t2[m][8 * q], t2[m][8 * q + 1], t2[m][8 * q + 2], t2[m][8 * q + 3], t2[m][8 * q + 4], t2[m][8 * q + 5], t2[m][8 * q + 6], t2[m][8 * q + 7]);
     }
 
-    // ---- phase 3: out^T = W3 relu(t2)^T + b3 + x^T  (round 5: TRANSPOSED -- rows = channels, columns = the wave's pixels, like t2 itself:
-    //      W3's fragment is the MFMA's first operand, the t2 registers its second; every accumulator sees the same products in the same K
-    //      order as before (an MFMA's operands commute), so the result is bit-identical.  A lane now owns ONE pixel and, per 32-channel tile,
-    //      four groups of four CONSECUTIVE channels (register 4 q + e <-> channel 8 q + 4 half + e): residual, upsampled addends and output
-    //      move as 16-byte accesses -- 16 loads and 16 stores per lane and output half instead of 64 + 64 four-byte ones -- and the 2x2
-    //      max-pools are taken across lanes (x neighbour = lane ^ 1, y neighbour = lane ^ 16). ----
-    unsigned char* const outp = reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * CO * 4;
-    const size_t pix_off = ((size_t)(ty0 + py) * p.W + (tx0 + px)) * (CO * 4);                                      // this lane's pixel (CIN == CO)
-    const size_t hpix_off = ((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + (px >> 1))) * (CO * 4);               // its half-resolution pixel
-    const bool pool_lane = (l31 & 17) == 0;   // even column of the wave's first row: stores the pooled pixel of its 2x2 quad
-    auto quad_max = [](float v) {             // max over the lane's 2x2 pixel quad (lanes ^1, ^16, ^17)
-        const float h = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1, 0, 3, 2]
-        return fmaxf(h, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, h), 0x401F)));                              // xor 16 inside 32 lanes
-    };
+    if constexpr (std::is_same<T, float>::value) {
+        // exact fp32 keeps round 3's phase 3 (rows = pixels, 4-byte accesses of 128 contiguous bytes): the transposed form below is bit-identical
+        // and measured 0.5-0.7 % SLOWER here, same box (5 542-5 560 against 5 500-5 527 us per average launch) -- the matrix pipe, not the
+        // epilogue's memory operations, bounds this instantiation
+        // ---- phase 3: out = W3 relu(t2) + b3 + x  (rows = the wave's pixels, columns = channels, as in the register-staged
+        //      kernel: its epilogue -- residual add, 4-byte stores of 128 contiguous bytes per pixel, in-lane pooling -- is kept) ----
+        unsigned char* const outp = reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * CO * 4;
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
-        f32x16 acc[4];
-        f32x4 xr[2][4];   // residual values of channel tiles 0 and 1, requested during the last two double-steps
-        auto load_res = [&](int i, f32x4 (&dst)[4]) {
+        for (int nh = 0; nh < 2; ++nh) {
+            f32x16 acc[4];
+            float xr[2][16];   // residual values of channel tiles 0 and 1, requested during the last two double-steps
+            auto load_res = [&](int i, float (&dst)[16]) {
+                const int n = nh * 128 + i * 32 + l31;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xin + pix_off + (nh * 128 + i * 32 + 8 * q + 4 * half) * 4);
-        };
+                for (int r = 0; r < 16; ++r) {
+                    const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    dst[r] = reinterpret_cast<const float*>(xin)[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n];
+                }
+            };
 #pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-            const int s0 = (TAIL ? 2 * BRF_W2_STAGES : 2 * BRF_KH_STAGES) + 8 * nh + 2 * dd;
-            br_wait_vm(0);   // the pair was requested a whole double-step ago
-            br_barrier();
-            ring_issue(s0 + 2);
-            ring_issue(s0 + 3);
-            if (dd >= 2) load_res(dd - 2, xr[dd - 2]);
-            if (dd == 0) {
+            for (int dd = 0; dd < 4; ++dd) {
+                const int s0 = (TAIL ? 2 * BRF_W2_STAGES : 2 * BRF_KH_STAGES) + 8 * nh + 2 * dd;
+                br_wait_vm(0);   // the pair was requested a whole double-step ago
+                br_barrier();
+                ring_issue(s0 + 2);
+                ring_issue(s0 + 3);
+                if (dd >= 2) load_res(dd - 2, xr[dd - 2]);
+                if (dd == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i) {
+                        const float bias = b3_lds[nh * 128 + i * 32 + l31];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 bb = *reinterpret_cast<const f32x4*>(b3_lds + nh * 128 + i * 32 + 8 * q + 4 * half);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = bb[e];
+                        for (int r = 0; r < 16; ++r) acc[i][r] = bias;
                     }
-            }
+                }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int k8 = 2 * dd + u, s = s0 + u, tile = k8 >> 1, q2 = k8 & 1;
-                // registers 8 q2 + 4 jj + e of t2 tile `tile` hold channels 32 tile + 16 q2 + 8 jj + 4 half + e: 16-byte chunk 2 jj + half of the stage
-                if constexpr (std::is_same<T, F32S>::value) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        mfma_pair<T, true>(*reinterpret_cast<const u32x4*>(wf0 + (s % BR_RING) * BR_STAGE_BYTES + i * 2048),
-                                           *reinterpret_cast<const u32x4*>(wf1 + (s % BR_RING) * BR_STAGE_BYTES + i * 2048), t2p[tile][q2], acc[i]);
-                } else {
+                for (int u = 0; u < 2; ++u) {
+                    const int k8 = 2 * dd + u, s = s0 + u, tile = k8 >> 1, q2 = k8 & 1;
+                    // registers 8 q2 + 4 jj + e of t2 tile `tile` hold channels 32 tile + 16 q2 + 8 jj + 4 half + e: 16-byte chunk 2 jj + half of the stage
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
-                            mfma_quad<T, false>(t2[tile][8 * q2 + 4 * jj], t2[tile][8 * q2 + 4 * jj + 1], t2[tile][8 * q2 + 4 * jj + 2], t2[tile][8 * q2 + 4 * jj + 3], wf, acc[i]);
+                            mfma_quad<T>(t2[tile][8 * q2 + 4 * jj], t2[tile][8 * q2 + 4 * jj + 1], t2[tile][8 * q2 + 4 * jj + 2], t2[tile][8 * q2 + 4 * jj + 3], wf, acc[i]);
                         }
                 }
             }
-        }
-        BR_STAMP(4 + 2 * nh);
-        // epilogue: D^T[row = channel nh*128 + 32 i + (r&3) + 8 (r>>2) + 4 half][col = this lane's pixel]
+            BR_STAMP(4 + 2 * nh);
+            // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4 half of the wave][col = channel nh*128 + 32 i + l31]
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 xv[4];
-            if (i < 2) {
+            for (int i = 0; i < 4; ++i) {
+                const int n = nh * 128 + i * 32 + l31;
+                float xv[16];
+                if (i < 2) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xv[q] = xr[i][q];
-            } else {
+                    for (int r = 0; r < 16; ++r) xv[r] = xr[i][r];
+                } else {
 #ifdef BRF_NO_LATE_RES   // development builds: what the two residual tiles requested in the epilogue cost
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xv[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int r = 0; r < 16; ++r) xv[r] = 0.0f;
 #else
-                load_res(i, xv);
+                    load_res(i, xv);
 #endif
-            }
+                }
+                if constexpr (UP) {
+                    // the wave's two tile rows share ONE half-resolution row and neighbouring columns one pixel: registers r, r^1, r^8,
+                    // r^9 take the same addend -> 4 loads per tile, key = bits 1 and 2 of r
+                    float t4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c4 = (nh * 128 + i * 32 + 8 * q + 4 * half) * 4;   // byte offset of the lane's four channels inside a pixel
-                if constexpr (UP) xv[q] += *reinterpret_cast<const f32x4*>(xin2 + hpix_off + c4);   // x = in + upsample(in2): the pixel's half-resolution parent
-                f32x4 o = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
-                o += xv[q];
-                if constexpr (ADD2)   // + nearest-upsample(add2): a second fp32 add, as upadd_kernel would have done on the stored tensor
-                    o += *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.add2) + (size_t)view * (p.H / 2) * (p.W / 2) * (CO * 4) + hpix_off + c4);
+                    for (int key = 0; key < 4; ++key)
+                        t4[key] = reinterpret_cast<const float*>(xin2)[((size_t)(ty0 / 2 + wave) * (p.W / 2) + tx0 / 2 + (key & 1) + 4 * (key >> 1) + 2 * half) * CIN + n];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xv[r] += t4[((r >> 1) & 1) + 2 * ((r >> 2) & 1)];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] += xv[r];
+                if constexpr (ADD2) {   // + nearest-upsample(add2): a second fp32 add, as upadd_kernel would have done on the stored tensor
+                    // (registers r, r^1, r^8, r^9 share one half-resolution pixel: key = bits 1 and 2 of r; one value live at a time -- the
+                    // kernel has no registers to spare)
+                    const float* const lrow = reinterpret_cast<const float*>(p.add2) + ((size_t)view * (p.H / 2) * (p.W / 2) + (size_t)(ty0 / 2 + wave) * (p.W / 2) + tx0 / 2 + 2 * half) * CO + n;
+#pragma unroll
+                    for (int key = 0; key < 4; ++key) {
+                        const float t = lrow[((key & 1) + 4 * (key >> 1)) * CO];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (((r >> 1) & 1) + 2 * ((r >> 2) & 1) == key) acc[i][r] += t;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n;
 #ifdef BRF_NT_STORES   // development switch: streaming stores of the block output (measured in round 4: see DESIGN.md 8)
-                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(outp + pix_off + c4));
+                    __builtin_nontemporal_store(acc[i][r], reinterpret_cast<float*>(outp) + po);
 #else
-                *reinterpret_cast<f32x4*>(outp + pix_off + c4) = o;
+                    reinterpret_cast<float*>(outp)[po] = acc[i][r];
 #endif
-                if constexpr (!UP) if (p.pool_in) {   // 2x2 max-pool of the block's INPUT (the skip values just added; the engine asks for it on plain blocks only)
-                    f32x4 m;
+                }
+                if constexpr (!UP) if (p.pool_in) {   // 2x2 max-pool of the block's INPUT (the skip values just added), same in-lane geometry as below (the engine asks for it on plain blocks only)
+                    float* const pp = reinterpret_cast<float*>(p.pool_in) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) m[e] = quad_max(xv[q][e]);
-                    if (pool_lane) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.pool_in) + (size_t)view * (p.H / 2) * (p.W / 2) * (CIN * 4) + hpix_off + c4) = m;
+                    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                        for (int b2 = 0; b2 < 2; ++b2) {
+                            const int r0 = 2 * a2 + 4 * b2;
+                            const float v = fmaxf(fmaxf(xv[r0], xv[r0 + 1]), fmaxf(xv[r0 + 8], xv[r0 + 9]));
+                            const int ppx = a2 + 4 * b2 + 2 * half;
+                            pp[((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + ppx)) * CIN + n] = v;
+                        }
                 }
                 if (p.pool) {
-                    f32x4 m;
+                    // 2x2 max-pool inside the lane: horizontal neighbour = register r^1, vertical neighbour = r^8
+                    float* const pp = reinterpret_cast<float*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) m[e] = quad_max(o[e]);
-                    if (pool_lane) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * (CO * 4) + hpix_off + c4) = m;
+                    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                        for (int b2 = 0; b2 < 2; ++b2) {
+                            const int r0 = 2 * a2 + 4 * b2;
+                            const float v = fmaxf(fmaxf(acc[i][r0], acc[i][r0 + 1]), fmaxf(acc[i][r0 + 8], acc[i][r0 + 9]));
+                            const int ppx = a2 + 4 * b2 + 2 * half;
+                            pp[((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + ppx)) * CO + n] = v;
+                        }
                 }
             }
+            BR_STAMP(5 + 2 * nh);
         }
-        BR_STAMP(5 + 2 * nh);
+    } else {
+        // ---- phase 3: out^T = W3 relu(t2)^T + b3 + x^T  (round 5, F32S: TRANSPOSED -- rows = channels, columns = the wave's pixels, like t2 itself:
+        //      W3's fragment is the MFMA's first operand, the t2 registers its second; every accumulator sees the same products in the same K
+        //      order as before (an MFMA's operands commute), so the result is bit-identical.  A lane now owns ONE pixel and, per 32-channel tile,
+        //      four groups of four CONSECUTIVE channels (register 4 q + e <-> channel 8 q + 4 half + e): residual, upsampled addends and output
+        //      move as 16-byte accesses -- 16 loads and 16 stores per lane and output half instead of 64 + 64 four-byte ones -- and the 2x2
+        //      max-pools are taken across lanes (x neighbour = lane ^ 1, y neighbour = lane ^ 16). ----
+        unsigned char* const outp = reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * CO * 4;
+        const size_t pix_off = ((size_t)(ty0 + py) * p.W + (tx0 + px)) * (CO * 4);                                      // this lane's pixel (CIN == CO)
+        const size_t hpix_off = ((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + (px >> 1))) * (CO * 4);               // its half-resolution pixel
+        const bool pool_lane = (l31 & 17) == 0;   // even column of the wave's first row: stores the pooled pixel of its 2x2 quad
+        auto quad_max = [](float v) {             // max over the lane's 2x2 pixel quad (lanes ^1, ^16, ^17)
+            const float h = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1, 0, 3, 2]
+            return fmaxf(h, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, h), 0x401F)));                              // xor 16 inside 32 lanes
+        };
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            f32x16 acc[4];
+            f32x4 xr[2][4];   // residual values of channel tiles 0 and 1, requested during the last two double-steps (all four requested there: no faster)
+            auto load_res = [&](int i, f32x4 (&dst)[4]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xin + pix_off + (nh * 128 + i * 32 + 8 * q + 4 * half) * 4);
+            };
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const int s0 = (TAIL ? 2 * BRF_W2_STAGES : 2 * BRF_KH_STAGES) + 8 * nh + 2 * dd;
+                br_wait_vm(0);   // the pair was requested a whole double-step ago
+                br_barrier();
+                ring_issue(s0 + 2);
+                ring_issue(s0 + 3);
+                if (dd >= 2) load_res(dd - 2, xr[dd - 2]);
+                if (dd == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 bb = *reinterpret_cast<const f32x4*>(b3_lds + nh * 128 + i * 32 + 8 * q + 4 * half);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][4 * q + e] = bb[e];
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k8 = 2 * dd + u, s = s0 + u, tile = k8 >> 1, q2 = k8 & 1;
+                    // registers 8 q2 + 4 jj + e of t2 tile `tile` hold channels 32 tile + 16 q2 + 8 jj + 4 half + e: 16-byte chunk 2 jj + half of the stage
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        mfma_pair<T, true>(*reinterpret_cast<const u32x4*>(wf0 + (s % BR_RING) * BR_STAGE_BYTES + i * 2048),
+                                           *reinterpret_cast<const u32x4*>(wf1 + (s % BR_RING) * BR_STAGE_BYTES + i * 2048), t2p[tile][q2], acc[i]);
+                }
+            }
+            BR_STAMP(4 + 2 * nh);
+            // epilogue: D^T[row = channel nh*128 + 32 i + (r&3) + 8 (r>>2) + 4 half][col = this lane's pixel]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 xv[4];
+                if (i < 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xv[q] = xr[i][q];
+                } else {
+#ifdef BRF_NO_LATE_RES   // development builds: what the two residual tiles requested in the epilogue cost
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xv[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#else
+                    load_res(i, xv);
+#endif
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c4 = (nh * 128 + i * 32 + 8 * q + 4 * half) * 4;   // byte offset of the lane's four channels inside a pixel
+                    if constexpr (UP) xv[q] += *reinterpret_cast<const f32x4*>(xin2 + hpix_off + c4);   // x = in + upsample(in2): the pixel's half-resolution parent
+                    f32x4 o = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+                    o += xv[q];
+                    if constexpr (ADD2)   // + nearest-upsample(add2): a second fp32 add, as upadd_kernel would have done on the stored tensor
+                        o += *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.add2) + (size_t)view * (p.H / 2) * (p.W / 2) * (CO * 4) + hpix_off + c4);
+#ifdef BRF_NT_STORES   // development switch: streaming stores of the block output (measured in round 4: see DESIGN.md 8)
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(outp + pix_off + c4));
+#else
+                    *reinterpret_cast<f32x4*>(outp + pix_off + c4) = o;
+#endif
+                    if constexpr (!UP) if (p.pool_in) {   // 2x2 max-pool of the block's INPUT (the skip values just added; the engine asks for it on plain blocks only)
+                        f32x4 m;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m[e] = quad_max(xv[q][e]);
+                        if (pool_lane) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.pool_in) + (size_t)view * (p.H / 2) * (p.W / 2) * (CIN * 4) + hpix_off + c4) = m;
+                    }
+                    if (p.pool) {
+                        f32x4 m;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m[e] = quad_max(o[e]);
+                        if (pool_lane) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * (CO * 4) + hpix_off + c4) = m;
+                    }
+                }
+            }
+            BR_STAMP(5 + 2 * nh);
+        }
     }
 }
 
