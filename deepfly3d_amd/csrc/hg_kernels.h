@@ -836,6 +836,146 @@ __global__ __launch_bounds__(256) void stem_relayout_kernel(const float* __restr
 }
 
 // -----------------------------------------------------------------------------------------------------
+// stem of the f32s engine: stem_lp_kernel's layout (K ky-major, 24 slots per patch row, 11 MFMA steps) with BOTH operands as IEEE-half
+// hi / lo pairs -- the image patch is split while it is staged (two 16-bit patches), the weights were split and re-laid once by
+// stem_relayout_f32s_kernel (two [64][184] tiles, hi at byte 0 and lo at byte 23 552 of the stem's slot in the pre-split blob copy) --
+// three MFMAs per step and output tile (x_hi w_hi + x_lo w_hi + x_hi w_lo), float32 accumulation, float32 output: 66 MFMAs per wave
+// and tile where the exact-fp32 stem_kernel issues 148 at four times the cycles each.
+// -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_f32s_kernel(StemArgs p) {
+    constexpr int PR = 21, PC = 37, PROW = 120;
+    constexpr int KP = 176, WPITCH = KP + 8;
+    constexpr int PATCH = PR * PROW + 64;
+    __shared__ __attribute__((aligned(16))) unsigned short patch[2][PATCH];       // [hi | lo]
+    __shared__ __attribute__((aligned(16))) unsigned short wl[2][64 * WPITCH];    // [hi | lo]
+    const int OH = p.H / 2, OW = p.W / 2;
+    const int tiles_x = OW / 16, tiles_y = OH / 8;
+    int b = blockIdx.x;
+    const int tx0 = (b % tiles_x) * 16;
+    b /= tiles_x;
+    const int ty0 = (b % tiles_y) * 8;
+    const int view = b / tiles_y;
+    const int tid = threadIdx.x;
+    {   // both weight tiles as they lie: 46 one-KB pieces by LDS-DMA, under the patch staging
+        const unsigned wl_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)&wl[0][0];
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        static_assert(64 * WPITCH * 2 == 23 * 1024, "23 whole pieces per tile");
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int pc = wv + 4 * k;
+            if (pc < 46) stem_glds_piece(p.w_bf16, (unsigned)pc * 1024u + (unsigned)(tid & 63) * 16u, wl_addr + (unsigned)pc * 1024u);
+        }
+    }
+    const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
+    const float* img = p.img + (size_t)view * p.H * p.W * 3;
+    constexpr int NIT = (PR * PC + 255) / 256;
+    float pv[NIT][3];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int i = tid + 256 * j;
+        const int r = i / PC, pxl = i - r * PC;
+        const int y = iy0 + r, x = ix0 + pxl;
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+        if (i < PR * PC && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+            if (p.u8.frames) {
+                float res[3];
+                df3d_pre::pixel(p.u8.frames + (size_t)view * p.u8.FH * p.u8.FW * p.u8.FC, p.u8.FH, p.u8.FW, p.u8.FC, p.u8.flip && p.u8.flip[view], p.H, p.W, y, x,
+                                p.u8.nm, res);
+                v0 = res[0];
+                v1 = res[1];
+                v2 = res[2];
+            } else {
+                const float* const src = img + ((size_t)y * p.W + x) * 3;
+                v0 = src[0];
+                v1 = src[1];
+                v2 = src[2];
+            }
+        }
+        pv[j][0] = v0;
+        pv[j][1] = v1;
+        pv[j][2] = v2;
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int i = tid + 256 * j;
+        if (i < PR * PC) {
+            const int r = i / PC, pxl = i - r * PC;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const _Float16 h = (_Float16)pv[j][c];
+                patch[0][r * PROW + 3 * pxl + c] = __builtin_bit_cast(unsigned short, h);
+                patch[1][r * PROW + 3 * pxl + c] = __builtin_bit_cast(unsigned short, (_Float16)(pv[j][c] - (float)h));
+            }
+        }
+    }
+    for (int i = tid; i < PR * (PROW - PC * 3) + 64; i += 256) {   // the pad cells (read against zero weights) are zero
+        const int r = i / (PROW - PC * 3), c = i - r * (PROW - PC * 3);
+        const int at = i < PR * (PROW - PC * 3) ? r * PROW + PC * 3 + c : PR * PROW + (i - PR * (PROW - PC * 3));
+        patch[0][at] = 0;
+        patch[1][at] = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's weight pieces have landed
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, half = lane >> 5;
+    const int py = wave * 2 + (m >> 4), px = m & 15;
+    const int aoff = (2 * py) * PROW + 6 * px;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+#pragma unroll
+    for (int g = 0; g < KP / 16; ++g) {
+        const int kp = 16 * g + 8 * half;
+        const int ky = kp / 24, kk = kp % 24;
+        u32x4 ah = {0u, 0u, 0u, 0u}, al = {0u, 0u, 0u, 0u};
+        if (kp < 168) {
+            const unsigned* const aph = reinterpret_cast<const unsigned*>(&patch[0][aoff + ky * PROW + kk]);
+            const unsigned* const apl = reinterpret_cast<const unsigned*>(&patch[1][aoff + ky * PROW + kk]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ah[e] = aph[e];
+                al[e] = apl[e];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f16x8 wh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(&wl[0][(32 * t + m) * WPITCH + kp]));
+            const f16x8 wlo = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(&wl[1][(32 * t + m) * WPITCH + kp]));
+            f32x16& acc = t ? acc1 : acc0;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), wh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), wh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), wlo, acc, 0, 0, 0);
+        }
+    }
+    // epilogue as stem_kernel<float>: lane = channel, register = pixel; 4-byte stores of 128 contiguous bytes per pixel and tile
+    const int n = lane & 31;
+    const float bias0 = p.bias[n], bias1 = p.bias[32 + n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int oy = ty0 + wave * 2 + (mm >> 4), ox = tx0 + (mm & 15);
+        const size_t o = (((size_t)view * OH + oy) * OW + ox) * 64;
+        reinterpret_cast<float*>(p.out)[o + n] = fmaxf(acc0[r] + bias0, 0.0f);
+        reinterpret_cast<float*>(p.out)[o + 32 + n] = fmaxf(acc1[r] + bias1, 0.0f);
+    }
+}
+
+// one-time re-layout of the stem weights for stem_f32s_kernel: f32 [148][64] -> two IEEE-half [64][184] tiles, hi = rn(w) and lo = rn(w - hi)
+__global__ __launch_bounds__(256) void stem_relayout_f32s_kernel(const float* __restrict__ w, unsigned short* __restrict__ out) {
+    constexpr int WPITCH = 184;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 64 * WPITCH) return;
+    const int n = i / WPITCH, kp = i % WPITCH;
+    const int ky = kp / 24, kk = kp % 24;
+    float v = 0.0f;
+    if (kp < 168 && kk < 21) v = w[(ky * 21 + kk) * 64 + n];
+    const _Float16 h = (_Float16)v;
+    out[i] = __builtin_bit_cast(unsigned short, h);
+    out[64 * WPITCH + i] = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
+}
+
+// -----------------------------------------------------------------------------------------------------
 // 2x2 max-pool and nearest-upsample + add: one thread per 16-byte channel chunk
 // -----------------------------------------------------------------------------------------------------
 // bf16 as an ORDERED 16-bit integer and back (the map is its own inverse): a negative float's magnitude bits are flipped, so

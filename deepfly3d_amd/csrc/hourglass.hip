@@ -788,10 +788,14 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                 }
                 const int blocks = n * (h->H / 2 / 8) * (h->W / 2 / 16);
                 const double opx = (double)n * (h->H / 2) * (h->W / 2);
-                ScopedTimer tm(h, s, std::string(eb == 2 ? "stem_lp_kernel<" : "stem_kernel<") + TypeName<StorageT<T>>::value + ">", 2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb), st.m1_elems * n * eb);
-                if constexpr (sizeof(T) == 2)
+                ScopedTimer tm(h, s, std::is_same<T, F32S>::value ? std::string("stem_f32s_kernel") : std::string(eb == 2 ? "stem_lp_kernel<" : "stem_kernel<") + TypeName<StorageT<T>>::value + ">",
+                               2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb), st.m1_elems * n * eb);
+                if constexpr (sizeof(T) == 2) {
                     hipLaunchKernelGGL((stem_lp_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
-                else
+                } else if constexpr (std::is_same<T, F32S>::value) {
+                    a.w_bf16 = wb + st.conv.w_off * eb;   // the hi / lo half tiles in the stem's slot of the pre-split copy (stem_relayout_f32s_kernel)
+                    hipLaunchKernelGGL(stem_f32s_kernel, dim3(blocks), dim3(256), 0, s, a);
+                } else
                     hipLaunchKernelGGL((stem_kernel<StorageT<T>>), dim3(std::min(blocks, 3 * cu_count())), dim3(256), 0, s, a);   // persistent: weights once per workgroup
                 DF3D_LAUNCH_CHECK();
                 break;
@@ -1337,6 +1341,9 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
             // Biases and BatchNorm vectors are transformed along with the rest and never read from the copy.
             hipLaunchKernelGGL(f32s_presplit_kernel, dim3(1024), dim3(256), 0, df3d::as_stream(stream), reinterpret_cast<const u32x4*>(blob_dev),
                                reinterpret_cast<u32x4*>(lowp_dev), h->blob_floats / 16);
+            // the stem's weights: two half-precision [64][184] tiles (hi, lo) in its slot of the copy (exactly the slot's 47 104 bytes)
+            hipLaunchKernelGGL(stem_relayout_f32s_kernel, dim3((64 * 184 + 255) / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + h->steps[0].conv.w_off,
+                               reinterpret_cast<unsigned short*>(reinterpret_cast<float*>(lowp_dev) + h->steps[0].conv.w_off));
             blob_dev = reinterpret_cast<const float*>(lowp_dev);   // (restored below: h->blob stays the caller's float32 blob)
         }
         for (const Step& st : h->steps) {
