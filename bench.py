@@ -53,9 +53,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# /opt/skills/guides/MI355X_MICROARCH.md (dense).  f32s forms every float32 product from FOUR half-precision products (two-way split of both
-# operands): its matrix-pipe roof in float32 FLOPs is the half-precision peak / 4
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "f32s": 625.0}
+# /opt/skills/guides/MI355X_MICROARCH.md (dense).  f32s forms every float32 product from THREE half-precision products (two-way split of both
+# operands, the lo x lo term dropped): its matrix-pipe roof in float32 FLOPs is the half-precision peak / 3
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "f32s": 2500.0 / 3}
 PEAK_HBM_GBS = 8000.0
 DTYPE_WORDS = {"f32": "fp32", "bf16": "bf16 (all convolutions on MFMA, fp32 accumulate)", "f16": "IEEE-half f16 (all convolutions on MFMA, fp32 accumulate)",
                "f32s": "fp32 tensors and weights, every product as a two-way IEEE-half split of both operands on the 16-bit matrix pipe (fp32 accumulate)"}

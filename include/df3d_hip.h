@@ -34,9 +34,12 @@ extern "C" {
 #define DF3D_DTYPE_F32 0
 #define DF3D_DTYPE_BF16 1
 #define DF3D_DTYPE_F16 2  /* IEEE half activations + weights, fp32 accumulate: the bf16 engine's kernels on the other 16-bit format */
-#define DF3D_DTYPE_F32S 3 /* float32 tensors, weights and accumulation -- the F32 engine's plan, buffers and kernels -- with every product formed on the
-                             half-precision matrix pipe from a two-way IEEE-half split of both operands (x = hi + lo to 2^-22 |x|); operands must lie
-                             inside the half range (|x| < 65 504), which batch-normalised activations do.  Not bit-identical to F32: a few 1e-6 relative */
+#define DF3D_DTYPE_F32S 3 /* float32 tensors, weights and accumulation -- the F32 engine's plan, workspace and kernels -- with every product formed on the
+                             half-precision matrix pipe from a two-way IEEE-half split of both operands (x = hi + lo to 2^-22 |x|): three MFMAs per
+                             K step (hi hi + lo hi + hi lo, the 2^-22 lo lo term dropped) where exact fp32 takes eight four times as long.  Operands
+                             must lie inside the half range (|x| < 65 504), which batch-normalised activations and their weights do.  Not
+                             bit-identical to F32: heat-maps differ by ~1.5e-6 of their range (the same 5e-5 test tolerance, the same arg-max cells).
+                             Needs the df3d_hg_lowp_bytes() buffer (the pre-split copy of the weights and the streams packed from it) */
 
 const char* df3d_last_error(void);
 /* ABI revision of the library: DF3D_ABI_VERSION of the header it was built from.  It changes whenever an entry point's signature or
@@ -307,7 +310,10 @@ size_t df3d_hg_blob_floats(const df3d_hg* h);
  * df3d_hg_lowp_bytes(h) bytes (256-byte aligned; NULL is accepted when that size is 0): the bf16 copy of the blob (bf16
  * engines) and, for both dtypes, the "weight streams" of the 256 -> 128 -> 128 -> 256 bottlenecks -- their weights repacked
  * as the sequence of 8 KB LDS images the kernel pulls through its LDS-DMA ring (option "ring", default 1); bf16 engines also
- * keep the heads' fc / fc_ / score_ weights in that form and layer1's whole weight set as one LDS image (option "l1"). */
+ * keep the heads' fc / fc_ / score_ weights in that form and layer1's whole weight set as one LDS image (option "l1").
+ * DF3D_DTYPE_F32S: a float32-sized copy of the blob with every 16-float K step of every weight row stored as its IEEE-half hi / lo
+ * parts in MFMA operand order (and the stem's weights as two half-precision tiles), followed by the streams packed from that copy;
+ * lowp_dev must not be NULL. */
 size_t df3d_hg_lowp_bytes(const df3d_hg* h);
 int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void* stream);
 /* knobs: "fuse" = 1 (default) | 0: run 256->128->128->256 bottlenecks as one fused kernel -- must be set before

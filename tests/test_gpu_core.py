@@ -392,7 +392,7 @@ def test_full_size_workload_properties(native_lib, cuda, golden_dir, dtype):
         assert np.abs(p3[t].cpu().numpy() - X[0]).max() < 1e-6 * max(1.0, np.abs(X).max())
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16", "f32s"])
 def test_forward_from_camera_frames_equals_preprocess_then_forward(native_lib, cuda, dtype):
     """df3d_hg_forward_u8 (the stem samples the uint8 frames itself) is bit for bit df3d_hg_forward(df3d_preprocess_u8(frames)):
     grey and 3-channel frames, flipped and not, a frame size that is not a multiple of the network input, non-trivial mean / std."""
