@@ -7,7 +7,7 @@ TAG=${1:-r03}
 OUT=$R/gpurun_out/${TAG}_counters
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for dt in ${DTYPES:-f32 bf16 f16}; do
+for dt in ${DTYPES:-f32 bf16 f16 f32s}; do
   i=0
   for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES" \
              "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \

@@ -16,7 +16,7 @@ python bench.py --rank-share 8 --stream-frames 100000 --ba-window 1000 --force-c
 python bench.py --rank-share 8 --stream-frames 100000 --ba-window 1000 --force-collective --dtype bf16 --no-cpu-baseline --no-roofline > "$OUT/rankshare_bf16_cfg4.log" 2>&1
 python bench.py --strong --stream-frames 12800 --ba-window 1000 --dtype f16 --no-cpu-baseline --no-roofline > "$OUT/strong_f16_cfg4_n1.log" 2>&1
 python bench.py --strong --stream-frames 2560 --no-cpu-baseline --no-roofline > "$OUT/strong_f32_cfg3_n1.log" 2>&1
-for dt in f16 f32; do DT=$dt STEPS=$([ $dt = f16 ] && echo 60 || echo 12) bash scripts/power_probe.sh > "$OUT/power_$dt.txt" 2>&1; cp gpurun_out/power_${dt}_samples.txt "$OUT/" 2>/dev/null; done
+for dt in f16 f32 f32s; do DT=$dt STEPS=$([ $dt = f32 ] && echo 12 || echo 40) bash scripts/power_probe.sh > "$OUT/power_$dt.txt" 2>&1; cp gpurun_out/power_${dt}_samples.txt "$OUT/" 2>/dev/null; done
 python tests/perf/probe_ba.py 1000 > "$OUT/ba_1000.txt" 2>&1; python tests/perf/probe_ba.py 15 > "$OUT/ba_15.txt" 2>&1
 python tests/perf/probe_ba_sections.py 1000 > "$OUT/ba_sections_1000.txt" 2>&1; python tests/perf/probe_ba_sections.py 15 > "$OUT/ba_sections_15.txt" 2>&1
 du -sh "$OUT"; tail -1 "$OUT/f16_bench.log" | cut -c1-300

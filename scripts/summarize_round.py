@@ -2,7 +2,7 @@
 
     python scripts/summarize_round.py r03
 
-* per dtype (f32, bf16, f16): kernel stats + FETCH/WRITE traffic (scripts/summarize_profile.py; rewrites profiles/traffic.json
+* per dtype (f32, bf16, f16, f32s): kernel stats + FETCH/WRITE traffic (scripts/summarize_profile.py; rewrites profiles/traffic.json
   from scratch, stamped with the kernel-source hash) and the SQ counter table (scripts/summarize_counters.py)
 * the bench lines of the same run (gpurun_out/<tag>/<dtype>_bench.log -> profiles/<tag>_<dtype>_bench.json) and, when present,
   the full rank-share lines (rankshare_*.log -> profiles/<tag>_rankshare_*.json)
@@ -23,7 +23,7 @@ def main():
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
         os.remove(tj)
-    for dt in ("f32", "bf16", "f16"):
+    for dt in ("f32", "bf16", "f16", "f32s"):
         if not os.path.isdir(os.path.join(src, f"{dt}_stats")):
             continue
         subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "summarize_profile.py"), f"{tag}_{dt}", os.path.join(src, f"{dt}_stats"),
