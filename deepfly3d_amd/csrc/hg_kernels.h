@@ -704,12 +704,13 @@ __global__ __launch_bounds__(256) void stem_lp_kernel(StemArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned short wl[64 * WPITCH];
     const int OH = p.H / 2, OW = p.W / 2;
     const int tiles_x = OW / 16, tiles_y = OH / 8;
-    int b = blockIdx.x;
-    const int tx0 = (b % tiles_x) * 16;
-    b /= tiles_x;
-    const int ty0 = (b % tiles_y) * 8;
-    const int view = b / tiles_y;
+    const int ntiles = p.V * tiles_y * tiles_x;
     const int tid = threadIdx.x;
+    // PERSISTENT (round 5, as stem_kernel<float> since round 3): a workgroup walks tiles b, b + gridDim.x, ...: the 23 KB weight tile enters
+    // LDS ONCE per workgroup (per tile it was 1.4 x the tile's output bytes), and the next tile's patch is gathered into registers before the
+    // K loop and written behind it.  Same MFMA order: bit-identical.
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
 
     // weights: the [64][184] 16-bit tile was laid out once by stem_relayout_kernel (wl[n][ky*24 + kk] = w[ky*21 + kk][n]); it is
     // copied as it lies, 23 one-KB pieces, by LDS-DMA (no registers, no ds_write: the copy runs under the patch staging below)
@@ -723,50 +724,61 @@ __global__ __launch_bounds__(256) void stem_lp_kernel(StemArgs p) {
             if (pc < 23) stem_glds_piece(p.w_bf16, (unsigned)pc * 1024u + (unsigned)(tid & 63) * 16u, wl_addr + (unsigned)pc * 1024u);
         }
     }
-    const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
-    const float* img = p.img + (size_t)view * p.H * p.W * 3;
     // one item = one patch pixel (three contiguous floats): the index arithmetic and the bounds test are per pixel, not per value.
     // ALL of a thread's items are requested before the first is stored (as a rolled loop the staging was four load -> store round
-    // trips in series: this kernel has 22 MFMAs per wave and lives on its prologue)
+    // trips in series)
     constexpr int NIT = (PR * PC + 255) / 256;
     float pv[NIT][3];
+    auto gather = [&](int t) {
+        int b = t;
+        const int tx0 = (b % tiles_x) * 16;
+        b /= tiles_x;
+        const int ty0 = (b % tiles_y) * 8;
+        const int view = b / tiles_y;
+        const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
+        const float* img = p.img + (size_t)view * p.H * p.W * 3;
 #pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-        const int i = tid + 256 * j;
-        const int r = i / PC, pxl = i - r * PC;
-        const int y = iy0 + r, x = ix0 + pxl;
-        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
-        if (i < PR * PC && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
-            if (p.u8.frames) {
-                float res[3];
-                df3d_pre::pixel(p.u8.frames + (size_t)view * p.u8.FH * p.u8.FW * p.u8.FC, p.u8.FH, p.u8.FW, p.u8.FC, p.u8.flip && p.u8.flip[view], p.H, p.W, y, x,
-                                p.u8.nm, res);
-                v0 = res[0];
-                v1 = res[1];
-                v2 = res[2];
-            } else {
-                const float* const src = img + ((size_t)y * p.W + x) * 3;
-                v0 = src[0];
-                v1 = src[1];
-                v2 = src[2];
+        for (int j = 0; j < NIT; ++j) {
+            const int i = tid + 256 * j;
+            const int r = i / PC, pxl = i - r * PC;
+            const int y = iy0 + r, x = ix0 + pxl;
+            float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+            if (i < PR * PC && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+                if (p.u8.frames) {
+                    float res[3];
+                    df3d_pre::pixel(p.u8.frames + (size_t)view * p.u8.FH * p.u8.FW * p.u8.FC, p.u8.FH, p.u8.FW, p.u8.FC, p.u8.flip && p.u8.flip[view], p.H, p.W, y, x,
+                                    p.u8.nm, res);
+                    v0 = res[0];
+                    v1 = res[1];
+                    v2 = res[2];
+                } else {
+                    const float* const src = img + ((size_t)y * p.W + x) * 3;
+                    v0 = src[0];
+                    v1 = src[1];
+                    v2 = src[2];
+                }
+            }
+            pv[j][0] = v0;
+            pv[j][1] = v1;
+            pv[j][2] = v2;
+        }
+    };
+    auto scatter = [&]() {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int i = tid + 256 * j;
+            if (i < PR * PC) {
+                const int r = i / PC, pxl = i - r * PC;
+                unsigned short* const dst = patch + r * PROW + 3 * pxl;
+                dst[0] = Lp<T>::from_f32(pv[j][0]);
+                dst[1] = Lp<T>::from_f32(pv[j][1]);
+                dst[2] = Lp<T>::from_f32(pv[j][2]);
             }
         }
-        pv[j][0] = v0;
-        pv[j][1] = v1;
-        pv[j][2] = v2;
-    }
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-        const int i = tid + 256 * j;
-        if (i < PR * PC) {
-            const int r = i / PC, pxl = i - r * PC;
-            unsigned short* const dst = patch + r * PROW + 3 * pxl;
-            dst[0] = Lp<T>::from_f32(pv[j][0]);
-            dst[1] = Lp<T>::from_f32(pv[j][1]);
-            dst[2] = Lp<T>::from_f32(pv[j][2]);
-        }
-    }
-    // the pad cells behind the 111 values of a row and behind the last row (read by the last K slots against zero weights) are zero
+    };
+    gather(tile);
+    scatter();
+    // the pad cells behind the 111 values of a row and behind the last row (read by the last K slots against zero weights) are zero; no tile writes them
     for (int i = tid; i < PR * (PROW - PC * 3) + 64; i += 256) {
         const int r = i / (PROW - PC * 3), c = i - r * (PROW - PC * 3);
         patch[i < PR * (PROW - PC * 3) ? r * PROW + PC * 3 + c : PR * PROW + (i - PR * (PROW - PC * 3))] = 0;
@@ -780,45 +792,60 @@ __global__ __launch_bounds__(256) void stem_lp_kernel(StemArgs p) {
     const unsigned short* const abase = patch + (2 * py) * PROW + 6 * px;   // 12*px bytes: 4-byte aligned
     const unsigned short* const wrow0 = wl + m * WPITCH;
     const unsigned short* const wrow1 = wl + (32 + m) * WPITCH;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
-#pragma unroll
-    for (int g = 0; g < KP / 16; ++g) {
-        const int kp = 16 * g + 8 * half;          // first k' of this lane's 8 slots
-        const int ky = kp / 24, kk = kp % 24;       // 8 consecutive taps of patch row 2*py + ky (kk in {0, 8, 16})
-        u32x4 av = {0u, 0u, 0u, 0u};
-        if (kp < 168) {
-            const unsigned* ap = reinterpret_cast<const unsigned*>(abase + ky * PROW + kk);
-            av[0] = ap[0];
-            av[1] = ap[1];
-            av[2] = ap[2];
-            av[3] = ap[3];   // taps 21..23 of the row multiply zero weights
-        }
-        const u32x4 b0 = *reinterpret_cast<const u32x4*>(wrow0 + kp);
-        const u32x4 b1 = *reinterpret_cast<const u32x4*>(wrow1 + kp);
-        acc0 = Lp<T>::mfma(av, b0, acc0);
-        acc1 = Lp<T>::mfma(av, b1, acc1);
-    }
-    // epilogue: adjacent lanes hold adjacent channels of the same pixel; exchanging one register between lane pairs
-    // lets every lane store TWO channels (4 bytes) of one pixel: even lanes take pixel-register r, odd lanes r + 1
     const int n = lane & 31;
     const int odd = lane & 1;
     const float bias0 = p.bias[n], bias1 = p.bias[32 + n];
+    for (;;) {
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) gather(next);   // requested now, consumed behind the K loop
+        f32x16 acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        const float v0a = fmaxf(acc0[r] + bias0, 0.0f), v0b = fmaxf(acc0[r + 1] + bias0, 0.0f);
-        const float v1a = fmaxf(acc1[r] + bias1, 0.0f), v1b = fmaxf(acc1[r + 1] + bias1, 0.0f);
-        const float g0 = __shfl_xor(odd ? v0a : v0b, 1, 64);   // even gets partner's value for register r, odd for r + 1
-        const float g1 = __shfl_xor(odd ? v1a : v1b, 1, 64);
-        const int rr = r + odd;
-        const int mm = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
-        const int oy = ty0 + wave * 2 + (mm >> 4), ox = tx0 + (mm & 15);
-        const size_t o = (((size_t)view * OH + oy) * OW + ox) * 64 + (n & ~1);
-        const unsigned w0 = odd ? Lp<T>::pack2(g0, v0b) : Lp<T>::pack2(v0a, g0);
-        const unsigned w1 = odd ? Lp<T>::pack2(g1, v1b) : Lp<T>::pack2(v1a, g1);
-        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.out) + o) = w0;
-        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.out) + o + 32) = w1;
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < KP / 16; ++g) {
+            const int kp = 16 * g + 8 * half;          // first k' of this lane's 8 slots
+            const int ky = kp / 24, kk = kp % 24;       // 8 consecutive taps of patch row 2*py + ky (kk in {0, 8, 16})
+            u32x4 av = {0u, 0u, 0u, 0u};
+            if (kp < 168) {
+                const unsigned* ap = reinterpret_cast<const unsigned*>(abase + ky * PROW + kk);
+                av[0] = ap[0];
+                av[1] = ap[1];
+                av[2] = ap[2];
+                av[3] = ap[3];   // taps 21..23 of the row multiply zero weights
+            }
+            const u32x4 b0 = *reinterpret_cast<const u32x4*>(wrow0 + kp);
+            const u32x4 b1 = *reinterpret_cast<const u32x4*>(wrow1 + kp);
+            acc0 = Lp<T>::mfma(av, b0, acc0);
+            acc1 = Lp<T>::mfma(av, b1, acc1);
+        }
+        // epilogue: adjacent lanes hold adjacent channels of the same pixel; exchanging one register between lane pairs
+        // lets every lane store TWO channels (4 bytes) of one pixel: even lanes take pixel-register r, odd lanes r + 1
+        int b = tile;
+        const int tx0 = (b % tiles_x) * 16;
+        b /= tiles_x;
+        const int ty0 = (b % tiles_y) * 8;
+        const int view = b / tiles_y;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float v0a = fmaxf(acc0[r] + bias0, 0.0f), v0b = fmaxf(acc0[r + 1] + bias0, 0.0f);
+            const float v1a = fmaxf(acc1[r] + bias1, 0.0f), v1b = fmaxf(acc1[r + 1] + bias1, 0.0f);
+            const float g0 = __shfl_xor(odd ? v0a : v0b, 1, 64);   // even gets partner's value for register r, odd for r + 1
+            const float g1 = __shfl_xor(odd ? v1a : v1b, 1, 64);
+            const int rr = r + odd;
+            const int mm = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+            const int oy = ty0 + wave * 2 + (mm >> 4), ox = tx0 + (mm & 15);
+            const size_t o = (((size_t)view * OH + oy) * OW + ox) * 64 + (n & ~1);
+            const unsigned w0 = odd ? Lp<T>::pack2(g0, v0b) : Lp<T>::pack2(v0a, g0);
+            const unsigned w1 = odd ? Lp<T>::pack2(g1, v1b) : Lp<T>::pack2(v1a, g1);
+            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.out) + o) = w0;
+            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(p.out) + o + 32) = w1;
+        }
+        if (!has_next) break;
+        __syncthreads();   // every wave is done reading the patch
+        scatter();
+        __syncthreads();
+        tile = next;
     }
 }
 
@@ -850,12 +877,10 @@ __global__ __launch_bounds__(256) void stem_f32s_kernel(StemArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned short wl[2][64 * WPITCH];    // [hi | lo]
     const int OH = p.H / 2, OW = p.W / 2;
     const int tiles_x = OW / 16, tiles_y = OH / 8;
-    int b = blockIdx.x;
-    const int tx0 = (b % tiles_x) * 16;
-    b /= tiles_x;
-    const int ty0 = (b % tiles_y) * 8;
-    const int view = b / tiles_y;
+    const int ntiles = p.V * tiles_y * tiles_x;
     const int tid = threadIdx.x;
+    int tile = blockIdx.x;   // PERSISTENT, as the other stems: the 46 KB of weight tiles enter LDS once per workgroup
+    if (tile >= ntiles) return;
     {   // both weight tiles as they lie: 46 one-KB pieces by LDS-DMA, under the patch staging
         const unsigned wl_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)&wl[0][0];
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -866,49 +891,60 @@ __global__ __launch_bounds__(256) void stem_f32s_kernel(StemArgs p) {
             if (pc < 46) stem_glds_piece(p.w_bf16, (unsigned)pc * 1024u + (unsigned)(tid & 63) * 16u, wl_addr + (unsigned)pc * 1024u);
         }
     }
-    const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
-    const float* img = p.img + (size_t)view * p.H * p.W * 3;
     constexpr int NIT = (PR * PC + 255) / 256;
     float pv[NIT][3];
+    auto gather = [&](int t) {
+        int b = t;
+        const int tx0 = (b % tiles_x) * 16;
+        b /= tiles_x;
+        const int ty0 = (b % tiles_y) * 8;
+        const int view = b / tiles_y;
+        const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
+        const float* img = p.img + (size_t)view * p.H * p.W * 3;
 #pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-        const int i = tid + 256 * j;
-        const int r = i / PC, pxl = i - r * PC;
-        const int y = iy0 + r, x = ix0 + pxl;
-        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
-        if (i < PR * PC && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
-            if (p.u8.frames) {
-                float res[3];
-                df3d_pre::pixel(p.u8.frames + (size_t)view * p.u8.FH * p.u8.FW * p.u8.FC, p.u8.FH, p.u8.FW, p.u8.FC, p.u8.flip && p.u8.flip[view], p.H, p.W, y, x,
-                                p.u8.nm, res);
-                v0 = res[0];
-                v1 = res[1];
-                v2 = res[2];
-            } else {
-                const float* const src = img + ((size_t)y * p.W + x) * 3;
-                v0 = src[0];
-                v1 = src[1];
-                v2 = src[2];
-            }
-        }
-        pv[j][0] = v0;
-        pv[j][1] = v1;
-        pv[j][2] = v2;
-    }
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-        const int i = tid + 256 * j;
-        if (i < PR * PC) {
+        for (int j = 0; j < NIT; ++j) {
+            const int i = tid + 256 * j;
             const int r = i / PC, pxl = i - r * PC;
+            const int y = iy0 + r, x = ix0 + pxl;
+            float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+            if (i < PR * PC && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+                if (p.u8.frames) {
+                    float res[3];
+                    df3d_pre::pixel(p.u8.frames + (size_t)view * p.u8.FH * p.u8.FW * p.u8.FC, p.u8.FH, p.u8.FW, p.u8.FC, p.u8.flip && p.u8.flip[view], p.H, p.W, y, x,
+                                    p.u8.nm, res);
+                    v0 = res[0];
+                    v1 = res[1];
+                    v2 = res[2];
+                } else {
+                    const float* const src = img + ((size_t)y * p.W + x) * 3;
+                    v0 = src[0];
+                    v1 = src[1];
+                    v2 = src[2];
+                }
+            }
+            pv[j][0] = v0;
+            pv[j][1] = v1;
+            pv[j][2] = v2;
+        }
+    };
+    auto scatter = [&]() {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const _Float16 h = (_Float16)pv[j][c];
-                patch[0][r * PROW + 3 * pxl + c] = __builtin_bit_cast(unsigned short, h);
-                patch[1][r * PROW + 3 * pxl + c] = __builtin_bit_cast(unsigned short, (_Float16)(pv[j][c] - (float)h));
+        for (int j = 0; j < NIT; ++j) {
+            const int i = tid + 256 * j;
+            if (i < PR * PC) {
+                const int r = i / PC, pxl = i - r * PC;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const _Float16 h = (_Float16)pv[j][c];
+                    patch[0][r * PROW + 3 * pxl + c] = __builtin_bit_cast(unsigned short, h);
+                    patch[1][r * PROW + 3 * pxl + c] = __builtin_bit_cast(unsigned short, (_Float16)(pv[j][c] - (float)h));
+                }
             }
         }
-    }
-    for (int i = tid; i < PR * (PROW - PC * 3) + 64; i += 256) {   // the pad cells (read against zero weights) are zero
+    };
+    gather(tile);
+    scatter();
+    for (int i = tid; i < PR * (PROW - PC * 3) + 64; i += 256) {   // the pad cells (read against zero weights) are zero; no tile writes them
         const int r = i / (PROW - PC * 3), c = i - r * (PROW - PC * 3);
         const int at = i < PR * (PROW - PC * 3) ? r * PROW + PC * 3 + c : PR * PROW + (i - PR * (PROW - PC * 3));
         patch[0][at] = 0;
@@ -921,43 +957,58 @@ __global__ __launch_bounds__(256) void stem_f32s_kernel(StemArgs p) {
     const int m = lane & 31, half = lane >> 5;
     const int py = wave * 2 + (m >> 4), px = m & 15;
     const int aoff = (2 * py) * PROW + 6 * px;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
-#pragma unroll
-    for (int g = 0; g < KP / 16; ++g) {
-        const int kp = 16 * g + 8 * half;
-        const int ky = kp / 24, kk = kp % 24;
-        u32x4 ah = {0u, 0u, 0u, 0u}, al = {0u, 0u, 0u, 0u};
-        if (kp < 168) {
-            const unsigned* const aph = reinterpret_cast<const unsigned*>(&patch[0][aoff + ky * PROW + kk]);
-            const unsigned* const apl = reinterpret_cast<const unsigned*>(&patch[1][aoff + ky * PROW + kk]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                ah[e] = aph[e];
-                al[e] = apl[e];
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f16x8 wh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(&wl[0][(32 * t + m) * WPITCH + kp]));
-            const f16x8 wlo = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(&wl[1][(32 * t + m) * WPITCH + kp]));
-            f32x16& acc = t ? acc1 : acc0;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), wh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), wh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), wlo, acc, 0, 0, 0);
-        }
-    }
-    // epilogue as stem_kernel<float>: lane = channel, register = pixel; 4-byte stores of 128 contiguous bytes per pixel and tile
     const int n = lane & 31;
     const float bias0 = p.bias[n], bias1 = p.bias[32 + n];
+    for (;;) {
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < ntiles;
+        if (has_next) gather(next);   // requested now, consumed behind the K loop
+        f32x16 acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int mm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int oy = ty0 + wave * 2 + (mm >> 4), ox = tx0 + (mm & 15);
-        const size_t o = (((size_t)view * OH + oy) * OW + ox) * 64;
-        reinterpret_cast<float*>(p.out)[o + n] = fmaxf(acc0[r] + bias0, 0.0f);
-        reinterpret_cast<float*>(p.out)[o + 32 + n] = fmaxf(acc1[r] + bias1, 0.0f);
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < KP / 16; ++g) {
+            const int kp = 16 * g + 8 * half;
+            const int ky = kp / 24, kk = kp % 24;
+            u32x4 ah = {0u, 0u, 0u, 0u}, al = {0u, 0u, 0u, 0u};
+            if (kp < 168) {
+                const unsigned* const aph = reinterpret_cast<const unsigned*>(&patch[0][aoff + ky * PROW + kk]);
+                const unsigned* const apl = reinterpret_cast<const unsigned*>(&patch[1][aoff + ky * PROW + kk]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ah[e] = aph[e];
+                    al[e] = apl[e];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f16x8 wh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(&wl[0][(32 * t + m) * WPITCH + kp]));
+                const f16x8 wlo = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(&wl[1][(32 * t + m) * WPITCH + kp]));
+                f32x16& acc = t ? acc1 : acc0;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), wh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), wh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), wlo, acc, 0, 0, 0);
+            }
+        }
+        // epilogue as stem_kernel<float>: lane = channel, register = pixel; 4-byte stores of 128 contiguous bytes per pixel and tile
+        int b = tile;
+        const int tx0 = (b % tiles_x) * 16;
+        b /= tiles_x;
+        const int ty0 = (b % tiles_y) * 8;
+        const int view = b / tiles_y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int oy = ty0 + wave * 2 + (mm >> 4), ox = tx0 + (mm & 15);
+            const size_t o = (((size_t)view * OH + oy) * OW + ox) * 64;
+            reinterpret_cast<float*>(p.out)[o + n] = fmaxf(acc0[r] + bias0, 0.0f);
+            reinterpret_cast<float*>(p.out)[o + 32 + n] = fmaxf(acc1[r] + bias1, 0.0f);
+        }
+        if (!has_next) break;
+        __syncthreads();   // every wave is done reading the patches
+        scatter();
+        __syncthreads();
+        tile = next;
     }
 }
 

@@ -791,10 +791,10 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                 ScopedTimer tm(h, s, std::is_same<T, F32S>::value ? std::string("stem_f32s_kernel") : std::string(eb == 2 ? "stem_lp_kernel<" : "stem_kernel<") + TypeName<StorageT<T>>::value + ">",
                                2.0 * opx * 147 * 64, opx * (12.0 * 4 + 64.0 * eb), st.m1_elems * n * eb);
                 if constexpr (sizeof(T) == 2) {
-                    hipLaunchKernelGGL((stem_lp_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
+                    hipLaunchKernelGGL((stem_lp_kernel<T>), dim3(std::min(blocks, 4 * cu_count())), dim3(256), 0, s, a);   // persistent: weights once per workgroup
                 } else if constexpr (std::is_same<T, F32S>::value) {
                     a.w_bf16 = wb + st.conv.w_off * eb;   // the hi / lo half tiles in the stem's slot of the pre-split copy (stem_relayout_f32s_kernel)
-                    hipLaunchKernelGGL(stem_f32s_kernel, dim3(blocks), dim3(256), 0, s, a);
+                    hipLaunchKernelGGL(stem_f32s_kernel, dim3(std::min(blocks, 2 * cu_count())), dim3(256), 0, s, a);   // persistent (57 KB of LDS: two per CU)
                 } else
                     hipLaunchKernelGGL((stem_kernel<StorageT<T>>), dim3(std::min(blocks, 3 * cu_count())), dim3(256), 0, s, a);   // persistent: weights once per workgroup
                 DF3D_LAUNCH_CHECK();
