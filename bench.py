@@ -475,10 +475,14 @@ def hourglass_leg(a, sd, dtype, frames, calib, dev, total_frames, config_words):
     if not a.no_roofline:
         leg["roofline"] = job.roofline(dtype)
     if dtype == "f32s":   # the leg's price: what it differs by from the exact-fp32 engine, measured here on 2 frames of the run's own input
-        ref = HourglassEngine(sd, dtype="f32", device=dev).forward(frames[:2].reshape(14, 256, 512, 3))
-        got = eng.forward(frames[:2].reshape(14, 256, 512, 3))
+        x = frames[:2].reshape(14, 256, 512, 3).contiguous()
+        exact = HourglassEngine(sd, dtype="f32", device=dev)
+        ref = exact.forward(x).clone()
+        got = eng.forward(x).clone()
+        torch.cuda.synchronize()   # both engines have finished before either goes away
         leg["max_rel_diff_vs_f32_engine"] = float((got - ref).abs().max() / ref.abs().max())
         leg["argmax_cells_identical_to_f32_engine"] = bool(torch.equal(got.flatten(2).argmax(-1), ref.flatten(2).argmax(-1)))
+        del exact
     del job, eng
     return leg
 
