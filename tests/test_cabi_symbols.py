@@ -130,6 +130,31 @@ def test_engine_plan_accounting(native_lib):
         native_lib.df3d_hg_destroy(h)
 
 
+def test_f32s_engine_shares_the_f32_plan_and_needs_its_weight_copy(native_lib):
+    """DF3D_DTYPE_F32S (split half-precision products on float32 tensors) is the F32 engine as far as a caller's buffers go: the same plan, the
+    same workspace and work accounting; its lowp buffer = a float32-sized pre-split copy of the blob + the F32 engine's streams; set_weights
+    refuses to run without it (argument checks come before any device work, so this runs on CPU)."""
+    from deepfly3d_amd import _native
+
+    assert _native.DF3D_DTYPE_F32S == 3
+    hs = {}
+    for dt in (_native.DF3D_DTYPE_F32, _native.DF3D_DTYPE_F32S):
+        h = ctypes.c_void_p()
+        assert native_lib.df3d_hg_create(dt, 2, ctypes.byref(h)) == 0
+        hs[dt] = h
+    f32, f32s = hs[_native.DF3D_DTYPE_F32], hs[_native.DF3D_DTYPE_F32S]
+    assert native_lib.df3d_hg_num_steps(f32) == native_lib.df3d_hg_num_steps(f32s)
+    assert native_lib.df3d_hg_blob_floats(f32) == native_lib.df3d_hg_blob_floats(f32s)
+    for n in (1, 7, 896):
+        assert native_lib.df3d_hg_workspace_bytes(f32, n) == native_lib.df3d_hg_workspace_bytes(f32s, n)
+    copy = (native_lib.df3d_hg_blob_floats(f32) * 4 + 255) & ~255
+    assert native_lib.df3d_hg_lowp_bytes(f32s) == copy + native_lib.df3d_hg_lowp_bytes(f32)
+    rc = native_lib.df3d_hg_set_weights(f32s, ctypes.c_void_p(256), None, None)
+    assert rc == -1 and b"f32s" in native_lib.df3d_last_error()
+    for h in hs.values():
+        native_lib.df3d_hg_destroy(h)
+
+
 def test_no_gpu_fails_loudly(native_lib):
     import torch
 
