@@ -292,7 +292,7 @@ def test_fused_upsample_add_is_bit_identical(native_lib, cuda, oracle_net, image
             assert torch.equal(on.forward_upto(x, k), off.forward_upto(x, index_off[name])), name
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f32", "f16"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "f16", "f32s"])
 @pytest.mark.parametrize("height,width,n", [(256, 512, 3), (128, 256, 2), (64, 192, 1)])
 def test_weight_ring_bottleneck_is_bit_identical(native_lib, cuda, oracle_net, height, width, n, dtype):
     """The LDS-DMA weight-ring form of the 256 -> 128 -> 128 -> 256 bottleneck (csrc/hg_bt_ring.h, hg_bt_ring_f32.h: weights
@@ -352,7 +352,7 @@ def test_resident_weight_layer1_is_bit_identical(native_lib, cuda, oracle_net, h
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["bf16", "f32", "f16"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "f16", "f32s"])
 def test_repeated_forwards_are_bit_stable_under_concurrent_load(native_lib, cuda, dtype):
     """The weight rings rely on COUNTED vector-memory waits (csrc/hg_bt_ring.h, hg_head.h): a wrong count would show up as a
     rare, timing-dependent difference.  Repeat forwards at several batch sizes while a second engine keeps the memory system
@@ -377,7 +377,7 @@ def test_repeated_forwards_are_bit_stable_under_concurrent_load(native_lib, cuda
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["bf16", "f32", "f16"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "f16", "f32s"])
 @pytest.mark.parametrize("height,width,n", [(64, 64, 1), (128, 64, 2), (64, 512, 1), (192, 128, 3), (64, 64, 9)])
 def test_default_kernels_match_the_register_staged_kernels_on_small_and_odd_shapes(native_lib, cuda, height, width, n, dtype):
     """Everything round 2 added to the default plan (weight rings in the bottlenecks and heads, the LDS-resident layer1 kernel,
@@ -486,8 +486,9 @@ def test_round4_ring_bottleneck_is_bit_identical_to_round3s(native_lib, cuda, or
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
 @pytest.mark.parametrize("height,width,n", [(256, 512, 3), (128, 256, 2), (64, 192, 1)])
-def test_fp32_split_conv1_is_bit_identical(native_lib, cuda, oracle_net, height, width, n):
+def test_fp32_split_conv1_is_bit_identical(native_lib, cuda, oracle_net, height, width, n, dtype):
     """fp32 `split1`: the first 1x1 convolution of the identity-skip bottlenecks computed ONCE per pixel by a kernel of its own
     (csrc/hg_c1_f32.h) instead of on every tile's halo, the tile kernel pulling its t1 halo by LDS-DMA (out-of-image pixels from
     a page of zeros): same accumulation order, so every plan step and the heat-maps are bit-identical to the fused kernels
@@ -499,8 +500,9 @@ def test_fp32_split_conv1_is_bit_identical(native_lib, cuda, oracle_net, height,
 
     sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
     img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(11 * height + width), dtype=torch.float32).to(cuda)
-    on = HourglassEngine(sd, dtype="f32", device=cuda, height=height, width=width, split1=1)
-    off = HourglassEngine(sd, dtype="f32", device=cuda, height=height, width=width, split1=0)
+    # (f32s: the same three half-precision products per K step in the same order whichever operand the weights are: bit-identical too)
+    on = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, split1=1)
+    off = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, split1=0)
     assert [s[0] for s in on.steps()] == [s[0] for s in off.steps()]
     for k in range(1, len(on.steps()) + 1):
         a, b = on.forward_upto(img, k), off.forward_upto(img, k)
