@@ -350,7 +350,7 @@ def test_cli_two_ranks_match_one_rank(native_lib, cuda, tmp_path, golden_dir):
     assert np.allclose(one["points3d_wo_procrustes"], two["points3d_wo_procrustes"], atol=1e-9)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32s", "bf16", "f16"])
 def test_full_size_workload_properties(native_lib, cuda, golden_dir, dtype):
     """BASELINE configs[1] / configs[2] at FULL size (1 000 frames x 7 views of 256x512x3, one GPU), checked through
     size-independent properties: the run is deterministic (bit-identical twice), every frame's result is independent
