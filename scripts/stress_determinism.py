@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 sd = synthetic_state_dict(0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 bad = 0
-for dtype in ("f16", "bf16", "f32"):
+for dtype in ("f16", "bf16", "f32", "f32s"):
     eng = HourglassEngine(sd, dtype=dtype, device=dev)
     for n in (1, 7, 35, 120):
         img = torch.rand((n, 256, 512, 3), generator=torch.Generator().manual_seed(n), dtype=torch.float32).to(dev)
