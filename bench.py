@@ -37,6 +37,9 @@ Roofline fractions (per kernel and for the dominant one), spelled out because a 
   frac_hbm_m1    bytes the fusion model M1 of SURVEY.md 8(d) charges (every convolution's input and output) / time / 8 TB/s
                  -- a convention: it exceeds what any kernel moves once convolutions are fused
   frac_hbm_pmc   HBM bytes rocprofv3's counters saw ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, profiles/traffic.json) / time / 8 TB/s
+The whole step's HBM rate -- BASELINE's "hourglass HBM GB/s vs peak" -- is printed three ways in `config` (and in every hourglass leg):
+hourglass_gbs_m1_end_to_end (the M1 convention), hourglass_gbs_pmc_end_to_end (bytes the counters saw: traffic.json x this run's launch counts,
+when it covers the step) and hourglass_gbs_min_end_to_end (inputs once + outputs once per launch), each over this run's step time.
 `bound` is the larger of frac_mfma and frac_hbm_pmc (frac_hbm_min when no counter pass covers the kernel); `frac` is that one.
 """
 import argparse
@@ -223,6 +226,11 @@ def measure_roofline(engine, dtype, run_steps, nprof):
         per.append(row)
     per.sort(key=lambda d: -d["total_ms"])
     _native.check(lib.df3d_hg_profile(engine.h, 0))
+    # the whole hourglass step's HBM bytes as the counters saw them (every kernel of the step has a PMC figure, else None): BASELINE's
+    # "hourglass HBM GB/s vs peak" as MOVED bytes, beside the M1 convention of config.hourglass_gbs_m1_end_to_end
+    covered = sum(k["total_ms"] for k in per if k["bytes_pmc"]) / max(sum(k["total_ms"] for k in per), 1e-30)
+    step_pmc = sum(k["launches"] * k["bytes_pmc"] for k in per if k["bytes_pmc"]) / nprof if covered > 0.99 else None
+    step_min = sum(k["launches"] * k["bytes_min"] for k in per) / nprof
     dom = per[0]
     hbm_frac = dom["frac_hbm_pmc"] if dom["frac_hbm_pmc"] is not None else dom["frac_hbm_min"]
     hbm_bytes = dom["bytes_pmc"] if dom["frac_hbm_pmc"] is not None else dom["bytes_min"]
@@ -244,6 +252,9 @@ def measure_roofline(engine, dtype, run_steps, nprof):
         "traffic_kernel_source_sha": traffic_src,
         "traffic_is_current": (traffic_src == kernel_source_sha()) if traffic_src else None,
         "avg_launch_us": dom["avg_us"],
+        "step_hbm_bytes_pmc": step_pmc,   # per hourglass step (all kernels): counters; None unless traffic.json covers > 99 % of the step's kernel time
+        "step_hbm_bytes_min": step_min,   # ... and the least the step's launches can move (inputs once + outputs once per launch)
+        "step_kernel_ms": sum(k["total_ms"] for k in per) / nprof,
         "kernels": per,
     }
 
@@ -474,6 +485,7 @@ def hourglass_leg(a, sd, dtype, frames, calib, dev, total_frames, config_words):
     }
     if not a.no_roofline:
         leg["roofline"] = job.roofline(dtype)
+        add_step_hbm(leg, leg["roofline"], sec)
     if dtype == "f32s":   # the leg's price: what it differs by from the exact-fp32 engine, measured here on 2 frames of the run's own input
         x = frames[:2].reshape(14, 256, 512, 3).contiguous()
         exact = HourglassEngine(sd, dtype="f32", device=dev)
@@ -485,6 +497,15 @@ def hourglass_leg(a, sd, dtype, frames, calib, dev, total_frames, config_words):
         del exact
     del job, eng
     return leg
+
+
+def add_step_hbm(dst, roof, sec):
+    """BASELINE's second metric, "hourglass HBM GB/s vs peak", as bytes MOVED per step (rocprofv3 counters of profiles/traffic.json x this run's
+    launch counts) over this run's step time -- beside the M1 convention, which charges fused-away traffic."""
+    if roof.get("step_hbm_bytes_pmc"):
+        dst["hourglass_gbs_pmc_end_to_end"] = roof["step_hbm_bytes_pmc"] / sec / 1e9
+        dst["hourglass_frac_hbm_pmc_end_to_end"] = roof["step_hbm_bytes_pmc"] / sec / 1e9 / PEAK_HBM_GBS
+    dst["hourglass_gbs_min_end_to_end"] = roof["step_hbm_bytes_min"] / sec / 1e9
 
 
 def share_leg(a, sd, dtype, frames, calib, dev):
@@ -730,6 +751,8 @@ def main(argv=None):
         }
         if roof is not None:
             line["roofline"] = roof
+            if per_step == 1.0:
+                add_step_hbm(line["config"], roof, sec)
         line.update(legs)
         if not a.no_cpu_baseline and world == 1 and a.rank_share == 0 and not a.strong:
             try:

@@ -39,6 +39,11 @@ def test_default_line_has_every_leg_and_every_fraction(native_lib, cuda):
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f32" and d["unit"] == "frames/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert abs(d["value"] - 64 / (2 * d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "configs[1]" in d["config"]["workload"]
+    # BASELINE's second metric (hourglass HBM GB/s vs peak) by three byte models: least possible <= counted (when traffic.json covers the step) <= M1
+    c = d["config"]
+    assert 0 < c["hourglass_gbs_min_end_to_end"] < c["hourglass_gbs_m1_end_to_end"] and c["hourglass_frac_hbm_m1_end_to_end"] < 1.0
+    if "hourglass_gbs_pmc_end_to_end" in c:
+        assert 0.9 * c["hourglass_gbs_min_end_to_end"] < c["hourglass_gbs_pmc_end_to_end"] < 8000.0
     _check_roofline(d["roofline"], "f32")
     assert d["roofline"]["bound"] == "mfma" and "bottleneck_ring_f32_kernel" in d["roofline"]["kernel"]
     for key, dt in (("config1_f32_split", "f32s"), ("config2_bf16", "bf16"), ("config2_f16", "f16")):
