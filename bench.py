@@ -190,7 +190,7 @@ def cpu_baseline(state_dict, frames_cpu, calib, target_seconds):
     }
 
 
-def measure_roofline(engine, dtype, run_steps, nprof):
+def measure_roofline(engine, dtype, run_steps, nprof, default_size=True):
     """HIP events around every launch of each kernel class (same stream), over `nprof` steps; every kernel priced against
     both roofs with every byte model (module docstring), the dominant kernel's larger fraction is the line's `frac`."""
     import ctypes
@@ -229,7 +229,8 @@ def measure_roofline(engine, dtype, run_steps, nprof):
     # the whole hourglass step's HBM bytes as the counters saw them (every kernel of the step has a PMC figure, else None): BASELINE's
     # "hourglass HBM GB/s vs peak" as MOVED bytes, beside the M1 convention of config.hourglass_gbs_m1_end_to_end
     covered = sum(k["total_ms"] for k in per if k["bytes_pmc"]) / max(sum(k["total_ms"] for k in per), 1e-30)
-    step_pmc = sum(k["launches"] * k["bytes_pmc"] for k in per if k["bytes_pmc"]) / nprof if covered > 0.99 else None
+    # (traffic.json holds bytes per launch AT THE DEFAULT STEP SIZE, 128 frames: no step figure for other sizes)
+    step_pmc = sum(k["launches"] * k["bytes_pmc"] for k in per if k["bytes_pmc"]) / nprof if covered > 0.99 and default_size else None
     step_min = sum(k["launches"] * k["bytes_min"] for k in per) / nprof
     dom = per[0]
     hbm_frac = dom["frac_hbm_pmc"] if dom["frac_hbm_pmc"] is not None else dom["frac_hbm_min"]
@@ -445,7 +446,8 @@ class Job:
         return elapsed, gather_ok
 
     def roofline(self, dtype):
-        return measure_roofline(self.engine, dtype, lambda n: [self.step(i, record=False, solve=False) for i in range(n)], min(self.steps, 4))
+        return measure_roofline(self.engine, dtype, lambda n: [self.step(i, record=False, solve=False) for i in range(n)], min(self.steps, 4),
+                                default_size=self.fps_step == 128)
 
     def close(self):
         if self.ba_pool is not None:
