@@ -551,6 +551,18 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
                         xch[hc][c] = v;
                     }
             }
+            // float32: the skip values of this pass (4-byte pieces in the accumulators' layout: lane = channel, register = pixel) are requested
+            // NOW too -- round 5; they used to be requested in the epilogue, their latency exposed four times per workgroup
+            float xr4[EB == 4 ? NI : 1][16];
+            if constexpr (EB == 4) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        xr4[i][r] = m < p.M ? reinterpret_cast<const float*>(p.x)[(size_t)m * 256 + nh * CH + i * 32 + l31] : 0.0f;
+                    }
+            }
             loadC(nh, 0);
             storeC(0);
             __syncthreads();
@@ -605,17 +617,11 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs p) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int n = nh * CH + i * 32 + l31;
-                    const float bias = p.bfc_[n] + p.bsc_[n];
-                    float xr[16];
+                    const float bias = bout_lds[n];   // bfc_ + bsc_, staged once (the same float32 sum the two global loads gave)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        xr[r] = m < p.M ? reinterpret_cast<const float*>(p.x)[(size_t)m * 256 + n] : 0.0f;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const long long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (m < p.M) reinterpret_cast<float*>(p.out)[(size_t)m * 256 + n] = acc[i][r] + bias + xr[r];
+                        if (m < p.M) reinterpret_cast<float*>(p.out)[(size_t)m * 256 + n] = acc[i][r] + bias + xr4[i][r];
                     }
                 }
             } else {
