@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void bt_l1f_pack_kernel(const float* __restric
     *reinterpret_cast<u32x4*>(stream + (size_t)s * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(src);
 }
 
-// BtRingArgs: in = x [V, H, W, 64], t1in = [V, H, W, 64] (conv1's output), zeros, out = [V, H, W, 128], pool (optional) = [V, H/2, W/2, 128],
+// BtRingArgs: in = x [V, H, W, 64], t1in = [V, H, W, 64] (conv1's output), zeros, out = [V, H, W, 128] or nullptr (round 5: the engine's
+// plan asks for the pooled tensor only -- layer1's full-resolution output has no other reader), pool (optional) = [V, H/2, W/2, 128],
 // wstream, b2 [64], b3 [128], bd [128].
 template <typename T = float>   // float or F32S (split products)
 __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void layer1_tail_f32_kernel(BtRingArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            outp[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n] = acc[i][r];
+            if (p.out) outp[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n] = acc[i][r];   // (out == nullptr: pooled output only)
         }
         if (p.pool) {   // horizontal neighbour = register r ^ 1, vertical neighbour = r ^ 8
             float* const pp = reinterpret_cast<float*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;

@@ -326,6 +326,23 @@ struct df3d_hg {
                 st.wstream_c1 = (long long)stream_bytes;
                 stream_bytes += (size_t)(64 / 16) * BR_STAGE_BYTES;
                 st.t1 = new_tensor(tx.h, tx.w, planes);
+                if (want_pool && only_pool) {   // round 5: as the 16-bit layer1 kernel, the tail writes the pooled tensor only (the full-resolution
+                                                // output, 15 of the block's 37 GB per 896 views, has no other reader)
+                    st.pool_only = true;
+                    st.out = new_tensor(tx.h / 2, tx.w / 2, cout);
+                    const int virt = new_virtual_tensor(tx.h, tx.w, cout);
+                    pooled_of[virt] = st.out;
+                    elems_per_view += (double)tx.h * tx.w * cout * 1.25;  // model M1 still counts the pooling pass
+                    push_step(st);
+                    const double px = (double)tx.h * tx.w;
+                    account_conv(px, 1, cin, planes, false);
+                    account_conv(px, 9, planes, planes, false);
+                    account_conv(px, 1, cin, cout, false);
+                    account_conv(px, 1, planes, cout, true);
+                    m1_close();
+                    free_tensor(st.t1);
+                    return virt;
+                }
             }
             if (ring && split1 && !lp() && cin == 128 && planes == 128 && ds && x2 < 0 && a2 < 0 && !want_pool && tx.h % BT_TH == 0 && tx.w % BT_TW == 0) {
                 st.l2f = true;   // fp32 layer2, the same split form
@@ -936,13 +953,15 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                             DF3D_LAUNCH_CHECK();
                         }
                         BtRingArgs r{};
-                        r.in = a.in; r.out = a.out; r.pool = a.pool;
+                        r.in = a.in;
+                        r.out = st.pool_only ? nullptr : a.out;
+                        r.pool = st.pool_only ? a.out : a.pool;
                         r.t1in = c.t1;
                         r.zeros = sb + h->zero_off;
                         r.wstream = sb + st.wstream;
                         r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd;
                         r.V = n; r.H = ti.h; r.W = ti.w;
-                        ScopedTimer tm(h, s, std::string("layer1_tail_f32_kernel<") + tname + ">", 2.0 * px * (9.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl), px * 4.0 * (cin + pl + 2.0 * pl), st.m1_elems * n * eb);
+                        ScopedTimer tm(h, s, std::string("layer1_tail_f32_kernel<") + tname + ">", 2.0 * px * (9.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl), px * 4.0 * (cin + pl + (st.pool_only ? 0.5 * pl : 2.0 * pl)), st.m1_elems * n * eb);
                         static unsigned attr_t = 0;
                         if (first_use_on_this_device(attr_t))
                             DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer1_tail_f32_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, L1F_LDS_BYTES));

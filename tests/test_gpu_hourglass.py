@@ -47,6 +47,16 @@ def _rel_err(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
+def _pooled_like(got, other):
+    """layer1 in the default plans writes only the 2x2 max-pooled copy of its output (the full-resolution tensor has no other reader:
+    16-bit since round 2, the fp32 / f32s split form since round 5); a plan without that kernel writes the full tensor.  Bring `other`
+    (NHWC) to `got`'s resolution -- max-pooling is exact, so bit-identity survives it."""
+    if tuple(got.shape) == tuple(other.shape):
+        return other
+    assert got.shape[1] * 2 == other.shape[1] and got.shape[2] * 2 == other.shape[2], (got.shape, other.shape)
+    return torch.nn.functional.max_pool2d(other.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
+
+
 # f32s (round 5): the f32 engine's plan and float32 tensors with every product formed from two-way IEEE-half splits on the 16-bit matrix
 # pipe (include/df3d_hip.h DF3D_DTYPE_F32S) -- held to the SAME tolerance as the exact-fp32 engine, step by step.
 @pytest.mark.parametrize("dtype,fuse,row_bytes,fuse_upadd", [("f32", True, 0, True), ("f32", True, 0, False), ("f32", False, 0, False), ("f32", False, 64, False),
@@ -66,6 +76,8 @@ def test_fp32_every_step_matches_oracle(native_lib, cuda, oracle_net, images, tr
         eng._workspace(img.shape[0]).fill_(0xFF)   # NaN-poisoned workspace: a step reading memory this forward has not written shows it
         got = eng.forward_upto(img, k).cpu()
         ref = traced[name]
+        if name == "layer1.0.conv3" and fuse:   # the split-form layer1 tail writes only the pooled tensor (round 5)
+            ref = traced["maxpool"]
         assert tuple(got.shape) == tuple(ref.shape), (name, got.shape, ref.shape)
         err = _rel_err(got, ref)
         if err > worst[0]:
@@ -310,8 +322,9 @@ def test_weight_ring_bottleneck_is_bit_identical(native_lib, cuda, oracle_net, h
     index_off = {name: k for k, (name, _) in enumerate(steps_off, start=1)}
     assert set(name for name, _ in steps) <= set(index_off) and len(steps_off) - len(steps) in (0, 1)
     for k, (name, hwc) in enumerate(steps, start=1):
-        assert steps_off[index_off[name] - 1][1] == hwc
+        assert steps_off[index_off[name] - 1][1] == hwc or name == "layer1.0.conv3"   # (pooled-only output in the default fp32 / f32s plan)
         a, b = on.forward_upto(img, k), off.forward_upto(img, index_off[name])
+        b = _pooled_like(a, b)
         assert torch.equal(a, b), f"step {k} {name} differs: max |diff| {(a - b).abs().max().item():.3e}"
     assert torch.equal(on.forward(img), off.forward(img))
     # repeated launches are deterministic (no dependence on DMA timing)
@@ -344,6 +357,7 @@ def test_resident_weight_layer1_is_bit_identical(native_lib, cuda, oracle_net, h
     assert torch.equal(on.forward_upto(img, k1), pooled)
     for k in range(k1 + 1, len(names_on) + 1):
         a, b = on.forward_upto(img, k), off.forward_upto(img, k)
+        b = _pooled_like(a, b)
         assert torch.equal(a, b), f"step {k} {names_on[k - 1]} differs: max |diff| {(a - b).abs().max().item():.3e}"
     first = on.forward(img).clone()
     assert torch.equal(first, off.forward(img))
@@ -455,6 +469,7 @@ def test_direct_w2_fragments_are_bit_identical(native_lib, cuda, oracle_net, dty
     assert [s[0] for s in on.steps()] == [s[0] for s in off.steps()]
     for k in range(1, len(on.steps()) + 1):
         a, b = on.forward_upto(img, k), off.forward_upto(img, k)
+        b = _pooled_like(a, b)
         assert torch.equal(a, b), f"step {k} {on.steps()[k - 1][0]} differs: max |diff| {(a.float() - b.float()).abs().max().item():.3e}"
     first = on.forward(img).clone()
     assert torch.equal(first, off.forward(img))
@@ -478,6 +493,7 @@ def test_round4_ring_bottleneck_is_bit_identical_to_round3s(native_lib, cuda, or
     assert on.steps() == off.steps()
     for k in range(1, len(on.steps()) + 1):
         a, b = on.forward_upto(img, k), off.forward_upto(img, k)
+        b = _pooled_like(a, b)
         assert torch.equal(a, b), f"step {k} {on.steps()[k - 1][0]} differs: max |diff| {(a - b).abs().max().item():.3e}"
     first = on.forward(img).clone()
     assert torch.equal(first, off.forward(img))
@@ -506,6 +522,7 @@ def test_fp32_split_conv1_is_bit_identical(native_lib, cuda, oracle_net, height,
     assert [s[0] for s in on.steps()] == [s[0] for s in off.steps()]
     for k in range(1, len(on.steps()) + 1):
         a, b = on.forward_upto(img, k), off.forward_upto(img, k)
+        b = _pooled_like(a, b)
         assert torch.equal(a, b), f"step {k} {on.steps()[k - 1][0]} differs: max |diff| {(a - b).abs().max().item():.3e}"
     first = on.forward(img).clone()
     assert torch.equal(first, off.forward(img))
