@@ -120,6 +120,10 @@ struct df3d_hg {
     int ring2 = 1;        // 16-bit ring bottlenecks (with w2d): 1 (default) = round 4's form (hg_bt_ring.h MODE 2: phase 3 without DMA round trips on its
                           // path, streaming output stores); 0 = round 3's kernels (the A/B); bit-identical either way
     int split1 = 1;       // fp32: 1 (default) = plain 256 -> 128 -> 128 -> 256 blocks run as conv1 (every pixel once) + tail (hg_c1_f32.h), bit-identical
+                          // (development: 8 + mask splits only the identity blocks (1), layer1 (2), layer2 (4))
+    bool split_id() const { return split1 == 1 || (split1 >= 8 && (split1 & 1)); }
+    bool split_l1() const { return split1 == 1 || (split1 >= 8 && (split1 & 2)); }
+    bool split_l2() const { return split1 == 1 || (split1 >= 8 && (split1 & 4)); }
     bool uses_zero_page = false;
     size_t zero_off = 0;  // byte offset of 256 zero bytes behind the weight streams (split form: the 3x3 padding of the tail's LDS-DMA)
     int no_reuse = 0;     // 1 = the alias-free workspace plan: no tensor ever takes a released tensor's memory (tests: the default plan must match it bit for bit)
@@ -312,13 +316,13 @@ struct df3d_hg {
                     pooled_of[x] = st.pool_in;
                     elems_per_view += (double)tx.h * tx.w * cin * 1.25;  // model M1 still counts the pooling pass
                 }
-                if (split1 && !lp()) {   // fp32 split form: conv1 on every pixel once, the rest on tiles
+                if (split_id() && !lp()) {   // fp32 split form: conv1 on every pixel once, the rest on tiles
                     st.wstream_c1 = (long long)stream_bytes;
                     stream_bytes += (size_t)C1_NSTAGE * BR_STAGE_BYTES;
                     st.t1 = new_tensor(tx.h, tx.w, planes);
                 }
             }
-            if (ring && split1 && !lp() && cin == 64 && planes == 64 && ds && x2 < 0 && a2 < 0 && tx.h % BT_TH == 0 && tx.w % BT_TW == 0) {
+            if (ring && split_l1() && !lp() && cin == 64 && planes == 64 && ds && x2 < 0 && a2 < 0 && tx.h % BT_TH == 0 && tx.w % BT_TW == 0) {
                 // fp32 layer1 in the split form: conv1 on every pixel once, the rest on tiles (hg_l1_f32.h)
                 st.l1f = true;
                 st.wstream = (long long)stream_bytes;
@@ -344,7 +348,7 @@ struct df3d_hg {
                     return virt;
                 }
             }
-            if (ring && split1 && !lp() && cin == 128 && planes == 128 && ds && x2 < 0 && a2 < 0 && !want_pool && tx.h % BT_TH == 0 && tx.w % BT_TW == 0) {
+            if (ring && split_l2() && !lp() && cin == 128 && planes == 128 && ds && x2 < 0 && a2 < 0 && !want_pool && tx.h % BT_TH == 0 && tx.w % BT_TW == 0) {
                 st.l2f = true;   // fp32 layer2, the same split form
                 st.wstream = (long long)stream_bytes;
                 stream_bytes += (size_t)L2F_NSTAGE * BR_STAGE_BYTES;
@@ -1245,7 +1249,7 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
         return DF3D_OK;
     }
     if (!strcmp(key, "split1")) {
-        DF3D_CHECK_ARG(value == 0 || value == 1, "split1 must be 0 or 1");
+        DF3D_CHECK_ARG(value == 0 || value == 1 || (value >= 8 && value < 16), "split1 must be 0, 1 or 8 + a mask (1 identity blocks, 2 layer1, 4 layer2)");
         DF3D_CHECK_ARG(h->blob == nullptr, "set 'split1' before df3d_hg_set_weights (it changes the plan and the weight streams)");
         h->split1 = value;
         h->build();

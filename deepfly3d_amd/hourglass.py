@@ -229,7 +229,7 @@ class HourglassEngine:
         if split1 is None and os.environ.get("DF3D_SPLIT1"):
             split1 = int(os.environ["DF3D_SPLIT1"])
         if split1 is not None and fp32_storage:  # fp32: conv1 of the identity-skip bottlenecks as a launch of its own (csrc/hg_c1_f32.h), bit-identical
-            _native.check(self.lib.df3d_hg_set_option(self.h, b"split1", 1 if split1 else 0), "df3d_hg_set_option")
+            _native.check(self.lib.df3d_hg_set_option(self.h, b"split1", int(split1)), "df3d_hg_set_option")   # (0, 1, or 8 + mask: development)
         if w2d is None and os.environ.get("DF3D_W2D"):
             w2d = int(os.environ["DF3D_W2D"])
         if w2d is not None and not fp32_storage:  # 16-bit: the 3x3's weights of the ring bottlenecks as direct per-wave fragment loads (csrc/hg_bt_ring.h), bit-identical
