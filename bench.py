@@ -60,6 +60,7 @@ if ROOT not in sys.path:
 # operands, the lo x lo term dropped): its matrix-pipe roof in float32 FLOPs is the half-precision peak / 3
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "f32s": 2500.0 / 3}
 PEAK_HBM_GBS = 8000.0
+DTYPE_SHORT = {"f32": "fp32", "bf16": "bf16", "f16": "f16", "f32s": "fp32 with split-half products"}
 DTYPE_WORDS = {"f32": "fp32", "bf16": "bf16 (all convolutions on MFMA, fp32 accumulate)", "f16": "IEEE-half f16 (all convolutions on MFMA, fp32 accumulate)",
                "f32s": "fp32 tensors and weights, every product as a two-way IEEE-half split of both operands on the 16-bit matrix pipe (fp32 accumulate)"}
 
@@ -92,6 +93,14 @@ def parse(argv=None):
     ap.add_argument("--no-bf16-leg", "--no-legs", dest="no_legs", action="store_true",
                     help="skip the attached legs (configs[2] in bf16 and f16, the configs[4] share)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region rank 0 recomputes a strided sample of EVERY rank's frames on its own GPU (the peers' frame pools are "
+                         "seeded by rank, so rank 0 can regenerate them) and requires the gathered records to be bit-identical; the line then carries "
+                         "`verify`, `per_rank_frames_per_s`, `gather_ms`, `rccl_world`")
+    ap.add_argument("--full", action="store_true",
+                    help="print the whole record (per-kernel tables, legends, long workload texts: tens of KB) instead of the <= 4 KB line")
+    ap.add_argument("--tables", default=None,
+                    help="where the whole record goes beside the short line (default gpurun_out/bench_full_<dtype>.json; '-' = nowhere)")
     return ap.parse_args(argv)
 
 
@@ -260,6 +269,42 @@ def measure_roofline(engine, dtype, run_steps, nprof, default_size=True):
     }
 
 
+POOL_CHUNK = 64   # frames per generator call (bounded temporary memory); part of the pool's definition: `pool_frames_of` replays it
+
+
+def fill_pool(frames, seed_rank, dev):
+    """The resident frame pool of rank `seed_rank`: seeded uniform values, drawn POOL_CHUNK frames at a time."""
+    gen = torch.Generator(device=dev).manual_seed(seed_rank)
+    for i in range(0, frames.shape[0], POOL_CHUNK):
+        frames[i : i + POOL_CHUNK].uniform_(0.0, 1.0, generator=gen)
+
+
+def pool_frames_of(seed_rank, pool, wanted, dev):
+    """Frames `wanted` (sorted pool indices) of rank `seed_rank`'s pool, regenerated on `dev` by replaying that rank's generator calls
+    chunk by chunk (0.7 GB of temporary memory, not the peer's 11 GB pool)."""
+    gen = torch.Generator(device=dev).manual_seed(seed_rank)
+    out = torch.empty((len(wanted), 7, 256, 512, 3), dtype=torch.float32, device=dev)
+    tmp = torch.empty((POOL_CHUNK, 7, 256, 512, 3), dtype=torch.float32, device=dev)
+    last = max(wanted) if wanted else -1
+    for i in range(0, last + 1, POOL_CHUNK):
+        n = min(POOL_CHUNK, pool - i)
+        tmp[:n].uniform_(0.0, 1.0, generator=gen)
+        for k, w in enumerate(wanted):
+            if i <= w < i + n:
+                out[k] = tmp[w - i]
+    return out
+
+
+def verify_sample_plan(ranges, per_rank):
+    """[(rank, [local frame indices])]: first, last and evenly strided interior frames of every rank's non-empty range."""
+    plan = []
+    for r, (t0, t1) in enumerate(ranges):
+        n = t1 - t0
+        if n > 0:
+            plan.append((r, sorted({int(round(x)) for x in np.linspace(0, n - 1, min(per_rank, n))})))
+    return plan
+
+
 class Job:
     """One workload on one engine: frames streamed from the resident pool through the pipeline in steps, optional bundle
     adjustment per window on a worker thread, optional packed gather -- timed as the contract asks."""
@@ -410,17 +455,26 @@ class Job:
         if tl is not None:
             tl["ev0"] = torch.cuda.Event(enable_timing=True)
             tl["ev0"].record()
+        ev_a = ev_b = None
+        if self.a.verify and self.dev.type == "cuda":   # this rank's own batches on the GPU clock (no host synchronisation added)
+            ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev_a.record()
         for i in range(self.steps):
             if i * self.fps_step < self.total_frames:   # (strong scaling: a shorter shard has fewer batches)
                 self.step(i)
+        if ev_b is not None:
+            ev_b.record()
         marks = [time.perf_counter()]
         self.join_recalibrations()
         marks.append(time.perf_counter())
         gathered = self.gather()
         marks.append(time.perf_counter())
         self.aligned = self.sequence_tail(gathered)
-        torch.cuda.synchronize()
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
         marks.append(time.perf_counter())
+        self.gathered = gathered
+        self.own_steps_ms = ev_a.elapsed_time(ev_b) if ev_b is not None else 1e3 * (marks[0] - t_start)
         self.tail_ms = {"steps_enqueued": 1e3 * (marks[0] - t_start), "recalibrations_joined": 1e3 * (marks[1] - marks[0]),
                         "gather": 1e3 * (marks[2] - marks[1]), "procrustes_and_drain": 1e3 * (marks[3] - marks[2])}
         if self.world > 1:
@@ -444,6 +498,50 @@ class Job:
         if self.collective and self.rank == 0 and self.world == 1:  # the 1-rank collective must hand back exactly what went in
             gather_ok = all(torch.equal(g, o) for g, o in zip(gathered[:3], self.outs))
         return elapsed, gather_ok
+
+    def verify(self, ranges, per_rank=6):
+        """--verify, after the timed region.  Every rank reports the rate of its own batches; rank 0 then recomputes a strided sample of every
+        rank's frames on ITS device and compares with the gathered records bit for bit (tests/test_gpu_core.py:
+        test_batch_composition_does_not_change_results is why this must hold: a frame's record does not depend on the batch it ran in,
+        nor on the GPU it ran on).  Returns the line's fields on rank 0, None elsewhere."""
+        dist = torch.distributed
+        mine = torch.tensor([self.total_frames / max(self.own_steps_ms, 1e-9) * 1e3], dtype=torch.float64, device=self.dev)
+        rates = [mine.clone() for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(rates, mine)
+        if self.rank != 0:
+            return None
+        got = self.gathered[:3] if self.gathered is not None else self.outs
+        plan = verify_sample_plan(ranges, per_rank)
+        checked, bad = 0, []
+        for r, local in plan:
+            t0 = ranges[r][0]
+            outs = self.recompute(r, local, t0)
+            idx = torch.tensor([t0 + k for k in local], device=got[2].device)
+            same = (torch.equal(outs[0].to(got[0].device), got[0][:, idx]) and torch.equal(outs[1].to(got[1].device), got[1][:, idx])
+                    and torch.equal(outs[2].to(got[2].device), got[2][idx]))
+            checked += len(local)
+            if not same:
+                bad.append(r)
+        out = {"verify": {"frames_recomputed_on_rank0": checked, "ranks_sampled": len(plan), "bit_identical": not bad, "ranks_differing": bad},
+               "per_rank_frames_per_s": [float(x.item()) for x in rates], "gather_ms": self.tail_ms.get("gather"),
+               "rccl_world": dist.get_world_size() if dist.is_initialized() else 1}
+        if bad:
+            raise SystemExit(f"--verify: gathered records of rank(s) {bad} differ from rank 0's recomputation: {json.dumps(out)}")
+        return out
+
+    def recompute(self, r, local, t0):
+        """Rank `r`'s local frames `local` through THIS rank's pipeline, as one batch."""
+        outs = self.pipe.allocate_outputs(len(local))
+        self.pipe.run_batch(self.frames_of_rank(r, local), *outs, 0)
+        return outs
+
+    def frames_of_rank(self, r, local):
+        """The input frames rank `r` fed for its local frame indices `local` (frame f of a rank = its pool[f % pool])."""
+        want = sorted({k % self.pool for k in local})
+        got = pool_frames_of(r, self.pool, want, self.dev) if r != self.rank else self.frames[torch.tensor(want, device=self.dev)]
+        pos = {w: i for i, w in enumerate(want)}
+        return got[torch.tensor([pos[k % self.pool] for k in local], device=self.dev)]
 
     def roofline(self, dtype):
         return measure_roofline(self.engine, dtype, lambda n: [self.step(i, record=False, solve=False) for i in range(n)], min(self.steps, 4),
@@ -479,6 +577,7 @@ def hourglass_leg(a, sd, dtype, frames, calib, dev, total_frames, config_words):
     sec = elapsed / a.steps
     leg = {
         "workload": f"{config_words}: {total_frames} frames x 7 views of 256x512x3, 2-stack hourglass {DTYPE_WORDS[dtype]}, arg-max + 38-joint layout + fp64 DLT with fixed calib.pkl",
+        "workload_short": f"{config_words.split(' on ')[0]}: {total_frames} frames x 7 views, hourglass {DTYPE_SHORT[dtype]}",
         "value": total_frames / elapsed, "unit": "frames/s", "steps": a.steps, "ms_per_step": 1e3 * sec, "dtype": dtype,
         "hourglass_tflops_end_to_end": fl / sec / 1e12,
         "hourglass_frac_mfma_end_to_end": fl / sec / 1e12 / PEAK_TFLOPS[dtype],
@@ -527,6 +626,7 @@ def share_leg(a, sd, dtype, frames, calib, dev):
         "workload": f"BASELINE configs[4], a short share on one GPU: rank 0 of 8 ranks of a 16000-frame 7-view stream = {total} frames through the resident pool, "
                     f"2-stack hourglass {DTYPE_WORDS[dtype]}, arg-max + 38-joint layout + fp64 DLT, bundle-adjustment re-calibration every 1000 frames, "
                     "packed gather (frame records + window cameras) executed on a 1-rank RCCL group; the full 13 000-frame share: profiles/r03_rankshare_*.json",
+        "workload_short": f"BASELINE configs[4], rank 0 of 8 of a 16000-frame stream: {total} frames, hourglass {DTYPE_SHORT[dtype]}, BA every 1000 frames, gather on a 1-rank RCCL group",
         "value": total / elapsed, "unit": "frames/s", "dtype": dtype, "frames": total, "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
         "bundle_adjust_runs": len(job.ba_runs), "bundle_adjust_nfev": job.ba_runs, "bundle_adjust_wall_ms": job.ba_ms[-len(job.ba_runs):],
         "gather_roundtrip_exact": ok, "collective_backend": torch.distributed.get_backend(),
@@ -592,10 +692,24 @@ def dry_run(a):
     if a.ba_window and cams is None:
         cams = torch.zeros((0, 7, 12), dtype=torch.float64)
     num = global_frames if global_frames is not None else total * world
+    t_gather = time.perf_counter()
     got = dd.gather_results(*job.outs, num_frames=num, rank=rank, world_size=world, align=align, cameras=cams)
+    job.tail_ms = {"gather": 1e3 * (time.perf_counter() - t_gather)}
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t_start
+    verified = None
+    if a.verify:   # the real run's Job.verify, with the stub recomputing a peer's frames (it stamps global frame indices)
+        ranges = [(c, b) for c, b, _ in shards] if shards else [(r * total, (r + 1) * total) for r in range(world)]
+
+        def recompute(r, local, first):
+            outs = job.pipe.allocate_outputs(len(local))
+            for k, f in enumerate(local):
+                _StubPipeline(first + f - k).run_batch(job.frames[:1], *outs, k)
+            return outs
+
+        job.recompute, job.gathered, job.own_steps_ms = recompute, got, 1e3 * (t_gather - t_start)
+        verified = job.verify(ranges)
     if rank == 0:
         p2, cf, p3 = got[:3]
         seq = torch.arange(num, dtype=torch.float64)
@@ -605,10 +719,68 @@ def dry_run(a):
         print(json.dumps({"metric": "frames/sec (7-view 2D->3D)", "dry_run": True, "value": num / elapsed, "unit": "frames/s (CPU stub: control flow only)", "n_gpus": world,
                           "steps": a.steps, "scaling": "strong" if a.strong else "weak", "frames_per_gpu": [b - c for c, b, _ in shards] if shards else total,
                           "collective_backend": torch.distributed.get_backend() if world > 1 else None, "gather_check": ok,
-                          "windows_gathered": int(got[3].shape[0]) if a.ba_window else None}), flush=True)
+                          "windows_gathered": int(got[3].shape[0]) if a.ba_window else None, **(verified or {})}), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def _sig(x, digits=7):
+    """Floats to `digits` significant digits, recursively: the line is read by people and by a driver with a size limit."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+_ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_is", "fractions", "traffic", "traffic_is_current", "avg_launch_us",
+              "step_hbm_bytes_pmc", "step_hbm_bytes_min", "step_kernel_ms", "executed", "direct_equivalent_tflops")
+_LEG_ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us")
+
+
+def short_line(full):
+    """The ONE stdout line, <= 4 KB (tests/test_gpu_bench.py asserts the size): the headline, `config` with a one-sentence workload, `roofline`
+    without the per-kernel table, every leg as its rate + its dominant kernel's roofline + its one-off fields, `cpu_baseline`.  Everything
+    dropped here is in the side file the line names (`tables`)."""
+    out = {}
+    for k, v in full.items():
+        if k == "roofline":
+            out[k] = {q: v[q] for q in _ROOF_KEEP if q in v}
+        elif k == "config":
+            out[k] = {q: w for q, w in v.items() if w is not None and q != "hbm_m1_note"}
+            out[k]["workload"] = out[k].pop("workload_short", v["workload"][:200])
+        elif isinstance(v, dict) and "value" in v and k != "cpu_baseline":   # an attached leg
+            leg = {q: w for q, w in v.items() if q not in ("roofline", "workload", "workload_short", "unit") and not q.startswith("hourglass_")}
+            leg["workload"] = v.get("workload_short", v["workload"][:100])
+            if "roofline" in v:
+                leg["roofline"] = {q: v["roofline"][q] for q in _LEG_ROOF_KEEP}
+            for q in ("hourglass_frac_mfma_end_to_end", "hourglass_frac_hbm_m1_end_to_end", "hourglass_frac_hbm_pmc_end_to_end"):
+                if q in v:
+                    leg[q] = v[q]
+            out[k] = leg
+        else:
+            out[k] = v
+    return _sig(out)
+
+
+def emit(full, a):
+    """Rank 0's output: the whole record to the side file, the short line (or, with --full, the whole record) as the one stdout line."""
+    path = a.tables
+    if path is None:
+        path = os.path.join(ROOT, "gpurun_out", f"bench_full_{full['dtype']}.json")
+    if path != "-":
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(full, f)
+                f.write("\n")
+            full["tables"] = os.path.relpath(path, ROOT)
+        except OSError as e:   # a read-only tree: the line still goes out
+            full["tables"] = f"not written: {e!r}"
+    print(json.dumps(full if a.full else short_line(full)), flush=True)
 
 
 def strong_plan(stream_frames, world, align, frames_per_step):
@@ -667,13 +839,16 @@ def main(argv=None):
 
     pool = a.pool_frames or min(max(a.steps, 1) * fps_step, 1024)
     pool = max(fps_step, (pool // fps_step) * fps_step)
-    gen = torch.Generator(device=dev).manual_seed(rank)
     frames = torch.empty((pool, 7, 256, 512, 3), dtype=torch.float32, device=dev)
-    for i in range(0, pool, 64):  # bounded temporary memory
-        frames[i : i + 64].uniform_(0.0, 1.0, generator=gen)
+    fill_pool(frames, rank, dev)
 
     job = Job(a, engine, frames, calib, dev, rank, world, total_frames, a.steps, a.ba_window, collective, a.force_collective, global_frames)
     elapsed, gather_ok = job.run(a.warmup)
+
+    verified = None
+    if a.verify:
+        ranges = [(t0, t1) for t0, t1, _ in shards] if a.strong else [(r * total_frames, (r + 1) * total_frames) for r in range(world)]
+        verified = job.verify(ranges)
 
     roof = None
     if not a.no_roofline and rank == 0:
@@ -715,6 +890,11 @@ def main(argv=None):
         else:
             workload = (f"BASELINE configs[{1 if a.dtype in ('f32', 'f32s') else 2}]: {total_frames} frames x 7 views of 256x512x3 per GPU, 2-stack hourglass {words}, "
                         "arg-max + 38-joint layout + fp64 DLT with fixed calib.pkl")
+        cfg_no = (4 if a.ba_window else 3) if (a.strong or a.rank_share or a.ba_window) else (1 if a.dtype in ("f32", "f32s") else 2)
+        short = (f"BASELINE configs[{cfg_no}]" + (", strong-scaled" if a.strong else f", rank 0 of {a.rank_share}" if a.rank_share else "")
+                 + f": {a.stream_frames if a.strong else total_frames} frames x 7 views 256x512x3" + ("" if a.strong else " per GPU")
+                 + f", 2-stack hourglass {DTYPE_SHORT[a.dtype]}, arg-max + 38-joint layout + fp64 DLT"
+                 + (f", BA every {a.ba_window}" if a.ba_window else "") + (", one packed gather + Procrustes on rank 0" if a.strong else ""))
         sec = ms_step * 1e-3
         line = {
             "metric": "frames/sec (7-view 2D->3D)",
@@ -729,9 +909,10 @@ def main(argv=None):
             "scaling": "strong" if a.strong else "weak",
             "vs_baseline": None,
             "dtype": a.dtype,
-            "data": "synthetic (seeded uniform frames resident in HBM, seeded synthetic hourglass weights, data/calib.pkl cameras)",
+            "data": "synthetic (seeded frames resident in HBM, seeded hourglass weights, data/calib.pkl cameras)",
             "config": {
                 "workload": workload,
+                "workload_short": short,
                 "frames_per_step": fps_step,
                 "frames_per_gpu": total_frames if not a.strong else [t1 - t0 for t0, t1, _ in shards],
                 "stream_frames": a.stream_frames if a.strong else None,
@@ -751,6 +932,8 @@ def main(argv=None):
                 "hbm_m1_note": "hourglass activation bytes of the fusion model M1 (SURVEY.md 8d: a convention, above what the fused kernels move) / step time / 8 TB/s",
             },
         }
+        if verified is not None:
+            line.update(verified)
         if roof is not None:
             line["roofline"] = roof
             if per_step == 1.0:
@@ -761,7 +944,7 @@ def main(argv=None):
                 line["cpu_baseline"] = cpu_baseline(sd, frames[:16].cpu(), calib, a.cpu_seconds)
             except Exception as e:  # the baseline is reporting only; never hide the GPU number
                 line["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(line), flush=True)
+        emit(line, a)
     job.close()
     if torch.distributed.is_initialized():
         if world > 1:

@@ -17,10 +17,10 @@ for lib in default ${LIBS:-}; do
 XX
     *) export DF3D_LIB=$R/$lib;;
   esac
-  env $envs python $R/bench.py --dtype $DT --steps 3 --warmup 1 --no-cpu-baseline --no-legs > $OUT/bench_$tag.log 2>&1
+  env $envs python $R/bench.py --dtype $DT --steps 3 --warmup 1 --full --no-cpu-baseline --no-legs > $OUT/bench_$tag.log 2>&1
   rm -rf $OUT/f_$tag $OUT/w_$tag
-  env $envs rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f_$tag -o pmc -- python $R/bench.py --dtype $DT --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-legs > /dev/null 2>&1
-  env $envs rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w_$tag -o pmc -- python $R/bench.py --dtype $DT --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-legs > /dev/null 2>&1
+  env $envs rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f_$tag -o pmc -- python $R/bench.py --dtype $DT --steps 1 --warmup 1 --full --no-cpu-baseline --no-roofline --no-legs > /dev/null 2>&1
+  env $envs rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w_$tag -o pmc -- python $R/bench.py --dtype $DT --steps 1 --warmup 1 --full --no-cpu-baseline --no-roofline --no-legs > /dev/null 2>&1
   find $OUT/f_$tag $OUT/w_$tag -name "*kernel_trace.csv" -delete
   python - <<PY
 import csv, glob, json, collections, re

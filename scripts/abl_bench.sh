@@ -10,7 +10,7 @@ for lib in default ${LIBS:-}; do
     *=*) unset DF3D_LIB; envs=$lib;;   # VAR=VALUE: the default library with that environment (e.g. DF3D_RING2=0)
     *) export DF3D_LIB=$R/$lib;;
   esac
-  env $envs python bench.py --dtype ${DT:-f16} --steps 2 --warmup 1 --no-cpu-baseline --no-legs 2>/dev/null | python -c "
+  env $envs python bench.py --dtype ${DT:-f16} --steps 2 --warmup 1 --full --no-cpu-baseline --no-legs 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

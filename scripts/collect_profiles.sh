@@ -13,8 +13,11 @@ for dt in f32 bf16 f16 f32s; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${dt}_write" -o pmc -- python "$R/bench.py" --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-bf16-leg > /dev/null 2>&1
   find "$OUT" -name "*kernel_trace.csv" -delete
 done
-python "$R/bench.py" > "$OUT/f32_bench.log" 2>&1
-python "$R/bench.py" --dtype bf16 --no-cpu-baseline > "$OUT/bf16_bench.log" 2>&1
-python "$R/bench.py" --dtype f16 --no-cpu-baseline > "$OUT/f16_bench.log" 2>&1
-python "$R/bench.py" --dtype f32s --no-cpu-baseline > "$OUT/f32s_bench.log" 2>&1
+# profiles/traffic.json from THIS collection first (round 5 wrote the kept lines before it: every one said traffic_is_current false)
+python "$R/scripts/summarize_round.py" $TAG --traffic-only > "$OUT/traffic_summary.log" 2>&1
+cd "$R"
+python bench.py --tables "$OUT/f32_bench_full.json" > "$OUT/f32_bench.log" 2>&1
+python bench.py --dtype bf16 --no-cpu-baseline --tables "$OUT/bf16_bench_full.json" > "$OUT/bf16_bench.log" 2>&1
+python bench.py --dtype f16 --no-cpu-baseline --tables "$OUT/f16_bench_full.json" > "$OUT/f16_bench.log" 2>&1
+python bench.py --dtype f32s --no-cpu-baseline --tables "$OUT/f32s_bench_full.json" > "$OUT/f32s_bench.log" 2>&1
 du -sh "$OUT"

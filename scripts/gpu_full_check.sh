@@ -20,7 +20,9 @@ python - <<PY
 import json
 l=[x for x in open("$OUT/bench_default.log") if x.startswith("{")]
 if l:
+    print("stdout JSON lines:", len(l), "bytes of the line:", len(l[-1].encode()))
     d=json.loads(l[-1])
+    d=json.load(open("$R/"+d["tables"]))   # the whole record beside the short line
     print("f32 frames/s", round(d["value"],1), "ms/step", round(d["ms_per_step"],2), "settle", d.get("warmup_settle"), "frac", round(d["roofline"]["frac"],4))
     for k in ("config1_f32_split","config2_bf16","config2_f16","config4_share"):
         if k in d: print(k, round(d[k].get("value",0),1), d[k].get("error",""))

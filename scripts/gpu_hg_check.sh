@@ -8,7 +8,7 @@ cd "$R"
 timeout 1200 python -m pytest ${TESTS:-tests/test_gpu_hourglass.py} -m gpu -q -s ${K:+-k "$K"} > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest.log"
 grep -E "peaked|worst|rel err|passed|failed|FAILED|rc=" "$OUT/pytest.log" | tail -40
 for dt in ${DTYPES:-}; do
-timeout 400 python bench.py --dtype $dt --no-cpu-baseline --no-bf16-leg > "$OUT/bench_$dt.log" 2>&1
+timeout 400 python bench.py --dtype $dt --full --no-cpu-baseline --no-bf16-leg > "$OUT/bench_$dt.log" 2>&1
 python - <<PY
 import json
 l=[x for x in open("$OUT/bench_$dt.log") if x.startswith("{")]

@@ -7,7 +7,7 @@ cd "$R"
 timeout 600 python -m pytest tests/test_gpu_hourglass.py -m gpu -x -q -k "${K:-layer1}" > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest.log"
 tail -15 "$OUT/pytest.log"
 for dt in ${DTYPES:-bf16}; do
-timeout 400 python bench.py --dtype $dt --no-cpu-baseline --no-bf16-leg > "$OUT/bench_$dt.log" 2>&1
+timeout 400 python bench.py --dtype $dt --full --no-cpu-baseline --no-bf16-leg > "$OUT/bench_$dt.log" 2>&1
 python - <<PY
 import json
 l=[x for x in open("$OUT/bench_$dt.log") if x.startswith("{")]

@@ -9,7 +9,7 @@ if [ -n "${K:-}" ]; then
 timeout 900 python -m pytest ${TESTS:-tests/test_gpu_hourglass.py} -m gpu -x -q -k "$K" > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest.log"; tail -5 "$OUT/pytest.log"
 fi
 for dt in ${DTYPES:-f16}; do
-timeout 400 python bench.py --dtype $dt --no-cpu-baseline --no-legs > "$OUT/bench_$dt.log" 2>&1
+timeout 400 python bench.py --dtype $dt --full --no-cpu-baseline --no-legs > "$OUT/bench_$dt.log" 2>&1
 python - <<PY
 import json
 l=[x for x in open("$OUT/bench_$dt.log") if x.startswith("{")]

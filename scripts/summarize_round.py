@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    traffic_only = "--traffic-only" in sys.argv[2:]   # collect_profiles.sh, ON the GPU box: profiles/traffic.json first, the kept bench lines after it
     src = os.path.join(ROOT, "gpurun_out", tag)
     cnt = os.path.join(ROOT, "gpurun_out", tag + "_counters")
     tj = os.path.join(ROOT, "profiles", "traffic.json")
@@ -31,12 +32,17 @@ def main():
         groups = sorted(glob.glob(os.path.join(cnt, f"{dt}_g[0-9]")))
         if groups:
             subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "summarize_counters.py"), f"{tag}_{dt}", *groups], check=True, stdout=subprocess.DEVNULL)
+    if traffic_only:
+        return
     for log in sorted(glob.glob(os.path.join(src, "*_bench.log")) + glob.glob(os.path.join(src, "rankshare_*.log"))):
         rows = [ln for ln in open(log) if ln.startswith("{")]
         if not rows:
             print("no JSON line in", log)
             continue
         d = json.loads(rows[-1])
+        full = os.path.join(src, os.path.basename(log)[: -len(".log")] + "_full.json")   # the whole record (per-kernel tables) beside the short line
+        if os.path.exists(full):
+            d = json.load(open(full))
         base = os.path.basename(log)[: -len(".log")]
         name = f"{tag}_{base}.json" if base.endswith("_bench") else f"{tag}_{base.split('_cfg')[0]}.json"
         with open(os.path.join(ROOT, "profiles", name), "w") as f:

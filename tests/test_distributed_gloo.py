@@ -283,7 +283,7 @@ def test_bench_eight_rank_dry_run_of_the_strong_scaled_stream():
     import subprocess
 
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--strong", "--stream-frames", "100000", "--ba-window", "1000", "--dry-run"],
+                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--strong", "--stream-frames", "100000", "--ba-window", "1000", "--dry-run", "--verify"],
                        cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -292,3 +292,33 @@ def test_bench_eight_rank_dry_run_of_the_strong_scaled_stream():
     assert d["dry_run"] is True and d["n_gpus"] == 8 and d["scaling"] == "strong" and d["steps"] == 102
     assert d["frames_per_gpu"] == [13000] * 4 + [12000] * 4 and d["collective_backend"] == "gloo"
     assert d["gather_check"] is True and d["windows_gathered"] == 100
+    # --verify: rank 0 recomputed a strided sample of EVERY rank's frames and found the gathered records bit-identical; per-rank rates, gather time
+    v = d["verify"]
+    assert v["bit_identical"] is True and v["ranks_sampled"] == 8 and v["frames_recomputed_on_rank0"] == 48 and v["ranks_differing"] == []
+    assert len(d["per_rank_frames_per_s"]) == 8 and all(x > 0 for x in d["per_rank_frames_per_s"]) and d["gather_ms"] > 0 and d["rccl_world"] == 8
+
+
+def test_verify_sample_plan_and_pool_replay():
+    """bench.py --verify's pure pieces: the sample covers first / last / interior frames of every non-empty range, and a peer's frame pool
+    regenerated chunk by chunk equals the pool that peer filled (CPU generator here; the GPU run uses the same code on `cuda`)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    plan = b.verify_sample_plan([(0, 13000), (13000, 13000), (13000, 13003), (13003, 13004)], 6)
+    assert [r for r, _ in plan] == [0, 2, 3]
+    assert plan[0][1][0] == 0 and plan[0][1][-1] == 12999 and len(plan[0][1]) == 6 and plan[1][1] == [0, 1, 2] and plan[2][1] == [0]
+    old = b.POOL_CHUNK
+    try:
+        b.POOL_CHUNK = 3
+        import torch
+
+        dev = torch.device("cpu")
+        pool = torch.empty((8, 7, 256, 512, 3))
+        b.fill_pool(pool, 5, dev)
+        got = b.pool_frames_of(5, 8, [0, 4, 7], dev)
+        assert torch.equal(got, pool[[0, 4, 7]])
+        assert not torch.equal(b.pool_frames_of(4, 8, [0], dev)[0], pool[0])   # another rank's seed: other frames
+    finally:
+        b.POOL_CHUNK = old
