@@ -225,7 +225,7 @@ def measure_roofline(engine, dtype, run_steps, nprof, default_size=True):
             continue
         name = buf.value.decode()
         sec = 1e-3 * ms.value / n.value   # average launch
-        pmc = traffic.get(name)
+        pmc = traffic.get(name) if default_size else None   # (traffic.json holds bytes per launch AT THE DEFAULT STEP SIZE, 128 frames)
         row = {"kernel": name, "launches": n.value, "avg_us": 1e6 * sec, "total_ms": ms.value, "tflops": fl.value / n.value / sec / 1e12,
                "bytes_min": by.value / n.value, "bytes_m1": m1.value / n.value, "bytes_pmc": pmc}
         row["frac_mfma"] = row["tflops"] / PEAK_TFLOPS[dtype]
@@ -725,7 +725,7 @@ def dry_run(a):
         torch.distributed.destroy_process_group()
 
 
-def _sig(x, digits=7):
+def _sig(x, digits=6):
     """Floats to `digits` significant digits, recursively: the line is read by people and by a driver with a size limit."""
     if isinstance(x, float):
         return float(f"{x:.{digits}g}")
@@ -737,7 +737,7 @@ def _sig(x, digits=7):
 
 
 _ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_is", "fractions", "traffic", "traffic_is_current", "avg_launch_us",
-              "step_hbm_bytes_pmc", "step_hbm_bytes_min", "step_kernel_ms", "executed", "direct_equivalent_tflops")
+              "step_hbm_bytes_pmc", "step_kernel_ms", "executed_tflops", "direct_equivalent_tflops")
 _LEG_ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us")
 
 
@@ -750,14 +750,14 @@ def short_line(full):
         if k == "roofline":
             out[k] = {q: v[q] for q in _ROOF_KEEP if q in v}
         elif k == "config":
-            out[k] = {q: w for q, w in v.items() if w is not None and q != "hbm_m1_note"}
+            out[k] = {q: w for q, w in v.items() if w is not None and q not in ("hbm_m1_note", "hourglass_gbs_min_end_to_end", "hourglass_tflops_end_to_end")}
             out[k]["workload"] = out[k].pop("workload_short", v["workload"][:200])
         elif isinstance(v, dict) and "value" in v and k != "cpu_baseline":   # an attached leg
             leg = {q: w for q, w in v.items() if q not in ("roofline", "workload", "workload_short", "unit") and not q.startswith("hourglass_")}
             leg["workload"] = v.get("workload_short", v["workload"][:100])
             if "roofline" in v:
                 leg["roofline"] = {q: v["roofline"][q] for q in _LEG_ROOF_KEEP}
-            for q in ("hourglass_frac_mfma_end_to_end", "hourglass_frac_hbm_m1_end_to_end", "hourglass_frac_hbm_pmc_end_to_end"):
+            for q in ("hourglass_frac_mfma_end_to_end", "hourglass_frac_hbm_pmc_end_to_end"):
                 if q in v:
                     leg[q] = v[q]
             out[k] = leg
