@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char, c_char_p, c_double, c_float, c_in
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DF3D_LIB") or os.path.join(_HERE, "libdf3d_hip.so")  # DF3D_LIB: developer override (kernel A/B builds)
 
-ABI_VERSION = 500
+ABI_VERSION = 600
 LSMR_AUTO, LSMR_BARRIERS, LSMR_LAUNCHES, LSMR_LOCAL, LSMR_ELEVEN = 0, 1, 2, 3, 11   # DF3D_LSMR_* of include/df3d_hip.h  # DF3D_ABI_VERSION of include/df3d_hip.h: the revision these prototypes were written against
 DF3D_EINVAL = -1  # include/df3d_hip.h
 DF3D_ENOSPC = -5
@@ -114,6 +114,7 @@ PROTOTYPES = {
     "df3d_hg_profile": (c_int, [c_void_p, c_int]),
     "df3d_hg_profile_count": (c_int, [c_void_p]),
     "df3d_hg_profile_read": (c_int, [c_void_p, c_int, c_char_p, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_int)]),
+    "df3d_hg_profile_executed_flops": (c_int, [c_void_p, c_int, POINTER(c_double)]),
     "df3d_hg_step_m1_bytes": (c_double, [c_void_p, c_int, c_int]),
     "df3d_hg_num_steps": (c_int, [c_void_p]),
     "df3d_render_pose2d_grid": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, POINTER(c_int), c_int, POINTER(ctypes.c_ubyte), c_double, c_double, c_void_p, c_void_p]),

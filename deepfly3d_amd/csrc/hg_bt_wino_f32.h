@@ -1,0 +1,398 @@
+// fp32 identity-skip bottleneck tail (3x3 -> 1x1 -> + x) with the 3x3 convolution as WINOGRAD F(2x2, 3x3) on the exact-fp32 MFMA
+// (round 6).  The exact-fp32 engine sits at the matrix pipe's roof (0.88 of 157.3 TFLOP/s, hg_bt_ring_f32.h), so the only way left to make
+// it faster is to issue fewer MFMAs: 82 % of the tail's MFMAs are the 3x3 done as direct implicit GEMM (9 taps x 128 x 128 per pixel);
+// Winograd does a 2x2 output patch with 16 instead of 36 multiplies per (cin, cout) pair -- the tail's MFMA count falls to 0.545.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        d: 4x4 input patch of t1 (per channel), g: 3x3 weights (per cin, cout), Y: 2x2 outputs
+//
+// summed over the 128 input channels INSIDE the transformed domain: 16 "positions" p = 4 i + j, each a plain GEMM
+//   M_p [128 cout x 32 patches] = U_p [128 cout x 128 cin] . V_p [128 cin x 32 patches]
+// over the 32 patches (4 x 8) of an 8 x 16 output tile.  U = G g G^T is transformed once at df3d_hg_set_weights (fp64, rounded once:
+// bt_wino_pack_kernel), V = B^T d B costs adds only, Y = A^T M A costs adds only.
+//
+// Mapping (one workgroup = one 8 x 16 tile as before, but ONE wave per SIMD: a wave holds 16 positions x 16 accumulator registers = 256):
+//   * wave w owns output channels 32 w .. 32 w + 31 for all 32 patches and all 16 positions: its output transform is in-lane;
+//   * K is walked in 16 chunks of 8 input channels.  Per chunk the four waves build V (16 positions x 8 channels x 32 patches = 16 KB,
+//     double-buffered in LDS) from the t1 halo tile -- every wave a quarter, one channel of one patch per lane: 16 ds_read_b32, 32 adds,
+//     16 ds_write_b32, under the MFMAs of the chunk before -- and each wave then runs 16 x 4 MFMAs: B = V_p (one ds_read_b128), A = its own
+//     1 KB fragment of U_p straight from global memory (L2-resident, 1 MB per bottleneck, prefetched one chunk = 16 fragments ahead:
+//     nothing is shared between waves on the weight side, so no LDS ring and no barrier for it);  ONE barrier per chunk (4 096 MFMA cycles);
+//   * t2 = relu(Y + b2) (b2 is the start value of position (1,1), which enters all four outputs with weight +1) crosses to the
+//     pixel-major mapping of phase 3 through LDS (64 KB in the dead t1 region), and phase 3 is hg_bt_ring_f32.h's, unchanged:
+//     W3 through the 4-slot LDS-DMA ring (which takes the dead V buffers' place), residual add, ADD2 / UP / pooled outputs.
+//
+// LDS: V / ring 32 KB | t1 halo tile 90 KB (both 64-channel halves; t2 later) | b3 1 KB = 125 952 B: one workgroup per CU.
+// Not bit-identical to the direct form (different products): the engine option `wino` selects it, the tests hold it to the
+// fp32 tolerance against the torch oracle on every plan step, and `wino=0` keeps the direct kernels as the bit-identity reference.
+#pragma once
+#include "hg_bt_ring_f32.h"
+
+namespace hgk {
+
+constexpr int WN_CHUNKS = 16;                          // K chunks of 8 input channels
+constexpr int WN_U_BYTES = WN_CHUNKS * 16 * 4 * 1024;  // [chunk][pass][row group][wave] x 1 KB MFMA A fragments = 1 MiB per bottleneck
+constexpr int WN_V_BYTES = 16 * 1024;                  // one V chunk: [channel 4][row group 4][channel quad 2][patch 32] x 16 bytes
+constexpr int WN_T1_OFF = 2 * WN_V_BYTES;              // = BR_RING_BYTES: the W3 ring reuses the V buffers
+constexpr int WN_T1_BYTES = 2 * BR_T1_BYTES;           // both 64-channel halves of the 10 x 18 halo tile (92 160)
+constexpr int WN_T2_BYTES = BT_TH * BT_TW * 512;       // t2 [128 pixels][128 channels] fp32 (65 536), inside the t1 region
+constexpr int WN_B3_OFF = WN_T1_OFF + WN_T1_BYTES;
+constexpr int WN_LDS_BYTES = WN_B3_OFF + 1024;
+static_assert(WN_T1_OFF == BR_RING_BYTES, "the W3 ring takes the V buffers' place");
+static_assert(WN_T2_BYTES <= WN_T1_BYTES, "t2 lives in the t1 region");
+
+// W2' [9][128 cout][128 cin] fp32 (bn3 folded) -> U stream.  One thread per (cout, cin): G g G^T in fp64, each value rounded once.
+// Fragment (chunk c, pass e, row group g, wave w): lane (l31, half) holds U_{4 g + j}[32 w + l31][8 c + 4 half + e], j = 0..3 (pass e of a chunk
+// multiplies the K pair (8 c + e, 8 c + 4 + e) at all 16 positions: the same pairing the V fragments are read with).
+__global__ __launch_bounds__(256) void bt_wino_pack_kernel(const float* __restrict__ w2, float* __restrict__ ustream) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 128 * 128) return;
+    const int co = idx >> 7, ci = idx & 127;
+    double g[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = (double)w2[((size_t)(ky * 3 + kx) * 128 + co) * 128 + ci];
+    double t[4][3];   // G g
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        t[0][kx] = g[0][kx];
+        t[1][kx] = 0.5 * (g[0][kx] + g[1][kx] + g[2][kx]);
+        t[2][kx] = 0.5 * (g[0][kx] - g[1][kx] + g[2][kx]);
+        t[3][kx] = g[2][kx];
+    }
+    const int c = ci >> 3, half = (ci >> 2) & 1, e = ci & 3, w = co >> 5, l31 = co & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double u[4] = {t[i][0], 0.5 * (t[i][0] + t[i][1] + t[i][2]), 0.5 * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};   // (G g) G^T
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            ustream[((size_t)(((c * 4 + e) * 4 + i) * 4 + w) * 64 + half * 32 + l31) * 4 + j] = (float)u[j];
+    }
+}
+
+template <bool UP, bool ADD2 = false>
+__global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs p) {
+    static_assert(!(UP && ADD2), "the fused up-path sum is written by plain blocks");
+    using T = float;
+    constexpr int CIN = 256, CO = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const ring = smem;                      // phase 3 (the V double buffer until then)
+    unsigned char* const t1_lds = smem + WN_T1_OFF;
+    float* const b3_lds = reinterpret_cast<float*>(smem + WN_B3_OFF);
+    const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
+    const unsigned t1_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)t1_lds;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tiles_x = p.W / BT_TW, tiles_y = p.H / BT_TH;
+    int b;   // XCD-aware tile order, as in bottleneck_ring_f32_kernel
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int tx0 = (b % tiles_x) * BT_TW;
+    b /= tiles_x;
+    const int ty0 = (b % tiles_y) * BT_TH;
+    const int view = b / tiles_y;
+    const unsigned char* const xin = reinterpret_cast<const unsigned char*>(p.in) + (size_t)view * p.H * p.W * CIN * 4;
+    const unsigned char* const xin2 = UP ? reinterpret_cast<const unsigned char*>(p.in2) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN * 4 : nullptr;
+
+    // ---- the t1 halo tile by LDS-DMA, both halves at once (hg_bt_ring_f32.h t1_issue; half kh at t1 + kh * BR_T1_BYTES) -------------
+    {
+        const unsigned char* const tin = reinterpret_cast<const unsigned char*>(p.t1in) + (size_t)view * p.H * p.W * 512;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int pc = wave + 4 * k;
+                if (pc < BT_HALO / 4) {
+                    const int hp = 4 * pc + (lane >> 4);
+                    const int hy = hp / BT_HW, hx = hp % BT_HW;
+                    const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+                    const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                    const unsigned chunk = (unsigned)((lane & 15) ^ br_t1_swz(hp));
+                    const unsigned char* const src = ok ? tin + ((size_t)y * p.W + x) * 512 + kh * 256 + chunk * 16 : reinterpret_cast<const unsigned char*>(p.zeros) + chunk * 16;
+                    br_glds_piece64(src, t1_addr + (unsigned)(kh * BR_T1_BYTES + pc * 1024));
+                }
+            }
+    }
+    // ---- U fragments straight from global memory (L2) into the MFMA A registers: fragment (chunk c, pass e, row group g) is 1 KB per wave,
+    //      lane (l31, half) -> U_{4 g + j}[32 wave + l31][8 c + 4 half + e], j = 0..3.  Rolling prefetch three passes (3 072 MFMA cycles) ahead:
+    //      at the start of pass e the registers of the pass before are free and take (c + 1, e - 1) [pass 0: (c, 3)] ----------------------------
+    const unsigned char* const ufrag = reinterpret_cast<const unsigned char*>(p.w2d) + (size_t)wave * 1024 + (size_t)lane * 16;
+    auto uload = [&](int c, int e, f32x4 (&dst)[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const f32x4*>(ufrag + (size_t)((c * 4 + e) * 4 + g) * 4096);
+    };
+    f32x4 ufr[4][4];
+    uload(0, 0, ufr[0]);
+    uload(0, 1, ufr[1]);
+    uload(0, 2, ufr[2]);
+    b3_lds[tid] = p.b3[tid];
+
+    // accumulators: position (1,1) starts at b2 (it enters all four outputs of a patch with weight +1), the others at zero
+    f32x16 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + 32 * wave + 8 * q + 4 * half);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[5][4 * q + e] = bb[e];
+    }
+
+    // ---- input transform: lane -> (patch 8 wave + (lane & 7), channel quad (lane >> 3) & 1, channel lane >> 4) of the chunk -----------
+    // t1 element (halo pixel hp, channel 64 kh + 4 kq + e) sits at hp * 256 + ((kq ^ swz(hp)) << 4) + 4 e of half kh (br_t1_swz): the 64 lanes
+    // of a read touch 64 different banks; chunk c's quads are kq = 2 (c & 7) + {0, 1}: an XOR of the address with (c & 7) << 5
+    const int ptx = lane & 7, pkq = (lane >> 3) & 1, pe = lane >> 4;
+    unsigned rd[4];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+        const int hx = 2 * ptx + bb, hp = (2 * wave) * BT_HW + hx;
+        rd[bb] = (unsigned)(hp * 256 + ((pkq ^ (hx & 15)) << 4) + 4 * pe);
+    }
+    // V chunk image [channel e 4][row group g 4][quad kq 2][patch 32][j 4] floats: the 16 bytes a lane writes per g are V_{4 g + 0..3} of its
+    // (patch, channel), the 16 bytes a lane reads per (e, g) are the B values of MFMAs (4 g + j, e) for its patch; patch n of quad kq sits in
+    // slot n ^ 8 kq (writes of a 16-lane group -- 8 patches x 2 quads -- then fall into 16 different 16-byte slots of the bank row)
+    const unsigned vwr = (unsigned)(pe * 4096 + pkq * 512 + (((8 * wave + ptx) ^ (pkq << 3)) << 4));
+    const unsigned vrd = (unsigned)(half * 512 + ((l31 ^ (half << 3)) << 4));
+    float td[4][4], tt[4][4];
+    auto t_read = [&](int c) {   // the 4 x 4 patch of chunk c's channel
+        const unsigned char* const src = t1_lds + (c >> 3) * BR_T1_BYTES;
+        const unsigned x = (unsigned)((c & 7) << 5);
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) td[a][bb] = *reinterpret_cast<const float*>(src + (rd[bb] ^ x) + a * (BT_HW * 256));
+    };
+    auto t_cols = [&]() {   // B^T d
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tt[0][j] = td[0][j] - td[2][j];
+            tt[1][j] = td[1][j] + td[2][j];
+            tt[2][j] = td[2][j] - td[1][j];
+            tt[3][j] = td[1][j] - td[3][j];
+        }
+    };
+    auto t_rows_write = [&](int buf) {   // (B^T d) B -> V buffer
+        unsigned char* const dst = ring + buf * WN_V_BYTES + vwr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(dst + i * 1024) = f32x4{tt[i][0] - tt[i][2], tt[i][1] + tt[i][2], tt[i][2] - tt[i][1], tt[i][1] - tt[i][3]};
+    };
+
+    // both t1 halves of this wave have landed once only the loads issued behind them are outstanding; the barrier makes it all four waves'
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    br_barrier();
+    t_read(0);
+    t_cols();
+    t_rows_write(0);
+    br_barrier();
+
+    // ---- phase 2: 16 chunks x 4 passes (K pair e) x 16 positions.  One straight-line body per chunk; the scheduling fences pin, per pass, the
+    //      U loads, the V fragment reads of the NEXT pass and a quarter of the next chunk's input transform among that pass's 16 MFMAs ------
+    f32x4 vf[2][4];
+#pragma unroll 1
+    for (int c = 0; c < WN_CHUNKS; ++c) {
+        const int cn = c + 1 < WN_CHUNKS ? c + 1 : c;   // (the last chunk rebuilds its own V into the other buffer and re-requests its own fragments:
+                                                        // one code path)
+        const unsigned char* const vb = ring + (c & 1) * WN_V_BYTES + vrd;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) vf[0][g] = *reinterpret_cast<const f32x4*>(vb + g * 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (e == 0) uload(c, 3, ufr[3]);
+            else uload(cn, e - 1, ufr[e - 1]);
+            if (e < 3) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) vf[(e + 1) & 1][g] = *reinterpret_cast<const f32x4*>(vb + (e + 1) * 4096 + g * 1024);
+            }
+            if (e == 0) t_read(cn);
+            if (e == 1) t_cols();
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[e][q >> 2][q & 3], vf[e & 1][q >> 2][q & 3], acc[q], 0, 0, 0);
+            if (e == 2) t_rows_write((c + 1) & 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        br_barrier();   // V(c) is read by every wave, V(c + 1) written by every wave
+    }
+
+    // ---- W3 stages into the ring (the V buffers are dead), residual prefetch and phase 3 as in bottleneck_ring_f32_kernel ---------------
+    const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
+    auto ring_issue = [&](int k) {   // W3 stage k (0..15) -> slot k % 4; this wave copies pieces 2 wave, 2 wave + 1
+        if (k < BRF_W3_STAGES) {
+            const unsigned dst = ring_addr + (unsigned)(k % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048;
+            br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)(2 * BRF_KH_STAGES + k) * BR_STAGE_BYTES, wvoff, dst);
+        }
+    };
+    ring_issue(0);
+    ring_issue(1);
+
+    // ---- output transform Y = A^T M A, ReLU, t2 -> LDS (pixel-major, 16-byte chunk ch of pixel (y, x) in slot ch ^ (x & 15) ^ ((y >> 1) & 1)
+    //      of its 256-byte half row: conflict-free for these writes (16 lanes = 8 patch columns x 2 patch rows) and for phase 3's reads) ----
+    {
+        unsigned char* const t2_lds = t1_lds;
+        const int ty = l31 >> 3, tx = l31 & 7;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 y[2][2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * q + e;
+                float s[2][4];   // A^T M: rows
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s[0][j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
+                    s[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    y[a][0][e] = br_relu(s[a][0] + s[a][1] + s[a][2]);
+                    y[a][1][e] = br_relu(s[a][1] - s[a][2] - s[a][3]);
+                }
+            }
+            const int ch = 8 * wave + 2 * q + half;   // 16-byte chunk of channels 32 wave + 8 q + 4 half ..
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int yy = 2 * ty + a, xx = 2 * tx + bb;
+                    const int slot = (ch & 16) | ((ch & 15) ^ (xx & 15) ^ ((yy >> 1) & 1));
+                    *reinterpret_cast<f32x4*>(t2_lds + (yy * BT_TW + xx) * 512 + (slot << 4)) = y[a][bb];
+                }
+        }
+    }
+    br_barrier();
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;   // this wave's 32 pixels (phase 3)
+    f32x16 t2[4];
+    {
+        const unsigned char* const row = t1_lds + (py * BT_TW + px) * 512;
+        const int f = (px & 15) ^ (wave & 1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {   // registers 4 g + e of tile m: channels 32 m + 8 g + 4 half + e = chunk 8 m + 2 g + half
+                const int ch = 8 * m + 2 * g + half;
+                const int slot = (ch & 16) | ((ch & 15) ^ f);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(row + (slot << 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t2[m][4 * g + e] = v[e];
+            }
+    }
+    const unsigned char* const wf0 = ring + br_swz(l31, half);
+    const unsigned char* const wf1 = ring + br_swz(l31, 2 + half);
+
+    // ---- phase 3: out = W3 relu(t2) + b3 + x  (bottleneck_ring_f32_kernel's exact-fp32 form: rows = the wave's pixels, columns = channels) ----
+    unsigned char* const outp = reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * CO * 4;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+        f32x16 o[4];
+        float xr[2][16];   // residual values of channel tiles 0 and 1, requested during the last two double-steps
+        auto load_res = [&](int i, float (&dst)[16]) {
+            const int n = nh * 128 + i * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                dst[r] = reinterpret_cast<const float*>(xin)[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n];
+            }
+        };
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            const int k0 = 8 * nh + 2 * dd;
+            br_wait_vm(0);   // the pair was requested a whole double-step ago
+            br_barrier();
+            ring_issue(k0 + 2);
+            ring_issue(k0 + 3);
+            if (dd >= 2) load_res(dd - 2, xr[dd - 2]);
+            if (dd == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float bias = b3_lds[nh * 128 + i * 32 + l31];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] = bias;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k8 = 2 * dd + u, s = k0 + u, tile = k8 >> 1, q2 = k8 & 1;
+                // registers 8 q2 + 4 jj + e of t2 tile `tile` hold channels 32 tile + 16 q2 + 8 jj + 4 half + e: 16-byte chunk 2 jj + half of the stage
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
+                        mfma_quad<T>(t2[tile][8 * q2 + 4 * jj], t2[tile][8 * q2 + 4 * jj + 1], t2[tile][8 * q2 + 4 * jj + 2], t2[tile][8 * q2 + 4 * jj + 3], wf, o[i]);
+                    }
+            }
+        }
+        // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4 half of the wave][col = channel nh*128 + 32 i + l31]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = nh * 128 + i * 32 + l31;
+            float xv[16];
+            if (i < 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xv[r] = xr[i][r];
+            } else {
+                load_res(i, xv);
+            }
+            if constexpr (UP) {
+                float t4[4];
+#pragma unroll
+                for (int key = 0; key < 4; ++key)
+                    t4[key] = reinterpret_cast<const float*>(xin2)[((size_t)(ty0 / 2 + wave) * (p.W / 2) + tx0 / 2 + (key & 1) + 4 * (key >> 1) + 2 * half) * CIN + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xv[r] += t4[((r >> 1) & 1) + 2 * ((r >> 2) & 1)];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] += xv[r];
+            if constexpr (ADD2) {   // + nearest-upsample(add2): a second fp32 add, as upadd_kernel would have done on the stored tensor
+                const float* const lrow = reinterpret_cast<const float*>(p.add2) + ((size_t)view * (p.H / 2) * (p.W / 2) + (size_t)(ty0 / 2 + wave) * (p.W / 2) + tx0 / 2 + 2 * half) * CO + n;
+#pragma unroll
+                for (int key = 0; key < 4; ++key) {
+                    const float t = lrow[((key & 1) + 4 * (key >> 1)) * CO];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (((r >> 1) & 1) + 2 * ((r >> 2) & 1) == key) o[i][r] += t;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n;
+                reinterpret_cast<float*>(outp)[po] = o[i][r];
+            }
+            if constexpr (!UP) if (p.pool_in) {   // 2x2 max-pool of the block's INPUT (the skip values just added)
+                float* const pp = reinterpret_cast<float*>(p.pool_in) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN;
+#pragma unroll
+                for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        const int r0 = 2 * a2 + 4 * b2;
+                        const float v = fmaxf(fmaxf(xv[r0], xv[r0 + 1]), fmaxf(xv[r0 + 8], xv[r0 + 9]));
+                        const int ppx = a2 + 4 * b2 + 2 * half;
+                        pp[((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + ppx)) * CIN + n] = v;
+                    }
+            }
+            if (p.pool) {   // 2x2 max-pool inside the lane: horizontal neighbour = register r^1, vertical neighbour = r^8
+                float* const pp = reinterpret_cast<float*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;
+#pragma unroll
+                for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        const int r0 = 2 * a2 + 4 * b2;
+                        const float v = fmaxf(fmaxf(o[i][r0], o[i][r0 + 1]), fmaxf(o[i][r0 + 8], o[i][r0 + 9]));
+                        const int ppx = a2 + 4 * b2 + 2 * half;
+                        pp[((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + ppx)) * CO + n] = v;
+                    }
+            }
+        }
+    }
+}
+
+}  // namespace hgk

@@ -20,6 +20,7 @@
 #include "hg_bt_ring_f32.h"
 #include "hg_c1_f32.h"
 #include "hg_l1_f32.h"
+#include "hg_bt_wino_f32.h"
 
 using namespace hgk;
 
@@ -121,6 +122,8 @@ struct df3d_hg {
                           // path, streaming output stores); 0 = round 3's kernels (the A/B); bit-identical either way
     int split1 = 1;       // fp32: 1 (default) = plain 256 -> 128 -> 128 -> 256 blocks run as conv1 (every pixel once) + tail (hg_c1_f32.h), bit-identical
                           // (development: 8 + mask splits only the identity blocks (1), layer1 (2), layer2 (4))
+    int wino = 0;         // exact-fp32 engine, split identity blocks: 1 = the tail's 3x3 as Winograd F(2x2, 3x3) (hg_bt_wino_f32.h: 0.545 of the direct
+                          // tail's MFMAs; fp32 tolerance against the oracle, NOT bit-identical to the direct kernels), 0 = direct implicit GEMM
     bool split_id() const { return split1 == 1 || (split1 >= 8 && (split1 & 1)); }
     bool split_l1() const { return split1 == 1 || (split1 >= 8 && (split1 & 2)); }
     bool split_l2() const { return split1 == 1 || (split1 >= 8 && (split1 & 4)); }
@@ -146,7 +149,7 @@ struct df3d_hg {
 
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg)
     bool profiling = false;
-    struct Timed { hipEvent_t a, b; int cls; double flops, bytes, bytes_m1; };
+    struct Timed { hipEvent_t a, b; int cls; double flops, bytes, bytes_m1, flops_executed; };
     std::vector<std::string> kernel_names;  // class id -> kernel instantiation name (as rocprofv3 prints it, shortened)
     int kernel_class(const std::string& name) {
         for (size_t i = 0; i < kernel_names.size(); ++i)
@@ -320,6 +323,10 @@ struct df3d_hg {
                     st.wstream_c1 = (long long)stream_bytes;
                     stream_bytes += (size_t)C1_NSTAGE * BR_STAGE_BYTES;
                     st.t1 = new_tensor(tx.h, tx.w, planes);
+                    if (wino && dtype == DF3D_DTYPE_F32) {   // the tail's 3x3 in the Winograd domain: U = G g G^T as per-wave MFMA fragments
+                        st.wstream_w2d = (long long)stream_bytes;
+                        stream_bytes += (size_t)WN_U_BYTES;
+                    }
                 }
             }
             if (ring && split_l1() && !lp() && cin == 64 && planes == 64 && ds && x2 < 0 && a2 < 0 && tx.h % BT_TH == 0 && tx.w % BT_TW == 0) {
@@ -697,12 +704,13 @@ struct ScopedTimer {
     bool on;
     // bytes = the least this launch can move (inputs read once, outputs written once, intermediates on chip); bytes_m1 = what the
     // fusion model M1 of SURVEY.md 8(d) charges for the same work (every convolution's input and output, pooling and upsample passes)
-    ScopedTimer(df3d_hg* h_, hipStream_t s_, const std::string& name, double flops, double bytes, double bytes_m1) : h(h_), s(s_), on(h_->profiling) {
+    ScopedTimer(df3d_hg* h_, hipStream_t s_, const std::string& name, double flops, double bytes, double bytes_m1, double flops_executed = -1.0) : h(h_), s(s_), on(h_->profiling) {
         if (!on) return;
         t.a = get_event(h);
         t.b = get_event(h);
         t.cls = h->kernel_class(name);
         t.flops = flops;
+        t.flops_executed = flops_executed >= 0.0 ? flops_executed : flops;
         t.bytes = bytes;
         t.bytes_m1 = bytes_m1;
         (void)hipEventRecord(t.a, s);
@@ -770,6 +778,16 @@ int launch_ring_f32(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t 
     if (first_use_on_this_device(attr_done))
         DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_ring_f32_kernel<UP, ADD2, TAIL, T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipLaunchKernelGGL((bottleneck_ring_f32_kernel<UP, ADD2, TAIL, T>), dim3(blocks), dim3(256), lds_bytes, s, r);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+template <bool UP, bool ADD2>
+int launch_wino_f32(const BtRingArgs& r, int blocks, hipStream_t s) {
+    static unsigned attr_done = 0;
+    if (first_use_on_this_device(attr_done))
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_wino_f32_kernel<UP, ADD2>), hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
+    hipLaunchKernelGGL((bottleneck_wino_f32_kernel<UP, ADD2>), dim3(blocks), dim3(256), WN_LDS_BYTES, s, r);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }
@@ -1020,6 +1038,15 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                             DF3D_LAUNCH_CHECK();
                         }
                     }
+                    if (split && std::is_same<T, float>::value && r.w2d) {   // option `wino`: the tail with its 3x3 in the Winograd domain
+                        const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
+                        // FLOPs: the direct form's (what the block computes, in the reference's terms); the kernel EXECUTES 16/36 of the 3x3's
+                        ScopedTimer tm(h, s, std::string("bottleneck_wino_f32_kernel<") + (a.in2 ? "true, false>" : a.add2 ? "false, true>" : "false, false>"),
+                                       2.0 * px * (9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl + pl), st.m1_elems * n * eb, 2.0 * px * (4.0 * pl * pl + 2.0 * pl * pl));
+                        const int rc = a.in2 ? launch_wino_f32<true, false>(r, blocks, s) : a.add2 ? launch_wino_f32<false, true>(r, blocks, s) : launch_wino_f32<false, false>(r, blocks, s);
+                        if (rc) return rc;
+                        break;
+                    }
                     const char* const flags2 = split ? (a.in2 ? "true, false, true, " : a.add2 ? "false, true, true, " : "false, false, true, ")
                                                      : a.in2 ? "true, false, false, " : a.add2 ? "false, true, false, " : "false, false, false, ";
                     ScopedTimer tm(h, s, eb == 2 ? std::string("bottleneck_ring_kernel<") + tname + (a.in2 ? ", true, 256, false, " : a.add2 ? ", false, 256, true, " : ", false, 256, false, ") + std::to_string(ring_mode(r, h->ring2)) + ">"
@@ -1255,6 +1282,13 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
         h->build();
         return DF3D_OK;
     }
+    if (!strcmp(key, "wino")) {
+        DF3D_CHECK_ARG(value == 0 || value == 1, "wino must be 0 or 1");
+        DF3D_CHECK_ARG(h->blob == nullptr, "set 'wino' before df3d_hg_set_weights (it changes the weight streams)");
+        h->wino = value;
+        h->build();
+        return DF3D_OK;
+    }
     if (!strcmp(key, "no_reuse")) {
         DF3D_CHECK_ARG(value == 0 || value == 1, "no_reuse must be 0 or 1");
         DF3D_CHECK_ARG(h->blob == nullptr, "set 'no_reuse' before df3d_hg_set_weights (it changes the workspace plan)");
@@ -1394,6 +1428,9 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
             if (st.wstream_c1 >= 0)
                 hipLaunchKernelGGL(bt_c1_pack_f32_kernel, dim3((C1_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
                                    blob_dev + st.conv.w_off, reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_c1);
+            if (st.wstream_w2d >= 0 && h->dtype == DF3D_DTYPE_F32)
+                hipLaunchKernelGGL(bt_wino_pack_kernel, dim3(128 * 128 / 256), dim3(256), 0, df3d::as_stream(stream),
+                                   blob_dev + st.conv2b.w_off, reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_w2d));
         }
         if (h->uses_zero_page)
             DF3D_HIP(hipMemsetAsync(reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + h->zero_off, 0, 256, df3d::as_stream(stream)));
@@ -1481,6 +1518,15 @@ int df3d_hg_profile_read(df3d_hg* h, int kernel_class, char* name_buf, int bufle
         *bytes_m1 += t.bytes_m1;
         *launches += 1;
     }
+    return DF3D_OK;
+}
+
+int df3d_hg_profile_executed_flops(df3d_hg* h, int kernel_class, double* flops_executed) {
+    DF3D_CHECK_ARG(h && flops_executed, "null argument");
+    DF3D_CHECK_ARG(kernel_class >= 0 && kernel_class < (int)h->kernel_names.size(), "kernel_class out of range");
+    *flops_executed = 0.0;
+    for (auto& t : h->timed)
+        if (t.cls == kernel_class) *flops_executed += t.flops_executed;
     return DF3D_OK;
 }
 

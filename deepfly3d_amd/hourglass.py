@@ -202,7 +202,7 @@ class HourglassEngine:
     """The device engine: `forward(images_nhwc) -> heat-maps (n, 19, H/4, W/4)` on the current torch stream."""
 
     def __init__(self, state_dict, dtype="f32", num_stacks=2, device=None, height=256, width=512, row_bytes=0, fuse=True, fuse_upadd=None, ring=None, l1=None,
-                 chain_views=None, split1=None, w2d=None, ring2=None, strict=None, no_reuse=False):
+                 chain_views=None, split1=None, w2d=None, ring2=None, strict=None, no_reuse=False, wino=None):
         _native.require_gpu()
         self.lib = _native.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -230,6 +230,10 @@ class HourglassEngine:
             split1 = int(os.environ["DF3D_SPLIT1"])
         if split1 is not None and fp32_storage:  # fp32: conv1 of the identity-skip bottlenecks as a launch of its own (csrc/hg_c1_f32.h), bit-identical
             _native.check(self.lib.df3d_hg_set_option(self.h, b"split1", int(split1)), "df3d_hg_set_option")   # (0, 1, or 8 + mask: development)
+        if wino is None and os.environ.get("DF3D_WINO"):
+            wino = int(os.environ["DF3D_WINO"])
+        if wino is not None and dtype == "f32":  # exact fp32: the identity blocks' 3x3 as Winograd F(2x2, 3x3) (csrc/hg_bt_wino_f32.h); fp32 tolerance, not bit-identical to wino=0
+            _native.check(self.lib.df3d_hg_set_option(self.h, b"wino", 1 if wino else 0), "df3d_hg_set_option")
         if w2d is None and os.environ.get("DF3D_W2D"):
             w2d = int(os.environ["DF3D_W2D"])
         if w2d is not None and not fp32_storage:  # 16-bit: the 3x3's weights of the ring bottlenecks as direct per-wave fragment loads (csrc/hg_bt_ring.h), bit-identical

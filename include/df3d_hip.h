@@ -44,9 +44,9 @@ extern "C" {
 const char* df3d_last_error(void);
 /* ABI revision of the library: DF3D_ABI_VERSION of the header it was built from.  It changes whenever an entry point's signature or
  * a struct layout does (round 3 inserted `resize` into df3d_preprocess_u8 / df3d_hg_forward_u8 and `bytes_m1` into
- * df3d_hg_profile_read: 300; round 4: 400; round 5 added df3d_ba_lsmr_form and grew df3d_ba_lsmr_work_doubles: 500); a caller compares it with the header it compiled against before its first call
+ * df3d_hg_profile_read: 300; round 4: 400; round 5 added df3d_ba_lsmr_form and grew df3d_ba_lsmr_work_doubles: 500; round 6 added df3d_hg_profile_executed_flops: 600); a caller compares it with the header it compiled against before its first call
  * (deepfly3d_amd/_native.py:load does). */
-#define DF3D_ABI_VERSION 500
+#define DF3D_ABI_VERSION 600
 int df3d_version(void);
 /* number of visible HIP devices (<0 on error); name of device `dev` copied to buf */
 int df3d_device_count(void);
@@ -327,7 +327,10 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
  * fragments loaded straight from global memory (288 KB more stream space per bottleneck) -- both before the weights, both
  * bit-identical to their 0 form;  "chain_views" = 0 (default) | n: chains of full-resolution steps in chunks of n views;
  * "no_reuse" = 0 (default) | 1: the alias-free workspace plan (no tensor is ever given memory another tensor has released: ~5x the workspace) --
- * the reference form the aliasing tests compare the default plan with, bit for bit; before the weights */
+ * the reference form the aliasing tests compare the default plan with, bit for bit; before the weights;
+ * "wino" = 0 | 1 (exact fp32 with "split1"): the 3x3 of the 256->128->128->256 identity blocks as Winograd F(2x2, 3x3) -- 16 instead of 36 multiplies per
+ * 2x2 output patch and (cin, cout) pair, 1 MB more stream space per block; the SAME float32 tolerance against the reference arithmetic, but NOT bit-identical
+ * to the direct form ("wino" = 0: the bit-identity reference of the other options); before the weights */
 int df3d_hg_set_option(df3d_hg* h, const char* key, int value);
 size_t df3d_hg_workspace_bytes(const df3d_hg* h, int n);
 int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_dev, void* workspace_dev,
@@ -355,6 +358,10 @@ int df3d_hg_profile(df3d_hg* h, int enable);
 int df3d_hg_profile_count(const df3d_hg* h);
 int df3d_hg_profile_read(df3d_hg* h, int index, char* name_buf, int buflen, double* ms, double* flops, double* bytes, double* bytes_m1,
                          int* launches);
+/* (round 6) FLOPs the launches of kernel `index` EXECUTED on the matrix pipe, summed like df3d_hg_profile_read's `flops`.  Equal to `flops` (the
+ * direct-convolution count of the plan steps, the reference's arithmetic) for every kernel except the Winograd tail of option "wino", which does a
+ * 3x3 with 16/36 of the direct form's multiplies: a roofline fraction is executed FLOPs over peak, never direct-equivalent FLOPs over peak. */
+int df3d_hg_profile_executed_flops(df3d_hg* h, int index, double* flops_executed);
 /* debugging / layer-wise parity: number of plan steps, and run only steps [0, upto) then copy the
  * tensor produced by step upto-1 (NHWC, engine dtype widened to float32) into out_dev */
 int df3d_hg_num_steps(const df3d_hg* h);
