@@ -27,6 +27,10 @@
 #pragma once
 #include "hg_bt_ring_f32.h"
 
+#ifndef WN_ABL
+#define WN_ABL 0   // development builds (scripts/build_variant.sh): ablation mask of phase 2 -- 1 no U loads, 2 no input transform, 4 no chunk barrier, 8 no V fragment reads
+#endif
+
 namespace hgk {
 
 constexpr int WN_CHUNKS = 16;                          // K chunks of 8 input channels
@@ -36,7 +40,7 @@ constexpr int WN_T1_OFF = 2 * WN_V_BYTES;              // = BR_RING_BYTES: the W
 constexpr int WN_T1_BYTES = 2 * BR_T1_BYTES;           // both 64-channel halves of the 10 x 18 halo tile (92 160)
 constexpr int WN_T2_BYTES = BT_TH * BT_TW * 512;       // t2 [128 pixels][128 channels] fp32 (65 536), inside the t1 region
 constexpr int WN_B3_OFF = WN_T1_OFF + WN_T1_BYTES;
-constexpr int WN_LDS_BYTES = WN_B3_OFF + 1024;
+constexpr int WN_LDS_BYTES = WN_B3_OFF + 1024 + 512;   // b3 [256] | b2 [128]
 static_assert(WN_T1_OFF == BR_RING_BYTES, "the W3 ring takes the V buffers' place");
 static_assert(WN_T2_BYTES <= WN_T1_BYTES, "t2 lives in the t1 region");
 
@@ -70,6 +74,36 @@ __global__ __launch_bounds__(256) void bt_wino_pack_kernel(const float* __restri
     }
 }
 
+// The four U fragments of a pass as ONE inline-assembly statement with vector addresses (a2 = fragment 1's address: fragments 0 / 1 at -4096 / 0,
+// a4 = fragment 3's: fragments 2 / 3).  Left to hipcc the loads sink behind the MFMAs that still read the registers it wants to reuse for them
+// (issued at the END of the pass they belong to, a vmcnt(1) at the top of every chunk: 580 cycles each); with "=&v" outputs they are issued where
+// they stand, into registers of their own.  Vector addresses because a scalar base restored from a spill lane by v_readlane right in front of the
+// statement is a VALU-writes-SGPR -> VMEM hazard the hazard recogniser cannot see inside inline assembly (measured: a memory access fault).
+__device__ __forceinline__ void wn_uload4(f32x4 (&d)[4], const void* a2, const void* a4) {
+    asm volatile("global_load_dwordx4 %0, %4, off offset:-4096\n\tglobal_load_dwordx4 %1, %4, off\n\t"
+                 "global_load_dwordx4 %2, %5, off offset:-4096\n\tglobal_load_dwordx4 %3, %5, off"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                 : "v"(a2), "v"(a4)
+                 : "memory");
+}
+// ... and the counted wait that makes a pass's four fragments valid (operations retire in issue order: N = the loads issued behind them); it names
+// the registers as read-write operands, so the MFMAs that consume them depend on it
+template <int N>
+__device__ __forceinline__ void wn_uwait(f32x4 (&u)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : "n"(N) : "memory");
+}
+// a float add / subtract the SLP vectoriser cannot pair up (its v_pk_add_f32 forms of the input transform cost 70 instructions for 32 adds)
+__device__ __forceinline__ float wn_add(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float wn_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <bool UP, bool ADD2 = false>
 __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs p) {
     static_assert(!(UP && ADD2), "the fused up-path sum is written by plain blocks");
@@ -79,6 +113,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
     unsigned char* const ring = smem;                      // phase 3 (the V double buffer until then)
     unsigned char* const t1_lds = smem + WN_T1_OFF;
     float* const b3_lds = reinterpret_cast<float*>(smem + WN_B3_OFF);
+    float* const b2_lds = b3_lds + 256;
     const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
     const unsigned t1_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)t1_lds;
 
@@ -86,20 +121,24 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int tiles_x = p.W / BT_TW, tiles_y = p.H / BT_TH;
-    int b;   // XCD-aware tile order, as in bottleneck_ring_f32_kernel
-    {
-        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
-        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    }
-    const int tx0 = (b % tiles_x) * BT_TW;
-    b /= tiles_x;
-    const int ty0 = (b % tiles_y) * BT_TH;
-    const int view = b / tiles_y;
-    const unsigned char* const xin = reinterpret_cast<const unsigned char*>(p.in) + (size_t)view * p.H * p.W * CIN * 4;
-    const unsigned char* const xin2 = UP ? reinterpret_cast<const unsigned char*>(p.in2) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN * 4 : nullptr;
-
-    // ---- the t1 halo tile by LDS-DMA, both halves at once (hg_bt_ring_f32.h t1_issue; half kh at t1 + kh * BR_T1_BYTES) -------------
-    {
+    const int ntiles = p.V * tiles_y * tiles_x;
+    // PERSISTENT: one workgroup per CU walks tiles vb = blockIdx.x, + gridDim.x, ... (a single resident workgroup has nobody to hide its
+    // prologue behind: the next tile's t1 halo is requested while this tile's phase 3 runs).  XCD-aware order as in bottleneck_ring_f32_kernel:
+    // virtual block vb runs on XCD vb % 8 (the grid is a multiple of 8, or one tile per workgroup) and XCD x takes the x-th contiguous eighth.
+    auto tile_of = [&](int vb, int& tx0, int& ty0, int& view) {
+        const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
+        int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+        tx0 = (b % tiles_x) * BT_TW;
+        b /= tiles_x;
+        ty0 = (b % tiles_y) * BT_TH;
+        view = b / tiles_y;
+    };
+    // the t1 halo tile by LDS-DMA, both 64-channel halves (hg_bt_ring_f32.h t1_issue; half kh at t1 + kh * BR_T1_BYTES)
+    auto t1_issue = [&](int tx0, int ty0, int view) {
+        // (the per-piece lane constants -- halo pixel, swizzled chunk -- are recomputed at every call: hoisted out of the tile loop they would be
+        // ~70 registers alive across phase 2, i.e. scratch spills; the empty asm hides the lane index's loop invariance from the compiler)
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
         const unsigned char* const tin = reinterpret_cast<const unsigned char*>(p.t1in) + (size_t)view * p.H * p.W * 512;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
@@ -107,42 +146,26 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
             for (int k = 0; k < 12; ++k) {
                 const int pc = wave + 4 * k;
                 if (pc < BT_HALO / 4) {
-                    const int hp = 4 * pc + (lane >> 4);
+                    const int hp = 4 * pc + (lane_ >> 4);
                     const int hy = hp / BT_HW, hx = hp % BT_HW;
                     const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
                     const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-                    const unsigned chunk = (unsigned)((lane & 15) ^ br_t1_swz(hp));
+                    const unsigned chunk = (unsigned)((lane_ & 15) ^ br_t1_swz(hp));
                     const unsigned char* const src = ok ? tin + ((size_t)y * p.W + x) * 512 + kh * 256 + chunk * 16 : reinterpret_cast<const unsigned char*>(p.zeros) + chunk * 16;
                     br_glds_piece64(src, t1_addr + (unsigned)(kh * BR_T1_BYTES + pc * 1024));
                 }
             }
-    }
+    };
+
     // ---- U fragments straight from global memory (L2) into the MFMA A registers: fragment (chunk c, pass e, row group g) is 1 KB per wave,
     //      lane (l31, half) -> U_{4 g + j}[32 wave + l31][8 c + 4 half + e], j = 0..3.  Rolling prefetch three passes (3 072 MFMA cycles) ahead:
     //      at the start of pass e the registers of the pass before are free and take (c + 1, e - 1) [pass 0: (c, 3)] ----------------------------
-    const unsigned char* const ufrag = reinterpret_cast<const unsigned char*>(p.w2d) + (size_t)wave * 1024 + (size_t)lane * 16;
+    unsigned uoff = (unsigned)(wave * 1024 + lane * 16);   // (uniform base + one 32-bit lane offset; made opaque per tile, or the compiler
+                                                           // keeps the twelve addresses of a tile's first loads alive -- in scratch -- across the loop)
     auto uload = [&](int c, int e, f32x4 (&dst)[4]) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const f32x4*>(ufrag + (size_t)((c * 4 + e) * 4 + g) * 4096);
+        const unsigned char* const ub = reinterpret_cast<const unsigned char*>(p.w2d) + (size_t)(c * 4 + e) * 16384 + uoff;
+        wn_uload4(dst, ub + 4096, ub + 3 * 4096);
     };
-    f32x4 ufr[4][4];
-    uload(0, 0, ufr[0]);
-    uload(0, 1, ufr[1]);
-    uload(0, 2, ufr[2]);
-    b3_lds[tid] = p.b3[tid];
-
-    // accumulators: position (1,1) starts at b2 (it enters all four outputs of a patch with weight +1), the others at zero
-    f32x16 acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + 32 * wave + 8 * q + 4 * half);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[5][4 * q + e] = bb[e];
-    }
 
     // ---- input transform: lane -> (patch 8 wave + (lane & 7), channel quad (lane >> 3) & 1, channel lane >> 4) of the chunk -----------
     // t1 element (halo pixel hp, channel 64 kh + 4 kq + e) sits at hp * 256 + ((kq ^ swz(hp)) << 4) + 4 e of half kh (br_t1_swz): the 64 lanes
@@ -171,58 +194,18 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
     auto t_cols = [&]() {   // B^T d
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            tt[0][j] = td[0][j] - td[2][j];
-            tt[1][j] = td[1][j] + td[2][j];
-            tt[2][j] = td[2][j] - td[1][j];
-            tt[3][j] = td[1][j] - td[3][j];
+            tt[0][j] = wn_sub(td[0][j], td[2][j]);
+            tt[1][j] = wn_add(td[1][j], td[2][j]);
+            tt[2][j] = wn_sub(td[2][j], td[1][j]);
+            tt[3][j] = wn_sub(td[1][j], td[3][j]);
         }
     };
     auto t_rows_write = [&](int buf) {   // (B^T d) B -> V buffer
         unsigned char* const dst = ring + buf * WN_V_BYTES + vwr;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4*>(dst + i * 1024) = f32x4{tt[i][0] - tt[i][2], tt[i][1] + tt[i][2], tt[i][2] - tt[i][1], tt[i][1] - tt[i][3]};
+            *reinterpret_cast<f32x4*>(dst + i * 1024) = f32x4{wn_sub(tt[i][0], tt[i][2]), wn_add(tt[i][1], tt[i][2]), wn_sub(tt[i][2], tt[i][1]), wn_sub(tt[i][1], tt[i][3])};
     };
-
-    // both t1 halves of this wave have landed once only the loads issued behind them are outstanding; the barrier makes it all four waves'
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    br_barrier();
-    t_read(0);
-    t_cols();
-    t_rows_write(0);
-    br_barrier();
-
-    // ---- phase 2: 16 chunks x 4 passes (K pair e) x 16 positions.  One straight-line body per chunk; the scheduling fences pin, per pass, the
-    //      U loads, the V fragment reads of the NEXT pass and a quarter of the next chunk's input transform among that pass's 16 MFMAs ------
-    f32x4 vf[2][4];
-#pragma unroll 1
-    for (int c = 0; c < WN_CHUNKS; ++c) {
-        const int cn = c + 1 < WN_CHUNKS ? c + 1 : c;   // (the last chunk rebuilds its own V into the other buffer and re-requests its own fragments:
-                                                        // one code path)
-        const unsigned char* const vb = ring + (c & 1) * WN_V_BYTES + vrd;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) vf[0][g] = *reinterpret_cast<const f32x4*>(vb + g * 1024);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (e == 0) uload(c, 3, ufr[3]);
-            else uload(cn, e - 1, ufr[e - 1]);
-            if (e < 3) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) vf[(e + 1) & 1][g] = *reinterpret_cast<const f32x4*>(vb + (e + 1) * 4096 + g * 1024);
-            }
-            if (e == 0) t_read(cn);
-            if (e == 1) t_cols();
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[e][q >> 2][q & 3], vf[e & 1][q >> 2][q & 3], acc[q], 0, 0, 0);
-            if (e == 2) t_rows_write((c + 1) & 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        br_barrier();   // V(c) is read by every wave, V(c + 1) written by every wave
-    }
-
-    // ---- W3 stages into the ring (the V buffers are dead), residual prefetch and phase 3 as in bottleneck_ring_f32_kernel ---------------
     const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
     auto ring_issue = [&](int k) {   // W3 stage k (0..15) -> slot k % 4; this wave copies pieces 2 wave, 2 wave + 1
         if (k < BRF_W3_STAGES) {
@@ -230,168 +213,279 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
             br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)(2 * BRF_KH_STAGES + k) * BR_STAGE_BYTES, wvoff, dst);
         }
     };
-    ring_issue(0);
-    ring_issue(1);
 
-    // ---- output transform Y = A^T M A, ReLU, t2 -> LDS (pixel-major, 16-byte chunk ch of pixel (y, x) in slot ch ^ (x & 15) ^ ((y >> 1) & 1)
-    //      of its 256-byte half row: conflict-free for these writes (16 lanes = 8 patch columns x 2 patch rows) and for phase 3's reads) ----
-    {
-        unsigned char* const t2_lds = t1_lds;
-        const int ty = l31 >> 3, tx = l31 & 7;
+#ifdef DF3D_BT_TIMING
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();   // (timing builds: scripts/probe_wino.py)
+#endif
+    int vb = blockIdx.x;
+    int tx0, ty0, view;
+    tile_of(vb, tx0, ty0, view);
+    t1_issue(tx0, ty0, view);
+    b3_lds[tid] = p.b3[tid];
+    if (tid < 128) b2_lds[tid] = p.b2[tid];
+    bool first = true;
+
+#pragma unroll 1
+    for (;;) {
+        const int vbn = vb + (int)gridDim.x;
+        const bool has_next = vbn < ntiles;
+        int ntx0 = 0, nty0 = 0, nview = 0;
+        if (has_next) tile_of(vbn, ntx0, nty0, nview);
+        // uniform byte offsets of this wave's two tile rows (full resolution) / its one half-resolution row inside a [V][H][W][256] fp32 tensor
+        const size_t ftile = (((size_t)view * p.H + ty0 + 2 * wave) * p.W + tx0) * (CO * 4);
+        const size_t htile = (((size_t)view * (p.H / 2) + ty0 / 2 + wave) * (p.W / 2) + tx0 / 2) * (CO * 4);
+        const unsigned char* const xtile = reinterpret_cast<const unsigned char*>(p.in) + ftile;
+
+        // accumulators (b2 is added to position (1,1) -- which enters all four outputs of a patch with weight +1 -- in the output transform: as a
+        // start value it would be a global load straight into accumulator registers, and the wait hipcc puts in front of the first MFMA that
+        // touches them sits inside the chunk loop: a vmcnt(0) per chunk, 580 cycles each)
+        f32x16 acc[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 y[2][2];
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+        f32x4 ufr[4][4];
+        asm volatile("" : "+v"(uoff));
+        uload(0, 0, ufr[0]);
+        uload(0, 1, ufr[1]);
+        uload(0, 2, ufr[2]);
+        // first tile: both t1 halves of this wave have landed once only the loads issued behind them are outstanding.  Later tiles: the halo was
+        // requested during the tile before's phase 3, whose counted waits and barriers have long published it.  The barrier: every wave is past
+        // its last reads of the ring (the tile before), V buffer 0 may be written
+        if (first) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        first = false;
+        br_barrier();
+        BR_STAMP(0);
+        t_read(0);
+        t_cols();
+        t_rows_write(0);
+        br_barrier();
+        BR_STAMP(1);
+
+        // ---- phase 2: 16 chunks x 4 passes (K pair e) x 16 positions.  One straight-line body per chunk; the scheduling fences pin, per pass, the
+        //      U loads, the V fragment reads of the NEXT pass and a quarter of the next chunk's input transform among that pass's 16 MFMAs ------
+        f32x4 vf[2][4];
+#pragma unroll 1
+        for (int c = 0; c < WN_CHUNKS; ++c) {
+            const int cn = c + 1 < WN_CHUNKS ? c + 1 : c;   // (the last chunk rebuilds its own V into the other buffer and re-requests its own fragments:
+                                                            // one code path)
+            const unsigned char* const vb_ = ring + (c & 1) * WN_V_BYTES + vrd;
+            if (!(WN_ABL & 8) || c == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) vf[0][g] = *reinterpret_cast<const f32x4*>(vb_ + g * 1024);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int r = 4 * q + e;
-                float s[2][4];   // A^T M: rows
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s[0][j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
-                    s[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(WN_ABL & 1)) {
+                    wn_uwait<8>(ufr[e]);   // this pass's fragments (requested three passes ago) have landed: behind them only two passes' 8 loads
+                    if (e == 0) uload(c, 3, ufr[3]);
+                    else uload(cn, e - 1, ufr[e - 1]);
+                    __builtin_amdgcn_sched_barrier(0);   // (... issued HERE: the scheduler would sink the statement behind the pass's MFMAs)
                 }
+                if (e < 3 && (!(WN_ABL & 8) || c == 0)) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    y[a][0][e] = br_relu(s[a][0] + s[a][1] + s[a][2]);
-                    y[a][1][e] = br_relu(s[a][1] - s[a][2] - s[a][3]);
+                    for (int g = 0; g < 4; ++g) vf[(e + 1) & 1][g] = *reinterpret_cast<const f32x4*>(vb_ + (e + 1) * 4096 + g * 1024);
                 }
+                if (e == 0 && !(WN_ABL & 2)) t_read(cn);
+                if (e == 1 && !(WN_ABL & 2)) t_cols();
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[e][q >> 2][q & 3], vf[e & 1][q >> 2][q & 3], acc[q], 0, 0, 0);
+                if (e == 2 && !(WN_ABL & 2)) t_rows_write((c + 1) & 1);
             }
-            const int ch = 8 * wave + 2 * q + half;   // 16-byte chunk of channels 32 wave + 8 q + 4 half ..
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                    const int yy = 2 * ty + a, xx = 2 * tx + bb;
-                    const int slot = (ch & 16) | ((ch & 15) ^ (xx & 15) ^ ((yy >> 1) & 1));
-                    *reinterpret_cast<f32x4*>(t2_lds + (yy * BT_TW + xx) * 512 + (slot << 4)) = y[a][bb];
-                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(WN_ABL & 4)) br_barrier();   // V(c) is read by every wave, V(c + 1) written by every wave
         }
-    }
-    br_barrier();
-    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;   // this wave's 32 pixels (phase 3)
-    f32x16 t2[4];
-    {
-        const unsigned char* const row = t1_lds + (py * BT_TW + px) * 512;
-        const int f = (px & 15) ^ (wave & 1);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {   // registers 4 g + e of tile m: channels 32 m + 8 g + 4 half + e = chunk 8 m + 2 g + half
-                const int ch = 8 * m + 2 * g + half;
-                const int slot = (ch & 16) | ((ch & 15) ^ f);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(row + (slot << 4));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t2[m][4 * g + e] = v[e];
-            }
-    }
-    const unsigned char* const wf0 = ring + br_swz(l31, half);
-    const unsigned char* const wf1 = ring + br_swz(l31, 2 + half);
 
-    // ---- phase 3: out = W3 relu(t2) + b3 + x  (bottleneck_ring_f32_kernel's exact-fp32 form: rows = the wave's pixels, columns = channels) ----
-    unsigned char* const outp = reinterpret_cast<unsigned char*>(p.out) + (size_t)view * p.H * p.W * CO * 4;
+        BR_STAMP(2);
+        // Everything phase 3 derives from the lane index is derived HERE, per tile, from a copy the compiler cannot see through: hoisted out of
+        // the tile loop these ~60 lane constants would live across phase 2, where the 256 + 256 registers are spoken for (scratch spills, and
+        // every reload a vmcnt(0) in the middle of the asynchronous machinery)
+        int lane3 = lane;
+        asm volatile("" : "+v"(lane3));
+        const int half3 = lane3 >> 5, l31_3 = lane3 & 31;
+        const unsigned char* const wf0 = ring + br_swz(l31_3, half3);
+        const unsigned char* const wf1 = ring + br_swz(l31_3, 2 + half3);
+        const int py = 2 * wave + (l31_3 >> 4), px = l31_3 & 15;   // this wave's 32 pixels (phase 3)
+        // phase 3's global addresses = (tile, register)-dependent UNIFORM part + one of two per-lane byte offsets (pixel 4 half / half-resolution
+        // pixel 2 half of the register's group, channel l31): scalar address arithmetic, two VGPRs -- not one address register pair per access
+        const unsigned lane_full = (unsigned)((4 * half3 * CO + l31_3) * 4);
+        const unsigned lane_half = (unsigned)((2 * half3 * CO + l31_3) * 4);
+        // W3 stages 0 .. 3 into the ring (both V buffers are dead): two double-steps ahead, so that phase 3's first two waits only have to let
+        // the residual loads below pass (operations retire in issue order: "at most 63 outstanding" covers anything older than 64 loads)
+        ring_issue(0);
+        ring_issue(1);
+        ring_issue(2);
+        ring_issue(3);
+
+        // ---- output transform Y = A^T M A, ReLU, t2 -> LDS (pixel-major, 16-byte chunk ch of pixel (y, x) in slot ch ^ (x & 15) ^ ((y >> 1) & 1)
+        //      of its 512-byte row: conflict-free for these writes (16 lanes = 8 patch columns x 2 patch rows) and for phase 3's reads).
+        //      Address = [pixel (2 ty, 2 tx) | lane part of the slot] ^ [(2 q ^ bb) << 4] + (16 a + bb) * 512: one lane base, XOR constants ----
+        {
+            const int ty = l31_3 >> 3, tx = l31_3 & 7;
+            const unsigned wbase = (unsigned)((32 * ty + 2 * tx) * 512 + ((((8 * wave + half3) ^ (2 * tx) ^ (ty & 1)) & 31) << 4));
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
-        f32x16 o[4];
-        float xr[2][16];   // residual values of channel tiles 0 and 1, requested during the last two double-steps
-        auto load_res = [&](int i, float (&dst)[16]) {
-            const int n = nh * 128 + i * 32 + l31;
+            for (int q = 0; q < 4; ++q) {
+                f32x4 y[2][2];
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b2_lds + 32 * wave + 8 * q + 4 * half3);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
-                dst[r] = reinterpret_cast<const float*>(xin)[((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CIN + n];
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q + e;
+                    float s[2][4];   // A^T M: rows
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float m1 = j == 1 ? acc[4 + j][r] + bb[e] : acc[4 + j][r];
+                        s[0][j] = acc[j][r] + m1 + acc[8 + j][r];
+                        s[1][j] = m1 - acc[8 + j][r] - acc[12 + j][r];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        y[a][0][e] = br_relu(s[a][0] + s[a][1] + s[a][2]);
+                        y[a][1][e] = br_relu(s[a][1] - s[a][2] - s[a][3]);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb)
+                        *reinterpret_cast<f32x4*>(t1_lds + (wbase ^ (unsigned)(((2 * q) ^ bb) << 4)) + (16 * a + bb) * 512) = y[a][bb];
             }
-        };
+        }
+        // ---- residual values (and the ADD2 addends) of the whole tile, requested as soon as the 256 accumulators of phase 2 are dead (one wave per SIMD:
+        //      nobody hides a load issued in an epilogue; the 512-register file has room for them beside phase 3): first used 16 000 cycles from here ----
+        float xres[2][4][16];
 #pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-            const int k0 = 8 * nh + 2 * dd;
-            br_wait_vm(0);   // the pair was requested a whole double-step ago
-            br_barrier();
-            ring_issue(k0 + 2);
-            ring_issue(k0 + 3);
-            if (dd >= 2) load_res(dd - 2, xr[dd - 2]);
-            if (dd == 0) {
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pl0 = (r & 3) + 8 * (r >> 2);   // + 4 half: the lane's part
+                    xres[nh][i][r] = *reinterpret_cast<const float*>(xtile + ((size_t)(pl0 >> 4) * p.W + (pl0 & 15)) * (CIN * 4) + (nh * 128 + i * 32) * 4 + lane_full);
+                }
+            }
+        float a2v[ADD2 ? 2 : 1][4][4];
+        if constexpr (ADD2) {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float bias = b3_lds[nh * 128 + i * 32 + l31];
+                    const unsigned char* const lrow = reinterpret_cast<const unsigned char*>(p.add2) + htile + (nh * 128 + i * 32) * 4;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[i][r] = bias;
+                    for (int key = 0; key < 4; ++key) a2v[nh][i][key] = *reinterpret_cast<const float*>(lrow + ((key & 1) + 4 * (key >> 1)) * (CO * 4) + lane_half);
                 }
-            }
+        }
+        BR_STAMP(3);
+        br_barrier();
+        f32x16 t2[4];
+        {
+            const unsigned rbase = (unsigned)((py * BT_TW + px) * 512 + ((half3 ^ (px & 15) ^ (wave & 1)) << 4));
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int k8 = 2 * dd + u, s = k0 + u, tile = k8 >> 1, q2 = k8 & 1;
-                // registers 8 q2 + 4 jj + e of t2 tile `tile` hold channels 32 tile + 16 q2 + 8 jj + 4 half + e: 16-byte chunk 2 jj + half of the stage
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
+                for (int g = 0; g < 4; ++g) {   // registers 4 g + e of tile m: channels 32 m + 8 g + 4 half + e = chunk 8 m + 2 g + half, in slot chunk ^ f
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(t1_lds + (rbase ^ (unsigned)((8 * m + 2 * g) << 4)));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t2[m][4 * g + e] = v[e];
+                }
+        }
+
+        BR_STAMP(4);
+        // ---- phase 3: out = W3 relu(t2) + b3 + x  (bottleneck_ring_f32_kernel's exact-fp32 form: rows = the wave's pixels, columns = channels) ----
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            f32x16 o[4];
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const int k0 = 8 * nh + 2 * dd;
+                // the pair was requested a double-step (first two: an output transform) ago.  Counted waits where younger operations need not have
+                // retired: the 128+ residual loads behind stages 0 .. 3, the >= 64 stores of the first half's epilogue behind stages 8, 9
+                if ((nh == 0 && dd < 2) || (nh == 1 && dd == 0)) br_wait_vm(63);
+                else br_wait_vm(0);
+                br_barrier();
+                if (nh == 0 && dd == 0) {
+                    if (has_next) t1_issue(ntx0, nty0, nview);   // every wave holds its t2 in registers: the t1 region takes the next tile's halo
+                } else {
+                    ring_issue(k0 + 2);
+                    ring_issue(k0 + 3);
+                }
+                if (dd == 0) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
-                        mfma_quad<T>(t2[tile][8 * q2 + 4 * jj], t2[tile][8 * q2 + 4 * jj + 1], t2[tile][8 * q2 + 4 * jj + 2], t2[tile][8 * q2 + 4 * jj + 3], wf, o[i]);
+                        const float bias = b3_lds[nh * 128 + i * 32 + l31_3];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[i][r] = bias;
                     }
-            }
-        }
-        // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4 half of the wave][col = channel nh*128 + 32 i + l31]
+                }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = nh * 128 + i * 32 + l31;
-            float xv[16];
-            if (i < 2) {
+                for (int u = 0; u < 2; ++u) {
+                    const int k8 = 2 * dd + u, s = k0 + u, tile = k8 >> 1, q2 = k8 & 1;
+                    // registers 8 q2 + 4 jj + e of t2 tile `tile` hold channels 32 tile + 16 q2 + 8 jj + 4 half + e: 16-byte chunk 2 jj + half of the stage
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xv[r] = xr[i][r];
-            } else {
-                load_res(i, xv);
-            }
-            if constexpr (UP) {
-                float t4[4];
+                    for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int key = 0; key < 4; ++key)
-                    t4[key] = reinterpret_cast<const float*>(xin2)[((size_t)(ty0 / 2 + wave) * (p.W / 2) + tx0 / 2 + (key & 1) + 4 * (key >> 1) + 2 * half) * CIN + n];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xv[r] += t4[((r >> 1) & 1) + 2 * ((r >> 2) & 1)];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] += xv[r];
-            if constexpr (ADD2) {   // + nearest-upsample(add2): a second fp32 add, as upadd_kernel would have done on the stored tensor
-                const float* const lrow = reinterpret_cast<const float*>(p.add2) + ((size_t)view * (p.H / 2) * (p.W / 2) + (size_t)(ty0 / 2 + wave) * (p.W / 2) + tx0 / 2 + 2 * half) * CO + n;
-#pragma unroll
-                for (int key = 0; key < 4; ++key) {
-                    const float t = lrow[((key & 1) + 4 * (key >> 1)) * CO];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (((r >> 1) & 1) + 2 * ((r >> 2) & 1) == key) o[i][r] += t;
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
+                            mfma_quad<T>(t2[tile][8 * q2 + 4 * jj], t2[tile][8 * q2 + 4 * jj + 1], t2[tile][8 * q2 + 4 * jj + 2], t2[tile][8 * q2 + 4 * jj + 3], wf, o[i]);
+                        }
                 }
             }
+            BR_STAMP(5 + 2 * nh);
+            // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4 half of the wave][col = channel nh*128 + 32 i + l31]
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pl = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const size_t po = ((size_t)(ty0 + 2 * wave + (pl >> 4)) * p.W + (tx0 + (pl & 15))) * CO + n;
-                reinterpret_cast<float*>(outp)[po] = o[i][r];
+            for (int i = 0; i < 4; ++i) {
+                const int nb = (nh * 128 + i * 32) * 4;   // byte offset of the tile's channel group (+ l31 in the lane offsets)
+                float xv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xv[r] = xres[nh][i][r];
+                if constexpr (UP) {
+                    float t4[4];
+#pragma unroll
+                    for (int key = 0; key < 4; ++key)
+                        t4[key] = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.in2) + htile + ((key & 1) + 4 * (key >> 1)) * (CIN * 4) + nb + lane_half);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xv[r] += t4[((r >> 1) & 1) + 2 * ((r >> 2) & 1)];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] += xv[r];
+                if constexpr (ADD2) {   // + nearest-upsample(add2): a second fp32 add, as upadd_kernel would have done on the stored tensor
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] += a2v[nh][i][((r >> 1) & 1) + 2 * ((r >> 2) & 1)];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pl0 = (r & 3) + 8 * (r >> 2);
+                    *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(p.out) + ftile + ((size_t)(pl0 >> 4) * p.W + (pl0 & 15)) * (CO * 4) + nb + lane_full) = o[i][r];
+                }
+                if constexpr (!UP) if (p.pool_in) {   // 2x2 max-pool of the block's INPUT (the skip values just added)
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                        for (int b2 = 0; b2 < 2; ++b2) {
+                            const int r0 = 2 * a2 + 4 * b2;
+                            const float v = fmaxf(fmaxf(xv[r0], xv[r0 + 1]), fmaxf(xv[r0 + 8], xv[r0 + 9]));
+                            *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(p.pool_in) + htile + (a2 + 4 * b2) * (CIN * 4) + nb + lane_half) = v;
+                        }
+                }
+                if (p.pool) {   // 2x2 max-pool inside the lane: horizontal neighbour = register r^1, vertical neighbour = r^8
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                        for (int b2 = 0; b2 < 2; ++b2) {
+                            const int r0 = 2 * a2 + 4 * b2;
+                            const float v = fmaxf(fmaxf(o[i][r0], o[i][r0 + 1]), fmaxf(o[i][r0 + 8], o[i][r0 + 9]));
+                            *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(p.pool) + htile + (a2 + 4 * b2) * (CO * 4) + nb + lane_half) = v;
+                        }
+                }
             }
-            if constexpr (!UP) if (p.pool_in) {   // 2x2 max-pool of the block's INPUT (the skip values just added)
-                float* const pp = reinterpret_cast<float*>(p.pool_in) + (size_t)view * (p.H / 2) * (p.W / 2) * CIN;
-#pragma unroll
-                for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-                    for (int b2 = 0; b2 < 2; ++b2) {
-                        const int r0 = 2 * a2 + 4 * b2;
-                        const float v = fmaxf(fmaxf(xv[r0], xv[r0 + 1]), fmaxf(xv[r0 + 8], xv[r0 + 9]));
-                        const int ppx = a2 + 4 * b2 + 2 * half;
-                        pp[((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + ppx)) * CIN + n] = v;
-                    }
-            }
-            if (p.pool) {   // 2x2 max-pool inside the lane: horizontal neighbour = register r^1, vertical neighbour = r^8
-                float* const pp = reinterpret_cast<float*>(p.pool) + (size_t)view * (p.H / 2) * (p.W / 2) * CO;
-#pragma unroll
-                for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-                    for (int b2 = 0; b2 < 2; ++b2) {
-                        const int r0 = 2 * a2 + 4 * b2;
-                        const float v = fmaxf(fmaxf(o[i][r0], o[i][r0 + 1]), fmaxf(o[i][r0 + 8], o[i][r0 + 9]));
-                        const int ppx = a2 + 4 * b2 + 2 * half;
-                        pp[((size_t)(ty0 / 2 + wave) * (p.W / 2) + (tx0 / 2 + ppx)) * CO + n] = v;
-                    }
-            }
+            BR_STAMP(6 + 2 * nh);
         }
+        if (!has_next) break;
+        vb = vbn;
+        tx0 = ntx0;
+        ty0 = nty0;
+        view = nview;
     }
 }
 

@@ -787,7 +787,10 @@ int launch_wino_f32(const BtRingArgs& r, int blocks, hipStream_t s) {
     static unsigned attr_done = 0;
     if (first_use_on_this_device(attr_done))
         DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_wino_f32_kernel<UP, ADD2>), hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
-    hipLaunchKernelGGL((bottleneck_wino_f32_kernel<UP, ADD2>), dim3(blocks), dim3(256), WN_LDS_BYTES, s, r);
+    // persistent: one workgroup per CU (it needs the whole register file), walking tiles with stride gridDim; a multiple of 8 keeps virtual
+    // block ids on their XCD (hg_bt_wino_f32.h tile_of)
+    const int cus = cu_count() & ~7;
+    hipLaunchKernelGGL((bottleneck_wino_f32_kernel<UP, ADD2>), dim3(blocks <= cus ? blocks : cus), dim3(256), WN_LDS_BYTES, s, r);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }
