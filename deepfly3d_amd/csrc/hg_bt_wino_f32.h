@@ -45,8 +45,10 @@ static_assert(WN_T1_OFF == BR_RING_BYTES, "the W3 ring takes the V buffers' plac
 static_assert(WN_T2_BYTES <= WN_T1_BYTES, "t2 lives in the t1 region");
 
 // W2' [9][128 cout][128 cin] fp32 (bn3 folded) -> U stream.  One thread per (cout, cin): G g G^T in fp64, each value rounded once.
-// Fragment (chunk c, pass e, row group g, wave w): lane (l31, half) holds U_{4 g + j}[32 w + l31][8 c + 4 half + e], j = 0..3 (pass e of a chunk
-// multiplies the K pair (8 c + e, 8 c + 4 + e) at all 16 positions: the same pairing the V fragments are read with).
+// Fragment (chunk c, pass e, wave w, column j) = 1 KB: lane (l31, half) holds U'_{i j}[32 w + l31][8 c + 4 half + e], i = 0..3 (pass e of a chunk
+// multiplies the K pair (8 c + e, 8 c + 4 + e) at all 16 positions; a wave's four fragments of a pass are 4 KB contiguous: one scalar base,
+// immediate offsets).  U' = s_i s_j U with s_2 = -1: the input transform builds row 2 / column 2 of V with the opposite sign (d1 - d2 instead of
+// d2 - d1: its packed adds then need no operand swap), and the products U' V' = U V are unchanged.
 __global__ __launch_bounds__(256) void bt_wino_pack_kernel(const float* __restrict__ w2, float* __restrict__ ustream) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= 128 * 128) return;
@@ -70,20 +72,25 @@ __global__ __launch_bounds__(256) void bt_wino_pack_kernel(const float* __restri
         const double u[4] = {t[i][0], 0.5 * (t[i][0] + t[i][1] + t[i][2]), 0.5 * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};   // (G g) G^T
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            ustream[((size_t)(((c * 4 + e) * 4 + i) * 4 + w) * 64 + half * 32 + l31) * 4 + j] = (float)u[j];
+            ustream[((size_t)(((c * 4 + e) * 4 + w) * 4 + j) * 64 + half * 32 + l31) * 4 + i] = (float)(((i == 2) != (j == 2)) ? -u[j] : u[j]);
     }
 }
 
-// The four U fragments of a pass as ONE inline-assembly statement with vector addresses (a2 = fragment 1's address: fragments 0 / 1 at -4096 / 0,
-// a4 = fragment 3's: fragments 2 / 3).  Left to hipcc the loads sink behind the MFMAs that still read the registers it wants to reuse for them
-// (issued at the END of the pass they belong to, a vmcnt(1) at the top of every chunk: 580 cycles each); with "=&v" outputs they are issued where
-// they stand, into registers of their own.  Vector addresses because a scalar base restored from a spill lane by v_readlane right in front of the
-// statement is a VALU-writes-SGPR -> VMEM hazard the hazard recogniser cannot see inside inline assembly (measured: a memory access fault).
-__device__ __forceinline__ void wn_uload4(f32x4 (&d)[4], const void* a2, const void* a4) {
-    asm volatile("global_load_dwordx4 %0, %4, off offset:-4096\n\tglobal_load_dwordx4 %1, %4, off\n\t"
-                 "global_load_dwordx4 %2, %5, off offset:-4096\n\tglobal_load_dwordx4 %3, %5, off"
+// What an instruction costs between two of a wave's fp32 MFMAs when the wave is alone on its SIMD (tests/perf/ubench/mfma_f32_shadow.hip, cycles
+// added to a 64-cycle v_mfma_f32_32x32x2_f32): one VALU op 14, a clump of n VALU ops ~10 + 4.3 n (v_pk_add_f32 counts as one), global_load_dwordx4
+// with a 64-bit vector address 17.6, with a scalar base + 32-bit lane offset 6.6, LDS-DMA the same, ds_read_b128 2.0, ds_write_b128 3.1, SALU / s_nop 0.
+// The exact-fp32 MFMA evidently shares the vector ALU: NOTHING vector hides in its shadow.  Hence, in phase 2: scalar-base loads, the input
+// transform as sixteen packed adds in ONE clump, no address arithmetic on the vector side.
+// The four U fragments of a pass as ONE inline-assembly statement: scalar base (the wave's 4 KB of the pass), the lane's 16-byte offset, immediate
+// offsets.  Inline assembly because, left to hipcc, the loads sink behind the MFMAs that still read the registers it wants to reuse for them (issued
+// at the END of the pass they belong to, a vmcnt(1) at the top of every chunk: 580 cycles each); with "=&v" outputs and a scheduling fence behind
+// the statement they are issued where they stand.  The s_nop: a base restored from a spill lane by v_readlane right in front of the statement is a
+// VALU-writes-SGPR -> VMEM-reads-it hazard (5 wait states) that the hazard recogniser cannot see inside inline assembly (measured: a memory fault).
+__device__ __forceinline__ void wn_uload4(f32x4 (&d)[4], const void* sbase, unsigned voff) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                 "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"
                  : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
-                 : "v"(a2), "v"(a4)
+                 : "v"(voff), "s"(sbase)
                  : "memory");
 }
 // ... and the counted wait that makes a pass's four fragments valid (operations retire in issue order: N = the loads issued behind them); it names
@@ -92,16 +99,34 @@ template <int N>
 __device__ __forceinline__ void wn_uwait(f32x4 (&u)[4]) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : "n"(N) : "memory");
 }
-// a float add / subtract the SLP vectoriser cannot pair up (its v_pk_add_f32 forms of the input transform cost 70 instructions for 32 adds)
-__device__ __forceinline__ float wn_add(float a, float b) {
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float wn_sub(float a, float b) {
-    float r;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+// The input transform of one (patch, channel): V' = B'^T d B' as SIXTEEN packed adds in one statement (one VALU clump per chunk).
+// In: P[b] = (d[0][b], d[1][b]), Q[b] = (d[2][b], d[3][b]) -- the register pairs the two ds_read2st64_b32 of patch column b deliver.
+// Rows first: per column b,  T[b] = (d0 - d2, d1 + d2),  S[b] = (d1 - d2, d1 - d3)   [row 2 with the opposite sign: see bt_wino_pack_kernel];
+// then columns, on whole pairs: j = 0: X0 - X2, 1: X1 + X2, 2: X1 - X2 (opposite sign), 3: X1 - X3 for X = T (rows 0, 1) and X = S (rows 2, 3).
+// Out: VT[j] = (V'[0][j], V'[1][j]), VS[j] = (V'[2][j], V'[3][j]).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wn_transform(const f32x2 (&P)[4], const f32x2 (&Q)[4], f32x2 (&VT)[4], f32x2 (&VS)[4]) {
+    f32x2 T0, T1, T2, T3, S0, S1, S2, S3;
+    asm volatile(
+        "v_pk_add_f32 %8, %16, %20 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %12, %16, %20 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %9, %17, %21 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %13, %17, %21 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %10, %18, %22 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %14, %18, %22 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %11, %19, %23 op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_add_f32 %15, %19, %23 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %8, %10 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %9, %10\n\t"
+        "v_pk_add_f32 %2, %9, %10 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %3, %9, %11 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %4, %12, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %5, %13, %14\n\t"
+        "v_pk_add_f32 %6, %13, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %7, %13, %15 neg_lo:[0,1] neg_hi:[0,1]"
+        : "=&v"(VT[0]), "=&v"(VT[1]), "=&v"(VT[2]), "=&v"(VT[3]), "=&v"(VS[0]), "=&v"(VS[1]), "=&v"(VS[2]), "=&v"(VS[3]),
+          "=&v"(T0), "=&v"(T1), "=&v"(T2), "=&v"(T3), "=&v"(S0), "=&v"(S1), "=&v"(S2), "=&v"(S3)
+        : "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(Q[0]), "v"(Q[1]), "v"(Q[2]), "v"(Q[3]));
 }
 
 template <bool UP, bool ADD2 = false>
@@ -157,15 +182,13 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
             }
     };
 
-    // ---- U fragments straight from global memory (L2) into the MFMA A registers: fragment (chunk c, pass e, row group g) is 1 KB per wave,
-    //      lane (l31, half) -> U_{4 g + j}[32 wave + l31][8 c + 4 half + e], j = 0..3.  Rolling prefetch three passes (3 072 MFMA cycles) ahead:
-    //      at the start of pass e the registers of the pass before are free and take (c + 1, e - 1) [pass 0: (c, 3)] ----------------------------
-    unsigned uoff = (unsigned)(wave * 1024 + lane * 16);   // (uniform base + one 32-bit lane offset; made opaque per tile, or the compiler
-                                                           // keeps the twelve addresses of a tile's first loads alive -- in scratch -- across the loop)
-    auto uload = [&](int c, int e, f32x4 (&dst)[4]) {
-        const unsigned char* const ub = reinterpret_cast<const unsigned char*>(p.w2d) + (size_t)(c * 4 + e) * 16384 + uoff;
-        wn_uload4(dst, ub + 4096, ub + 3 * 4096);
-    };
+    // ---- U fragments straight from global memory (L2) into the MFMA A registers: the wave's four fragments (columns j = 0..3) of (chunk c, pass e)
+    //      are 4 KB at U + ((4 c + e) 4 + wave) 4096; lane (l31, half) of fragment j -> U'_{i j}[32 wave + l31][8 c + 4 half + e], i = 0..3.
+    //      Rolling prefetch three passes (3 072 MFMA cycles) ahead: at the start of pass e the registers of the pass before are free and take
+    //      (c + 1, e - 1) [pass 0: (c, 3)] -------------------------------------------------------------------------------------------------------
+    const unsigned uoff = (unsigned)(lane * 16);
+    const unsigned char* const ubase = reinterpret_cast<const unsigned char*>(p.w2d) + (size_t)wave * 4096;
+    auto uload = [&](int c, int e, f32x4 (&dst)[4]) { wn_uload4(dst, ubase + (size_t)(c * 4 + e) * 16384, uoff); };
 
     // ---- input transform: lane -> (patch 8 wave + (lane & 7), channel quad (lane >> 3) & 1, channel lane >> 4) of the chunk -----------
     // t1 element (halo pixel hp, channel 64 kh + 4 kq + e) sits at hp * 256 + ((kq ^ swz(hp)) << 4) + 4 e of half kh (br_t1_swz): the 64 lanes
@@ -177,34 +200,26 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         const int hx = 2 * ptx + bb, hp = (2 * wave) * BT_HW + hx;
         rd[bb] = (unsigned)(hp * 256 + ((pkq ^ (hx & 15)) << 4) + 4 * pe);
     }
-    // V chunk image [channel e 4][row group g 4][quad kq 2][patch 32][j 4] floats: the 16 bytes a lane writes per g are V_{4 g + 0..3} of its
-    // (patch, channel), the 16 bytes a lane reads per (e, g) are the B values of MFMAs (4 g + j, e) for its patch; patch n of quad kq sits in
-    // slot n ^ 8 kq (writes of a 16-lane group -- 8 patches x 2 quads -- then fall into 16 different 16-byte slots of the bank row)
+    // V chunk image [channel e 4][column j 4][quad kq 2][patch 32][row i 4] floats: the 16 bytes a lane writes per column j (two 8-byte halves)
+    // are V'_{0..3, j} of its (patch, channel), the 16 bytes a lane reads per (e, j) are the B values of MFMAs (4 i + j, e) for its patch; patch n of
+    // quad kq sits in slot n ^ 8 kq (a permuted 512-byte row either way)
     const unsigned vwr = (unsigned)(pe * 4096 + pkq * 512 + (((8 * wave + ptx) ^ (pkq << 3)) << 4));
     const unsigned vrd = (unsigned)(half * 512 + ((l31 ^ (half << 3)) << 4));
-    float td[4][4], tt[4][4];
-    auto t_read = [&](int c) {   // the 4 x 4 patch of chunk c's channel
-        const unsigned char* const src = t1_lds + (c >> 3) * BR_T1_BYTES;
-        const unsigned x = (unsigned)((c & 7) << 5);
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) td[a][bb] = *reinterpret_cast<const float*>(src + (rd[bb] ^ x) + a * (BT_HW * 256));
+    f32x2 tP[4], tQ[4];
+    auto t_read = [&](int c, int bb) {   // column bb of the 4 x 4 patch of chunk c's channel: rows (0, 1) and (2, 3) as register pairs
+        const unsigned char* const src = t1_lds + (c >> 3) * BR_T1_BYTES + (rd[bb] ^ (unsigned)((c & 7) << 5));
+        tP[bb] = f32x2{*reinterpret_cast<const float*>(src), *reinterpret_cast<const float*>(src + BT_HW * 256)};
+        tQ[bb] = f32x2{*reinterpret_cast<const float*>(src + 2 * BT_HW * 256), *reinterpret_cast<const float*>(src + 3 * BT_HW * 256)};
     };
-    auto t_cols = [&]() {   // B^T d
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tt[0][j] = wn_sub(td[0][j], td[2][j]);
-            tt[1][j] = wn_add(td[1][j], td[2][j]);
-            tt[2][j] = wn_sub(td[2][j], td[1][j]);
-            tt[3][j] = wn_sub(td[1][j], td[3][j]);
-        }
-    };
-    auto t_rows_write = [&](int buf) {   // (B^T d) B -> V buffer
+    auto t_transform_write = [&](int buf) {   // sixteen packed adds in one clump, eight 8-byte stores
+        f32x2 vt[4], vs[4];
+        wn_transform(tP, tQ, vt, vs);
         unsigned char* const dst = ring + buf * WN_V_BYTES + vwr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4*>(dst + i * 1024) = f32x4{wn_sub(tt[i][0], tt[i][2]), wn_add(tt[i][1], tt[i][2]), wn_sub(tt[i][2], tt[i][1]), wn_sub(tt[i][1], tt[i][3])};
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<f32x2*>(dst + j * 1024) = vt[j];
+            *reinterpret_cast<f32x2*>(dst + j * 1024 + 8) = vs[j];
+        }
     };
     const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
     auto ring_issue = [&](int k) {   // W3 stage k (0..15) -> slot k % 4; this wave copies pieces 2 wave, 2 wave + 1
@@ -245,7 +260,6 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
         f32x4 ufr[4][4];
-        asm volatile("" : "+v"(uoff));
         uload(0, 0, ufr[0]);
         uload(0, 1, ufr[1]);
         uload(0, 2, ufr[2]);
@@ -256,9 +270,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         first = false;
         br_barrier();
         BR_STAMP(0);
-        t_read(0);
-        t_cols();
-        t_rows_write(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) t_read(0, g);
+        t_transform_write(0);
         br_barrier();
         BR_STAMP(1);
 
@@ -283,16 +297,19 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                     else uload(cn, e - 1, ufr[e - 1]);
                     __builtin_amdgcn_sched_barrier(0);   // (... issued HERE: the scheduler would sink the statement behind the pass's MFMAs)
                 }
-                if (e < 3 && (!(WN_ABL & 8) || c == 0)) {
+                // four groups (columns j) of four MFMAs (rows i); LDS instructions are all but free between MFMAs, so each group carries one V
+                // fragment read for the next pass and, in pass 0, the patch reads of the NEXT chunk's input transform; the transform's VALU
+                // work is ONE clump per chunk (pass 2: a whole pass behind its reads), its stores follow it
+                if (e == 2 && !(WN_ABL & 2)) t_transform_write((c + 1) & 1);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) vf[(e + 1) & 1][g] = *reinterpret_cast<const f32x4*>(vb_ + (e + 1) * 4096 + g * 1024);
+                for (int g = 0; g < 4; ++g) {
+                    if (e < 3 && (!(WN_ABL & 8) || c == 0)) vf[(e + 1) & 1][g] = *reinterpret_cast<const f32x4*>(vb_ + (e + 1) * 4096 + g * 1024);
+                    if (e == 0 && !(WN_ABL & 2)) t_read(cn, g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[4 * i + g] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[e][g][i], vf[e & 1][g][i], acc[4 * i + g], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (e == 0 && !(WN_ABL & 2)) t_read(cn);
-                if (e == 1 && !(WN_ABL & 2)) t_cols();
-#pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[e][q >> 2][q & 3], vf[e & 1][q >> 2][q & 3], acc[q], 0, 0, 0);
-                if (e == 2 && !(WN_ABL & 2)) t_rows_write((c + 1) & 1);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!(WN_ABL & 4)) br_barrier();   // V(c) is read by every wave, V(c + 1) written by every wave
