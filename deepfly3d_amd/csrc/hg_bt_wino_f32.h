@@ -35,12 +35,16 @@ namespace hgk {
 
 constexpr int WN_CHUNKS = 16;                          // K chunks of 8 input channels
 constexpr int WN_U_BYTES = WN_CHUNKS * 16 * 4 * 1024;  // [chunk][pass][row group][wave] x 1 KB MFMA A fragments = 1 MiB per bottleneck
+constexpr int WN_W3_BYTES = BRF_W3_STAGES * BR_STAGE_BYTES;   // behind U: W3's 16 stage images with their rows permuted (bt_wino_pack_w3_kernel)
+constexpr int WN_STREAM_BYTES = WN_U_BYTES + WN_W3_BYTES;
 constexpr int WN_V_BYTES = 16 * 1024;                  // one V chunk: [channel 4][row group 4][channel quad 2][patch 32] x 16 bytes
 constexpr int WN_T1_OFF = 2 * WN_V_BYTES;              // = BR_RING_BYTES: the W3 ring reuses the V buffers
 constexpr int WN_T1_BYTES = 2 * BR_T1_BYTES;           // both 64-channel halves of the 10 x 18 halo tile (92 160)
 constexpr int WN_T2_BYTES = BT_TH * BT_TW * 512;       // t2 [128 pixels][128 channels] fp32 (65 536), inside the t1 region
 constexpr int WN_B3_OFF = WN_T1_OFF + WN_T1_BYTES;
-constexpr int WN_LDS_BYTES = WN_B3_OFF + 1024 + 512;   // b3 [256] | b2 [128]
+constexpr int WN_RING2_OFF = WN_B3_OFF + 1024 + 512;   // b3 [256] | b2 [128] | W3 ring slots 4 .. 7
+constexpr int WN_LDS_BYTES = WN_RING2_OFF + BR_RING_BYTES;
+static_assert(WN_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 static_assert(WN_T1_OFF == BR_RING_BYTES, "the W3 ring takes the V buffers' place");
 static_assert(WN_T2_BYTES <= WN_T1_BYTES, "t2 lives in the t1 region");
 
@@ -74,6 +78,18 @@ __global__ __launch_bounds__(256) void bt_wino_pack_kernel(const float* __restri
         for (int j = 0; j < 4; ++j)
             ustream[((size_t)(((c * 4 + e) * 4 + w) * 4 + j) * 64 + half * 32 + l31) * 4 + i] = (float)(((i == 2) != (j == 2)) ? -u[j] : u[j]);
     }
+}
+
+// W3 [256][128] fp32 -> 16 stage images (hg_bt_ring_f32.h's: output half nh, 16-float K slice k8; 128 rows x 64 bytes, br_swz) with the ROWS PERMUTED:
+// row 32 i + l of an image holds output channel 128 nh + 4 l + i.  Phase 3's accumulator tile i, column l31 is then channel 4 l31 + i: the lane's
+// four tiles are four CONSECUTIVE channels of one pixel, and residual, addends, output and pooled outputs move as 16-byte accesses (a quarter of the
+// vector-memory instructions, each of which this one-wave-per-SIMD kernel pays for in full; and a wave may have only 64 of them in flight).
+__global__ __launch_bounds__(256) void bt_wino_pack_w3_kernel(const float* __restrict__ w3, unsigned char* __restrict__ stream) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= BRF_W3_STAGES * 512) return;
+    const int k = idx >> 9, rem = idx & 511, c = rem & 3, r = rem >> 2, nh = k >> 3, k8 = k & 7;
+    const int ch = 4 * (r & 31) + (r >> 5);
+    *reinterpret_cast<u32x4*>(stream + (size_t)k * BR_STAGE_BYTES + br_swz(r, c)) = *reinterpret_cast<const u32x4*>(w3 + ((size_t)nh * 128 + ch) * 128 + 16 * k8 + 4 * c);
 }
 
 // What an instruction costs between two of a wave's fp32 MFMAs when the wave is alone on its SIMD (tests/perf/ubench/mfma_f32_shadow.hip, cycles
@@ -222,11 +238,16 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         }
     };
     const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
-    auto ring_issue = [&](int k) {   // W3 stage k (0..15) -> slot k % 4; this wave copies pieces 2 wave, 2 wave + 1
-        if (k < BRF_W3_STAGES) {
-            const unsigned dst = ring_addr + (unsigned)(k % BR_RING) * BR_STAGE_BYTES + (unsigned)wave * 2048;
-            br_glds_stage(reinterpret_cast<const unsigned char*>(p.wstream) + (size_t)(2 * BRF_KH_STAGES + k) * BR_STAGE_BYTES, wvoff, dst);
-        }
+    // W3's 16 stages in two sets of eight (one per 128-channel output half): stage k -> slot k % 8, slots 0 .. 3 where the V buffers were, 4 .. 7
+    // in a region of their own.  A whole half is resident before its K loop starts: no wait, no barrier inside the loop (operations retire in
+    // issue order, so a wait for a young ring stage would also wait for every older load -- the tile's 128 KB of residual values, the next
+    // tile's halo, which all 256 workgroups request within the same microsecond)
+    auto ring_slot = [](int k) { return (k & 7) < 4 ? (k & 7) * BR_STAGE_BYTES : WN_RING2_OFF + ((k & 7) - 4) * BR_STAGE_BYTES; };
+    auto ring_issue8 = [&](int nh) {   // this wave copies pieces 2 wave, 2 wave + 1 of each stage
+#pragma unroll
+        for (int k = 8 * nh; k < 8 * nh + 8; ++k)
+            br_glds_stage(reinterpret_cast<const unsigned char*>(p.w2d) + WN_U_BYTES + (size_t)k * BR_STAGE_BYTES, wvoff,
+                          ring_addr + (unsigned)ring_slot(k) + (unsigned)wave * 2048);
     };
 
 #ifdef DF3D_BT_TIMING
@@ -326,15 +347,11 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         const unsigned char* const wf1 = ring + br_swz(l31_3, 2 + half3);
         const int py = 2 * wave + (l31_3 >> 4), px = l31_3 & 15;   // this wave's 32 pixels (phase 3)
         // phase 3's global addresses = (tile, register)-dependent UNIFORM part + one of two per-lane byte offsets (pixel 4 half / half-resolution
-        // pixel 2 half of the register's group, channel l31): scalar address arithmetic, two VGPRs -- not one address register pair per access
-        const unsigned lane_full = (unsigned)((4 * half3 * CO + l31_3) * 4);
-        const unsigned lane_half = (unsigned)((2 * half3 * CO + l31_3) * 4);
-        // W3 stages 0 .. 3 into the ring (both V buffers are dead): two double-steps ahead, so that phase 3's first two waits only have to let
-        // the residual loads below pass (operations retire in issue order: "at most 63 outstanding" covers anything older than 64 loads)
-        ring_issue(0);
-        ring_issue(1);
-        ring_issue(2);
-        ring_issue(3);
+        // pixel 2 half of the register's group, channels 4 l31 .. 4 l31 + 3 -- bt_wino_pack_w3_kernel): scalar address arithmetic, two VGPRs -- not one address register pair per access
+        const unsigned lane_full = (unsigned)((4 * half3 * CO + 4 * l31_3) * 4);
+        const unsigned lane_half = (unsigned)((2 * half3 * CO + 4 * l31_3) * 4);
+        // W3's first half into the ring (both V buffers are dead; slots 4 .. 7 were last read a tile ago): it lands under the output transform
+        ring_issue8(0);
 
         // ---- output transform Y = A^T M A, ReLU, t2 -> LDS (pixel-major, 16-byte chunk ch of pixel (y, x) in slot ch ^ (x & 15) ^ ((y >> 1) & 1)
         //      of its 512-byte row: conflict-free for these writes (16 lanes = 8 patch columns x 2 patch rows) and for phase 3's reads).
@@ -369,32 +386,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                         *reinterpret_cast<f32x4*>(t1_lds + (wbase ^ (unsigned)(((2 * q) ^ bb) << 4)) + (16 * a + bb) * 512) = y[a][bb];
             }
         }
-        // ---- residual values (and the ADD2 addends) of the whole tile, requested as soon as the 256 accumulators of phase 2 are dead (one wave per SIMD:
-        //      nobody hides a load issued in an epilogue; the 512-register file has room for them beside phase 3): first used 16 000 cycles from here ----
-        float xres[2][4][16];
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pl0 = (r & 3) + 8 * (r >> 2);   // + 4 half: the lane's part
-                    xres[nh][i][r] = *reinterpret_cast<const float*>(xtile + ((size_t)(pl0 >> 4) * p.W + (pl0 & 15)) * (CIN * 4) + (nh * 128 + i * 32) * 4 + lane_full);
-                }
-            }
-        float a2v[ADD2 ? 2 : 1][4][4];
-        if constexpr (ADD2) {
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned char* const lrow = reinterpret_cast<const unsigned char*>(p.add2) + htile + (nh * 128 + i * 32) * 4;
-#pragma unroll
-                    for (int key = 0; key < 4; ++key) a2v[nh][i][key] = *reinterpret_cast<const float*>(lrow + ((key & 1) + 4 * (key >> 1)) * (CO * 4) + lane_half);
-                }
-        }
         BR_STAMP(3);
-        br_barrier();
+        br_wait_vm(0);   // the ring's first half (and whatever is older: the tile before's stores, a whole tile ago)
+        br_barrier();    // t2 and the eight stages are every wave's
         f32x16 t2[4];
         {
             const unsigned rbase = (unsigned)((py * BT_TW + px) * 512 + ((half3 ^ (px & 15) ^ (wave & 1)) << 4));
@@ -408,6 +402,26 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                 }
         }
 
+        br_barrier();   // every wave holds its t2 in registers: the t1 region may take the next tile's halo
+        if (has_next) t1_issue(ntx0, nty0, nview);
+        // ---- residual values (and the ADD2 addends) of the whole tile, requested here -- behind the ring's first half (no ring wait has to let them pass), 16 000 MFMA cycles
+        //      in front of their first use (one wave per SIMD: nobody hides a load issued in an epilogue; the 512-register file has room) ----
+        f32x4 xres[2][16];   // [output half][register r <-> pixel (r & 3) + 8 (r >> 2) + 4 half]: channels 128 nh + 4 l31 .. + 3
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pl0 = (r & 3) + 8 * (r >> 2);   // + 4 half: the lane's part
+                xres[nh][r] = *reinterpret_cast<const f32x4*>(xtile + ((size_t)(pl0 >> 4) * p.W + (pl0 & 15)) * (CIN * 4) + nh * 512 + lane_full);
+            }
+        f32x4 a2v[ADD2 ? 2 : 1][4];
+        if constexpr (ADD2) {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int key = 0; key < 4; ++key)
+                    a2v[nh][key] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.add2) + htile + ((key & 1) + 4 * (key >> 1)) * (CO * 4) + nh * 512 + lane_half);
+        }
         BR_STAMP(4);
         // ---- phase 3: out = W3 relu(t2) + b3 + x  (bottleneck_ring_f32_kernel's exact-fp32 form: rows = the wave's pixels, columns = channels) ----
 #pragma unroll
@@ -416,21 +430,16 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) {
                 const int k0 = 8 * nh + 2 * dd;
-                // the pair was requested a double-step (first two: an output transform) ago.  Counted waits where younger operations need not have
-                // retired: the 128+ residual loads behind stages 0 .. 3, the >= 64 stores of the first half's epilogue behind stages 8, 9
-                if ((nh == 0 && dd < 2) || (nh == 1 && dd == 0)) br_wait_vm(63);
-                else br_wait_vm(0);
-                br_barrier();
-                if (nh == 0 && dd == 0) {
-                    if (has_next) t1_issue(ntx0, nty0, nview);   // every wave holds its t2 in registers: the t1 region takes the next tile's halo
-                } else {
-                    ring_issue(k0 + 2);
-                    ring_issue(k0 + 3);
+                if (nh == 1 && dd == 0) {
+                    // the second half's stages were requested behind the first K loop; younger than them are only the >= 64 stores of the first
+                    // half's epilogue, which need not have drained
+                    br_wait_vm(63);
+                    br_barrier();
                 }
                 if (dd == 0) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float bias = b3_lds[nh * 128 + i * 32 + l31_3];
+                        const float bias = b3_lds[nh * 128 + 4 * l31_3 + i];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) o[i][r] = bias;
                     }
@@ -443,58 +452,49 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + (s % BR_RING) * BR_STAGE_BYTES + i * 2048);
+                            const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + ring_slot(s) + i * 2048);
                             mfma_quad<T>(t2[tile][8 * q2 + 4 * jj], t2[tile][8 * q2 + 4 * jj + 1], t2[tile][8 * q2 + 4 * jj + 2], t2[tile][8 * q2 + 4 * jj + 3], wf, o[i]);
                         }
                 }
             }
+            if (nh == 0) {
+                br_barrier();     // every wave is through the first half's eight stages
+                ring_issue8(1);   // ... the second half's land under the epilogue
+            }
             BR_STAMP(5 + 2 * nh);
-            // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4 half of the wave][col = channel nh*128 + 32 i + l31]
+            // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4 half of the wave][col = channel nh*128 + 4 l31 + i]: register r of the four tiles = four
+            // consecutive channels of one pixel
+            // -- walked by 2x2 pixel quads (registers r0, r0 + 1, r0 + 8, r0 + 9: horizontal neighbour r ^ 1, vertical r ^ 8; one half-resolution pixel),
+            // so that only four 16-byte values are alive at a time and the max-pools stay inside the lane
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int nb = (nh * 128 + i * 32) * 4;   // byte offset of the tile's channel group (+ l31 in the lane offsets)
-                float xv[16];
+            for (int key = 0; key < 4; ++key) {
+                const int r0 = 2 * (key & 1) + 4 * (key >> 1);
+                const int hoff = ((key & 1) + 4 * (key >> 1)) * (CO * 4) + nh * 512;   // the quad's half-resolution pixel (+ 2 half in the lane offset)
+                f32x4 xv[4], ov[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xv[r] = xres[nh][i][r];
+                for (int t = 0; t < 4; ++t) xv[t] = xres[nh][r0 + (t & 1) + 8 * (t >> 1)];
                 if constexpr (UP) {
-                    float t4[4];
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.in2) + htile + hoff + lane_half);
 #pragma unroll
-                    for (int key = 0; key < 4; ++key)
-                        t4[key] = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.in2) + htile + ((key & 1) + 4 * (key >> 1)) * (CIN * 4) + nb + lane_half);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) xv[r] += t4[((r >> 1) & 1) + 2 * ((r >> 2) & 1)];
+                    for (int t = 0; t < 4; ++t) xv[t] += t4;
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] += xv[r];
-                if constexpr (ADD2) {   // + nearest-upsample(add2): a second fp32 add, as upadd_kernel would have done on the stored tensor
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[i][r] += a2v[nh][i][((r >> 1) & 1) + 2 * ((r >> 2) & 1)];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int t = 0; t < 4; ++t) {
+                    const int r = r0 + (t & 1) + 8 * (t >> 1);
+                    ov[t] = f32x4{o[0][r], o[1][r], o[2][r], o[3][r]} + xv[t];
+                    if constexpr (ADD2) ov[t] += a2v[nh][key];   // a second fp32 add, as upadd_kernel would have done on the stored tensor
                     const int pl0 = (r & 3) + 8 * (r >> 2);
-                    *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(p.out) + ftile + ((size_t)(pl0 >> 4) * p.W + (pl0 & 15)) * (CO * 4) + nb + lane_full) = o[i][r];
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.out) + ftile + ((size_t)(pl0 >> 4) * p.W + (pl0 & 15)) * (CO * 4) + nh * 512 + lane_full) = ov[t];
                 }
-                if constexpr (!UP) if (p.pool_in) {   // 2x2 max-pool of the block's INPUT (the skip values just added)
+                auto max4 = [](const f32x4 (&v)[4]) {
+                    f32x4 m;
 #pragma unroll
-                    for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-                        for (int b2 = 0; b2 < 2; ++b2) {
-                            const int r0 = 2 * a2 + 4 * b2;
-                            const float v = fmaxf(fmaxf(xv[r0], xv[r0 + 1]), fmaxf(xv[r0 + 8], xv[r0 + 9]));
-                            *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(p.pool_in) + htile + (a2 + 4 * b2) * (CIN * 4) + nb + lane_half) = v;
-                        }
-                }
-                if (p.pool) {   // 2x2 max-pool inside the lane: horizontal neighbour = register r^1, vertical neighbour = r^8
-#pragma unroll
-                    for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-                        for (int b2 = 0; b2 < 2; ++b2) {
-                            const int r0 = 2 * a2 + 4 * b2;
-                            const float v = fmaxf(fmaxf(o[i][r0], o[i][r0 + 1]), fmaxf(o[i][r0 + 8], o[i][r0 + 9]));
-                            *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(p.pool) + htile + (a2 + 4 * b2) * (CO * 4) + nb + lane_half) = v;
-                        }
-                }
+                    for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(v[0][e], v[1][e]), fmaxf(v[2][e], v[3][e]));
+                    return m;
+                };
+                if constexpr (!UP) if (p.pool_in)   // 2x2 max-pool of the block's INPUT (the skip values just added)
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.pool_in) + htile + hoff + lane_half) = max4(xv);
+                if (p.pool) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.pool) + htile + hoff + lane_half) = max4(ov);
             }
             BR_STAMP(6 + 2 * nh);
         }

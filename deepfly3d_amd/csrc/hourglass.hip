@@ -325,7 +325,7 @@ struct df3d_hg {
                     st.t1 = new_tensor(tx.h, tx.w, planes);
                     if (wino && dtype == DF3D_DTYPE_F32) {   // the tail's 3x3 in the Winograd domain: U = G g G^T as per-wave MFMA fragments
                         st.wstream_w2d = (long long)stream_bytes;
-                        stream_bytes += (size_t)WN_U_BYTES;
+                        stream_bytes += (size_t)WN_STREAM_BYTES;   // U, then W3 with permuted rows
                     }
                 }
             }
@@ -1432,8 +1432,11 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
                 hipLaunchKernelGGL(bt_c1_pack_f32_kernel, dim3((C1_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),
                                    blob_dev + st.conv.w_off, reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_c1);
             if (st.wstream_w2d >= 0 && h->dtype == DF3D_DTYPE_F32)
-                hipLaunchKernelGGL(bt_wino_pack_kernel, dim3(128 * 128 / 256), dim3(256), 0, df3d::as_stream(stream),
-                                   blob_dev + st.conv2b.w_off, reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_w2d));
+            {
+                unsigned char* const ws = reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_w2d;
+                hipLaunchKernelGGL(bt_wino_pack_kernel, dim3(128 * 128 / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv2b.w_off, reinterpret_cast<float*>(ws));
+                hipLaunchKernelGGL(bt_wino_pack_w3_kernel, dim3(BRF_W3_STAGES * 512 / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv3b.w_off, ws + WN_U_BYTES);
+            }
         }
         if (h->uses_zero_page)
             DF3D_HIP(hipMemsetAsync(reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + h->zero_off, 0, 256, df3d::as_stream(stream)));
