@@ -221,16 +221,25 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
     // quad kq sits in slot n ^ 8 kq (a permuted 512-byte row either way)
     const unsigned vwr = (unsigned)(pe * 4096 + pkq * 512 + (((8 * wave + ptx) ^ (pkq << 3)) << 4));
     const unsigned vrd = (unsigned)(half * 512 + ((l31 ^ (half << 3)) << 4));
+    // three V buffers (chunk c is read from buffer c % 3 while chunk c + 2 is built into (c + 2) % 3: a chunk's first fragments can then be
+    // requested before the barrier that ends the chunk in front of it): 0, 1 where the W3 ring's slots 0 .. 3 will be, 2 where its slots 4 .. 7 will be
+    auto vbuf_off = [](int b) { return b < 2 ? b * WN_V_BYTES : WN_RING2_OFF; };
     f32x2 tP[4], tQ[4];
-    auto t_read = [&](int c, int bb) {   // column bb of the 4 x 4 patch of chunk c's channel: rows (0, 1) and (2, 3) as register pairs
-        const unsigned char* const src = t1_lds + (c >> 3) * BR_T1_BYTES + (rd[bb] ^ (unsigned)((c & 7) << 5));
-        tP[bb] = f32x2{*reinterpret_cast<const float*>(src), *reinterpret_cast<const float*>(src + BT_HW * 256)};
-        tQ[bb] = f32x2{*reinterpret_cast<const float*>(src + 2 * BT_HW * 256), *reinterpret_cast<const float*>(src + 3 * BT_HW * 256)};
+    unsigned ta[4];   // LDS addresses of the next patch reads (computed in the VALU clump of the chunk before: no lone VALU instruction in phase 2)
+    auto t_addr = [&](int c) {   // chunk c's patch columns
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) ta[bb] = (rd[bb] ^ (unsigned)((c & 7) << 5)) + (t1_addr + (unsigned)((c >> 3) * BR_T1_BYTES));   // (a complete LDS address: one v_xad_u32)
     };
-    auto t_transform_write = [&](int buf) {   // sixteen packed adds in one clump, eight 8-byte stores
+    auto t_read = [&](int bb) {   // column bb of the 4 x 4 patch: rows (0, 1) and (2, 3) as register pairs
+        typedef const __attribute__((address_space(3))) float* lds_f;
+        tP[bb] = f32x2{*(lds_f)(size_t)ta[bb], *(lds_f)(size_t)(ta[bb] + BT_HW * 256)};
+        tQ[bb] = f32x2{*(lds_f)(size_t)(ta[bb] + 2 * BT_HW * 256), *(lds_f)(size_t)(ta[bb] + 3 * BT_HW * 256)};
+    };
+    auto t_transform_write = [&](int buf, int c_next_addr) {   // sixteen packed adds + the next reads' four addresses in one clump, then the stores
         f32x2 vt[4], vs[4];
         wn_transform(tP, tQ, vt, vs);
-        unsigned char* const dst = ring + buf * WN_V_BYTES + vwr;
+        t_addr(c_next_addr);
+        unsigned char* const dst = smem + vbuf_off(buf) + vwr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             *reinterpret_cast<f32x2*>(dst + j * 1024) = vt[j];
@@ -275,11 +284,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         // accumulators (b2 is added to position (1,1) -- which enters all four outputs of a patch with weight +1 -- in the output transform: as a
         // start value it would be a global load straight into accumulator registers, and the wait hipcc puts in front of the first MFMA that
         // touches them sits inside the chunk loop: a vmcnt(0) per chunk, 580 cycles each)
-        f32x16 acc[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+        f32x16 acc[16];   // (their first MFMAs take a zero addend: chunk 0, pass 0)
         f32x4 ufr[4][4];
         uload(0, 0, ufr[0]);
         uload(0, 1, ufr[1]);
@@ -291,21 +296,31 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         first = false;
         br_barrier();
         BR_STAMP(0);
+        asm volatile("" : "+v"(rd[0]), "+v"(rd[1]), "+v"(rd[2]), "+v"(rd[3]));   // (or the first chunks' read addresses are hoisted out of the tile loop: 12 registers kept alive in scratch)
+        t_addr(0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) t_read(0, g);
-        t_transform_write(0);
+        for (int g = 0; g < 4; ++g) t_read(g);
+        t_transform_write(0, 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) t_read(g);
+        t_transform_write(1, 2);
         br_barrier();
         BR_STAMP(1);
 
-        // ---- phase 2: 16 chunks x 4 passes (K pair e) x 16 positions.  One straight-line body per chunk; the scheduling fences pin, per pass, the
-        //      U loads, the V fragment reads of the NEXT pass and a quarter of the next chunk's input transform among that pass's 16 MFMAs ------
+        // ---- phase 2: 16 chunks x 4 passes (K pair e) x 4 columns x 4 rows.  Chunk c: MFMAs on V(c) (buffer c % 3) while V(c + 2) is built.
+        //      Nothing vector-side hides behind an fp32 MFMA here, so a chunk issues, beside its 64 MFMAs: 16 U loads (scalar base), 16 + 8 LDS
+        //      reads, 4 LDS stores, ONE clump of 20 VALU instructions, one barrier -------------------------------------------------------------
         f32x4 vf[2][4];
-#pragma unroll 1
-        for (int c = 0; c < WN_CHUNKS; ++c) {
-            const int cn = c + 1 < WN_CHUNKS ? c + 1 : c;   // (the last chunk rebuilds its own V into the other buffer and re-requests its own fragments:
-                                                            // one code path)
-            const unsigned char* const vb_ = ring + (c & 1) * WN_V_BYTES + vrd;
-            if (!(WN_ABL & 8) || c == 0) {
+        // c: the chunk (runtime); BR = c % 3 and FIRST = (c == 0) as compile-time tags
+        auto chunk = [&](int c, auto br_tag, auto first_tag) {
+            constexpr int BR = decltype(br_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const int cn = c + 1 < WN_CHUNKS ? c + 1 : c;   // (the last chunks re-request fragments / rebuild buffers nobody reads any more: one code path)
+            const int c2 = c + 2 < WN_CHUNKS ? c + 2 : WN_CHUNKS - 1, c3 = c + 3 < WN_CHUNKS ? c + 3 : WN_CHUNKS - 1;
+            (void)c2;
+            const unsigned char* const vb_ = smem + vbuf_off(BR) + vrd;
+            const unsigned char* const vn_ = smem + vbuf_off((BR + 1) % 3) + vrd;
+            if (FIRST) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) vf[0][g] = *reinterpret_cast<const f32x4*>(vb_ + g * 1024);
             }
@@ -318,22 +333,35 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                     else uload(cn, e - 1, ufr[e - 1]);
                     __builtin_amdgcn_sched_barrier(0);   // (... issued HERE: the scheduler would sink the statement behind the pass's MFMAs)
                 }
-                // four groups (columns j) of four MFMAs (rows i); LDS instructions are all but free between MFMAs, so each group carries one V
-                // fragment read for the next pass and, in pass 0, the patch reads of the NEXT chunk's input transform; the transform's VALU
-                // work is ONE clump per chunk (pass 2: a whole pass behind its reads), its stores follow it
-                if (e == 2 && !(WN_ABL & 2)) t_transform_write((c + 1) & 1);
+                if (e == 2 && !(WN_ABL & 2)) {
+                    t_transform_write((BR + 2) % 3, c3);   // V(c + 2) from the patch read in pass 0; addresses for the reads of chunk c + 1's pass 0
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if (e < 3 && (!(WN_ABL & 8) || c == 0)) vf[(e + 1) & 1][g] = *reinterpret_cast<const f32x4*>(vb_ + (e + 1) * 4096 + g * 1024);
-                    if (e == 0 && !(WN_ABL & 2)) t_read(cn, g);
+                    // LDS instructions are all but free between MFMAs: one V fragment read for the next pass (pass 3: the NEXT chunk's pass 0,
+                    // whose buffer was complete a barrier ago) and, in pass 0, a column of the patch V(c + 2) is built from
+                    if (e < 3) vf[(e + 1) & 1][g] = *reinterpret_cast<const f32x4*>(vb_ + (e + 1) * 4096 + g * 1024);
+                    else vf[0][g] = *reinterpret_cast<const f32x4*>(vn_ + g * 1024);
+                    if (e == 0 && !(WN_ABL & 2)) t_read(g);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[4 * i + g] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[e][g][i], vf[e & 1][g][i], acc[4 * i + g], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) {
+                        if (FIRST && e == 0)   // a tile's first product into each accumulator starts from zero: no 256 v_accvgpr_write per tile
+                            acc[4 * i + g] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[e][g][i], vf[e & 1][g][i], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+                        else
+                            acc[4 * i + g] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufr[e][g][i], vf[e & 1][g][i], acc[4 * i + g], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(WN_ABL & 4)) br_barrier();   // V(c) is read by every wave, V(c + 1) written by every wave
+            if (!(WN_ABL & 4)) br_barrier();   // V(c) is read by every wave (its buffer is rebuilt two chunks on), V(c + 2) written by every wave
+        };
+        chunk(0, std::integral_constant<int, 0>{}, std::true_type{});
+#pragma unroll 1
+        for (int c = 1; c < WN_CHUNKS; c += 3) {
+            chunk(c, std::integral_constant<int, 1>{}, std::false_type{});
+            chunk(c + 1, std::integral_constant<int, 2>{}, std::false_type{});
+            chunk(c + 2, std::integral_constant<int, 0>{}, std::false_type{});
         }
 
         BR_STAMP(2);
