@@ -32,7 +32,8 @@ ranks, one packed gather, Procrustes over the whole sequence on rank 0, all insi
 and rank 0's tail (gather / Procrustes ms) on the line.  N = 1 runs the whole stream on one GPU (the same pipeline as the default line).
 
 Roofline fractions (per kernel and for the dominant one), spelled out because a fused kernel has more than one byte count:
-  frac_mfma      algorithmic FLOPs / time / dense MFMA peak of the dtype
+  frac_mfma      FLOPs EXECUTED on the matrix pipe / time / dense MFMA peak of the dtype (the Winograd tail of the fp32 engine executes 16/36 of a
+                 3x3's direct FLOPs: its direct-equivalent rate is printed beside the fraction, never priced against the peak)
   frac_hbm_min   (inputs read once + outputs written once, intermediates on chip) / time / 8 TB/s -- the least the launch can move
   frac_hbm_m1    bytes the fusion model M1 of SURVEY.md 8(d) charges (every convolution's input and output) / time / 8 TB/s
                  -- a convention: it exceeds what any kernel moves once convolutions are fused
@@ -224,9 +225,14 @@ def measure_roofline(engine, dtype, run_steps, nprof, default_size=True):
         if not n.value:
             continue
         name = buf.value.decode()
+        ex = ctypes.c_double()
+        _native.check(lib.df3d_hg_profile_executed_flops(engine.h, k, ctypes.byref(ex)))
         sec = 1e-3 * ms.value / n.value   # average launch
         pmc = traffic.get(name) if default_size else None   # (traffic.json holds bytes per launch AT THE DEFAULT STEP SIZE, 128 frames)
-        row = {"kernel": name, "launches": n.value, "avg_us": 1e6 * sec, "total_ms": ms.value, "tflops": fl.value / n.value / sec / 1e12,
+        # tflops = what the launch EXECUTED on the matrix pipe; tflops_direct = the direct-convolution FLOPs of its plan steps (the reference's
+        # arithmetic; larger for the Winograd tail, which does a 3x3 with 16/36 of the multiplies) -- fractions of the roof are executed / peak
+        row = {"kernel": name, "launches": n.value, "avg_us": 1e6 * sec, "total_ms": ms.value, "tflops": ex.value / n.value / sec / 1e12,
+               "tflops_direct": fl.value / n.value / sec / 1e12, "flops_executed": ex.value, "flops_direct": fl.value,
                "bytes_min": by.value / n.value, "bytes_m1": m1.value / n.value, "bytes_pmc": pmc}
         row["frac_mfma"] = row["tflops"] / PEAK_TFLOPS[dtype]
         row["frac_hbm_min"] = row["bytes_min"] / sec / 1e9 / PEAK_HBM_GBS
@@ -255,7 +261,7 @@ def measure_roofline(engine, dtype, run_steps, nprof, default_size=True):
         "frac": dom["frac_mfma"] if bound == "mfma" else hbm_frac,
         "frac_is": "frac_mfma" if bound == "mfma" else ("frac_hbm_pmc" if dom["frac_hbm_pmc"] is not None else "frac_hbm_min"),
         "fractions": {k: dom[k] for k in ("frac_mfma", "frac_hbm_min", "frac_hbm_m1", "frac_hbm_pmc")},
-        "fractions_legend": "frac_mfma: algorithmic FLOPs / dense MFMA peak; frac_hbm_min: inputs once + outputs once / 8 TB/s; frac_hbm_m1: bytes of the "
+        "fractions_legend": "frac_mfma: executed FLOPs / dense MFMA peak; frac_hbm_min: inputs once + outputs once / 8 TB/s; frac_hbm_m1: bytes of the "
                             "fusion model M1 (SURVEY.md 8d: every convolution's input and output) / 8 TB/s, a convention above what fused kernels move; "
                             "frac_hbm_pmc: rocprofv3 FETCH/WRITE counters / 8 TB/s; bound = the larger of frac_mfma and frac_hbm_pmc",
         "traffic": dom["bytes_pmc"],  # HBM bytes per launch from rocprofv3 PMC passes ((2 x FETCH_SIZE + WRITE_SIZE) x 1024), profiles/traffic.json
@@ -265,6 +271,10 @@ def measure_roofline(engine, dtype, run_steps, nprof, default_size=True):
         "step_hbm_bytes_pmc": step_pmc,   # per hourglass step (all kernels): counters; None unless traffic.json covers > 99 % of the step's kernel time
         "step_hbm_bytes_min": step_min,   # ... and the least the step's launches can move (inputs once + outputs once per launch)
         "step_kernel_ms": sum(k["total_ms"] for k in per) / nprof,
+        "executed_tflops": dom["tflops"],                      # the dominant kernel: FLOPs executed on the matrix pipe / time (= `achieved` when MFMA-bound) ...
+        "direct_equivalent_tflops": dom["tflops_direct"],      # ... and the direct-convolution FLOPs of the same plan steps / time
+        "step_flops_executed": sum(k["flops_executed"] for k in per) / nprof,
+        "step_flops_direct": sum(k["flops_direct"] for k in per) / nprof,
         "kernels": per,
     }
 
@@ -587,6 +597,7 @@ def hourglass_leg(a, sd, dtype, frames, calib, dev, total_frames, config_words):
     if not a.no_roofline:
         leg["roofline"] = job.roofline(dtype)
         add_step_hbm(leg, leg["roofline"], sec)
+        add_step_flops(leg, leg["roofline"], sec, dtype)
     if dtype == "f32s":   # the leg's price: what it differs by from the exact-fp32 engine, measured here on 2 frames of the run's own input
         x = frames[:2].reshape(14, 256, 512, 3).contiguous()
         exact = HourglassEngine(sd, dtype="f32", device=dev)
@@ -598,6 +609,14 @@ def hourglass_leg(a, sd, dtype, frames, calib, dev, total_frames, config_words):
         del exact
     del job, eng
     return leg
+
+
+def add_step_flops(dst, roof, sec, dtype):
+    """The hourglass step's matrix-pipe rate as EXECUTED FLOPs (per-kernel counts of the roofline pass) over this run's step time: the fraction of
+    the roof; the direct-convolution rate (`hourglass_tflops_end_to_end`: the plan's FLOPs in the reference's arithmetic) stays beside it."""
+    if roof.get("step_flops_executed"):
+        dst["hourglass_tflops_executed_end_to_end"] = roof["step_flops_executed"] / sec / 1e12
+        dst["hourglass_frac_mfma_end_to_end"] = roof["step_flops_executed"] / sec / 1e12 / PEAK_TFLOPS[dtype]
 
 
 def add_step_hbm(dst, roof, sec):
@@ -737,7 +756,7 @@ def _sig(x, digits=6):
 
 
 _ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_is", "fractions", "traffic", "traffic_is_current", "avg_launch_us",
-              "step_hbm_bytes_pmc", "step_kernel_ms", "executed_tflops", "direct_equivalent_tflops")
+              "step_hbm_bytes_pmc", "step_kernel_ms", "direct_equivalent_tflops")
 _LEG_ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us")
 
 
@@ -750,7 +769,7 @@ def short_line(full):
         if k == "roofline":
             out[k] = {q: v[q] for q in _ROOF_KEEP if q in v}
         elif k == "config":
-            out[k] = {q: w for q, w in v.items() if w is not None and q not in ("hbm_m1_note", "hourglass_gbs_min_end_to_end", "hourglass_tflops_end_to_end")}
+            out[k] = {q: w for q, w in v.items() if w is not None and q not in ("hbm_m1_note", "hourglass_gbs_min_end_to_end")}
             out[k]["workload"] = out[k].pop("workload_short", v["workload"][:200])
         elif isinstance(v, dict) and "value" in v and k != "cpu_baseline":   # an attached leg
             leg = {q: w for q, w in v.items() if q not in ("roofline", "workload", "workload_short", "unit") and not q.startswith("hourglass_")}
@@ -925,8 +944,8 @@ def main(argv=None):
                 "bundle_adjust_runs_rank0": len(job.ba_runs) or None,
                 "bundle_adjust_nfev": job.ba_runs or None,
                 "bundle_adjust_wall_ms": job.ba_ms[-len(job.ba_runs):] if job.ba_runs else None,
-                "hourglass_tflops_end_to_end": per_step * fl / sec / 1e12,
-                "hourglass_frac_mfma_end_to_end": per_step * fl / sec / 1e12 / PEAK_TFLOPS[a.dtype],
+                "hourglass_tflops_end_to_end": per_step * fl / sec / 1e12,   # direct-convolution FLOPs of the plan (the reference's arithmetic) / step time
+                "hourglass_frac_mfma_end_to_end": None,   # executed FLOPs / peak: filled in by the roofline pass (add_step_flops)
                 "hourglass_gbs_m1_end_to_end": per_step * by / sec / 1e9,
                 "hourglass_frac_hbm_m1_end_to_end": per_step * by / sec / 1e9 / PEAK_HBM_GBS,
                 "hbm_m1_note": "hourglass activation bytes of the fusion model M1 (SURVEY.md 8d: a convention, above what the fused kernels move) / step time / 8 TB/s",
@@ -938,6 +957,7 @@ def main(argv=None):
             line["roofline"] = roof
             if per_step == 1.0:
                 add_step_hbm(line["config"], roof, sec)
+                add_step_flops(line["config"], roof, sec, a.dtype)
         line.update(legs)
         if not a.no_cpu_baseline and world == 1 and a.rank_share == 0 and not a.strong:
             try:

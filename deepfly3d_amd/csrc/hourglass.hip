@@ -122,8 +122,8 @@ struct df3d_hg {
                           // path, streaming output stores); 0 = round 3's kernels (the A/B); bit-identical either way
     int split1 = 1;       // fp32: 1 (default) = plain 256 -> 128 -> 128 -> 256 blocks run as conv1 (every pixel once) + tail (hg_c1_f32.h), bit-identical
                           // (development: 8 + mask splits only the identity blocks (1), layer1 (2), layer2 (4))
-    int wino = 0;         // exact-fp32 engine, split identity blocks: 1 = the tail's 3x3 as Winograd F(2x2, 3x3) (hg_bt_wino_f32.h: 0.545 of the direct
-                          // tail's MFMAs; fp32 tolerance against the oracle, NOT bit-identical to the direct kernels), 0 = direct implicit GEMM
+    int wino = 1;         // exact-fp32 engine, split identity blocks: 1 (default) = the tail's 3x3 as Winograd F(2x2, 3x3) (hg_bt_wino_f32.h: 0.545 of the
+                          // direct tail's MFMAs; fp32 tolerance against the oracle, NOT bit-identical to the direct kernels), 0 = direct implicit GEMM
     bool split_id() const { return split1 == 1 || (split1 >= 8 && (split1 & 1)); }
     bool split_l1() const { return split1 == 1 || (split1 >= 8 && (split1 & 2)); }
     bool split_l2() const { return split1 == 1 || (split1 >= 8 && (split1 & 4)); }

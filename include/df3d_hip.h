@@ -328,7 +328,7 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
  * bit-identical to their 0 form;  "chain_views" = 0 (default) | n: chains of full-resolution steps in chunks of n views;
  * "no_reuse" = 0 (default) | 1: the alias-free workspace plan (no tensor is ever given memory another tensor has released: ~5x the workspace) --
  * the reference form the aliasing tests compare the default plan with, bit for bit; before the weights;
- * "wino" = 0 | 1 (exact fp32 with "split1"): the 3x3 of the 256->128->128->256 identity blocks as Winograd F(2x2, 3x3) -- 16 instead of 36 multiplies per
+ * "wino" = 1 (default) | 0 (exact fp32 with "split1"): the 3x3 of the 256->128->128->256 identity blocks as Winograd F(2x2, 3x3) -- 16 instead of 36 multiplies per
  * 2x2 output patch and (cin, cout) pair, 1 MB more stream space per block; the SAME float32 tolerance against the reference arithmetic, but NOT bit-identical
  * to the direct form ("wino" = 0: the bit-identity reference of the other options); before the weights */
 int df3d_hg_set_option(df3d_hg* h, const char* key, int value);

@@ -315,7 +315,7 @@ def test_weight_ring_bottleneck_is_bit_identical(native_lib, cuda, oracle_net, h
 
     sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
     img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(3 * height + width), dtype=torch.float32).to(cuda)
-    on = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, ring=True)
+    on = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, ring=True, wino=0)   # (wino=0: the direct 3x3 is the bit-identity reference)
     off = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, ring=False)
     # same plan, except that the bf16 ring kernel also pools its INPUT where no producer has (one pooling step fewer)
     steps, steps_off = on.steps(), off.steps()
@@ -402,7 +402,7 @@ def test_default_kernels_match_the_register_staged_kernels_on_small_and_odd_shap
 
     sd = synthetic_state_dict(0)
     img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(7 * height + width), dtype=torch.float32).to(cuda)
-    new = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width)
+    new = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, wino=0)   # (fp32's Winograd tail is not bit-identical to anything direct: its own test below)
     old = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, ring=False, l1=False)
     assert torch.equal(new.forward(img), old.forward(img))
 
@@ -441,7 +441,7 @@ def test_f32_set_weights_without_a_scratch_buffer_falls_back_to_the_register_sta
     from deepfly3d_amd.synthetic import synthetic_state_dict
 
     img = torch.rand((2, 256, 512, 3), generator=torch.Generator().manual_seed(5), dtype=torch.float32).to(cuda)
-    eng = HourglassEngine(synthetic_state_dict(0), dtype="f32", device=cuda)
+    eng = HourglassEngine(synthetic_state_dict(0), dtype="f32", device=cuda, wino=0)   # (the direct kernels: the forms that are bit-identical to each other)
     ref = eng.forward(img).clone()
     assert eng.lib.df3d_hg_lowp_bytes(eng.h) > 0
     _native.check(eng.lib.df3d_hg_set_weights(eng.h, eng.blob.data_ptr(), None, torch.cuda.current_stream().cuda_stream), "df3d_hg_set_weights")
@@ -517,7 +517,7 @@ def test_fp32_split_conv1_is_bit_identical(native_lib, cuda, oracle_net, height,
     sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
     img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(11 * height + width), dtype=torch.float32).to(cuda)
     # (f32s: the same three half-precision products per K step in the same order whichever operand the weights are: bit-identical too)
-    on = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, split1=1)
+    on = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, split1=1, wino=0)
     off = HourglassEngine(sd, dtype=dtype, device=cuda, height=height, width=width, split1=0)
     assert [s[0] for s in on.steps()] == [s[0] for s in off.steps()]
     for k in range(1, len(on.steps()) + 1):
@@ -528,6 +528,38 @@ def test_fp32_split_conv1_is_bit_identical(native_lib, cuda, oracle_net, height,
     assert torch.equal(first, off.forward(img))
     for _ in range(3):
         assert torch.equal(on.forward(img), first)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse_upadd", [None, 2])
+@pytest.mark.parametrize("height,width,n", [(256, 512, 3), (128, 256, 2), (64, 192, 1)])
+def test_fp32_winograd_tail_matches_the_direct_kernels_within_fp32_tolerance(native_lib, cuda, oracle_net, height, width, n, fuse_upadd):
+    """fp32 `wino` (round 6, the default): the 3x3 of the identity-skip bottlenecks as Winograd F(2x2, 3x3) on the exact-fp32 MFMA
+    (csrc/hg_bt_wino_f32.h: 16 instead of 36 multiplies per 2x2 patch and channel pair -- different products, so NOT bit-identical to the direct
+    form).  Every plan step against the `wino=0` engine (itself bit-identical to the register-staged round-1 kernels) inside the tolerance the fp32
+    engine is held to against the oracle -- image borders (zero padding through the transform), the pooled and pooled-input side outputs, the
+    fused up-path sums on the producer (ADD2) and the consumer side (`fuse_upadd=2`: the UP kernel on every level), persistent workgroups with
+    fewer tiles than compute units -- and repeat-stable bit for bit."""
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
+    img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(13 * height + width), dtype=torch.float32).to(cuda)
+    on = HourglassEngine(sd, dtype="f32", device=cuda, height=height, width=width, wino=1, fuse_upadd=fuse_upadd)
+    off = HourglassEngine(sd, dtype="f32", device=cuda, height=height, width=width, wino=0, fuse_upadd=fuse_upadd)
+    assert [s_[0] for s_ in on.steps()] == [s_[0] for s_ in off.steps()]
+    worst = (0.0, None)
+    for k, (name, _) in enumerate(on.steps(), start=1):
+        on._workspace(n).fill_(0xFF)   # NaN-poisoned: a tile the persistent workgroups skipped would show
+        a, b = on.forward_upto(img, k).cpu(), off.forward_upto(img, k).cpu()
+        err = _rel_err(a, b)
+        worst = max(worst, (err, name))
+        assert err < FP32_TOL, f"step {k} {name}: rel err {err:.3e}"
+    first = on.forward(img).clone()
+    assert _rel_err(first.cpu(), off.forward(img).cpu()) < FP32_TOL
+    assert torch.equal(first.flatten(2).argmax(-1), off.forward(img).flatten(2).argmax(-1))
+    for _ in range(3):
+        assert torch.equal(on.forward(img), first)
+    print(f"winograd vs direct {height}x{width}: worst step {worst}")
 
 
 def _poison(eng, n):
