@@ -68,6 +68,7 @@ PROTOTYPES = {
     "df3d_jpeg_work_bytes": (c_size_t, [c_int, c_int, c_int, c_size_t]),
     "df3d_jpeg_decode_luma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_uint, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "df3d_heatmap_argmax": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "df3d_heatmap_argmax_checked": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "df3d_relayout_19_to_38": (c_int, [c_void_p, POINTER(c_int), c_int, c_void_p, c_void_p]),
     "df3d_triangulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "df3d_triangulate_scaled": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int, c_int, c_int, c_void_p, c_void_p]),

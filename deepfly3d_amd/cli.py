@@ -37,7 +37,9 @@ def parse_cli_args(argv=None):
                         "matrix cores with fp32 accumulation, ~6x faster; MEASURED on seeded synthetic weights against the fp32 oracle: heat-map confidences "
                         "6-8e-4 off on peaked maps, up to 2.8e-3 on flat ones (the reference's test tolerance is 2e-3, tests/test_df3d.py:173-178; "
                         "with the trained checkpoint unverified: tests/test_gpu_reference_pin.py decides once weights are present); bf16 = same speed, "
-                        "fp32's exponent range, 8 significant bits: confidences ~6e-3 off on peaked maps, outside that tolerance")
+                        "fp32's exponent range, 8 significant bits: confidences ~6e-3 off on peaked maps, outside that tolerance.  f16 / f32s refuse weights beyond "
+                        "the half range when they are loaded, and if an activation overflows on real images (an infinity or a NaN in any heat-map) the run "
+                        "stops with an error that says so instead of writing df3d_result.pkl: rerun with --dtype f32")
     args = p.parse_args(argv)
     inp = Path(args.input_folder).expanduser().resolve()
     args.output_folder = str(inp.with_name(inp.stem + "_df3d")) if args.output_folder is None else str(Path(args.output_folder).expanduser().resolve())

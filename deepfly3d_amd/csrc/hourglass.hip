@@ -1333,10 +1333,40 @@ size_t df3d_hg_lowp_bytes(const df3d_hg* h) {
     return h->stream_base() + h->stream_bytes;
 }
 
+namespace {
+// max |w| over the blob as an integer (the bit pattern of |x| orders like the value; an infinity or a NaN is >= 0x7f800000)
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = max(m, __float_as_uint(w[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+}  // namespace
+
 int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void* stream) {
     DF3D_CHECK_ARG(h && blob_dev, "null argument");
     const float* const blob_caller = blob_dev;
     DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(blob_dev) & 255) == 0, "blob must be 256-byte aligned");
+    if ((h->dtype == DF3D_DTYPE_F16 || h->dtype == DF3D_DTYPE_F32S) && lowp_dev != nullptr) {
+        // the half-precision engines need every operand inside the IEEE-half range: refuse weights (biases and folded BatchNorm vectors included)
+        // that are not -- here, with the number, instead of as inf / NaN heat-maps later (one 4-byte read-back; the first word of the
+        // caller's scratch buffer, which the packers below overwrite, is the reduction's cell)
+        unsigned* const cell = reinterpret_cast<unsigned*>(lowp_dev);
+        unsigned bits = 0;
+        DF3D_HIP(hipMemsetAsync(cell, 0, 4, df3d::as_stream(stream)));
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3(256), dim3(256), 0, df3d::as_stream(stream), blob_dev, h->blob_floats, cell);
+        DF3D_LAUNCH_CHECK();
+        DF3D_HIP(hipMemcpyAsync(&bits, cell, 4, hipMemcpyDeviceToHost, df3d::as_stream(stream)));
+        DF3D_HIP(hipStreamSynchronize(df3d::as_stream(stream)));
+        float absmax;
+        memcpy(&absmax, &bits, 4);
+        if (!(absmax <= 65504.0f)) {   // (also true for an infinity or a NaN among the weights)
+            df3d::set_error("max |w| = %g: the %s hourglass engine needs every weight inside the IEEE-half range (65504): use DF3D_DTYPE_F32 (or BF16)",
+                            (double)absmax, h->dtype == DF3D_DTYPE_F16 ? "F16" : "F32S");
+            return DF3D_EINVAL;
+        }
+    }
     if (h->lp()) {
         DF3D_CHECK_ARG(lowp_dev != nullptr, "a 16-bit engine needs a df3d_hg_lowp_bytes() device buffer");
         DF3D_CHECK_ARG((reinterpret_cast<uintptr_t>(lowp_dev) & 255) == 0, "lowp buffer must be 256-byte aligned");

@@ -262,6 +262,9 @@ class HourglassEngine:
             )
         self._ws = None
         self.num_classes = 19
+        # overflow guard (f16 / f32s need every activation inside the IEEE-half range): planes with an infinity or a NaN, counted on the device by
+        # the arg-max kernel of every batch (ops.heatmap_argmax(hm, nonfinite=engine.nonfinite_planes)); check_finite() reads it
+        self.nonfinite_planes = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def __del__(self):
         try:
@@ -270,6 +273,17 @@ class HourglassEngine:
                 self.h = None
         except Exception:
             pass
+
+    def check_finite(self, what="this recording"):
+        """Raise if any heat-map plane the arg-max kernel has seen since the last check held an infinity or a NaN (one 4-byte read-back: call it
+        once per recording, not per batch).  The reduced-precision engines overflow silently otherwise: inf / NaN heat-maps become a wrong
+        points2d / heatmap_confidence in the pickle (the bar: reference tests/test_df3d.py:167-178)."""
+        bad = int(self.nonfinite_planes.item())
+        if bad:
+            self.nonfinite_planes.zero_()
+            hint = ("its activations left the IEEE-half range (|x| < 65 504) on these weights / images: rerun with dtype='f32' (df3d-cli --dtype f32)"
+                    if self.dtype in ("f16", "f32s") else "rerun with dtype='f32' (df3d-cli --dtype f32)" if self.dtype == "bf16" else "the weights or the images hold non-finite values")
+            raise _native.NativeLibraryError(f"{bad} heat-map plane(s) of {what} hold infinities or NaNs ({self.dtype} hourglass engine): {hint}; no result was written")
 
     def _workspace(self, n):
         need = self.lib.df3d_hg_workspace_bytes(self.h, n)

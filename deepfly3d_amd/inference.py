@@ -165,7 +165,7 @@ def preprocess_u8(frames_u8, flip, out_hw=(256, 512)):
 def inference_views(images, engine, return_heatmap=False):
     """images: float32 NHWC [n, 256, 512, 3] cuda -> (points [n, 19, 2], conf [n, 19]) (+ heat-maps)."""
     hm = engine.forward(images)
-    pts, conf = ops.heatmap_argmax(hm)
+    pts, conf = ops.heatmap_argmax(hm, nonfinite=engine.nonfinite_planes)   # (the overflow guard: engine.check_finite() reads the counter)
     return (pts, conf, hm) if return_heatmap else (pts, conf)
 
 
@@ -175,7 +175,7 @@ def inference_frames(frames_u8, flip, engine, return_heatmap=False):
     if tuple(config["input_shape"]) != (engine.height, engine.width):
         raise ValueError("engine input size differs from config['input_shape']")
     hm = engine.forward_u8(frames_u8, flip, PREPROCESS["mean"], PREPROCESS["std"], resize=PREPROCESS["resize"])
-    pts, conf = ops.heatmap_argmax(hm)
+    pts, conf = ops.heatmap_argmax(hm, nonfinite=engine.nonfinite_planes)
     return (pts, conf, hm) if return_heatmap else (pts, conf)
 
 
@@ -265,6 +265,7 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
         done = True
     finally:
         reader.finish(check=done)   # a bad frame raises JpegDecodeError from inside the loop, within two batches of it
+    engine.check_finite(f"{folder} (frames {t_first}..{t_stop - 1})")   # a reduced-precision engine that overflowed: an error, not a pickle
     host = (lambda t: t) if as_device_tensors else (lambda t: t.cpu().numpy())
     out = [host(points)]
     if return_heatmap:

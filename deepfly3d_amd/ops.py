@@ -37,16 +37,21 @@ def _need(t, dtype, name):
 
 
 @_on_tensor_device
-def heatmap_argmax(heatmaps):
-    """heatmaps [n, J, H, W] float32 (cuda) -> (points [n, J, 2] float32 (row/H, col/W), conf [n, J] float32)."""
+def heatmap_argmax(heatmaps, nonfinite=None):
+    """heatmaps [n, J, H, W] float32 (cuda) -> (points [n, J, 2] float32 (row/H, col/W), conf [n, J] float32).
+    `nonfinite`: an int32 CUDA tensor of one element (zeroed by its owner) that is incremented once per plane holding an infinity or a NaN --
+    the overflow guard of the reduced-precision engines (HourglassEngine.check_finite reads it)."""
     lib = _native.load()
     _need(heatmaps, torch.float32, "heatmaps")
     n, j, h, w = heatmaps.shape
     pts = torch.empty((n, j, 2), dtype=torch.float32, device=heatmaps.device)
     conf = torch.empty((n, j), dtype=torch.float32, device=heatmaps.device)
+    if nonfinite is not None and not (nonfinite.is_cuda and nonfinite.dtype == torch.int32 and nonfinite.numel() == 1 and nonfinite.device == heatmaps.device):
+        raise ValueError("nonfinite must be a one-element int32 CUDA tensor on the heat-maps' device")
     _native.check(
-        lib.df3d_heatmap_argmax(heatmaps.data_ptr(), n, j, h, w, pts.data_ptr(), conf.data_ptr(), _stream(heatmaps)),
-        "df3d_heatmap_argmax",
+        lib.df3d_heatmap_argmax_checked(heatmaps.data_ptr(), n, j, h, w, pts.data_ptr(), conf.data_ptr(),
+                                        nonfinite.data_ptr() if nonfinite is not None else None, _stream(heatmaps)),
+        "df3d_heatmap_argmax_checked",
     )
     return pts, conf
 

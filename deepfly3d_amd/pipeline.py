@@ -34,7 +34,7 @@ class FramePipeline:
         F = frames.shape[0]
         views = frames.reshape(F * 7, *frames.shape[2:])
         hm = self.engine.forward(views)
-        pts, conf = ops.heatmap_argmax(hm)  # [F*7, 19, 2], [F*7, 19]
+        pts, conf = ops.heatmap_argmax(hm, nonfinite=self.engine.nonfinite_planes)  # [F*7, 19, 2], [F*7, 19]; counts planes with inf / NaN
         # (frame, camera) -> (camera, frame): a strided copy of F*7*19*3 numbers (data movement only)
         pts_ct = pts.reshape(F, 7, 19, 2).transpose(0, 1).contiguous()
         out_conf[:, t0 : t0 + F] = conf.reshape(F, 7, 19).transpose(0, 1)
@@ -48,6 +48,10 @@ class FramePipeline:
                 "df3d_triangulate_scaled",
             )
         out_points3d[t0 : t0 + F] = X
+
+    def check_finite(self, what="this frame range"):
+        """Once per run (one 4-byte read-back): refuse results of a reduced-precision engine that overflowed (HourglassEngine.check_finite)."""
+        self.engine.check_finite(what)
 
     def allocate_outputs(self, T):
         dev = self.device
@@ -63,4 +67,5 @@ class FramePipeline:
         outs = self.allocate_outputs(T)
         for t0 in range(0, T, frames_per_batch):
             self.run_batch(frames[t0 : t0 + frames_per_batch], *outs, t0)
+        self.check_finite()
         return outs

@@ -44,7 +44,7 @@ extern "C" {
 const char* df3d_last_error(void);
 /* ABI revision of the library: DF3D_ABI_VERSION of the header it was built from.  It changes whenever an entry point's signature or
  * a struct layout does (round 3 inserted `resize` into df3d_preprocess_u8 / df3d_hg_forward_u8 and `bytes_m1` into
- * df3d_hg_profile_read: 300; round 4: 400; round 5 added df3d_ba_lsmr_form and grew df3d_ba_lsmr_work_doubles: 500; round 6 added df3d_hg_profile_executed_flops: 600); a caller compares it with the header it compiled against before its first call
+ * df3d_hg_profile_read: 300; round 4: 400; round 5 added df3d_ba_lsmr_form and grew df3d_ba_lsmr_work_doubles: 500; round 6 added df3d_hg_profile_executed_flops and df3d_heatmap_argmax_checked: 600); a caller compares it with the header it compiled against before its first call
  * (deepfly3d_amd/_native.py:load does). */
 #define DF3D_ABI_VERSION 600
 int df3d_version(void);
@@ -116,6 +116,13 @@ int df3d_read_files(const char* const* paths, int n, unsigned char* dst, size_t 
  * ---------------------------------------------------------------------------------------------- */
 int df3d_heatmap_argmax(const float* hm_dev, int n, int joints, int h, int w, float* pts_dev, float* conf_dev,
                         void* stream);
+/* (round 6) the same, plus the overflow guard of the reduced-precision engines: *nonfinite_planes_dev (device int, zeroed by the caller, may be
+ * NULL) is incremented once for every plane that holds an infinity or a NaN anywhere -- the kernel reads every value anyway.  The F16 and F32S
+ * hourglass engines need every activation inside the IEEE-half range (|x| < 65 504); a trained checkpoint that leaves it turns into inf / NaN
+ * heat-maps and, without this flag, into a silently wrong points2d / heatmap_confidence (the bar it protects: reference tests/test_df3d.py:167-178).
+ * The host reads the counter once per recording (deepfly3d_amd/inference.py) and refuses the result, naming the dtype to rerun with. */
+int df3d_heatmap_argmax_checked(const float* hm_dev, int n, int joints, int h, int w, float* pts_dev, float* conf_dev,
+                                int* nonfinite_planes_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a4  19 -> 38 joint re-layout and un-flip.   Replaces reference df3d/core.py:187-203.

@@ -69,6 +69,33 @@ def test_argmax_values_are_grid_points(native_lib, cuda):
 
 
 # ---------------------------------------------------------------- a4 re-layout -------------------
+def test_argmax_counts_planes_with_non_finite_values(native_lib, cuda):
+    """df3d_heatmap_argmax_checked: the counter is incremented once per plane that holds an infinity or a NaN ANYWHERE (not only at the peak: a
+    NaN never wins the arg-max, so the confidences alone would hide it), clean planes leave it alone, points and confidences are those of the
+    unchecked call."""
+    from deepfly3d_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    hm = torch.rand((6, 19, 64, 128), generator=g, dtype=torch.float32).to(cuda)
+    flag = torch.zeros(1, dtype=torch.int32, device=cuda)
+    pts, conf = ops.heatmap_argmax(hm, nonfinite=flag)
+    assert int(flag.item()) == 0
+    ref_pts, ref_conf = ops.heatmap_argmax(hm)
+    assert torch.equal(pts, ref_pts) and torch.equal(conf, ref_conf)
+    hm[0, 3, 10, 77] = float("nan")      # off the peak, a lane's second quad
+    hm[2, 0, 63, 127] = float("inf")     # the plane's last value
+    hm[2, 18, 0, 0] = float("-inf")      # the plane's first value
+    hm[5, 7, 31, 64] = float("nan")
+    hm[5, 7, 31, 65] = float("inf")      # two in one plane: counted once
+    pts, conf = ops.heatmap_argmax(hm, nonfinite=flag)
+    assert int(flag.item()) == 4
+    assert bool(torch.isfinite(conf[0, 3])) and float(conf[2, 0]) == float("inf")
+    ops.heatmap_argmax(hm[1:2], nonfinite=flag)   # a clean slice adds nothing
+    assert int(flag.item()) == 4
+    with pytest.raises(ValueError):
+        ops.heatmap_argmax(hm, nonfinite=torch.zeros(1, dtype=torch.int64, device=cuda))
+
+
 @pytest.mark.parametrize("tag", ["id", "rev", "clc"])
 def test_relayout_matches_reference_vectors(native_lib, cuda, golden_dir, tag):
     from deepfly3d_amd import ops

@@ -552,7 +552,7 @@ def test_fp32_winograd_tail_matches_the_direct_kernels_within_fp32_tolerance(nat
         on._workspace(n).fill_(0xFF)   # NaN-poisoned: a tile the persistent workgroups skipped would show
         a, b = on.forward_upto(img, k).cpu(), off.forward_upto(img, k).cpu()
         err = _rel_err(a, b)
-        worst = max(worst, (err, name))
+        worst = max(worst, (err, name), key=lambda t: t[0])
         assert err < FP32_TOL, f"step {k} {name}: rel err {err:.3e}"
     first = on.forward(img).clone()
     assert _rel_err(first.cpu(), off.forward(img).cpu()) < FP32_TOL
@@ -560,6 +560,56 @@ def test_fp32_winograd_tail_matches_the_direct_kernels_within_fp32_tolerance(nat
     for _ in range(3):
         assert torch.equal(on.forward(img), first)
     print(f"winograd vs direct {height}x{width}: worst step {worst}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f16", "f32s"])
+def test_reduced_precision_overflow_is_an_error_not_a_result(native_lib, cuda, dtype):
+    """The f16 / f32s engines need every operand inside the IEEE-half range.  (1) Weights beyond it are refused when they are loaded, with the
+    number (df3d_hg_set_weights).  (2) Weights inside it whose ACTIVATIONS overflow -- here the synthetic network with its first BatchNorm scaled
+    until layer1 leaves the half range -- give inf / NaN heat-maps: the arg-max kernel counts such planes on the device and the pipeline raises a
+    NativeLibraryError that names the dtype and says `--dtype f32`, instead of handing back points (reference bar protected: tests/test_df3d.py:167-178);
+    the exact-fp32 engine runs the same weights to finite heat-maps."""
+    from deepfly3d_amd import _native, ops
+    from deepfly3d_amd.hourglass import HourglassEngine
+    from deepfly3d_amd.pipeline import FramePipeline
+    from deepfly3d_amd.synthetic import synthetic_state_dict
+
+    sd = synthetic_state_dict(0)
+    too_big = dict(sd)
+    k0 = next(k for k in sd if k.endswith("conv1.weight"))
+    too_big[k0] = sd[k0].copy()
+    too_big[k0].flat[0] = 1.0e5
+    with pytest.raises(_native.NativeLibraryError, match=r"max \|w\| = 100000.*half range"):
+        HourglassEngine(too_big, dtype=dtype, device=cuda)
+    HourglassEngine(too_big, dtype="f32", device=cuda)   # the exact engine takes them
+
+    hot = dict(sd)
+    for k in sd:   # the stem's BatchNorm: scale its output by 3e4 (weights stay < 65504, activations do not)
+        if k in ("bn1.weight", "bn1.bias"):
+            hot[k] = sd[k] * 3.0e4
+    assert any(k in ("bn1.weight", "bn1.bias") for k in sd)
+    img = torch.rand((14, 256, 512, 3), generator=torch.Generator().manual_seed(2), dtype=torch.float32).to(cuda)
+    exact = HourglassEngine(hot, dtype="f32", device=cuda)
+    hm32 = exact.forward(img)
+    assert bool(torch.isfinite(hm32).all())
+    ops.heatmap_argmax(hm32, nonfinite=exact.nonfinite_planes)
+    exact.check_finite()   # nothing to report
+    eng = HourglassEngine(hot, dtype=dtype, device=cuda)
+    hm = eng.forward(img)
+    assert not bool(torch.isfinite(hm).all()), "the fixture must overflow the half range"
+    ops.heatmap_argmax(hm, nonfinite=eng.nonfinite_planes)
+    with pytest.raises(_native.NativeLibraryError, match=rf"{dtype} hourglass engine.*--dtype f32"):
+        eng.check_finite("the fixture")
+    eng.check_finite()   # the counter was reset
+    # ... and through the frame pipeline (what bench.py and the sharded Core run): the error, not points
+    from deepfly3d_amd.config import load_calibration
+
+    cal = load_calibration()
+    calib = {k: np.stack([cal[c][k] for c in range(7)]) for k in ("R", "tvec", "intr")}
+    pipe = FramePipeline(eng, calib["R"], calib["tvec"], calib["intr"])
+    with pytest.raises(_native.NativeLibraryError, match="--dtype f32"):
+        pipe.run(img.reshape(2, 7, 256, 512, 3), frames_per_batch=2)
 
 
 def _poison(eng, n):
