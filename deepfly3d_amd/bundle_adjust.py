@@ -68,7 +68,9 @@ class BAProblemDevice:
     (frame, joint, camera) observation order, the per-point and per-camera groupings) -- on a 1 000-frame window the numpy version of
     this constructor cost 3 ms of host time, a quarter of the whole adjustment."""
 
-    def __init__(self, points2d_px, intr, device):
+    def __init__(self, points2d_px, intr, device, min_views=2):
+        """min_views: a joint is a 3-D point when at least this many cameras see it (2: what an adjustment needs; 1 only in tests of the LSMR
+        forms on problems the C ABI accepts but this module never builds)."""
         dev = torch.device(device)
         self.device = dev
         if isinstance(points2d_px, torch.Tensor):
@@ -77,7 +79,7 @@ class BAProblemDevice:
             p = torch.from_numpy(np.ascontiguousarray(points2d_px, dtype=np.float64)).to(dev)
         ncam, T, J, _ = p.shape
         vis = (p[..., 0] != 0) & (p[..., 1] != 0)                 # (ncam, T, J)
-        ok = vis.sum(dim=0) >= 2                                  # (T, J): the joints seen by at least two cameras = the 3-D points
+        ok = vis.sum(dim=0) >= int(min_views)                     # (T, J): the joints seen by at least two cameras = the 3-D points
         self.ok_dev = ok.reshape(-1)
         slot = torch.cumsum(self.ok_dev.to(torch.int64), 0) - 1   # point index of (t, j) where ok
         # observations in (frame, joint, camera) order: move the camera axis last; nonzero() lists them in that order

@@ -2,6 +2,7 @@
 // scipy.sparse.linalg.lsmr (the solver under the reference's bundle adjustment) statement by
 // statement, as restated in oracle/trf_lsmr.py:lsmr; this file is compiled with -ffp-contract=off (build.py), so every
 // product and sum rounds on its own, exactly as the CPython / numpy float arithmetic of the oracle does.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -719,6 +720,14 @@ __global__ __launch_bounds__(LT, 2) void lsmr_local_kernel(df3d_ba_problem p, Lo
     const int tid = (int)threadIdx.x, wg = (int)blockIdx.x;
     const int ncc = 6 * p.ncam, nar2 = 1 + ncc;
     const size_t nobs = (size_t)p.nobs;
+    if (a.wg_obs[gridDim.x] != p.nobs) {   // the partition does not cover the problem (see lsmr_local_partition_kernel): every workgroup leaves, before any all-reduce
+        if (wg == 0 && tid == 0) {
+            State bad{};
+            bad.istop = -2;
+            *reinterpret_cast<State*>(a.state_out) = bad;
+        }
+        return;
+    }
     const int o0 = a.wg_obs[wg], o1 = a.wg_obs[wg + 1], nob = o1 - o0;
     const int q0 = nob > 0 ? p.pt_idx[o0] : 0, npt = nob > 0 ? p.pt_idx[o1 - 1] + 1 - q0 : 0;
 
@@ -1013,14 +1022,19 @@ __global__ __launch_bounds__(LT, 2) void lsmr_local_kernel(df3d_ba_problem p, Lo
     }
 }
 
-// observation ranges of the data-local form: greedy, as many whole points as fit into LOBS observations; one thread (G <= 64 steps of a binary search)
+// observation ranges of the data-local form: greedy, as many whole points as fit into LOBS observations AND into the LT point-owner threads of a
+// workgroup; one thread (G <= 64 steps of a binary search).  The kernel's layout assumes what bundle_adjust.py guarantees (every point seen by
+// >= 2 cameras, <= 8 observations per point) but the C ABI does not: a problem with single-observation points has more than LT points per LOBS
+// observations, and a point of more than 8 observations can make the ranges run out before the observations do.  Either way the partition does
+// not cover [0, nobs) in gmax ranges: wg_obs[gmax] != nobs, which lsmr_local_kernel reports as "does not fit" (istop -2: the caller falls back
+// to the launch-based forms, which handle any problem).
 __global__ void lsmr_local_partition_kernel(const int* __restrict__ pt_start, int npts, int nobs, int gmax, int* __restrict__ wg_obs) {
     if (threadIdx.x || blockIdx.x) return;
     int start = 0, q = 0;
     wg_obs[0] = 0;
     for (int w = 0; w < gmax; ++w) {
         if (start < nobs) {
-            int lo = q, hi = npts;   // the largest point boundary <= start + LOBS
+            int lo = q, hi = npts < q + LT ? npts : q + LT;   // the largest point boundary <= start + LOBS, at most LT points on
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
                 if (pt_start[mid] <= start + LOBS) lo = mid;
@@ -1054,10 +1068,15 @@ int launch_local(const df3d_ba_problem& p, const double* Jc, const double* Jp, c
     if (want_dbg && !dbg && hipMalloc(&dbg, ((size_t)LDBG_CALLS * LMAXG * 98 + 16) * sizeof(double)) != hipSuccess) return -4;
     if (want_dbg) (void)hipMemsetAsync(dbg, 0, (size_t)LDBG_CALLS * LMAXG * 98 * sizeof(double), s);
     LocalArgs a{Jc, Jp, d, b, x, wg_obs, gr1, gr2, state_out, damp, atol, btol, ctol, maxiter, want_dbg ? dbg : nullptr};
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lsmr_local_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LocalLds)) != hipSuccess) return -3;
-        attr_set = true;
+    {   // the attribute is per DEVICE (a process may drive several GPUs) and the guard must be thread-safe: one bit per device ordinal
+        static std::atomic<unsigned long long> attr_set{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return -3;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(lsmr_local_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LocalLds)) != hipSuccess) return -3;
+            attr_set.fetch_or(bit, std::memory_order_release);
+        }
     }
     hipLaunchKernelGGL(lsmr_local_kernel, dim3(G), dim3(LT), sizeof(LocalLds), s, p, a);
     if (want_dbg) {   // development: every all-reduce's inputs and outputs of every workgroup, checked on the host

@@ -186,6 +186,46 @@ def test_every_lsmr_form_gives_the_same_bits(native_lib, cuda, tmp_path):
     assert a["i1000"][0] in (1.0, 2.0) and a["i1000"][1] < 200   # converged (atol / btol), not maxiter
 
 
+def test_data_local_lsmr_refuses_problems_outside_its_layout_and_falls_back(native_lib, cuda, golden_dir):
+    """The data-local LSMR kernel (csrc/ba_lsmr.hip: lsmr_local_kernel, the default form) lays a range of <= 1 024 observations over LT = 512
+    point-owner threads: enough for what bundle_adjust.py builds (every point seen by >= 2 cameras), NOT for every problem the C ABI accepts.
+    With single-observation points a range holds more than 512 points: round 5's partition gave those no owner (never updated, LDS read out of
+    bounds, a silently wrong solution with istop >= 0).  Now the partition caps the points per range, notices that its ranges no longer cover
+    the observations, and the form reports "does not fit": df3d_ba_lsmr_form(LOCAL) falls back to the launch-based form (info[7] != 0) and returns
+    ITS solution bit for bit."""
+    import ctypes
+
+    from deepfly3d_amd import _native, bundle_adjust as ba, ops
+
+    g = np.load(f"{golden_dir}/golden_2d.npz")
+    c = np.load(f"{golden_dir}/calib.npz")
+    px = np.tile(g["points2d"] * np.array([480.0, 960.0]), (1, 4, 1, 1))   # 60 frames x 38 joints
+    seen = px[..., 0] != 0
+    first = np.argmax(seen, axis=0)                                          # keep only the first camera that sees a joint
+    keep = np.arange(px.shape[0])[:, None, None] == first[None]
+    px = np.where((seen & keep)[..., None], px, 0.0)
+    prob = ba.BAProblemDevice(px, c["intr"], cuda, min_views=1)
+    assert prob.npts == prob.nobs and prob.npts > 1024, (prob.npts, prob.nobs)   # one observation per point: > 512 points per 1 024-observation range
+    dv = ba._Dev(prob)
+    rng = np.random.default_rng(1)
+    x0 = torch.from_numpy(np.concatenate([
+        np.concatenate([np.stack([ba._rotvec_from_matrix(c["R"][k]) for k in range(7)]), c["tvec"]], axis=1).ravel(),
+        rng.normal(0, 1, size=3 * prob.npts) + np.tile([0.0, 0.0, 100.0], prob.npts)])).to(cuda)
+    m, n, nobs = prob.m, prob.n, prob.nobs
+    f, Jc, Jp, sc, sci, tmp = dv.new(m), dv.new(12 * nobs), dv.new(6 * nobs), dv.new(n), dv.new(n), dv.new(n)
+    dv.eval(x0, f, Jc, Jp)
+    dv.colsq(Jc, Jp, tmp)
+    _native.check(dv.lib.df3d_ba_update_scale(tmp.data_ptr(), sci.data_ptr(), sc.data_ptr(), n, 1, dv.stream()))
+    work = dv.new(dv.lib.df3d_ba_lsmr_work_doubles(ctypes.byref(prob.c)))
+    xa, xb = dv.new(n), dv.new(n)
+    ia = dv.lsmr(Jc, Jp, sc, f, 0.37, xa, work, maxiter=40, form=_native.LSMR_LAUNCHES)
+    ib = dv.lsmr(Jc, Jp, sc, f, 0.37, xb, work, maxiter=40, form=_native.LSMR_LOCAL)
+    torch.cuda.synchronize()
+    assert ib[7] != 0.0, "the data-local form must report that this problem does not fit it"
+    assert ia[:7] == ib[:7] and torch.equal(xa, xb)
+    assert bool(torch.isfinite(xb).all()) and float(xb[42:].abs().max()) > 0   # every point was updated
+
+
 def test_persistent_lsmr_on_the_1000_frame_window_equals_the_two_kernel_form(native_lib, cuda, golden_dir, monkeypatch):
     """The same comparison on BASELINE configs[4]'s window (106 k observations: every phase has more virtual workgroups than the
     persistent grid has real ones, so each workgroup walks several): the whole adjustment -- cameras, cost, evaluation and LSMR
