@@ -285,6 +285,29 @@ class HourglassEngine:
                     if self.dtype in ("f16", "f32s") else "rerun with dtype='f32' (df3d-cli --dtype f32)" if self.dtype == "bf16" else "the weights or the images hold non-finite values")
             raise _native.NativeLibraryError(f"{bad} heat-map plane(s) of {what} hold infinities or NaNs ({self.dtype} hourglass engine): {hint}; no result was written")
 
+    # Reduced-precision engines against the exact one on a SAMPLE of the run's own input -- the guard that catches what the non-finite counter
+    # cannot: on gfx950 the half conversions SATURATE (a value beyond 65 504 becomes 65 504, not an infinity) and a ReLU scrubs NaNs to zero, so an
+    # f16 / f32s engine whose activations leave the half range returns FINITE, wrong heat-maps (measured: scripts/probe_overflow.py -- layer1
+    # 3.3e4 where the exact engine has 1.5e8).  Allowed heat-map difference, as a fraction of the exact heat-maps' range (tests hold the engines
+    # to tighter bars on synthetic weights: FP32_TOL / F16_TOL / BF16_TOL of tests/test_gpu_hourglass.py):
+    CANARY_TOL = {"f32s": 1e-4, "f16": 2e-2, "bf16": 6e-2}
+
+    def canary(self, exact, forward, what="the first batch"):
+        """`forward(engine)` -> heat-maps of the SAME few views through `engine`; compares this engine with `exact` (an f32 HourglassEngine of the
+        same weights).  Raises NativeLibraryError when they differ by more than CANARY_TOL[dtype] of the range or in a non-finite value."""
+        if self.dtype == "f32":
+            return 0.0
+        got = forward(self).clone()
+        ref = forward(exact)
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max()) / max(scale, 1e-30)
+        if not (err <= self.CANARY_TOL[self.dtype]):   # (also true for a NaN)
+            raise _native.NativeLibraryError(
+                f"the {self.dtype} hourglass engine's heat-maps differ from the exact fp32 engine's by {err:.3g} of their range on {what} (allowed "
+                f"{self.CANARY_TOL[self.dtype]:g}): its activations leave the range / precision of the format on these weights and images (half "
+                f"conversions saturate at 65 504); rerun with dtype='f32' (df3d-cli --dtype f32); no result was written")
+        return err
+
     def _workspace(self, n):
         need = self.lib.df3d_hg_workspace_bytes(self.h, n)
         if self._ws is None or self._ws.numel() < need:

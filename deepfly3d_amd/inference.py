@@ -255,6 +255,13 @@ def inference_folder(folder, camera_ids_to_flip=(), return_heatmap=False, return
             # file reads two batches ahead, H2D + JPEG decode one batch ahead on a second stream, under this batch's hourglass
             for k, luma in enumerate(reader.stream(paths)):
                 chunk = chunks[k]
+                if k == 0 and engine.dtype != "f32":
+                    # a reduced-precision engine proves itself on the recording's first views against the exact engine (same weights) before its
+                    # results count: saturated / overflowed activations give finite, wrong heat-maps (HourglassEngine.canary)
+                    exact = get_engine(dtype="f32", device=device, state_dict=state_dict)
+                    ns = min(7, luma.shape[0])
+                    engine.canary(exact, lambda e: e.forward_u8(luma[:ns], flips[0][:ns], PREPROCESS["mean"], PREPROCESS["std"], resize=PREPROCESS["resize"]),
+                                  what=f"the first {ns} views of {folder}")
                 res = inference_frames(luma, flips[k], engine, return_heatmap=return_heatmap)
                 # items are (camera, frame) in camera-major order = the flat order of points[ncam, T]: contiguous copies
                 lo = starts[k]

@@ -49,6 +49,12 @@ class FramePipeline:
             )
         out_points3d[t0 : t0 + F] = X
 
+    def canary(self, exact_engine, frames, what="the first frame"):
+        """A reduced-precision engine against the exact one (same weights) on the 7 views of `frames[0]` (HourglassEngine.canary): call once per
+        run, before its results count."""
+        views = frames[:1].reshape(7, *frames.shape[2:])
+        return self.engine.canary(exact_engine, lambda e: e.forward(views), what=what)
+
     def check_finite(self, what="this frame range"):
         """Once per run (one 4-byte read-back): refuse results of a reduced-precision engine that overflowed (HourglassEngine.check_finite)."""
         self.engine.check_finite(what)

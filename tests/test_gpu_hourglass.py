@@ -567,9 +567,9 @@ def test_fp32_winograd_tail_matches_the_direct_kernels_within_fp32_tolerance(nat
 def test_reduced_precision_overflow_is_an_error_not_a_result(native_lib, cuda, dtype):
     """The f16 / f32s engines need every operand inside the IEEE-half range.  (1) Weights beyond it are refused when they are loaded, with the
     number (df3d_hg_set_weights).  (2) Weights inside it whose ACTIVATIONS overflow -- here the synthetic network with its first BatchNorm scaled
-    until layer1 leaves the half range -- give inf / NaN heat-maps: the arg-max kernel counts such planes on the device and the pipeline raises a
-    NativeLibraryError that names the dtype and says `--dtype f32`, instead of handing back points (reference bar protected: tests/test_df3d.py:167-178);
-    the exact-fp32 engine runs the same weights to finite heat-maps."""
+    until layer1 leaves the half range -- give FINITE, wrong heat-maps on gfx950 (saturating conversions): the canary -- the run's first views through
+    the exact engine as well -- raises a NativeLibraryError that names the dtype and says `--dtype f32`, instead of handing back points (reference
+    bar protected: tests/test_df3d.py:167-178).  (3) Infinities / NaNs that do reach a heat-map are counted by the arg-max kernel and refused too."""
     from deepfly3d_amd import _native, ops
     from deepfly3d_amd.hourglass import HourglassEngine
     from deepfly3d_amd.pipeline import FramePipeline
@@ -586,21 +586,21 @@ def test_reduced_precision_overflow_is_an_error_not_a_result(native_lib, cuda, d
 
     hot = dict(sd)
     scaled = ("bn1.weight", "bn1.bias", "layer1.0.bn1.weight", "layer1.0.bn1.bias")
-    for k in scaled:   # the stem's BatchNorm and the one behind it: x 1e3 each -- every weight stays < 65504, layer1's activations reach ~1e6
-        hot[k] = sd[k] * 1.0e3
+    for k in scaled:   # the stem's BatchNorm and the one behind it: x 2e4 each -- every weight stays < 65504, the activations behind them do not
+        hot[k] = sd[k] * 2.0e4
     img = torch.rand((14, 256, 512, 3), generator=torch.Generator().manual_seed(2), dtype=torch.float32).to(cuda)
     exact = HourglassEngine(hot, dtype="f32", device=cuda)
     hm32 = exact.forward(img)
     assert bool(torch.isfinite(hm32).all())
     ops.heatmap_argmax(hm32, nonfinite=exact.nonfinite_planes)
     exact.check_finite()   # nothing to report
+    # gfx950's half conversions SATURATE and ReLUs scrub NaNs: the overflowed engine returns FINITE heat-maps, far from the exact ones -- the
+    # non-finite counter cannot see that, the canary (the same views through the exact engine) does
     eng = HourglassEngine(hot, dtype=dtype, device=cuda)
     hm = eng.forward(img)
-    assert not bool(torch.isfinite(hm).all()), "the fixture must overflow the half range"
-    ops.heatmap_argmax(hm, nonfinite=eng.nonfinite_planes)
-    with pytest.raises(_native.NativeLibraryError, match=rf"{dtype} hourglass engine.*--dtype f32"):
-        eng.check_finite("the fixture")
-    eng.check_finite()   # the counter was reset
+    assert _rel_err(hm.cpu(), hm32.cpu()) > 0.5, "the fixture must leave the half range"
+    with pytest.raises(_native.NativeLibraryError, match=rf"the {dtype} hourglass engine's heat-maps differ.*--dtype f32"):
+        eng.canary(exact, lambda e: e.forward(img[:7]), what="the fixture")
     # ... and through the frame pipeline (what bench.py and the sharded Core run): the error, not points
     from deepfly3d_amd.config import load_calibration
 
@@ -608,7 +608,18 @@ def test_reduced_precision_overflow_is_an_error_not_a_result(native_lib, cuda, d
     calib = {k: np.stack([cal[c][k] for c in range(7)]) for k in ("R", "tvec", "intr")}
     pipe = FramePipeline(eng, calib["R"], calib["tvec"], calib["intr"])
     with pytest.raises(_native.NativeLibraryError, match="--dtype f32"):
-        pipe.run(img.reshape(2, 7, 256, 512, 3), frames_per_batch=2)
+        pipe.canary(exact, img.reshape(2, 7, 256, 512, 3))
+    # healthy weights pass, with the difference reported
+    good, good32 = HourglassEngine(sd, dtype=dtype, device=cuda), HourglassEngine(sd, dtype="f32", device=cuda)
+    err = good.canary(good32, lambda e: e.forward(img[:7]))
+    assert 0 < err < HourglassEngine.CANARY_TOL[dtype] / 4, err
+    # the non-finite counter: an infinity planted in a heat-map is reported by check_finite, once
+    hm = good.forward(img).clone()
+    hm[3, 5, 7, 9] = float("inf")
+    ops.heatmap_argmax(hm, nonfinite=good.nonfinite_planes)
+    with pytest.raises(_native.NativeLibraryError, match=rf"1 heat-map plane.*{dtype} hourglass engine.*--dtype f32"):
+        good.check_finite("the fixture")
+    good.check_finite()   # the counter was reset
 
 
 def _poison(eng, n):
