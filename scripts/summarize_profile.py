@@ -46,13 +46,18 @@ def main():
         for r in rows[:25]:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
     if len(sys.argv) >= 5:
-        agg = collections.defaultdict(lambda: {"n": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+        # launches are counted PER PASS: bench.py's settle loop runs a variable number of untimed steps, so the FETCH and the WRITE pass need not see
+        # the same number of launches (round 5 divided both sums by the FETCH pass's count: every WRITE_SIZE of profiles/r05_f16_traffic.csv is
+        # 10/9 too large -- profiles/r06_ring_traffic.txt)
+        agg = collections.defaultdict(lambda: {"n": 0, "nw": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
         for d in sys.argv[3:5]:
             for r in csv.DictReader(open(glob.glob(os.path.join(d, "*counter_collection.csv"))[0])):
                 a = agg[short(r["Kernel_Name"])]
                 a[r["Counter_Name"]] += float(r["Counter_Value"])
                 if r["Counter_Name"] == "FETCH_SIZE":
                     a["n"] += 1
+                elif r["Counter_Name"] == "WRITE_SIZE":
+                    a["nw"] += 1
         traffic = {}
         tj = os.path.join(out_dir, "traffic.json")
         if os.path.exists(tj):
@@ -62,10 +67,10 @@ def main():
             w = csv.writer(f)
             w.writerow(["Name", "launches", "FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch", "hbm_bytes_per_launch=(2*FETCH+WRITE)*1024"])
             for k, a in sorted(agg.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"] + kv[1]["WRITE_SIZE"])):
-                if not a["n"] or "at::native" in k:
+                if not a["n"] or not a["nw"] or "at::native" in k:
                     continue
-                b = (2 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024
-                w.writerow([k, a["n"], a["FETCH_SIZE"] / a["n"], a["WRITE_SIZE"] / a["n"], b / a["n"]])
+                b = (2 * a["FETCH_SIZE"] / a["n"] + a["WRITE_SIZE"] / a["nw"]) * 1024 * a["n"]   # (per launch x the FETCH pass's launches)
+                w.writerow([k, a["n"], a["FETCH_SIZE"] / a["n"], a["WRITE_SIZE"] / a["nw"], b / a["n"]])
                 m = re.match(r"hgk::(\w+(?:<[^(]*>)?)\(", k)
                 if m:  # key = kernel instantiation exactly as bench.py's roofline.kernel names it
                     cls[m.group(1)][0] += a["n"]
