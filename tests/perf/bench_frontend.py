@@ -97,7 +97,7 @@ def main():
 
         # ---- end to end ---------------------------------------------------------------------------------------
         os.environ["DF3D_SYNTHETIC_WEIGHTS"] = "0"
-        for dt_name in ("f32", "f16", "bf16"):
+        for dt_name in ("f32", "f32s", "f16", "bf16"):
             inference.inference_folder(folder=folder, camera_ids_to_flip=[4, 5, 6], max_img_id=min(a.frames, 256) - 1, dtype=dt_name)  # warm-up: engine, full-size batch buffers
             torch.cuda.synchronize()
             t0 = time.perf_counter()
