@@ -54,7 +54,9 @@ def test_default_line_has_every_leg_and_every_fraction(native_lib, cuda):
     for key, kern in (("config1_f32_split", "F32S"), ("config2_bf16", "__hip_bfloat16"), ("config2_f16", "_Float16")):
         _check_leg_roofline(short[key]["roofline"])
         assert kern in short[key]["roofline"]["kernel"], short[key]["roofline"]   # the leg ran its own engine's kernels, not a fallback
-    assert "bottleneck_ring_f32_kernel" in short["roofline"]["kernel"] and "float" in short["roofline"]["kernel"]
+    assert "bottleneck_wino_f32_kernel" in short["roofline"]["kernel"]   # the exact-fp32 engine's default tail (round 6: Winograd)
+    # roofline honesty: the fraction is EXECUTED FLOPs over the peak (< 1); the direct-convolution rate of the same launches is printed beside it
+    assert short["roofline"]["frac"] < 1.0 and short["roofline"]["direct_equivalent_tflops"] > short["roofline"]["achieved"]
     with open(os.path.join(ROOT, short["tables"])) as f:
         d = json.load(f)
     assert abs(d["value"] - short["value"]) < 1e-4 * d["value"]
@@ -67,7 +69,8 @@ def test_default_line_has_every_leg_and_every_fraction(native_lib, cuda):
     if "hourglass_gbs_pmc_end_to_end" in c:
         assert 0.9 * c["hourglass_gbs_min_end_to_end"] < c["hourglass_gbs_pmc_end_to_end"] < 8000.0
     _check_roofline(d["roofline"], "f32")
-    assert d["roofline"]["bound"] == "mfma" and "bottleneck_ring_f32_kernel" in d["roofline"]["kernel"]
+    assert d["roofline"]["bound"] == "mfma" and "bottleneck_wino_f32_kernel" in d["roofline"]["kernel"]
+    assert 0 < c["hourglass_frac_mfma_end_to_end"] < 1.0 and c["hourglass_tflops_executed_end_to_end"] < c["hourglass_tflops_end_to_end"]
     for key, dt in (("config1_f32_split", "f32s"), ("config2_bf16", "bf16"), ("config2_f16", "f16")):
         leg = d[key]
         assert leg["dtype"] == dt and leg["value"] > 0 and ("configs[1]" if dt == "f32s" else "configs[2]") in leg["workload"]
