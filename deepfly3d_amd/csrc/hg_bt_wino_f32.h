@@ -37,6 +37,7 @@ constexpr int WN_CHUNKS = 16;                          // K chunks of 8 input ch
 constexpr int WN_U_BYTES = WN_CHUNKS * 16 * 4 * 1024;  // [chunk][pass][row group][wave] x 1 KB MFMA A fragments = 1 MiB per bottleneck
 constexpr int WN_W3_BYTES = BRF_W3_STAGES * BR_STAGE_BYTES;   // behind U: W3's 16 stage images with their rows permuted (bt_wino_pack_w3_kernel)
 constexpr int WN_STREAM_BYTES = WN_U_BYTES + WN_W3_BYTES;
+constexpr int WN_STREAM_BYTES_L2 = WN_U_BYTES + 2 * WN_W3_BYTES;   // layer2: U | W3 | Wd (the skip convolution's weights, rows permuted the same way)
 constexpr int WN_V_BYTES = 16 * 1024;                  // one V chunk: [channel 4][row group 4][channel quad 2][patch 32] x 16 bytes
 constexpr int WN_T1_OFF = 2 * WN_V_BYTES;              // = BR_RING_BYTES: the W3 ring reuses the V buffers
 constexpr int WN_T1_BYTES = 2 * BR_T1_BYTES;           // both 64-channel halves of the 10 x 18 halo tile (92 160)
@@ -145,11 +146,15 @@ __device__ __forceinline__ void wn_transform(const f32x2 (&P)[4], const f32x2 (&
         : "v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(Q[0]), "v"(Q[1]), "v"(Q[2]), "v"(Q[3]));
 }
 
-template <bool UP, bool ADD2 = false>
+// L2: fp32 layer2 (128 -> 128 -> 128 -> 256 with a 1x1 SKIP CONVOLUTION instead of the identity skip): the same phases 1-2 on its t1, and in
+// phase 3 the skip convolution accumulated into the same accumulators behind W3 (as layer2_tail_f32_kernel does): per output half eight more ring
+// stages (Wd, rows permuted like W3's) whose A operand is the raw x of the lane's pixel, prefetched from global memory in MFMA layout; no residual.
+template <bool UP, bool ADD2 = false, bool L2 = false>
 __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs p) {
     static_assert(!(UP && ADD2), "the fused up-path sum is written by plain blocks");
+    static_assert(!L2 || (!UP && !ADD2), "layer2 is a plain block");
     using T = float;
-    constexpr int CIN = 256, CO = 256;
+    constexpr int CIN = L2 ? 128 : 256, CO = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ring = smem;                      // phase 3 (the V double buffer until then)
     unsigned char* const t1_lds = smem + WN_T1_OFF;
@@ -252,9 +257,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
     // issue order, so a wait for a young ring stage would also wait for every older load -- the tile's 128 KB of residual values, the next
     // tile's halo, which all 256 workgroups request within the same microsecond)
     auto ring_slot = [](int k) { return (k & 7) < 4 ? (k & 7) * BR_STAGE_BYTES : WN_RING2_OFF + ((k & 7) - 4) * BR_STAGE_BYTES; };
-    auto ring_issue8 = [&](int nh) {   // this wave copies pieces 2 wave, 2 wave + 1 of each stage
+    auto ring_issue8 = [&](int set) {   // stage set: W3 half 0, W3 half 1 (, L2: Wd half 0, Wd half 1); this wave copies pieces 2 wave, 2 wave + 1 of each stage
 #pragma unroll
-        for (int k = 8 * nh; k < 8 * nh + 8; ++k)
+        for (int k = 8 * set; k < 8 * set + 8; ++k)
             br_glds_stage(reinterpret_cast<const unsigned char*>(p.w2d) + WN_U_BYTES + (size_t)k * BR_STAGE_BYTES, wvoff,
                           ring_addr + (unsigned)ring_slot(k) + (unsigned)wave * 2048);
     };
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
     int tx0, ty0, view;
     tile_of(vb, tx0, ty0, view);
     t1_issue(tx0, ty0, view);
-    b3_lds[tid] = p.b3[tid];
+    b3_lds[tid] = L2 ? p.b3[tid] + p.bd[tid] : p.b3[tid];   // (L2: b3 + bd as ONE float add, as the direct kernels)
     if (tid < 128) b2_lds[tid] = p.b2[tid];
     bool first = true;
 
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         // uniform byte offsets of this wave's two tile rows (full resolution) / its one half-resolution row inside a [V][H][W][256] fp32 tensor
         const size_t ftile = (((size_t)view * p.H + ty0 + 2 * wave) * p.W + tx0) * (CO * 4);
         const size_t htile = (((size_t)view * (p.H / 2) + ty0 / 2 + wave) * (p.W / 2) + tx0 / 2) * (CO * 4);
-        const unsigned char* const xtile = reinterpret_cast<const unsigned char*>(p.in) + ftile;
+        const unsigned char* const xtile = reinterpret_cast<const unsigned char*>(p.in) + (L2 ? ftile / 2 : ftile);   // (L2: x has 128 channels)
 
         // accumulators (b2 is added to position (1,1) -- which enters all four outputs of a patch with weight +1 -- in the output transform: as a
         // start value it would be a global load straight into accumulator registers, and the wait hipcc puts in front of the first MFMA that
@@ -434,13 +439,18 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         if (has_next) t1_issue(ntx0, nty0, nview);
         // ---- residual values (and the ADD2 addends) of the whole tile, requested here -- behind the ring's first half (no ring wait has to let them pass), 16 000 MFMA cycles
         //      in front of their first use (one wave per SIMD: nobody hides a load issued in an epilogue; the 512-register file has room) ----
-        f32x4 xres[2][16];   // [output half][register r <-> pixel (r & 3) + 8 (r >> 2) + 4 half]: channels 128 nh + 4 l31 .. + 3
+        f32x4 xres[L2 ? 1 : 2][16];   // [output half][register r <-> pixel (r & 3) + 8 (r >> 2) + 4 half]: channels 128 nh + 4 l31 .. + 3
+                                      // L2: [0][2 k8 + jj] = the skip convolution's A operand, x[this lane's pixel][16 k8 + 8 jj + 4 half ..]
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
+        for (int nh = 0; nh < (L2 ? 1 : 2); ++nh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int pl0 = (r & 3) + 8 * (r >> 2);   // + 4 half: the lane's part
-                xres[nh][r] = *reinterpret_cast<const f32x4*>(xtile + ((size_t)(pl0 >> 4) * p.W + (pl0 & 15)) * (CIN * 4) + nh * 512 + lane_full);
+                if constexpr (L2) {
+                    xres[0][r] = *reinterpret_cast<const f32x4*>(xtile + (8 * r) * 4 + (unsigned)((((l31_3 >> 4) * p.W + (l31_3 & 15)) * CIN + 4 * half3) * 4));
+                } else {
+                    const int pl0 = (r & 3) + 8 * (r >> 2);   // + 4 half: the lane's part
+                    xres[nh][r] = *reinterpret_cast<const f32x4*>(xtile + ((size_t)(pl0 >> 4) * p.W + (pl0 & 15)) * (CIN * 4) + nh * 512 + lane_full);
+                }
             }
         f32x4 a2v[ADD2 ? 2 : 1][4];
         if constexpr (ADD2) {
@@ -451,42 +461,54 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                     a2v[nh][key] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.add2) + htile + ((key & 1) + 4 * (key >> 1)) * (CO * 4) + nh * 512 + lane_half);
         }
         BR_STAMP(4);
-        // ---- phase 3: out = W3 relu(t2) + b3 + x  (bottleneck_ring_f32_kernel's exact-fp32 form: rows = the wave's pixels, columns = channels) ----
+        // ---- phase 3: out = W3 relu(t2) + b3 + x  (bottleneck_ring_f32_kernel's exact-fp32 form: rows = the wave's pixels, columns = channels);
+        //      L2: out = W3 relu(t2) + Wd x + (b3 + bd) ----
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
             f32x16 o[4];
+            if (nh == 1) {
+                // the second half's stages were requested behind the first half's K loop(s); younger than them are only the first half's epilogue's
+                // operations -- at least its 16 output stores -- which need not have drained (operations retire in issue order)
+                br_wait_vm(16);
+                br_barrier();
+            }
 #pragma unroll
-            for (int dd = 0; dd < 4; ++dd) {
-                const int k0 = 8 * nh + 2 * dd;
-                if (nh == 1 && dd == 0) {
-                    // the second half's stages were requested behind the first K loop; younger than them are only the >= 64 stores of the first
-                    // half's epilogue, which need not have drained
-                    br_wait_vm(63);
-                    br_barrier();
-                }
-                if (dd == 0) {
+            for (int i = 0; i < 4; ++i) {
+                const float bias = b3_lds[nh * 128 + 4 * l31_3 + i];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float bias = b3_lds[nh * 128 + 4 * l31_3 + i];
+                for (int r = 0; r < 16; ++r) o[i][r] = bias;
+            }
+            // eight resident stages, no wait, no barrier: stage k8 = the 16-float K slice 16 k8 .. of W3 (operand: registers 8 q2 + 4 jj + e of t2
+            // tile k8 >> 1 = channels 32 tile + 16 q2 + 8 jj + 4 half + e) or of Wd (operand: x of the lane's pixel, channels 16 k8 + 8 jj + 4 half + e)
+            auto kloop = [&](auto skip_tag) {
+                constexpr bool SKIP = decltype(skip_tag)::value;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) o[i][r] = bias;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int k8 = 2 * dd + u, s = k0 + u, tile = k8 >> 1, q2 = k8 & 1;
-                    // registers 8 q2 + 4 jj + e of t2 tile `tile` hold channels 32 tile + 16 q2 + 8 jj + 4 half + e: 16-byte chunk 2 jj + half of the stage
+                for (int k8 = 0; k8 < 8; ++k8) {
+                    const int tile = k8 >> 1, q2 = k8 & 1;
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + ring_slot(s) + i * 2048);
-                            mfma_quad<T>(t2[tile][8 * q2 + 4 * jj], t2[tile][8 * q2 + 4 * jj + 1], t2[tile][8 * q2 + 4 * jj + 2], t2[tile][8 * q2 + 4 * jj + 3], wf, o[i]);
+                            const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + ring_slot(k8) + i * 2048);
+                            if constexpr (SKIP) {
+                                const f32x4 xa = xres[0][2 * k8 + jj];
+                                mfma_quad<T>(xa[0], xa[1], xa[2], xa[3], wf, o[i]);
+                            } else {
+                                mfma_quad<T>(t2[tile][8 * q2 + 4 * jj], t2[tile][8 * q2 + 4 * jj + 1], t2[tile][8 * q2 + 4 * jj + 2], t2[tile][8 * q2 + 4 * jj + 3], wf, o[i]);
+                            }
                         }
                 }
+            };
+            kloop(std::false_type{});
+            if constexpr (L2) {
+                br_barrier();             // every wave is through W3's eight stages
+                ring_issue8(2 + nh);      // Wd of this half (L2-resident: the one exposed round trip of the half)
+                br_wait_vm(0);
+                br_barrier();
+                kloop(std::true_type{});
             }
             if (nh == 0) {
-                br_barrier();     // every wave is through the first half's eight stages
+                br_barrier();     // every wave is through the first half's stages
                 ring_issue8(1);   // ... the second half's land under the epilogue
             }
             BR_STAMP(5 + 2 * nh);
@@ -500,7 +522,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                 const int hoff = ((key & 1) + 4 * (key >> 1)) * (CO * 4) + nh * 512;   // the quad's half-resolution pixel (+ 2 half in the lane offset)
                 f32x4 xv[4], ov[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xv[t] = xres[nh][r0 + (t & 1) + 8 * (t >> 1)];
+                for (int t = 0; t < 4; ++t) xv[t] = L2 ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : xres[L2 ? 0 : nh][r0 + (t & 1) + 8 * (t >> 1)];
                 if constexpr (UP) {
                     const f32x4 t4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.in2) + htile + hoff + lane_half);
 #pragma unroll
@@ -509,7 +531,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int r = r0 + (t & 1) + 8 * (t >> 1);
-                    ov[t] = f32x4{o[0][r], o[1][r], o[2][r], o[3][r]} + xv[t];
+                    ov[t] = f32x4{o[0][r], o[1][r], o[2][r], o[3][r]};
+                    if constexpr (!L2) ov[t] += xv[t];
                     if constexpr (ADD2) ov[t] += a2v[nh][key];   // a second fp32 add, as upadd_kernel would have done on the stored tensor
                     const int pl0 = (r & 3) + 8 * (r >> 2);
                     *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.out) + ftile + ((size_t)(pl0 >> 4) * p.W + (pl0 & 15)) * (CO * 4) + nh * 512 + lane_full) = ov[t];
@@ -520,7 +543,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                     for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(v[0][e], v[1][e]), fmaxf(v[2][e], v[3][e]));
                     return m;
                 };
-                if constexpr (!UP) if (p.pool_in)   // 2x2 max-pool of the block's INPUT (the skip values just added)
+                if constexpr (!UP && !L2) if (p.pool_in)   // 2x2 max-pool of the block's INPUT (the skip values just added)
                     *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.pool_in) + htile + hoff + lane_half) = max4(xv);
                 if (p.pool) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.pool) + htile + hoff + lane_half) = max4(ov);
             }

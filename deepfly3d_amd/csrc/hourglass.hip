@@ -362,6 +362,10 @@ struct df3d_hg {
                 st.wstream_c1 = (long long)stream_bytes;
                 stream_bytes += (size_t)(128 / 16) * BR_STAGE_BYTES;
                 st.t1 = new_tensor(tx.h, tx.w, planes);
+                if (wino && dtype == DF3D_DTYPE_F32) {   // its 3x3 in the Winograd domain too (hg_bt_wino_f32.h, L2): U | W3 | Wd
+                    st.wstream_w2d = (long long)stream_bytes;
+                    stream_bytes += (size_t)WN_STREAM_BYTES_L2;
+                }
             }
             if (l1 && lp() && cin == 64 && planes == 64 && tx.h % 16 == 0 && tx.w % 16 == 0) {
                 st.l1 = true;   // all weights resident in LDS (hg_bt_l1.h)
@@ -782,15 +786,15 @@ int launch_ring_f32(const BtRingArgs& r, int blocks, int lds_bytes, hipStream_t 
     return DF3D_OK;
 }
 
-template <bool UP, bool ADD2>
+template <bool UP, bool ADD2, bool L2 = false>
 int launch_wino_f32(const BtRingArgs& r, int blocks, hipStream_t s) {
     static unsigned attr_done = 0;
     if (first_use_on_this_device(attr_done))
-        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_wino_f32_kernel<UP, ADD2>), hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
+        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_wino_f32_kernel<UP, ADD2, L2>), hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
     // persistent: one workgroup per CU (it needs the whole register file), walking tiles with stride gridDim; a multiple of 8 keeps virtual
     // block ids on their XCD (hg_bt_wino_f32.h tile_of)
     const int cus = cu_count() & ~7;
-    hipLaunchKernelGGL((bottleneck_wino_f32_kernel<UP, ADD2>), dim3(blocks <= cus ? blocks : cus), dim3(256), WN_LDS_BYTES, s, r);
+    hipLaunchKernelGGL((bottleneck_wino_f32_kernel<UP, ADD2, L2>), dim3(blocks <= cus ? blocks : cus), dim3(256), WN_LDS_BYTES, s, r);
     DF3D_LAUNCH_CHECK();
     return DF3D_OK;
 }
@@ -947,6 +951,13 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                         r.wstream = sb + st.wstream;
                         r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd;
                         r.V = n; r.H = ti.h; r.W = ti.w;
+                        if (std::is_same<T, float>::value && st.wstream_w2d >= 0) {   // option `wino`: layer2's 3x3 in the Winograd domain as well
+                            r.w2d = sb + st.wstream_w2d;
+                            ScopedTimer tw(h, s, "bottleneck_wino_f32_kernel<false, false, true>", 2.0 * px * (9.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl),
+                                           px * 4.0 * (cin + pl + 2.0 * pl), st.m1_elems * n * eb, 2.0 * px * (4.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl));
+                            if (int rc = launch_wino_f32<false, false, true>(r, n * (ti.h / BT_TH) * (ti.w / BT_TW), s)) return rc;
+                            break;
+                        }
                         ScopedTimer tm(h, s, std::string("layer2_tail_f32_kernel<") + tname + ">", 2.0 * px * (9.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl), px * 4.0 * (cin + pl + 2.0 * pl), st.m1_elems * n * eb);
                         static unsigned attr_t = 0;
                         if (first_use_on_this_device(attr_t))
@@ -1446,6 +1457,12 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
                                    blob_dev + st.conv3b.w_off, blob_dev + st.conv4b.w_off, reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
                 hipLaunchKernelGGL(bt_c1_pack_f32_kernel, dim3(((128 / 16) * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv.w_off,
                                    reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_c1, 128, 128);
+                if (st.wstream_w2d >= 0 && h->dtype == DF3D_DTYPE_F32) {
+                    unsigned char* const ws = reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_w2d;
+                    hipLaunchKernelGGL(bt_wino_pack_kernel, dim3(128 * 128 / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv2b.w_off, reinterpret_cast<float*>(ws));
+                    hipLaunchKernelGGL(bt_wino_pack_w3_kernel, dim3(BRF_W3_STAGES * 512 / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv3b.w_off, ws + WN_U_BYTES);
+                    hipLaunchKernelGGL(bt_wino_pack_w3_kernel, dim3(BRF_W3_STAGES * 512 / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv4b.w_off, ws + WN_U_BYTES + WN_W3_BYTES);
+                }
                 continue;
             }
             if (st.l1f) {
