@@ -368,6 +368,13 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
             chunk(c + 1, std::integral_constant<int, 2>{}, std::false_type{});
             chunk(c + 2, std::integral_constant<int, 0>{}, std::false_type{});
         }
+        // the last chunk re-requested fragments nobody multiplies: keep their registers named until they have landed (a load whose destination is
+        // dead to the compiler lands, asynchronously, in whatever the register holds by then)
+        if (!(WN_ABL & 1)) {
+            wn_uwait<4>(ufr[0]);
+            wn_uwait<0>(ufr[1]);
+            wn_uwait<0>(ufr[2]);
+        }
 
         BR_STAMP(2);
         // Everything phase 3 derives from the lane index is derived HERE, per tile, from a copy the compiler cannot see through: hoisted out of

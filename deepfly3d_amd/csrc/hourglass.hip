@@ -21,6 +21,7 @@
 #include "hg_c1_f32.h"
 #include "hg_l1_f32.h"
 #include "hg_bt_wino_f32.h"
+#include "hg_l1_wino_f32.h"
 
 using namespace hgk;
 
@@ -337,6 +338,10 @@ struct df3d_hg {
                 st.wstream_c1 = (long long)stream_bytes;
                 stream_bytes += (size_t)(64 / 16) * BR_STAGE_BYTES;
                 st.t1 = new_tensor(tx.h, tx.w, planes);
+                if (wino && dtype == DF3D_DTYPE_F32 && tx.w % L1W_TW == 0) {   // its 3x3 in the Winograd domain (hg_l1_wino_f32.h: 8 x 32 tiles): U | W3 | Wd
+                    st.wstream_w2d = (long long)stream_bytes;
+                    stream_bytes += (size_t)L1W_STREAM_BYTES;
+                }
                 if (want_pool && only_pool) {   // round 5: as the 16-bit layer1 kernel, the tail writes the pooled tensor only (the full-resolution
                                                 // output, 15 of the block's 37 GB per 896 views, has no other reader)
                     st.pool_only = true;
@@ -997,6 +1002,18 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                         r.wstream = sb + st.wstream;
                         r.b2 = a.b2; r.b3 = a.b3; r.bd = a.bd;
                         r.V = n; r.H = ti.h; r.W = ti.w;
+                        if (std::is_same<T, float>::value && st.wstream_w2d >= 0) {   // option `wino`: layer1's 3x3 in the Winograd domain (8 x 32 tiles, persistent)
+                            r.w2d = sb + st.wstream_w2d;
+                            ScopedTimer tw(h, s, "layer1_wino_f32_kernel", 2.0 * px * (9.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl),
+                                           px * 4.0 * (cin + pl + (st.pool_only ? 0.5 * pl : 2.0 * pl)), st.m1_elems * n * eb, 2.0 * px * (4.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl));
+                            static unsigned attr_w = 0;
+                            if (first_use_on_this_device(attr_w))
+                                DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer1_wino_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L1W_LDS_BYTES));
+                            const int tiles = n * (ti.h / BT_TH) * (ti.w / L1W_TW), cus = cu_count() & ~7;
+                            hipLaunchKernelGGL(layer1_wino_f32_kernel, dim3(tiles <= cus ? tiles : cus), dim3(256), L1W_LDS_BYTES, s, r);
+                            DF3D_LAUNCH_CHECK();
+                            break;
+                        }
                         ScopedTimer tm(h, s, std::string("layer1_tail_f32_kernel<") + tname + ">", 2.0 * px * (9.0 * pl * pl + (double)pl * 2 * pl + (double)cin * 2 * pl), px * 4.0 * (cin + pl + (st.pool_only ? 0.5 * pl : 2.0 * pl)), st.m1_elems * n * eb);
                         static unsigned attr_t = 0;
                         if (first_use_on_this_device(attr_t))
@@ -1470,6 +1487,12 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
                                    blob_dev + st.conv3b.w_off, blob_dev + st.conv4b.w_off, reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream);
                 hipLaunchKernelGGL(bt_c1_pack_f32_kernel, dim3(((64 / 16) * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv.w_off,
                                    reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_c1, 64, 64);
+                if (st.wstream_w2d >= 0 && h->dtype == DF3D_DTYPE_F32) {
+                    unsigned char* const ws = reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_w2d;
+                    hipLaunchKernelGGL(l1_wino_pack_u_kernel, dim3(64 * 64 / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv2b.w_off, reinterpret_cast<float*>(ws));
+                    hipLaunchKernelGGL(l1_wino_pack_w_kernel, dim3(4 * 512 / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv3b.w_off, ws + L1W_U_BYTES);
+                    hipLaunchKernelGGL(l1_wino_pack_w_kernel, dim3(4 * 512 / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv4b.w_off, ws + L1W_U_BYTES + L1W_W_BYTES);
+                }
                 continue;
             }
             hipLaunchKernelGGL(bt_ring_pack_f32_kernel, dim3((BRF_NSTAGE * 512 + 255) / 256), dim3(256), 0, df3d::as_stream(stream),

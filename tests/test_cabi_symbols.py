@@ -148,11 +148,11 @@ def test_f32s_engine_shares_the_f32_plan_and_needs_its_weight_copy(native_lib):
     for n in (1, 7, 896):
         assert native_lib.df3d_hg_workspace_bytes(f32, n) == native_lib.df3d_hg_workspace_bytes(f32s, n)
     copy = (native_lib.df3d_hg_blob_floats(f32) * 4 + 255) & ~255
-    # the exact-fp32 engine's default plan adds, per identity-skip bottleneck (23; layer2, with its skip convolution: 256 KiB of 1x1 weights), the Winograd-domain weights of its 3x3 (1 MiB) and W3 with
+    # the exact-fp32 engine's default plan adds, per identity-skip bottleneck (23; layer2, with its skip convolution: 256 KiB of 1x1 weights; layer1: 256 + 64 KiB), the Winograd-domain weights of its 3x3 (1 MiB) and W3 with
     # permuted rows (128 KiB): option "wino" (round 6); without it the two engines' streams are the same
     with_wino = native_lib.df3d_hg_lowp_bytes(f32)
     assert native_lib.df3d_hg_set_option(f32, b"wino", 0) == 0
-    assert with_wino - native_lib.df3d_hg_lowp_bytes(f32) == 23 * ((1 << 20) + (128 << 10)) + (1 << 20) + (256 << 10)
+    assert with_wino - native_lib.df3d_hg_lowp_bytes(f32) == 23 * ((1 << 20) + (128 << 10)) + (1 << 20) + (256 << 10) + (256 << 10) + (64 << 10)
     assert native_lib.df3d_hg_lowp_bytes(f32s) == copy + native_lib.df3d_hg_lowp_bytes(f32)
     rc = native_lib.df3d_hg_set_weights(f32s, ctypes.c_void_p(256), None, None)
     assert rc == -1 and b"f32s" in native_lib.df3d_last_error()
