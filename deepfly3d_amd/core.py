@@ -273,19 +273,24 @@ class Core:
         J = config["num_joints"]
         rows = np.zeros((0, 2 + 2 * J))
         if rank == 0 and self.camNet is not None and self.camNet.points2d is not None and self.camNet.points2d.shape[1] == self.num_images:
-            listed = [(c, i) for c, per_image in self.db.manual_corrections().items() for i in per_image if c < config["num_cameras"] and i < self.num_images]
-            if listed:
-                rows = np.stack([np.concatenate([[c, i], self.camNet.points2d[c, i].reshape(-1)]) for c, i in listed])
+            try:   # (a malformed correction entry must not leave the peers alone in the broadcasts below: it travels to agree())
+                listed = [(int(c), int(i)) for c, per_image in self.db.manual_corrections().items() for i in per_image if c < config["num_cameras"] and i < self.num_images]
+                if listed:
+                    cams, frames = np.array([c for c, _ in listed]), np.array([i for _, i in listed])
+                    rows = np.concatenate([cams[:, None], frames[:, None], self.camNet.points2d[cams, frames].reshape(len(listed), 2 * J)], axis=1).astype(np.float64)
+            except Exception as e:  # noqa: BLE001
+                bad, rows = bad or e, np.zeros((0, 2 + 2 * J))
         count = dd._wire_tensor(torch.tensor([rows.shape[0]], dtype=torch.int64).to(dev), None)
         dist.broadcast(count, src=0)
         if int(count.cpu()[0]):
             wire = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float64)) if rank == 0 else torch.zeros((int(count.cpu()[0]), 2 + 2 * J), dtype=torch.float64)
             wire = dd._wire_tensor(wire.to(dev), None)
             dist.broadcast(wire, src=0)
-            for row in wire.cpu().numpy():
-                c, i = int(row[0]), int(row[1])
-                if t0 <= i < t1:
-                    px[c, i - t0] = torch.from_numpy(row[2:].reshape(J, 2)).to(px.device)
+            table = wire.cpu()
+            mine = (table[:, 1] >= t0) & (table[:, 1] < t1)
+            if bool(mine.any()):   # one indexed assignment (rows of one (camera, frame) are unique: the store is a dict of dicts)
+                table = table[mine]
+                px[table[:, 0].long().to(px.device), (table[:, 1].long() - t0).to(px.device)] = table[:, 2:].reshape(-1, J, 2).to(px.device)
         X = ops.triangulate(rec[1:].reshape(7, 3, 4).numpy(), px) if t1 > t0 else torch.zeros((0, config["num_joints"], 3), dtype=torch.float64, device=dev)
         logger.debug(f"rank {rank} of {world}: triangulated frames [{t0}, {t1}) on {dev}")
         full = dd.gather_frames(X, 0, self.num_images)

@@ -600,9 +600,13 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;   // every sh
 //     43-double reduction had every workgroup re-reading 72 KB per sweep: 12.6 us per call; flags: G x 8 bytes per sweep.
 // Returns false on a timeout (a workgroup that never became resident).
 constexpr int LDBG_CALLS_FWD = 64;
+// The granules / flags are double-buffered by epoch parity (LAR1_STRIDE / LAR2_STRIDE apart): a workgroup can only publish epoch e + 2 after every
+// workgroup published e + 1, i.e. finished sweeping e -- two all-reduces over the same granules may then follow each other directly (the
+// beta == 0 branch skips the second one in between).
+constexpr size_t LAR1_STRIDE = (size_t)LMAXG * 4, LAR2_STRIDE = (size_t)LMAXG * (16 + 49);
 __device__ bool all_reduce(LocalLds& L, unsigned long long* gran_, int n, unsigned epoch, double* dbg = nullptr, int call = 0) {
     constexpr int LDBG_CALLS = LDBG_CALLS_FWD;
-    gu64* const gran = (gu64*)gran_;
+    gu64* const gran = (gu64*)gran_ + (epoch & 1u) * (n <= 2 ? LAR1_STRIDE : LAR2_STRIDE);
     const int G = (int)gridDim.x, wg = (int)blockIdx.x, tid = (int)threadIdx.x;
     __syncthreads();   // L.own is complete
     if (G == 1) {
@@ -1051,7 +1055,7 @@ __global__ void lsmr_local_partition_kernel(const int* __restrict__ pt_start, in
 
 int local_max_workgroups() { return LMAXG; }
 int local_workgroups_for(int nobs) { return (nobs + (LOBS - 8) - 1) / (LOBS - 8); }   // a range holds at least LOBS - 7 observations (a point has <= 8)
-size_t local_scratch_bytes() { return (size_t)(LMAXG + 1) * sizeof(int) + 64 + (size_t)LMAXG * (4 + 16 + 49) * sizeof(unsigned long long); }
+size_t local_scratch_bytes() { return (size_t)(LMAXG + 1) * sizeof(int) + 64 + 2 * (LAR1_STRIDE + LAR2_STRIDE) * sizeof(unsigned long long); }
 
 // the whole run in one launch; `scratch`: local_scratch_bytes() bytes of device memory (zeroed here); state_out: >= sizeof(State)
 int launch_local(const df3d_ba_problem& p, const double* Jc, const double* Jp, const double* d, const double* b, double* x, double damp, double atol,
@@ -1061,7 +1065,7 @@ int launch_local(const df3d_ba_problem& p, const double* Jc, const double* Jp, c
     if (hipMemsetAsync(scratch, 0, local_scratch_bytes(), s) != hipSuccess) return -2;
     int* const wg_obs = reinterpret_cast<int*>(scratch);
     unsigned long long* const gr1 = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(scratch) + (((size_t)(LMAXG + 1) * sizeof(int) + 63) & ~size_t(63)));
-    unsigned long long* const gr2 = gr1 + (size_t)LMAXG * 4;
+    unsigned long long* const gr2 = gr1 + 2 * LAR1_STRIDE;
     hipLaunchKernelGGL(lsmr_local_partition_kernel, dim3(1), dim3(64), 0, s, p.pt_start, p.npts, p.nobs, G, wg_obs);
     static double* dbg = nullptr;
     static const bool want_dbg = getenv("DF3D_LSMR_DEBUG") != nullptr;

@@ -145,7 +145,7 @@ def test_bundle_adjust_window_1000_frames(native_lib, cuda, golden_dir):
 def test_every_lsmr_form_gives_the_same_bits(native_lib, cuda, tmp_path):
     """Round 4: an LSMR iteration is two kernels (csrc/ba_lsmr.hip: the scalar steps run in every workgroup's prologue, u and v stay
     un-normalised, the camera entries of v live in the state) instead of round 3's eleven.  Round 5: the whole run is ONE persistent
-    kernel, the two kernel boundaries of an iteration replaced by grid-wide barriers (the default).  The iterate sequence is the
+    kernel, the two kernel boundaries of an iteration replaced by grid-wide barriers (form PERSISTENT; AUTO resolves to the data-local form where it fits).  The iterate sequence is the
     parity requirement of a7 (the reference's solver stops after 3-4 outer iterations on a problem with a free gauge),
     so every form must reproduce round 3's arithmetic exactly: same solution vector and same (istop, itn, |r|, |A^T r|, |A|, cond, |x|)
     after 16, 17, 18, 32, 33, 48 iterations and at convergence, on the reference's own sample problem -- the persistent form at several

@@ -81,7 +81,10 @@ def test_default_line_has_every_leg_and_every_fraction(native_lib, cuda):
     sh = d["config4_share"]
     assert "error" not in sh, sh
     assert sh["frames"] == 2000 and sh["bundle_adjust_runs"] == 2 and sh["gather_roundtrip_exact"] is True and sh["collective_backend"] == "nccl"
-    assert sh["value"] > 0   # (rates are printed, never compared: a fresh box's clocks are still ramping in a run this short)
+    assert sh["value"] > 0
+    # a loose ORDER of the rates (bench.py settles the clocks before it times; the measured ratios are 1.8x / 3x): a leg that silently ran a slow or
+    # fallback path would land below the exact-fp32 engine
+    assert d["config1_f32_split"]["value"] > d["value"] and d["config2_bf16"]["value"] > d["value"] and d["config2_f16"]["value"] > d["value"]
     print("rates (frames/s): f32", round(d["value"], 1), "f32 split", round(d["config1_f32_split"]["value"], 1), "bf16", round(d["config2_bf16"]["value"], 1), "f16", round(d["config2_f16"]["value"], 1),
           "configs[4] share", round(sh["value"], 1), "cpu port", round(d["cpu_baseline"]["value"], 3))
     cb = d["cpu_baseline"]
