@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char, c_char_p, c_double, c_float, c_in
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DF3D_LIB") or os.path.join(_HERE, "libdf3d_hip.so")  # DF3D_LIB: developer override (kernel A/B builds)
 
-ABI_VERSION = 600
+ABI_VERSION = 610
 LSMR_AUTO, LSMR_BARRIERS, LSMR_LAUNCHES, LSMR_LOCAL, LSMR_ELEVEN = 0, 1, 2, 3, 11   # DF3D_LSMR_* of include/df3d_hip.h  # DF3D_ABI_VERSION of include/df3d_hip.h: the revision these prototypes were written against
 DF3D_EINVAL = -1  # include/df3d_hip.h
 DF3D_ENOSPC = -5
@@ -99,6 +99,20 @@ PROTOTYPES = {
     "df3d_vec_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "df3d_vec_absmax": (c_int, [c_void_p, c_size_t, POINTER(c_double), c_void_p, c_void_p]),
     "df3d_ba_update_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "df3d_ba_trf_subspace": (
+        c_int,
+        [POINTER(BAProblem), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p, POINTER(c_double), c_void_p, c_int],
+    ),
+    "df3d_ba_trf_trial": (
+        c_int,
+        [POINTER(BAProblem), c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p, POINTER(c_double), c_void_p],
+    ),
+    "df3d_ba_trf_linearize": (
+        c_int,
+        [POINTER(BAProblem), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    ),
     "df3d_hg_create": (c_int, [c_int, c_int, POINTER(c_void_p)]),
     "df3d_hg_destroy": (None, [c_void_p]),
     "df3d_hg_set_input": (c_int, [c_void_p, c_int, c_int]),

@@ -17,6 +17,7 @@ here on the host, every vector operation runs in libdf3d_hip.so:
 There is no CPU fallback.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -215,11 +216,18 @@ def _solve_trust_region_2d(B, g, Delta):
     return p[:, np.argmin(value)]
 
 
-def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, lsmr_form=_native.LSMR_AUTO):
+def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, lsmr_form=_native.LSMR_AUTO, device_scalars=None):
     """Trust-region-reflective least squares without bounds, LSMR subspace step, x_scale='jac'.
     x0: device float64 [n].  Returns dict(x=device tensor, cost, nfev, njev, status, lsmr_iters, optimality).
     lsmr_form: DF3D_LSMR_* of include/df3d_hip.h (AUTO: one persistent data-local kernel per inner solve; LAUNCHES when the adjustment
-    runs beside other work on the device)."""
+    runs beside other work on the device).
+    device_scalars (default True; DF3D_TRF_HOST_SCALARS=1 in the environment turns it off): the driver's scalars stay on the device -- one
+    read-back per outer iteration and one per trial step (df3d_ba_trf_* of include/df3d_hip.h) instead of seven and one; the same
+    arithmetic, the same iterates (tests/test_gpu_ba.py compares the two)."""
+    if device_scalars is None:
+        device_scalars = os.environ.get("DF3D_TRF_HOST_SCALARS", "0") in ("", "0")
+    if device_scalars:
+        return _solve_trf_device_scalars(prob, x0, ftol, xtol, gtol, max_nfev, lsmr_form)
     dv = _Dev(prob)
     m, n, nobs = prob.m, prob.n, prob.nobs
     x = x0.clone()
@@ -350,6 +358,106 @@ def solve_trf(prob, x0, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, lsmr_for
             njev += 1
             dv.rmatvec(Jc, Jp, None, f, g)
             refresh_scale(False)
+    if status is None:
+        status = 0
+    return dict(x=x, cost=cost, nfev=nfev, njev=njev, status=status, lsmr_iters=lsmr_iters, optimality=g_norm, lsmr_fallbacks=lsmr_fallbacks)
+
+
+def _solve_trf_device_scalars(prob, x0, ftol, xtol, gtol, max_nfev, lsmr_form):
+    """solve_trf with the scalars of an outer iteration left on the device (see there): the host keeps the trust radius, the 2x2
+    subproblem and the acceptance logic -- everything that decides what is enqueued next."""
+    dv = _Dev(prob)
+    lib, P, st = dv.lib, ctypes.byref(prob.c), dv.stream()
+    m, n, nobs = prob.m, prob.n, prob.nobs
+    x = x0.clone()
+    f, f_new, Js0, Js1, tmp_m = (dv.new(m) for _ in range(5))
+    Jc, Jp = dv.new(12 * nobs), dv.new(6 * nobs)
+    g, g_h, gn_h, scale, scale_inv, tmp_n, step, s0, s1, step_h, x_new = (dv.new(n) for _ in range(11))
+    work = dv.new(lib.df3d_ba_lsmr_work_doubles(P))
+    scratch = dv.scratch
+
+    def linearize(xv, fv, eval_f, first):
+        _native.check(lib.df3d_ba_trf_linearize(P, xv.data_ptr(), fv.data_ptr(), 1 if eval_f else 0, Jc.data_ptr(), Jp.data_ptr(), g.data_ptr(), tmp_n.data_ptr(),
+                                                scale_inv.data_ptr(), scale.data_ptr(), 1 if first else 0, scratch.data_ptr(), st), "df3d_ba_trf_linearize")
+
+    linearize(x, f, True, True)
+    nfev = njev = 1
+    dv.mul(x, scale_inv, tmp_n)
+    ff0, d2 = dv.dots((f, f), (tmp_n, tmp_n))
+    cost = 0.5 * ff0
+    Delta = float(np.sqrt(d2))
+    if Delta == 0:
+        Delta = 1.0
+    if max_nfev is None:
+        max_nfev = n * 100
+    status = None
+    lsmr_iters = []
+    lsmr_fallbacks = 0
+    g_norm = None
+    sub = (ctypes.c_double * 19)()
+    tri = (ctypes.c_double * 6)()
+    while True:
+        if status is not None or nfev == max_nfev:
+            g_norm = dv.absmax(g)
+            if g_norm < gtol:
+                status = 1
+            break
+        _native.check(lib.df3d_ba_trf_subspace(P, Jc.data_ptr(), Jp.data_ptr(), scale.data_ptr(), g.data_ptr(), f.data_ptr(), Delta, g_h.data_ptr(), gn_h.data_ptr(),
+                                               s0.data_ptr(), s1.data_ptr(), Js0.data_ptr(), Js1.data_ptr(), tmp_m.data_ptr(), work.data_ptr(), scratch.data_ptr(),
+                                               sub, st, lsmr_form), "df3d_ba_trf_subspace")
+        g_norm = sub[0]
+        if g_norm < gtol:   # (what was enqueued behind |g|_inf is not looked at)
+            status = 1
+            break
+        lsmr_iters.append(int(sub[12]))
+        lsmr_fallbacks += int(sub[18]) != 0
+        B_S = np.array([[sub[6], sub[7]], [sub[7], sub[8]]])
+        g_S = np.array([sub[9], sub[10]])
+        actual_reduction = -1.0
+        cost_new = cost
+        while actual_reduction <= 0 and nfev < max_nfev:
+            p_S = _solve_trust_region_2d(B_S, g_S, Delta)
+            _native.check(lib.df3d_ba_trf_trial(P, float(p_S[0]), float(p_S[1]), s0.data_ptr(), s1.data_ptr(), Js0.data_ptr(), Js1.data_ptr(), scale.data_ptr(),
+                                                x.data_ptr(), g_h.data_ptr(), step_h.data_ptr(), tmp_m.data_ptr(), step.data_ptr(), x_new.data_ptr(), f_new.data_ptr(),
+                                                scratch.data_ptr(), tri, st), "df3d_ba_trf_trial")
+            nfev += 1
+            jp2, sg, sh2, ff, st2, xx = tri
+            predicted_reduction = -(0.5 * jp2 + sg)
+            step_h_norm = float(np.sqrt(sh2))
+            cost_new = 0.5 * ff
+            if not np.isfinite(cost_new):
+                Delta = 0.25 * step_h_norm
+                continue
+            actual_reduction = cost - cost_new
+            if predicted_reduction > 0:
+                ratio = actual_reduction / predicted_reduction
+            elif predicted_reduction == actual_reduction == 0:
+                ratio = 1
+            else:
+                ratio = 0
+            Delta_new = Delta
+            if ratio < 0.25:
+                Delta_new = 0.25 * step_h_norm
+            elif ratio > 0.75 and step_h_norm > 0.95 * Delta:
+                Delta_new = 2.0 * Delta
+            step_norm = float(np.sqrt(st2))
+            ftol_ok = actual_reduction < ftol * cost and ratio > 0.25
+            xtol_ok = step_norm < xtol * (xtol + float(np.sqrt(xx)))
+            if ftol_ok and xtol_ok:
+                status = 4
+            elif ftol_ok:
+                status = 2
+            elif xtol_ok:
+                status = 3
+            if status is not None:
+                break
+            Delta = Delta_new
+        if actual_reduction > 0:
+            x, x_new = x_new, x
+            f, f_new = f_new, f
+            cost = cost_new
+            linearize(x, f, False, False)
+            njev += 1
     if status is None:
         status = 0
     return dict(x=x, cost=cost, nfev=nfev, njev=njev, status=status, lsmr_iters=lsmr_iters, optimality=g_norm, lsmr_fallbacks=lsmr_fallbacks)

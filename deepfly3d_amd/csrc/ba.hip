@@ -906,3 +906,231 @@ int df3d_ba_lsmr(const df3d_ba_problem* p, const double* Jc, const double* Jp, c
 }
 
 }  // extern "C"
+
+// ---- round 6: the trust-region driver's scalars stay on the device ------------------------------------------------------------------
+// One outer iteration of bundle_adjust.py:solve_trf used to read back seven groups of scalars (|g|_inf; the Cauchy model's two dots; the
+// LSMR state; r01; |s1|; the 2x2 model's five dots; the trial step's six): each a stream synchronisation with the device idle behind it.
+// df3d_ba_trf_subspace enqueues everything between "g is known" and "the 2-D model is known" -- the damping, the LSMR solve that reads it
+// from device memory, the QR of [g_h, gn_h], J_h S and the model's dots -- and reads ONE block back; df3d_ba_trf_trial is a trial step with
+// its one read-back; df3d_ba_trf_linearize the re-linearisation (no read-back).  The arithmetic is the Python driver's, operation for
+// operation (same kernels for every vector operation and reduction; the scalar expressions below are written without contraction), so
+// the iterate sequence -- nfev, LSMR counts, every bit of x -- is unchanged (tests/test_gpu_ba.py compares the two drivers).
+namespace {
+enum { TR_GNORM = 0, TR_JG2, TR_GH2, TR_DAMP, TR_CS0, TR_R01, TR_MR01, TR_N1SQ, TR_CS1, TR_B00, TR_B01, TR_B11, TR_GS0, TR_GS1, TR_ONE, TR_SLOTS };
+constexpr int TR_OFFSET = 8 * RED_BLOCKS + 16;   // the block's place in scratch_dev (behind the dots' partials and results)
+static_assert(TR_OFFSET + TR_SLOTS <= DF3D_BA_SCRATCH_DOUBLES, "scratch");
+
+// out = (*ca) x + (*cb) y (y / cb may be null): axpby_kernel with its coefficients in device memory
+__global__ __launch_bounds__(256) void axpby_dev_kernel(const double* __restrict__ ca, const double* x, const double* __restrict__ cb, const double* y, double* out, size_t n) {
+    const double a = *ca, b = y ? *cb : 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double v = a * x[i];
+        if (y) v += b * y[i];
+        out[i] = v;
+    }
+}
+// WHICH 0: the Tikhonov term of the 1-D Cauchy model along -g_h (solve_trf: `damp`) and the scale of s0;  1: -r01;  2: the scale of s1
+template <int WHICH>
+__global__ void trf_scalar_kernel(double* __restrict__ tr, double Delta) {
+#pragma clang fp contract(off)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (WHICH == 0) {
+        const double jg2 = tr[TR_JG2], gh2 = tr[TR_GH2];
+        const double a = 0.5 * jg2, b = -gh2;
+        const double n0 = sqrt(gh2);
+        const double to_tr = Delta / n0;
+        double ag = fmin(0.0 * (a * 0.0 + b), to_tr * (a * to_tr + b));
+        if (a != 0) {
+            const double ext = -0.5 * b / a;
+            if (0 < ext && ext < to_tr) ag = fmin(ag, ext * (a * ext + b));
+        }
+        const double reg = -ag / (Delta * Delta);
+        tr[TR_DAMP] = n0 > 0 ? sqrt(reg) : 0.0;   // (g == 0: the caller stops on |g|_inf before it looks at anything else)
+        tr[TR_CS0] = n0 > 0 ? -1.0 / n0 : 0.0;
+        tr[TR_ONE] = 1.0;
+    } else if (WHICH == 1) {
+        tr[TR_MR01] = -tr[TR_R01];
+    } else {
+        tr[TR_CS1] = -1.0 / sqrt(tr[TR_N1SQ]);
+    }
+}
+
+int enqueue_dots(int count, const double* const* a, const double* const* b, const size_t* n, double* scratch, double* result, hipStream_t s) {
+    DotBatch q{};
+    int gmax = 1;
+    for (int j = 0; j < count; ++j) {
+        q.a[j] = a[j];
+        q.b[j] = b[j];
+        q.n[j] = n[j];
+        q.g[j] = grid_for(n[j]);
+        gmax = q.g[j] > gmax ? q.g[j] : gmax;
+    }
+    hipLaunchKernelGGL(dots_kernel, dim3(gmax, count), dim3(256), 0, s, q, scratch);
+    hipLaunchKernelGGL(dots_final_kernel, dim3(count), dim3(256), 0, s, q, scratch, result);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+int resolve_form(int form_arg) {   // df3d_ba_lsmr_form's rule: lsmr_run's numbering
+    int want = form_arg;
+    if (want == DF3D_LSMR_AUTO) {
+        const char* e = getenv("DF3D_LSMR_KERNELS");
+        const int k = e ? atoi(e) : 0;
+        want = k == 11 ? DF3D_LSMR_ELEVEN : k == 2 ? DF3D_LSMR_LAUNCHES : k == 1 ? DF3D_LSMR_BARRIERS : DF3D_LSMR_LOCAL;
+    }
+    return want == DF3D_LSMR_ELEVEN ? 11 : want == DF3D_LSMR_LAUNCHES ? 2 : want == DF3D_LSMR_BARRIERS ? 0 : 3;
+}
+}  // namespace
+
+extern "C" {
+
+int df3d_ba_trf_subspace(const df3d_ba_problem* p, const double* Jc, const double* Jp, const double* scale_dev, const double* g_dev, const double* f_dev,
+                         double Delta, double* g_h, double* gn_h, double* s0, double* s1, double* Js0, double* Js1, double* tmp_m, double* work_dev,
+                         double* scratch_dev, double* out_host, void* stream, int form_arg) {
+    if (int rc = check_problem(p)) return rc;
+    DF3D_CHECK_ARG(Jc && Jp && scale_dev && g_dev && f_dev && g_h && gn_h && s0 && s1 && Js0 && Js1 && tmp_m && work_dev && scratch_dev && out_host, "null pointer");
+    DF3D_CHECK_ARG(form_arg == DF3D_LSMR_AUTO || form_arg == DF3D_LSMR_BARRIERS || form_arg == DF3D_LSMR_LAUNCHES || form_arg == DF3D_LSMR_LOCAL ||
+                       form_arg == DF3D_LSMR_ELEVEN, "unknown LSMR form");
+    DF3D_CHECK_ARG(Delta > 0, "the trust radius must be positive");
+    hipStream_t s = df3d::as_stream(stream);
+    const size_t m = 2 * (size_t)p->nobs, n = 6 * (size_t)p->ncam + 3 * (size_t)p->npts;
+    double* const tr = scratch_dev + TR_OFFSET;
+    const int gn = grid_for(n);
+    // |g|_inf; g_h = D g; the Cauchy model's two dots; the damping
+    hipLaunchKernelGGL(absmax_kernel, dim3(gn), dim3(256), 0, s, g_dev, n, scratch_dev);
+    hipLaunchKernelGGL(absmax_kernel, dim3(1), dim3(256), 0, s, scratch_dev, (size_t)gn, tr + TR_GNORM);
+    hipLaunchKernelGGL(mul_kernel, dim3(gn), dim3(256), 0, s, scale_dev, g_dev, g_h, n);
+    if (int rc = launch_matvec(p, Jc, Jp, scale_dev, g_h, tmp_m, s)) return rc;
+    {
+        const double* a[2] = {tmp_m, g_h};
+        const size_t len[2] = {m, n};
+        if (int rc = enqueue_dots(2, a, a, len, scratch_dev, tr + TR_JG2, s)) return rc;
+    }
+    hipLaunchKernelGGL(trf_scalar_kernel<0>, dim3(1), dim3(64), 0, s, tr, Delta);
+    DF3D_LAUNCH_CHECK();
+
+    double info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int maxiter = (int)(m < n ? m : n);
+    const double atol = 1e-6, btol = 1e-6, conlim = 1e8;   // solve_trf's (scipy's tr_options defaults for lsmr inside least_squares)
+    int form = resolve_form(form_arg);
+    bool local = form == 3 && df3d_lsmr::local_fits(*p);
+    double* const lscratch = work_dev + (2 * m + 4 * n + DF3D_BA_SCRATCH_DOUBLES + 64 + 2 * df3d_lsmr::FUSED_DOUBLES + 3 * df3d_lsmr::FUSED_RED + 8);
+    double* const lstate = lscratch + (df3d_lsmr::local_scratch_bytes() + 7) / 8;
+    auto lsmr_on_host_damp = [&](int f) -> int {   // the forms whose set-up runs on the host: one more read-back for the damping
+        double damp = 0.0;
+        if (int rc = read_back(tr + TR_DAMP, &damp, s)) return rc;
+        int rc = lsmr_run(p, Jc, Jp, scale_dev, f_dev, damp, atol, btol, conlim, maxiter, gn_h, work_dev, info, stream, f);
+        if (rc == DF3D_OK && f == 0 && info[0] < 0) {
+            rc = lsmr_run(p, Jc, Jp, scale_dev, f_dev, damp, atol, btol, conlim, maxiter, gn_h, work_dev, info, stream, 2);
+            if (rc == DF3D_OK) info[7] = 1;
+        }
+        return rc;
+    };
+    if (local) {
+        if (df3d_lsmr::launch_local(*p, Jc, Jp, scale_dev, f_dev, gn_h, 0.0, atol, btol, 1.0 / conlim, maxiter, lscratch, lstate, s, tr + TR_DAMP) < 0) local = false;
+        DF3D_LAUNCH_CHECK();
+    }
+    if (!local) {
+        if (int rc = lsmr_on_host_damp(form == 3 ? 2 : form)) return rc;
+        if (form == 3) info[7] = 2;
+    }
+    // S = qr([g_h, gn_h]) with LAPACK's signs, J_h S, the 2x2 model
+    auto subspace = [&]() -> int {
+        hipLaunchKernelGGL(axpby_dev_kernel, dim3(gn), dim3(256), 0, s, tr + TR_CS0, g_h, nullptr, nullptr, s0, n);
+        {
+            const double* a[1] = {s0};
+            const double* b[1] = {gn_h};
+            const size_t len[1] = {n};
+            if (int rc = enqueue_dots(1, a, b, len, scratch_dev, tr + TR_R01, s)) return rc;
+        }
+        hipLaunchKernelGGL(trf_scalar_kernel<1>, dim3(1), dim3(64), 0, s, tr, Delta);
+        hipLaunchKernelGGL(axpby_dev_kernel, dim3(gn), dim3(256), 0, s, tr + TR_ONE, gn_h, tr + TR_MR01, s0, s1, n);
+        {
+            const double* a[1] = {s1};
+            const size_t len[1] = {n};
+            if (int rc = enqueue_dots(1, a, a, len, scratch_dev, tr + TR_N1SQ, s)) return rc;
+        }
+        hipLaunchKernelGGL(trf_scalar_kernel<2>, dim3(1), dim3(64), 0, s, tr, Delta);
+        hipLaunchKernelGGL(axpby_dev_kernel, dim3(gn), dim3(256), 0, s, tr + TR_CS1, s1, nullptr, nullptr, s1, n);
+        if (int rc = launch_matvec(p, Jc, Jp, scale_dev, s0, Js0, s)) return rc;
+        if (int rc = launch_matvec(p, Jc, Jp, scale_dev, s1, Js1, s)) return rc;
+        const double* a[5] = {Js0, Js0, Js1, s0, s1};
+        const double* b[5] = {Js0, Js1, Js1, g_h, g_h};
+        const size_t len[5] = {m, m, m, n, n};
+        return enqueue_dots(5, a, b, len, scratch_dev, tr + TR_B00, s);
+    };
+    if (int rc = subspace()) return rc;
+    double host[TR_SLOTS];
+    df3d_lsmr::State now{};
+    DF3D_HIP(hipMemcpyAsync(host, tr, sizeof(host), hipMemcpyDeviceToHost, s));
+    if (local) DF3D_HIP(hipMemcpyAsync(&now, lstate, sizeof(now), hipMemcpyDeviceToHost, s));
+    DF3D_HIP(hipStreamSynchronize(s));
+    if (local) {
+        if (now.istop < 0) {
+            // the layout check on the device refused the problem, or the persistent kernel timed out waiting for its peers: the solve is
+            // repeated from its inputs in the two-kernel form (df3d_ba_lsmr_form's rule), and what was built on its result with it
+            const bool timeout = now.istop == -1;
+            if (int rc = lsmr_on_host_damp(2)) return rc;
+            info[7] = timeout ? 1 : 2;
+            if (int rc = subspace()) return rc;
+            DF3D_HIP(hipMemcpyAsync(host, tr, sizeof(host), hipMemcpyDeviceToHost, s));
+            DF3D_HIP(hipStreamSynchronize(s));
+        } else {
+            info[0] = now.istop;
+            info[1] = now.itn;
+            info[2] = now.normr;
+            info[3] = now.normar;
+            info[4] = now.normA;
+            info[5] = now.condA;
+            info[6] = now.normx;
+            info[7] = 0;
+        }
+    }
+    out_host[0] = host[TR_GNORM];
+    out_host[1] = host[TR_JG2];
+    out_host[2] = host[TR_GH2];
+    out_host[3] = host[TR_DAMP];
+    out_host[4] = host[TR_R01];
+    out_host[5] = host[TR_N1SQ];
+    for (int k = 0; k < 5; ++k) out_host[6 + k] = host[TR_B00 + k];
+    for (int k = 0; k < 8; ++k) out_host[11 + k] = info[k];
+    return DF3D_OK;
+}
+
+int df3d_ba_trf_trial(const df3d_ba_problem* p, double p0, double p1, const double* s0, const double* s1, const double* Js0, const double* Js1,
+                      const double* scale_dev, const double* x_dev, const double* g_h, double* step_h, double* tmp_m, double* step, double* x_new,
+                      double* f_new, double* scratch_dev, double* out_host, void* stream) {
+    if (int rc = check_problem(p)) return rc;
+    DF3D_CHECK_ARG(s0 && s1 && Js0 && Js1 && scale_dev && x_dev && g_h && step_h && tmp_m && step && x_new && f_new && scratch_dev && out_host, "null pointer");
+    hipStream_t s = df3d::as_stream(stream);
+    const size_t m = 2 * (size_t)p->nobs, n = 6 * (size_t)p->ncam + 3 * (size_t)p->npts;
+    const int gm = grid_for(m), gn = grid_for(n);
+    hipLaunchKernelGGL(axpby_kernel<false>, dim3(gn), dim3(256), 0, s, p0, s0, p1, s1, step_h, n, nullptr);
+    hipLaunchKernelGGL(axpby_kernel<false>, dim3(gm), dim3(256), 0, s, p0, Js0, p1, Js1, tmp_m, m, nullptr);   // J_h step = p0 J_h s0 + p1 J_h s1
+    hipLaunchKernelGGL(mul_kernel, dim3(gn), dim3(256), 0, s, scale_dev, step_h, step, n);
+    hipLaunchKernelGGL(axpby_kernel<false>, dim3(gn), dim3(256), 0, s, 1.0, x_dev, 1.0, step, x_new, n, nullptr);
+    hipLaunchKernelGGL(ba_eval_kernel, dim3((p->nobs + 255) / 256), dim3(256), 0, s, *p, x_new, f_new, nullptr, nullptr);
+    const double* a[6] = {tmp_m, step_h, step_h, f_new, step, x_dev};
+    const double* b[6] = {tmp_m, g_h, step_h, f_new, step, x_dev};
+    const size_t len[6] = {m, n, n, m, n, n};
+    double* const result = scratch_dev + 8 * RED_BLOCKS;
+    if (int rc = enqueue_dots(6, a, b, len, scratch_dev, result, s)) return rc;
+    DF3D_HIP(hipMemcpyAsync(out_host, result, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    DF3D_HIP(hipStreamSynchronize(s));
+    return DF3D_OK;
+}
+
+int df3d_ba_trf_linearize(const df3d_ba_problem* p, const double* x_dev, double* f_dev, int eval_f, double* Jc, double* Jp, double* g_dev, double* colsq_dev,
+                          double* scale_inv_dev, double* scale_dev, int first, double* scratch_dev, void* stream) {
+    if (int rc = check_problem(p)) return rc;
+    DF3D_CHECK_ARG(x_dev && f_dev && Jc && Jp && g_dev && colsq_dev && scale_inv_dev && scale_dev && scratch_dev, "null pointer");
+    hipStream_t s = df3d::as_stream(stream);
+    const size_t n = 6 * (size_t)p->ncam + 3 * (size_t)p->npts;
+    hipLaunchKernelGGL(ba_eval_kernel, dim3((p->nobs + 255) / 256), dim3(256), 0, s, *p, x_dev, eval_f ? f_dev : nullptr, Jc, Jp);
+    if (int rc = launch_rmatvec(p, Jc, Jp, nullptr, f_dev, g_dev, scratch_dev, s)) return rc;   // g = J^T f
+    if (int rc = df3d_ba_colsq(p, Jc, Jp, colsq_dev, scratch_dev, stream)) return rc;
+    hipLaunchKernelGGL(update_scale_kernel, dim3(grid_for(n)), dim3(256), 0, s, colsq_dev, scale_inv_dev, scale_dev, n, first);
+    DF3D_LAUNCH_CHECK();
+    return DF3D_OK;
+}
+
+}  // extern "C"

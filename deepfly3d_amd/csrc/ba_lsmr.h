@@ -81,7 +81,9 @@ int local_workgroups_for(int nobs);
 int local_max_workgroups();
 size_t local_scratch_bytes();
 int launch_local(const df3d_ba_problem& p, const double* Jc, const double* Jp, const double* d, const double* b, double* x, double damp, double atol,
-                 double btol, double ctol, int maxiter, void* scratch, double* state_out, hipStream_t s);
+                 double btol, double ctol, int maxiter, void* scratch, double* state_out, hipStream_t s, const double* damp_dev = nullptr);
+// whether launch_local can take the problem at all (the layout itself is checked on the device: istop -2)
+bool local_fits(const df3d_ba_problem& p);
 
 // step A: beta = |u| from `count` partials;  step B: alpha = |v| and the rotations;  step C: |x| and the stopping tests.
 // One workgroup each; no-ops once st->istop != 0.

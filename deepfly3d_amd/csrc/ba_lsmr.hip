@@ -713,6 +713,7 @@ struct LocalArgs {
     unsigned long long *gr1, *gr2;     // granules of the two all-reduces: G x 4, G x 2 (1 + 6 ncam); zeroed in front of the launch
     double* state_out;                 // the final State (workgroup 0)
     double damp, atol, btol, ctol;
+    const double* damp_dev;            // when not null: the damping is read HERE (a scalar an earlier kernel of the stream left on the device)
     int maxiter;
     double* dbg;                       // development (DF3D_LSMR_DEBUG=1): per all-reduce call [call][workgroup][own 49 | res 49], or nullptr
 };
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(LT, 2) void lsmr_local_kernel(df3d_ba_problem p, Lo
 #pragma unroll
     for (int e = 0; e < 3; ++e) h[e] = v[e];
     if (tid < 48) L.hcam[tid] = L.vcam[tid];
-    if (tid == 0) local_init_state(&L.S, alpha, beta, normb, a.damp, a.atol, a.btol, a.ctol, a.maxiter);
+    if (tid == 0) local_init_state(&L.S, alpha, beta, normb, a.damp_dev ? *a.damp_dev : a.damp, a.atol, a.btol, a.ctol, a.maxiter);
     __syncthreads();
     const bool trivial = L.S.normar == 0 || L.S.normb == 0;
 
@@ -1057,9 +1058,11 @@ int local_max_workgroups() { return LMAXG; }
 int local_workgroups_for(int nobs) { return (nobs + (LOBS - 8) - 1) / (LOBS - 8); }   // a range holds at least LOBS - 7 observations (a point has <= 8)
 size_t local_scratch_bytes() { return (size_t)(LMAXG + 1) * sizeof(int) + 64 + 2 * (LAR1_STRIDE + LAR2_STRIDE) * sizeof(unsigned long long); }
 
+bool local_fits(const df3d_ba_problem& p) { return local_workgroups_for(p.nobs) <= LMAXG && 1 + 6 * p.ncam <= 49; }
+
 // the whole run in one launch; `scratch`: local_scratch_bytes() bytes of device memory (zeroed here); state_out: >= sizeof(State)
 int launch_local(const df3d_ba_problem& p, const double* Jc, const double* Jp, const double* d, const double* b, double* x, double damp, double atol,
-                 double btol, double ctol, int maxiter, void* scratch, double* state_out, hipStream_t s) {
+                 double btol, double ctol, int maxiter, void* scratch, double* state_out, hipStream_t s, const double* damp_dev) {
     const int G = local_workgroups_for(p.nobs);
     if (G > LMAXG || 1 + 6 * p.ncam > 49) return -1;
     if (hipMemsetAsync(scratch, 0, local_scratch_bytes(), s) != hipSuccess) return -2;
@@ -1071,7 +1074,7 @@ int launch_local(const df3d_ba_problem& p, const double* Jc, const double* Jp, c
     static const bool want_dbg = getenv("DF3D_LSMR_DEBUG") != nullptr;
     if (want_dbg && !dbg && hipMalloc(&dbg, ((size_t)LDBG_CALLS * LMAXG * 98 + 16) * sizeof(double)) != hipSuccess) return -4;
     if (want_dbg) (void)hipMemsetAsync(dbg, 0, (size_t)LDBG_CALLS * LMAXG * 98 * sizeof(double), s);
-    LocalArgs a{Jc, Jp, d, b, x, wg_obs, gr1, gr2, state_out, damp, atol, btol, ctol, maxiter, want_dbg ? dbg : nullptr};
+    LocalArgs a{Jc, Jp, d, b, x, wg_obs, gr1, gr2, state_out, damp, atol, btol, ctol, damp_dev, maxiter, want_dbg ? dbg : nullptr};
     {   // the attribute is per DEVICE (a process may drive several GPUs) and the guard must be thread-safe: one bit per device ordinal
         static std::atomic<unsigned long long> attr_set{0};
         int dev = 0;

@@ -1072,7 +1072,7 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                     if (split && std::is_same<T, float>::value && r.w2d) {   // option `wino`: the tail with its 3x3 in the Winograd domain
                         const int blocks = n * (ti.h / BT_TH) * (ti.w / BT_TW);
                         // FLOPs: the direct form's (what the block computes, in the reference's terms); the kernel EXECUTES 16/36 of the 3x3's
-                        ScopedTimer tm(h, s, std::string("bottleneck_wino_f32_kernel<") + (a.in2 ? "true, false>" : a.add2 ? "false, true>" : "false, false>"),
+                        ScopedTimer tm(h, s, std::string("bottleneck_wino_f32_kernel<") + (a.in2 ? "true, false, false>" : a.add2 ? "false, true, false>" : "false, false, false>"),
                                        2.0 * px * (9.0 * pl * pl + 2.0 * pl * pl), px * eb * (cin + 2.0 * pl + pl), st.m1_elems * n * eb, 2.0 * px * (4.0 * pl * pl + 2.0 * pl * pl));
                         const int rc = a.in2 ? launch_wino_f32<true, false>(r, blocks, s) : a.add2 ? launch_wino_f32<false, true>(r, blocks, s) : launch_wino_f32<false, false>(r, blocks, s);
                         if (rc) return rc;

@@ -44,9 +44,9 @@ extern "C" {
 const char* df3d_last_error(void);
 /* ABI revision of the library: DF3D_ABI_VERSION of the header it was built from.  It changes whenever an entry point's signature or
  * a struct layout does (round 3 inserted `resize` into df3d_preprocess_u8 / df3d_hg_forward_u8 and `bytes_m1` into
- * df3d_hg_profile_read: 300; round 4: 400; round 5 added df3d_ba_lsmr_form and grew df3d_ba_lsmr_work_doubles: 500; round 6 added df3d_hg_profile_executed_flops and df3d_heatmap_argmax_checked: 600); a caller compares it with the header it compiled against before its first call
+ * df3d_hg_profile_read: 300; round 4: 400; round 5 added df3d_ba_lsmr_form and grew df3d_ba_lsmr_work_doubles: 500; round 6 added df3d_hg_profile_executed_flops and df3d_heatmap_argmax_checked: 600, and the df3d_ba_trf_* entries: 610); a caller compares it with the header it compiled against before its first call
  * (deepfly3d_amd/_native.py:load does). */
-#define DF3D_ABI_VERSION 600
+#define DF3D_ABI_VERSION 610
 int df3d_version(void);
 /* number of visible HIP devices (<0 on error); name of device `dev` copied to buf */
 int df3d_device_count(void);
@@ -269,6 +269,28 @@ int df3d_vec_pairnorm_sum(const double* r_dev, size_t npairs, double* result_hos
  * scale = 1 / scale_inv */
 int df3d_ba_update_scale(const double* colsq_dev, double* scale_inv_dev, double* scale_dev, size_t n, int first,
                          void* stream);
+
+/* The trust-region driver with its scalars on the device (round 6): what deepfly3d_amd/bundle_adjust.py:solve_trf does between two
+ * evaluations, as three calls with ONE stream synchronisation each instead of one per scalar group.  They replace the solver loop of
+ * scipy.optimize.least_squares(method='trf', tr_solver='lsmr', x_scale='jac') that pyba runs (reference call site df3d/core.py:249);
+ * the arithmetic is that of the separate calls above, operation for operation (same kernels, same fixed summation orders).
+ * All vectors are device float64: n = 6 ncam + 3 npts columns, m = 2 nobs rows; scratch_dev: DF3D_BA_SCRATCH_DOUBLES; work_dev:
+ * df3d_ba_lsmr_work_doubles(p).
+ * df3d_ba_trf_subspace: from (J, scale, g = J^T f, f, Delta): |g|_inf, g_h = scale g, the damping of the 1-D Cauchy model, the LSMR step
+ *   gn_h (damping read from device memory by the data-local form; the other forms take one more read-back), the orthonormal basis
+ *   S = [s0 s1] of span{g_h, gn_h} (LAPACK's QR signs), J_h S and the 2x2 model.  out_host[19]: |g|_inf, |J_h g_h|^2, |g_h|^2, damp, r01,
+ *   |s1|^2 (before normalisation), B_S[0][0], B_S[0][1], B_S[1][1], g_S[0], g_S[1], then df3d_ba_lsmr's info[8].
+ * df3d_ba_trf_trial: step_h = p0 s0 + p1 s1, x_new = x + scale step_h, f_new = residuals(x_new); out_host[6]: |J_h step_h|^2, step_h . g_h,
+ *   |step_h|^2, |f_new|^2, |step|^2, |x|^2.
+ * df3d_ba_trf_linearize: J (and f when eval_f != 0) at x, g = J^T f, x_scale='jac' bookkeeping (first != 0: the first call); no read-back. */
+int df3d_ba_trf_subspace(const df3d_ba_problem* p, const double* Jc_dev, const double* Jp_dev, const double* scale_dev, const double* g_dev,
+                         const double* f_dev, double Delta, double* g_h_dev, double* gn_h_dev, double* s0_dev, double* s1_dev, double* Js0_dev,
+                         double* Js1_dev, double* tmp_m_dev, double* work_dev, double* scratch_dev, double* out_host, void* stream, int form);
+int df3d_ba_trf_trial(const df3d_ba_problem* p, double p0, double p1, const double* s0_dev, const double* s1_dev, const double* Js0_dev,
+                      const double* Js1_dev, const double* scale_dev, const double* x_dev, const double* g_h_dev, double* step_h_dev,
+                      double* tmp_m_dev, double* step_dev, double* x_new_dev, double* f_new_dev, double* scratch_dev, double* out_host, void* stream);
+int df3d_ba_trf_linearize(const df3d_ba_problem* p, const double* x_dev, double* f_dev, int eval_f, double* Jc_dev, double* Jp_dev, double* g_dev,
+                          double* colsq_dev, double* scale_inv_dev, double* scale_dev, int first, double* scratch_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a2  stacked-hourglass forward.   Replaces the network forward inside df2d's inference_folder

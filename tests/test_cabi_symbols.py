@@ -43,7 +43,7 @@ def test_argument_validation_without_gpu(native_lib):
     """Entry points validate arguments before touching the device, so this runs on CPU."""
     from deepfly3d_amd import _native
 
-    assert native_lib.df3d_version() == _native.ABI_VERSION == 600   # DF3D_ABI_VERSION of include/df3d_hip.h
+    assert native_lib.df3d_version() == _native.ABI_VERSION == 610   # DF3D_ABI_VERSION of include/df3d_hip.h
     rc = native_lib.df3d_heatmap_argmax(None, 1, 19, 3, 5, None, None, None)  # 15 pixels: not a multiple of 4
     assert rc == -1 and b"multiple of 4" in native_lib.df3d_last_error()
     order = (ctypes.c_int * 7)(0, 1, 2, 3, 4, 5, 5)

@@ -258,3 +258,32 @@ def test_persistent_lsmr_on_the_1000_frame_window_equals_the_two_kernel_form(nat
     print("local vs two-kernel form: dR %.2e dt %.2e dcost/cost %.2e" % (np.abs(loc[0] - got[0][0]).max(), np.abs(loc[1] - got[0][1]).max(), abs(loc[2] - got[0][2]) / got[0][2]))
     assert np.abs(loc[0] - got[0][0]).max() < 5e-6 and np.abs(loc[1] - got[0][1]).max() < 5e-5 and abs(loc[2] - got[0][2]) < 1e-6 * got[0][2]
     assert np.array_equal(loc[0], again[0]) and np.array_equal(loc[1], again[1]) and loc[2:] == again[2:]
+
+
+@pytest.mark.parametrize("frames", [15, 1000])
+def test_device_scalar_driver_reproduces_the_host_scalar_driver(native_lib, cuda, golden_dir, sample, monkeypatch, frames):
+    """Round 6: solve_trf keeps an outer iteration's scalars on the device (df3d_ba_trf_subspace / _trial / _linearize: one read-back per outer
+    iteration and one per trial step; the LSMR damping is read from device memory) instead of reading seven groups of scalars back.  The
+    arithmetic is the same operation for operation, so the whole adjustment -- cameras, cost, evaluation and LSMR counts -- is the host-scalar
+    driver's BIT FOR BIT, with the data-local LSMR form (damping from the device), with the launch-based form (damping read back), and when the
+    data-local form refuses (forced here through a problem with single-view points)."""
+    from deepfly3d_amd.bundle_adjust import bundle_adjust
+    from deepfly3d_amd.synthetic import synthetic_points2d
+
+    c = np.load(f"{golden_dir}/calib.npz")
+    if frames == 15:
+        px = sample["px"]
+    else:
+        g3 = np.load(f"{golden_dir}/golden_3d.npz")
+        rng = np.random.default_rng(0)
+        X = np.tile(g3["points3d_wo_procrustes"], (67, 1, 1))[:1000] + rng.normal(0, 0.05, size=(1000, 38, 3))
+        px = og.pixels_from_normalised(synthetic_points2d(X, g3["R"], g3["tvec"], g3["intr"]), [960, 480])
+    for form in ("0", "2"):
+        monkeypatch.setenv("DF3D_LSMR_KERNELS", form)
+        got = []
+        for host in ("1", "0"):
+            monkeypatch.setenv("DF3D_TRF_HOST_SCALARS", host)
+            R, t, info = bundle_adjust(px, c["R"], c["tvec"], c["intr"], device=cuda, return_info=True)
+            got.append((R, t, info["cost"], info["nfev"], info["njev"], info["status"], info["lsmr_iters"], info["optimality"]))
+        assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]), (form, np.abs(got[0][0] - got[1][0]).max())
+        assert got[0][2:] == got[1][2:], (form, got[0][2:], got[1][2:])
