@@ -28,7 +28,7 @@
 #include "hg_bt_ring_f32.h"
 
 #ifndef WN_ABL
-#define WN_ABL 0   // development builds (scripts/build_variant.sh): ablation mask of phase 2 -- 1 no U loads, 2 no input transform, 4 no chunk barrier, 8 no V fragment reads
+#define WN_ABL 0   // development builds (scripts/build_variant.sh): ablation mask -- phase 2: 1 no U loads, 2 no input transform, 4 no chunk barrier, 8 no V fragment reads; the rest of a tile: 16 no output transform, 32 no halo DMA for the next tile, 64 no residual / operand loads, 128 no output stores, 256 no phase-3 MFMAs
 #endif
 
 namespace hgk {
@@ -115,6 +115,11 @@ __device__ __forceinline__ void wn_uload4(f32x4 (&d)[4], const void* sbase, unsi
 template <int N>
 __device__ __forceinline__ void wn_uwait(f32x4 (&u)[4]) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : "n"(N) : "memory");
+}
+// one 16-byte load, scalar base + lane offset, issued where it stands (the residual tiles: hipcc sinks compiler-visible loads to their first use --
+// the epilogue -- and the wave then sits out an HBM round trip with nothing else to do; measured 4.7 % of the kernel)
+__device__ __forceinline__ void wn_xload1(f32x4& d, const void* sbase, unsigned voff) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
 // The input transform of one (patch, channel): V' = B'^T d B' as SIXTEEN packed adds in one statement (one VALU clump per chunk).
 // In: P[b] = (d[0][b], d[1][b]), Q[b] = (d[2][b], d[3][b]) -- the register pairs the two ds_read2st64_b32 of patch column b deliver.
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         // ---- output transform Y = A^T M A, ReLU, t2 -> LDS (pixel-major, 16-byte chunk ch of pixel (y, x) in slot ch ^ (x & 15) ^ ((y >> 1) & 1)
         //      of its 512-byte row: conflict-free for these writes (16 lanes = 8 patch columns x 2 patch rows) and for phase 3's reads).
         //      Address = [pixel (2 ty, 2 tx) | lane part of the slot] ^ [(2 q ^ bb) << 4] + (16 a + bb) * 512: one lane base, XOR constants ----
-        {
+        if (!(WN_ABL & 16)) {
             const int ty = l31_3 >> 3, tx = l31_3 & 7;
             const unsigned wbase = (unsigned)((32 * ty + 2 * tx) * 512 + ((((8 * wave + half3) ^ (2 * tx) ^ (ty & 1)) & 31) << 4));
 #pragma unroll
@@ -443,29 +448,43 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         }
 
         br_barrier();   // every wave holds its t2 in registers: the t1 region may take the next tile's halo
-        if (has_next) t1_issue(ntx0, nty0, nview);
+        if (has_next && !(WN_ABL & 32)) t1_issue(ntx0, nty0, nview);
         // ---- residual values (and the ADD2 addends) of the whole tile, requested here -- behind the ring's first half (no ring wait has to let them pass), 16 000 MFMA cycles
         //      in front of their first use (one wave per SIMD: nobody hides a load issued in an epilogue; the 512-register file has room) ----
-        f32x4 xres[L2 ? 1 : 2][16];   // [output half][register r <-> pixel (r & 3) + 8 (r >> 2) + 4 half]: channels 128 nh + 4 l31 .. + 3
-                                      // L2: [0][2 k8 + jj] = the skip convolution's A operand, x[this lane's pixel][16 k8 + 8 jj + 4 half ..]
+        f32x4 xres[1][16];   // !L2: the CURRENT output half's residual values, [register r <-> pixel (r & 3) + 8 (r >> 2) + 4 half]: channels 128 nh + 4 l31 .. + 3
+                             // L2: [0][2 k8 + jj] = the skip convolution's A operand, x[this lane's pixel][16 k8 + 8 jj + 4 half ..]
+        f32x4 exv[4];        // ADD2: the addends / UP: the half-resolution values of the current half's four pixel quads
+        static_assert(!(UP && ADD2), "one extra operand");
+        // (inline assembly: scalar base + lane offset, issued HERE -- half 0 now, 16 000 MFMA cycles in front of its epilogue; half 1 behind the
+        // first epilogue, into the same registers)
+        auto res_issue = [&](int nh) {
 #pragma unroll
-        for (int nh = 0; nh < (L2 ? 1 : 2); ++nh)
+            for (int g = 0; g < 4; ++g) {   // registers 4 g .. 4 g + 3: pixels 8 g .. 8 g + 3 (+ 4 half) = row g >> 1, columns 8 (g & 1) ..
+                if (WN_ABL & 64) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if constexpr (L2) {
-                    xres[0][r] = *reinterpret_cast<const f32x4*>(xtile + (8 * r) * 4 + (unsigned)((((l31_3 >> 4) * p.W + (l31_3 & 15)) * CIN + 4 * half3) * 4));
+                    for (int j = 0; j < 4; ++j) xres[0][4 * g + j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 } else {
-                    const int pl0 = (r & 3) + 8 * (r >> 2);   // + 4 half: the lane's part
-                    xres[nh][r] = *reinterpret_cast<const f32x4*>(xtile + ((size_t)(pl0 >> 4) * p.W + (pl0 & 15)) * (CIN * 4) + nh * 512 + lane_full);
+                    wn_uload4(*reinterpret_cast<f32x4(*)[4]>(&xres[0][4 * g]), xtile + ((size_t)(g >> 1) * p.W + 8 * (g & 1)) * (CIN * 4) + nh * 512, lane_full);
                 }
             }
-        f32x4 a2v[ADD2 ? 2 : 1][4];
-        if constexpr (ADD2) {
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh)
+            if constexpr (ADD2 || UP) {
 #pragma unroll
                 for (int key = 0; key < 4; ++key)
-                    a2v[nh][key] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.add2) + htile + ((key & 1) + 4 * (key >> 1)) * (CO * 4) + nh * 512 + lane_half);
+                    wn_xload1(exv[key], reinterpret_cast<const unsigned char*>(ADD2 ? p.add2 : p.in2) + htile + ((key & 1) + 4 * (key >> 1)) * (CO * 4) + nh * 512, lane_half);
+            }
+        };
+        auto res_wait = [&](auto n_tag) {   // the counted wait that makes them valid, naming the registers (the epilogue's reads depend on it)
+            constexpr int N = decltype(n_tag)::value;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wn_uwait<N>(*reinterpret_cast<f32x4(*)[4]>(&xres[0][4 * g]));
+            if constexpr (ADD2 || UP) wn_uwait<N>(exv);
+        };
+        if constexpr (L2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                xres[0][r] = *reinterpret_cast<const f32x4*>(xtile + (8 * r) * 4 + (unsigned)((((l31_3 >> 4) * p.W + (l31_3 & 15)) * CIN + 4 * half3) * 4));
+        } else {
+            res_issue(0);
         }
         BR_STAMP(4);
         // ---- phase 3: out = W3 relu(t2) + b3 + x  (bottleneck_ring_f32_kernel's exact-fp32 form: rows = the wave's pixels, columns = channels);
@@ -476,7 +495,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
             if (nh == 1) {
                 // the second half's stages were requested behind the first half's K loop(s); younger than them are only the first half's epilogue's
                 // operations -- at least its 16 output stores -- which need not have drained (operations retire in issue order)
-                br_wait_vm(16);
+                // (!L2: and the second half's residual loads: 16 + 4 with an extra operand)
+                br_wait_vm(L2 ? 16 : (ADD2 || UP) ? 36 : 32);
                 br_barrier();
             }
 #pragma unroll
@@ -497,6 +517,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + ring_slot(k8) + i * 2048);
+                            if (WN_ABL & 256) {
+                                o[i][0] += wf[0];
+                                continue;
+                            }
                             if constexpr (SKIP) {
                                 const f32x4 xa = xres[0][2 * k8 + jj];
                                 mfma_quad<T>(xa[0], xa[1], xa[2], xa[3], wf, o[i]);
@@ -519,6 +543,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                 ring_issue8(1);   // ... the second half's land under the epilogue
             }
             BR_STAMP(5 + 2 * nh);
+            if constexpr (!L2) {
+                if (!(WN_ABL & 64)) {
+                    if (nh == 0) res_wait(std::integral_constant<int, 16>{});   // younger: the sixteen stage pieces just requested
+                    else res_wait(std::integral_constant<int, 0>{});
+                }
+            }
             // epilogue: D[row = pixel (r&3) + 8(r>>2) + 4 half of the wave][col = channel nh*128 + 4 l31 + i]: register r of the four tiles = four
             // consecutive channels of one pixel
             // -- walked by 2x2 pixel quads (registers r0, r0 + 1, r0 + 8, r0 + 9: horizontal neighbour r ^ 1, vertical r ^ 8; one half-resolution pixel),
@@ -529,20 +559,20 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                 const int hoff = ((key & 1) + 4 * (key >> 1)) * (CO * 4) + nh * 512;   // the quad's half-resolution pixel (+ 2 half in the lane offset)
                 f32x4 xv[4], ov[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xv[t] = L2 ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : xres[L2 ? 0 : nh][r0 + (t & 1) + 8 * (t >> 1)];
+                for (int t = 0; t < 4; ++t) xv[t] = L2 ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : xres[0][r0 + (t & 1) + 8 * (t >> 1)];
                 if constexpr (UP) {
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.in2) + htile + hoff + lane_half);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) xv[t] += t4;
+                    for (int t = 0; t < 4; ++t) xv[t] += exv[key];
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int r = r0 + (t & 1) + 8 * (t >> 1);
                     ov[t] = f32x4{o[0][r], o[1][r], o[2][r], o[3][r]};
                     if constexpr (!L2) ov[t] += xv[t];
-                    if constexpr (ADD2) ov[t] += a2v[nh][key];   // a second fp32 add, as upadd_kernel would have done on the stored tensor
+                    if constexpr (ADD2) ov[t] += exv[key];   // a second fp32 add, as upadd_kernel would have done on the stored tensor
                     const int pl0 = (r & 3) + 8 * (r >> 2);
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.out) + ftile + ((size_t)(pl0 >> 4) * p.W + (pl0 & 15)) * (CO * 4) + nh * 512 + lane_full) = ov[t];
+                    if (!(WN_ABL & 128) || ov[t][0] == 12345.678f)
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.out) + ftile + ((size_t)(pl0 >> 4) * p.W + (pl0 & 15)) * (CO * 4) + nh * 512 + lane_full) = ov[t];
                 }
                 auto max4 = [](const f32x4 (&v)[4]) {
                     f32x4 m;
@@ -555,6 +585,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                 if (p.pool) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.pool) + htile + hoff + lane_half) = max4(ov);
             }
             BR_STAMP(6 + 2 * nh);
+            if constexpr (!L2) {
+                if (nh == 0) res_issue(1);
+            }
         }
         if (!has_next) break;
         vb = vbn;
