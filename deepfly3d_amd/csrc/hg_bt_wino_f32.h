@@ -121,6 +121,15 @@ __device__ __forceinline__ void wn_uwait(f32x4 (&u)[4]) {
 __device__ __forceinline__ void wn_xload1(f32x4& d, const void* sbase, unsigned voff) {
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
+// four 16-byte loads STEP bytes apart (scalar base + lane offset), issued where they stand
+template <int STEP>
+__device__ __forceinline__ void wn_xload4s(f32x4 (&d)[4], const void* sbase, unsigned voff) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:%6\n\t"
+                 "global_load_dwordx4 %2, %4, %5 offset:%7\n\tglobal_load_dwordx4 %3, %4, %5 offset:%8"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                 : "v"(voff), "s"(sbase), "n"(STEP), "n"(2 * STEP), "n"(3 * STEP)
+                 : "memory");
+}
 // The input transform of one (patch, channel): V' = B'^T d B' as SIXTEEN packed adds in one statement (one VALU clump per chunk).
 // In: P[b] = (d[0][b], d[1][b]), Q[b] = (d[2][b], d[3][b]) -- the register pairs the two ds_read2st64_b32 of patch column b deliver.
 // Rows first: per column b,  T[b] = (d0 - d2, d1 + d2),  S[b] = (d1 - d2, d1 - d3)   [row 2 with the opposite sign: see bt_wino_pack_kernel];
@@ -401,7 +410,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         // ---- output transform Y = A^T M A, ReLU, t2 -> LDS (pixel-major, 16-byte chunk ch of pixel (y, x) in slot ch ^ (x & 15) ^ ((y >> 1) & 1)
         //      of its 512-byte row: conflict-free for these writes (16 lanes = 8 patch columns x 2 patch rows) and for phase 3's reads).
         //      Address = [pixel (2 ty, 2 tx) | lane part of the slot] ^ [(2 q ^ bb) << 4] + (16 a + bb) * 512: one lane base, XOR constants ----
-        if (!(WN_ABL & 16)) {
+        if (WN_ABL & 16) {   // (timing only: one value that depends on every accumulator tile, so that phase 2 stays)
+            float keep = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) keep += acc[k][0];
+            *reinterpret_cast<float*>(t1_lds + lane3 * 4) = keep;
+        } else {
             const int ty = l31_3 >> 3, tx = l31_3 & 7;
             const unsigned wbase = (unsigned)((32 * ty + 2 * tx) * 512 + ((((8 * wave + half3) ^ (2 * tx) ^ (ty & 1)) & 31) << 4));
 #pragma unroll

@@ -305,13 +305,17 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
         br_barrier();   // every wave holds its t2: the t1 region may take the next tile's halo
         if (has_next) t1_issue(ntx0, nty0, nview);
         // the skip convolution's A operand: x of the lane's pixel, [mb][2 k8 + jj] = channels 16 k8 + 8 jj + 4 half ..
+        // (inline assembly, issued HERE: left to hipcc every pair of these loads sat right in front of the MFMAs that read it -- eight exposed round
+        // trips per tile)
         f32x4 xop[2][8];
+        {
+            const unsigned xlane = (unsigned)((((l31_3 >> 4) * p.W + (l31_3 & 15)) * 64 + 4 * half3) * 4);
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                xop[mb][r] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(p.in) + ptile * 256 + (16 * mb) * 256 + (8 * r) * 4 +
-                                                             (unsigned)((((l31_3 >> 4) * p.W + (l31_3 & 15)) * 64 + 4 * half3) * 4));
+                for (int r4 = 0; r4 < 2; ++r4)
+                    wn_xload4s<32>(*reinterpret_cast<f32x4(*)[4]>(&xop[mb][4 * r4]), reinterpret_cast<const unsigned char*>(p.in) + ptile * 256 + (16 * mb) * 256 + (32 * r4) * 4, xlane);
+        }
 
         // ---- phase 3: out = W3 relu(t2) + Wd x + (b3 + bd): eight resident stages, no wait, no barrier ------------------------------------------------
         f32x16 o[2][4];
@@ -326,6 +330,12 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int k8 = s & 3, tile = k8 >> 1, q2 = k8 & 1;
+            if (s == 4) {   // the x operand (requested 256 MFMAs ago; nothing younger is in flight)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r4 = 0; r4 < 2; ++r4) wn_uwait<0>(*reinterpret_cast<f32x4(*)[4]>(&xop[mb][4 * r4]));
+            }
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
