@@ -13,6 +13,10 @@
 
 namespace hgk {
 
+#ifndef L1W_ABL
+#define L1W_ABL 0   // development builds: 1 no U loads, 2 no input transform, 4 no chunk barrier, 16 no output transform, 32 no halo DMA for the next tile, 64 no x operand loads, 128 no stores, 256 no phase-3 MFMAs
+#endif
+
 constexpr int L1W_TW = 32, L1W_HW = L1W_TW + 2, L1W_HALO = 10 * L1W_HW;   // 340 halo pixels = 85 one-KB DMA pieces
 constexpr int L1W_CHUNKS = 8;
 constexpr int L1W_U_BYTES = L1W_CHUNKS * 4 * 2 * 4 * 1024;   // [chunk][pass][cout block][column] x 1 KB fragments = 256 KiB
@@ -209,20 +213,22 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (!LAST || e < 2) wn_uwait<8>(ufr[e]);
-                else if (e == 2) wn_uwait<4>(ufr[e]);
-                else wn_uwait<0>(ufr[e]);
-                if (e == 0) uload(c, 3, ufr[3]);
-                else if (!LAST) uload(cn, e - 1, ufr[e - 1]);
+                if (!(L1W_ABL & 1)) {
+                    if (!LAST || e < 2) wn_uwait<8>(ufr[e]);
+                    else if (e == 2) wn_uwait<4>(ufr[e]);
+                    else wn_uwait<0>(ufr[e]);
+                    if (e == 0) uload(c, 3, ufr[3]);
+                    else if (!LAST) uload(cn, e - 1, ufr[e - 1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (e == 2 && !LAST) {
+                if (e == 2 && !LAST && !(L1W_ABL & 2)) {
                     t_transform_write(BR ^ 1, c2);   // V(c + 1) from the patches read in pass 0; addresses for the reads of chunk c + 1's pass 0
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if (e < 3) vf[(e + 1) & 1][g] = *reinterpret_cast<const f32x4*>(vb_ + (e + 1) * 8192 + g * 2048);
-                    if (e == 0 && !LAST) {
+                    if (e == 0 && !LAST && !(L1W_ABL & 2)) {
                         t_read(0, g);
                         t_read(1, g);
                     }
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            br_barrier();
+            if (!(L1W_ABL & 4)) br_barrier();
         };
         chunk(0, std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{});
 #pragma unroll 1
@@ -256,7 +262,12 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
         const unsigned lane_full = (unsigned)((4 * half3 * 128 + 4 * l31_3) * 4);   // pixel 4 half of the register's group, channels 4 l31 ..
         const unsigned lane_half = (unsigned)((2 * half3 * 128 + 4 * l31_3) * 4);   // half-resolution pixel 2 half of the quad, channels 4 l31 ..
         ring_issue_all();
-        {
+        if (L1W_ABL & 16) {
+            float keep = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) keep += acc[k][0];
+            *reinterpret_cast<float*>(t1_lds + lane3 * 4) = keep;
+        } else {
             const int ty = l31_3 >> 3, txl = l31_3 & 7;
             const unsigned wbase = (unsigned)((64 * ty + 16 * ph + 2 * txl) * 256 + ((((8 * cb + half3) ^ (2 * txl) ^ (ty & 1)) & 15) << 4));
 #pragma unroll
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
                 }
         }
         br_barrier();   // every wave holds its t2: the t1 region may take the next tile's halo
-        if (has_next) t1_issue(ntx0, nty0, nview);
+        if (has_next && !(L1W_ABL & 32)) t1_issue(ntx0, nty0, nview);
         // the skip convolution's A operand: x of the lane's pixel, [mb][2 k8 + jj] = channels 16 k8 + 8 jj + 4 half ..
         // (inline assembly, issued HERE: left to hipcc every pair of these loads sat right in front of the MFMAs that read it -- eight exposed round
         // trips per tile)
@@ -314,6 +325,10 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int r4 = 0; r4 < 2; ++r4)
+                    if (L1W_ABL & 64) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xop[mb][4 * r4 + j] = f32x4{1.0f, 0.0f, 0.0f, 0.0f};
+                    } else
                     wn_xload4s<32>(*reinterpret_cast<f32x4(*)[4]>(&xop[mb][4 * r4]), reinterpret_cast<const unsigned char*>(p.in) + ptile * 256 + (16 * mb) * 256 + (32 * r4) * 4, xlane);
         }
 
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int k8 = s & 3, tile = k8 >> 1, q2 = k8 & 1;
-            if (s == 4) {   // the x operand (requested 256 MFMAs ago; nothing younger is in flight)
+            if (s == 4 && !(L1W_ABL & 64)) {   // the x operand (requested 256 MFMAs ago; nothing younger is in flight)
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -343,7 +358,9 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
                     const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + s * BR_STAGE_BYTES + i * 2048);
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb) {
-                        if (s < 4) {
+                        if (L1W_ABL & 256) {
+                            o[mb][i][0] += wf[0] + t2[mb][tile][s] + xop[mb][s][0];
+                        } else if (s < 4) {
                             mfma_quad<T>(t2[mb][tile][8 * q2 + 4 * jj], t2[mb][tile][8 * q2 + 4 * jj + 1], t2[mb][tile][8 * q2 + 4 * jj + 2], t2[mb][tile][8 * q2 + 4 * jj + 3], wf, o[mb][i]);
                         } else {
                             const f32x4 xa = xop[mb][2 * k8 + jj];
@@ -364,10 +381,10 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
                     const int r = r0 + (t & 1) + 8 * (t >> 1);
                     ov[t] = f32x4{o[mb][0][r], o[mb][1][r], o[mb][2][r], o[mb][3][r]};
                     const int pl0 = (r & 3) + 8 * (r >> 2);
-                    if (p.out)
+                    if (p.out && !(L1W_ABL & 128))
                         *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(p.out) + (ptile + (size_t)(pl0 >> 4) * p.W + 16 * mb + (pl0 & 15)) * 512 + lane_full) = ov[t];
                 }
-                if (p.pool) {
+                if (p.pool && (!(L1W_ABL & 128) || ov[0][0] == 12345.678f)) {
                     f32x4 m;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(ov[0][e], ov[1][e]), fmaxf(ov[2][e], ov[3][e]));
