@@ -74,6 +74,14 @@ def test_argument_validation_without_gpu(native_lib):
     assert native_lib.df3d_pose_normalize(p16, 10, 38, 1, p16, p16, 2, None) == -1
     assert native_lib.df3d_oneeuro_filter(p16, 10, 114, 0.0, 0.1, 2.0, 1.0, 1, 0.1, p16, None) == -1
     assert native_lib.df3d_oneeuro_filter(None, 0, 114, 100.0, 0.1, 2.0, 1.0, 1, 0.1, None, None) == 0  # no frames
+    # the trust-region driver's entries (ABI 610): a null problem / null vectors / a non-positive radius are argument errors, before any launch
+    out = (ctypes.c_double * 19)()
+    prob = _native.BAProblem()
+    args = [p16] * 5
+    assert native_lib.df3d_ba_trf_subspace(None, *args, 1.0, *([p16] * 9), out, None, 0) == -1
+    assert native_lib.df3d_ba_trf_subspace(ctypes.byref(prob), *args, 1.0, *([p16] * 9), out, None, 0) == -1   # an empty problem
+    assert native_lib.df3d_ba_trf_trial(None, 0.5, 0.5, *([p16] * 13), out, None) == -1
+    assert native_lib.df3d_ba_trf_linearize(None, p16, p16, 1, *([p16] * 6), 1, p16, None) == -1
 
 
 def test_native_file_reader(native_lib, tmp_path):
