@@ -194,34 +194,41 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         view = b / tiles_y;
     };
     // the t1 halo tile by LDS-DMA, both 64-channel halves (hg_bt_ring_f32.h t1_issue; half kh at t1 + kh * BR_T1_BYTES)
+    // ONE lane-derived register lives across phase 2 (uoff, the U loads' lane offset, opaque to the compiler); whatever else a tile derives from the
+    // lane index is recomputed from it where it is needed -- kept alive, `lane` itself sat in scratch and every reload was a vmcnt(0)
+    unsigned uoff = (unsigned)(lane * 16);
+    asm volatile("" : "+v"(uoff));
     auto t1_issue = [&](int tx0, int ty0, int view) {
-        // (the per-piece lane constants -- halo pixel, swizzled chunk -- are recomputed at every call: hoisted out of the tile loop they would be
-        // ~70 registers alive across phase 2, i.e. scratch spills; the empty asm hides the lane index's loop invariance from the compiler)
-        int lane_ = lane;
+        // the per-piece lane values (halo pixel, swizzled chunk) and the per-piece uniform values (piece index, LDS address) are recomputed at every
+        // call: hoisted out of the tile loop they are ~70 registers and ~50 spill lanes alive across phase 2 (the empty asms hide their loop invariance)
+        int lane_ = (int)(uoff >> 4);
         asm volatile("" : "+v"(lane_));
+        int wave_ = wave;
+        asm volatile("" : "+s"(wave_));
         const unsigned char* const tin = reinterpret_cast<const unsigned char*>(p.t1in) + (size_t)view * p.H * p.W * 512;
+        const unsigned char* const zer = reinterpret_cast<const unsigned char*>(p.zeros);
+        const int q = lane_ >> 4, slot = lane_ & 15;
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const int pc = wave + 4 * k;
-                if (pc < BT_HALO / 4) {
-                    const int hp = 4 * pc + (lane_ >> 4);
-                    const int hy = hp / BT_HW, hx = hp % BT_HW;
-                    const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
-                    const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-                    const unsigned chunk = (unsigned)((lane_ & 15) ^ br_t1_swz(hp));
-                    const unsigned char* const src = ok ? tin + ((size_t)y * p.W + x) * 512 + kh * 256 + chunk * 16 : reinterpret_cast<const unsigned char*>(p.zeros) + chunk * 16;
-                    br_glds_piece64(src, t1_addr + (unsigned)(kh * BR_T1_BYTES + pc * 1024));
-                }
+        for (int k = 0; k < 12; ++k) {
+            const int pc = wave_ + 4 * k;
+            if (pc < BT_HALO / 4) {
+                const int hp = 4 * pc + q;
+                const int hy = hp / BT_HW, hx = hp - hy * BT_HW;
+                const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
+                const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                const unsigned c16 = (unsigned)((slot ^ (hx & 15)) << 4);               // br_t1_swz(hp) = hx & 15
+                const unsigned in_view = (unsigned)((y * p.W + x) * 512) + c16;         // (a view's t1 is < 4 GB: 32-bit offsets, ONE 64-bit add per piece)
+                const unsigned char* const base = ok ? tin : zer;                       // pixels outside the image: the 256 zero bytes
+                br_glds_piece64(base + (ok ? in_view : c16), t1_addr + (unsigned)(pc * 1024));
+                br_glds_piece64(base + (ok ? in_view + 256u : c16), t1_addr + (unsigned)(BR_T1_BYTES + pc * 1024));
             }
+        }
     };
 
     // ---- U fragments straight from global memory (L2) into the MFMA A registers: the wave's four fragments (columns j = 0..3) of (chunk c, pass e)
     //      are 4 KB at U + ((4 c + e) 4 + wave) 4096; lane (l31, half) of fragment j -> U'_{i j}[32 wave + l31][8 c + 4 half + e], i = 0..3.
     //      Rolling prefetch three passes (3 072 MFMA cycles) ahead: at the start of pass e the registers of the pass before are free and take
     //      (c + 1, e - 1) [pass 0: (c, 3)] -------------------------------------------------------------------------------------------------------
-    const unsigned uoff = (unsigned)(lane * 16);
     const unsigned char* const ubase = reinterpret_cast<const unsigned char*>(p.w2d) + (size_t)wave * 4096;
     auto uload = [&](int c, int e, f32x4 (&dst)[4]) { wn_uload4(dst, ubase + (size_t)(c * 4 + e) * 16384, uoff); };
 
@@ -265,13 +272,14 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
             *reinterpret_cast<f32x2*>(dst + j * 1024 + 8) = vs[j];
         }
     };
-    const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
     // W3's 16 stages in two sets of eight (one per 128-channel output half): stage k -> slot k % 8, slots 0 .. 3 where the V buffers were, 4 .. 7
     // in a region of their own.  A whole half is resident before its K loop starts: no wait, no barrier inside the loop (operations retire in
     // issue order, so a wait for a young ring stage would also wait for every older load -- the tile's 128 KB of residual values, the next
     // tile's halo, which all 256 workgroups request within the same microsecond)
     auto ring_slot = [](int k) { return (k & 7) < 4 ? (k & 7) * BR_STAGE_BYTES : WN_RING2_OFF + ((k & 7) - 4) * BR_STAGE_BYTES; };
     auto ring_issue8 = [&](int set) {   // stage set: W3 half 0, W3 half 1 (, L2: Wd half 0, Wd half 1); this wave copies pieces 2 wave, 2 wave + 1 of each stage
+        unsigned wvoff = (unsigned)wave * 2048u + uoff;
+        asm volatile("" : "+v"(wvoff));   // (per call: not one more register across phase 2)
 #pragma unroll
         for (int k = 8 * set; k < 8 * set + 8; ++k)
             br_glds_stage(reinterpret_cast<const unsigned char*>(p.w2d) + WN_U_BYTES + (size_t)k * BR_STAGE_BYTES, wvoff,
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         // Everything phase 3 derives from the lane index is derived HERE, per tile, from a copy the compiler cannot see through: hoisted out of
         // the tile loop these ~60 lane constants would live across phase 2, where the 256 + 256 registers are spoken for (scratch spills, and
         // every reload a vmcnt(0) in the middle of the asynchronous machinery)
-        int lane3 = lane;
+        int lane3 = (int)(uoff >> 4);
         asm volatile("" : "+v"(lane3));
         const int half3 = lane3 >> 5, l31_3 = lane3 & 31;
         const unsigned char* const wf0 = ring + br_swz(l31_3, half3);

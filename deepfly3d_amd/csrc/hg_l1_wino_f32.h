@@ -95,25 +95,30 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
     };
     // the t1 halo tile (10 x 34 pixels x 64 channels) by LDS-DMA: piece pc = halo pixels 4 pc .. 4 pc + 3, lane -> (pixel, 16-byte slot) fetching the
     // chunk that belongs there (slot ^ (hx & 15)); pixels outside the image from the page of zeros
+    unsigned uoff = (unsigned)(lane * 16);   // the one lane-derived register that lives across phase 2 (see bottleneck_wino_f32_kernel)
+    asm volatile("" : "+v"(uoff));
     auto t1_issue = [&](int tx0, int ty0, int view) {
-        int lane_ = lane;
-        asm volatile("" : "+v"(lane_));   // (recomputed per call: see bottleneck_wino_f32_kernel)
+        int lane_ = (int)(uoff >> 4);
+        asm volatile("" : "+v"(lane_));   // (recomputed per call, lane values and uniform values alike: see bottleneck_wino_f32_kernel)
+        int wave_ = wave;
+        asm volatile("" : "+s"(wave_));
         const unsigned char* const tin = reinterpret_cast<const unsigned char*>(p.t1in) + (size_t)view * p.H * p.W * 256;
+        const unsigned char* const zer = reinterpret_cast<const unsigned char*>(p.zeros);
+        const int q = lane_ >> 4, slot = lane_ & 15;
 #pragma unroll
         for (int k = 0; k < 22; ++k) {
-            const int pc = wave + 4 * k;
+            const int pc = wave_ + 4 * k;
             if (pc < L1W_HALO / 4) {
-                const int hp = 4 * pc + (lane_ >> 4);
-                const int hy = hp / L1W_HW, hx = hp % L1W_HW;
+                const int hp = 4 * pc + q;
+                const int hy = hp / L1W_HW, hx = hp - hy * L1W_HW;
                 const int y = ty0 - 1 + hy, x = tx0 - 1 + hx;
                 const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-                const unsigned chunk = (unsigned)((lane_ & 15) ^ (hx & 15));
-                const unsigned char* const src = ok ? tin + ((size_t)y * p.W + x) * 256 + chunk * 16 : reinterpret_cast<const unsigned char*>(p.zeros) + chunk * 16;
-                br_glds_piece64(src, t1_addr + (unsigned)(pc * 1024));
+                const unsigned c16 = (unsigned)((slot ^ (hx & 15)) << 4);
+                const unsigned in_view = (unsigned)((y * p.W + x) * 256) + c16;   // (a view's t1 is < 4 GB)
+                br_glds_piece64((ok ? tin : zer) + (ok ? in_view : c16), t1_addr + (unsigned)(pc * 1024));
             }
         }
     };
-    const unsigned uoff = (unsigned)(lane * 16);
     const unsigned char* const ubase = reinterpret_cast<const unsigned char*>(p.w2d) + (size_t)cb * 4096;
     auto uload = [&](int c, int e, f32x4 (&dst)[4]) { wn_uload4(dst, ubase + (size_t)(c * 4 + e) * 8192, uoff); };
 
@@ -157,8 +162,9 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
                 *reinterpret_cast<f32x2*>(dst + it * 512 + j * 2048 + 8) = vs[it][j];
             }
     };
-    const unsigned wvoff = (unsigned)wave * 2048u + (unsigned)lane * 16u;
     auto ring_issue_all = [&]() {   // W3's four stages -> slots 0 .. 3, Wd's -> 4 .. 7; this wave copies pieces 2 wave, 2 wave + 1 of each
+        unsigned wvoff = (unsigned)wave * 2048u + uoff;
+        asm volatile("" : "+v"(wvoff));
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             br_glds_stage(reinterpret_cast<const unsigned char*>(p.w2d) + L1W_U_BYTES + (size_t)k * BR_STAGE_BYTES, wvoff, ring_addr + (unsigned)(k * BR_STAGE_BYTES + wave * 2048));
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
 
         // ---- phase 3 set-up: lane constants from an opaque copy of the lane index (see bottleneck_wino_f32_kernel), the eight weight stages into the
         //      dead V region, output transform, t2 across -------------------------------------------------------------------------------------------
-        int lane3 = lane;
+        int lane3 = (int)(uoff >> 4);
         asm volatile("" : "+v"(lane3));
         const int half3 = lane3 >> 5, l31_3 = lane3 & 31;
         const unsigned char* const wf0 = ring + br_swz(l31_3, half3);
