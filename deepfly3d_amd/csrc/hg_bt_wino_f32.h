@@ -28,7 +28,7 @@
 #include "hg_bt_ring_f32.h"
 
 #ifndef WN_ABL
-#define WN_ABL 0   // development builds (scripts/build_variant.sh): ablation mask -- phase 2: 1 no U loads, 2 no input transform, 4 no chunk barrier, 8 no V fragment reads; the rest of a tile: 16 no output transform, 32 no halo DMA for the next tile, 64 no residual / operand loads, 128 no output stores, 256 no phase-3 MFMAs
+#define WN_ABL 0   // development builds (scripts/build_variant.sh): ablation mask -- phase 2: 1 no U loads, 2 no input transform, 4 no chunk barrier, 8 no V fragment reads; the rest of a tile: 512 no patch reads, 1024 no V stores, 2048 no packed adds of the input transform; 16 no output transform, 32 no halo DMA for the next tile, 64 no residual / operand loads, 128 no output stores, 256 no phase-3 MFMAs
 #endif
 
 namespace hgk {
@@ -258,16 +258,32 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
     };
     auto t_read = [&](int bb) {   // column bb of the 4 x 4 patch: rows (0, 1) and (2, 3) as register pairs
         typedef const __attribute__((address_space(3))) float* lds_f;
+        if (WN_ABL & 512) {   // (timing only: no patch reads)
+            asm volatile("" : "+v"(tP[bb]), "+v"(tQ[bb]));
+            return;
+        }
         tP[bb] = f32x2{*(lds_f)(size_t)ta[bb], *(lds_f)(size_t)(ta[bb] + BT_HW * 256)};
         tQ[bb] = f32x2{*(lds_f)(size_t)(ta[bb] + 2 * BT_HW * 256), *(lds_f)(size_t)(ta[bb] + 3 * BT_HW * 256)};
     };
     auto t_transform_write = [&](int buf, int c_next_addr) {   // sixteen packed adds + the next reads' four addresses in one clump, then the stores
         f32x2 vt[4], vs[4];
-        wn_transform(tP, tQ, vt, vs);
+        if (WN_ABL & 2048) {   // (timing only: no packed adds)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                vt[j] = tP[j];
+                vs[j] = tQ[j];
+            }
+        } else {
+            wn_transform(tP, tQ, vt, vs);
+        }
         t_addr(c_next_addr);
         unsigned char* const dst = smem + vbuf_off(buf) + vwr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (WN_ABL & 1024) {   // (timing only: no V stores)
+                asm volatile("" ::"v"(vt[j]), "v"(vs[j]));
+                continue;
+            }
             *reinterpret_cast<f32x2*>(dst + j * 1024) = vt[j];
             *reinterpret_cast<f32x2*>(dst + j * 1024 + 8) = vs[j];
         }
