@@ -265,8 +265,20 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
         tP[bb] = f32x2{*(lds_f)(size_t)ta[bb], *(lds_f)(size_t)(ta[bb] + BT_HW * 256)};
         tQ[bb] = f32x2{*(lds_f)(size_t)(ta[bb] + 2 * BT_HW * 256), *(lds_f)(size_t)(ta[bb] + 3 * BT_HW * 256)};
     };
-    auto t_transform_write = [&](int buf, int c_next_addr) {   // sixteen packed adds + the next reads' four addresses in one clump, then the stores
-        f32x2 vt[4], vs[4];
+    f32x2 vt[4], vs[4];   // V' of the lane's (patch, channel): columns j = 0 .. 3, rows (0, 1) and (2, 3)
+    // sixteen packed adds + the next reads' four addresses in one clump
+    auto t_transform = [&](int c_next_addr) {
+        wn_transform(tP, tQ, vt, vs);
+        t_addr(c_next_addr);
+    };
+    // ... and column j's 16 bytes into V buffer `buf`: in phase 2 one store per MFMA group (between MFMAs an LDS instruction is all but free; the four
+    // stores right behind the clump cost 1.8 % of the kernel)
+    auto v_store = [&](int buf, int j) {
+        unsigned char* const dst = smem + vbuf_off(buf) + vwr;
+        *reinterpret_cast<f32x2*>(dst + j * 1024) = vt[j];
+        *reinterpret_cast<f32x2*>(dst + j * 1024 + 8) = vs[j];
+    };
+    auto t_transform_write = [&](int buf, int c_next_addr) {   // (tile entry: clump, then the stores)
         if (WN_ABL & 2048) {   // (timing only: no packed adds)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -377,7 +389,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                     __builtin_amdgcn_sched_barrier(0);   // (... issued HERE: the scheduler would sink the statement behind the pass's MFMAs)
                 }
                 if (e == 2 && !(WN_ABL & 2)) {
-                    t_transform_write((BR + 2) % 3, c3);   // V(c + 2) from the patch read in pass 0; addresses for the reads of chunk c + 1's pass 0
+                    if (WN_ABL & 4096) t_transform_write((BR + 2) % 3, c3);   // (development: the stores right behind the clump, as before)
+                    else t_transform(c3);   // V(c + 2) from the patch read in pass 0; addresses for the reads of chunk c + 1's pass 0
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -387,6 +400,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_wino_f32_kernel(BtRingArgs 
                     if (e < 3) vf[(e + 1) & 1][g] = *reinterpret_cast<const f32x4*>(vb_ + (e + 1) * 4096 + g * 1024);
                     else vf[0][g] = *reinterpret_cast<const f32x4*>(vn_ + g * 1024);
                     if (e == 0 && !(WN_ABL & 2)) t_read(g);
+                    if (e == 2 && !(WN_ABL & (2 | 4096 | 1024))) v_store((BR + 2) % 3, g);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (FIRST && e == 0)   // a tile's first product into each accumulator starts from zero: no 256 v_accvgpr_write per tile
