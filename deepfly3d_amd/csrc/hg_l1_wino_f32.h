@@ -148,19 +148,24 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
         tP[it][bb] = f32x2{*(lds_f)(size_t)ta[it][bb], *(lds_f)(size_t)(ta[it][bb] + L1W_HW * 256)};
         tQ[it][bb] = f32x2{*(lds_f)(size_t)(ta[it][bb] + 2 * L1W_HW * 256), *(lds_f)(size_t)(ta[it][bb] + 3 * L1W_HW * 256)};
     };
-    auto t_transform_write = [&](int buf, int c_next_addr) {   // 32 packed adds + eight addresses in one clump, then the stores
-        f32x2 vt[2][4], vs[2][4];
+    f32x2 vt[2][4], vs[2][4];
+    auto t_transform = [&](int c_next_addr) {   // 32 packed adds + eight addresses in one clump
         wn_transform(tP[0], tQ[0], vt[0], vs[0]);
         wn_transform(tP[1], tQ[1], vt[1], vs[1]);
         t_addr(c_next_addr);
+    };
+    auto v_store = [&](int buf, int j) {   // column j of both items (in phase 2: one column per MFMA group, see bottleneck_wino_f32_kernel)
         unsigned char* const dst = smem + buf * L1W_V_BYTES + vwr;
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
+        for (int it = 0; it < 2; ++it) {
+            *reinterpret_cast<f32x2*>(dst + it * 512 + j * 2048) = vt[it][j];
+            *reinterpret_cast<f32x2*>(dst + it * 512 + j * 2048 + 8) = vs[it][j];
+        }
+    };
+    auto t_transform_write = [&](int buf, int c_next_addr) {   // (tile entry: clump, then the stores)
+        t_transform(c_next_addr);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<f32x2*>(dst + it * 512 + j * 2048) = vt[it][j];
-                *reinterpret_cast<f32x2*>(dst + it * 512 + j * 2048 + 8) = vs[it][j];
-            }
+        for (int j = 0; j < 4; ++j) v_store(buf, j);
     };
     auto ring_issue_all = [&]() {   // W3's four stages -> slots 0 .. 3, Wd's -> 4 .. 7; this wave copies pieces 2 wave, 2 wave + 1 of each
         unsigned wvoff = (unsigned)wave * 2048u + uoff;
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (e == 2 && !LAST && !(L1W_ABL & 2)) {
-                    t_transform_write(BR ^ 1, c2);   // V(c + 1) from the patches read in pass 0; addresses for the reads of chunk c + 1's pass 0
+                    t_transform(c2);   // V(c + 1) from the patches read in pass 0; addresses for the reads of chunk c + 1's pass 0
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -238,6 +243,7 @@ __global__ __launch_bounds__(256, 1) void layer1_wino_f32_kernel(BtRingArgs p) {
                         t_read(0, g);
                         t_read(1, g);
                     }
+                    if (e == 2 && !LAST && !(L1W_ABL & 2)) v_store(BR ^ 1, g);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (FIRST && e == 0)
