@@ -22,6 +22,7 @@
 #include "hg_l1_f32.h"
 #include "hg_bt_wino_f32.h"
 #include "hg_l1_wino_f32.h"
+#include "hg_c1_res_f32.h"
 
 using namespace hgk;
 
@@ -125,6 +126,8 @@ struct df3d_hg {
                           // (development: 8 + mask splits only the identity blocks (1), layer1 (2), layer2 (4))
     int wino = 1;         // exact-fp32 engine, split identity blocks: 1 (default) = the tail's 3x3 as Winograd F(2x2, 3x3) (hg_bt_wino_f32.h: 0.545 of the
                           // direct tail's MFMAs; fp32 tolerance against the oracle, NOT bit-identical to the direct kernels), 0 = direct implicit GEMM
+    int c1res = 1;        // exact-fp32 engine with `wino`: 1 (default) = conv1 of the plain identity blocks with W1 resident in LDS (hg_c1_res_f32.h), bit-identical
+                          // to conv1_ring_f32_kernel (0); may be switched between forwards (it changes neither the plan nor the weight streams)
     bool split_id() const { return split1 == 1 || (split1 >= 8 && (split1 & 1)); }
     bool split_l1() const { return split1 == 1 || (split1 >= 8 && (split1 & 2)); }
     bool split_l2() const { return split1 == 1 || (split1 >= 8 && (split1 & 4)); }
@@ -326,7 +329,7 @@ struct df3d_hg {
                     st.t1 = new_tensor(tx.h, tx.w, planes);
                     if (wino && dtype == DF3D_DTYPE_F32) {   // the tail's 3x3 in the Winograd domain: U = G g G^T as per-wave MFMA fragments
                         st.wstream_w2d = (long long)stream_bytes;
-                        stream_bytes += (size_t)WN_STREAM_BYTES;   // U, then W3 with permuted rows
+                        stream_bytes += (size_t)WN_STREAM_BYTES + C1R_W_BYTES;   // U, then W3 with permuted rows, then W1 for the LDS-resident conv1 (hg_c1_res_f32.h)
                     }
                 }
             }
@@ -1052,7 +1055,8 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                             c.M = (long long)n * ti.h * ti.w;
                             r.t1in = c.t1;
                             r.zeros = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + h->zero_off;
-                            ScopedTimer tc(h, s, std::string(a.in2 ? "conv1_ring_f32_kernel<true, 256, 128, " : "conv1_ring_f32_kernel<false, 256, 128, ") + tname + ">", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);   // (as rocprofv3 prints them)
+                            const bool resident = std::is_same<T, float>::value && st.wstream_w2d >= 0 && !a.in2 && h->c1res;   // option `wino`: W1 resident in LDS
+                            ScopedTimer tc(h, s, resident ? std::string("conv1_res_f32_kernel") : std::string(a.in2 ? "conv1_ring_f32_kernel<true, 256, 128, " : "conv1_ring_f32_kernel<false, 256, 128, ") + tname + ">", 2.0 * px * cin * pl, px * 4.0 * (cin + pl), 0.0);   // (as rocprofv3 prints them)
                             static unsigned attr_c1[2] = {0, 0};
                             const void* const fn = a.in2 ? reinterpret_cast<const void*>(conv1_ring_f32_kernel<true, 256, 128, T>) : reinterpret_cast<const void*>(conv1_ring_f32_kernel<false, 256, 128, T>);
                             if (first_use_on_this_device(attr_c1[a.in2 ? 1 : 0]))
@@ -1062,7 +1066,15 @@ int run_steps(df3d_hg* h, const float* images_all, int n_all, int upto, float* h
                                 return DF3D_EINVAL;
                             }
                             const unsigned c1_grid = (unsigned)std::min<long long>(c.M / 128, 2LL * cu_count());   // persistent: two workgroups per CU
-                            if (a.in2)
+                            if (resident) {
+                                if constexpr (std::is_same<T, float>::value) {
+                                    static unsigned attr_c1r = 0;
+                                    if (first_use_on_this_device(attr_c1r))
+                                        DF3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_res_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C1R_LDS_BYTES));
+                                    c.wstream = reinterpret_cast<const unsigned char*>(h->lowp) + h->stream_base() + st.wstream_w2d + WN_STREAM_BYTES;
+                                    hipLaunchKernelGGL(conv1_res_f32_kernel, dim3((unsigned)std::min<long long>(c.M / 128, (long long)(cu_count() & ~7))), dim3(256), C1R_LDS_BYTES, s, c);
+                                }
+                            } else if (a.in2)
                                 hipLaunchKernelGGL((conv1_ring_f32_kernel<true, 256, 128, T>), dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
                             else
                                 hipLaunchKernelGGL((conv1_ring_f32_kernel<false, 256, 128, T>), dim3(c1_grid), dim3(256), C1_LDS_BYTES, s, c);
@@ -1320,6 +1332,11 @@ int df3d_hg_set_option(df3d_hg* h, const char* key, int value) {
         h->build();
         return DF3D_OK;
     }
+    if (!strcmp(key, "c1res")) {
+        DF3D_CHECK_ARG(value == 0 || value == 1, "c1res must be 0 or 1");
+        h->c1res = value;
+        return DF3D_OK;
+    }
     if (!strcmp(key, "no_reuse")) {
         DF3D_CHECK_ARG(value == 0 || value == 1, "no_reuse must be 0 or 1");
         DF3D_CHECK_ARG(h->blob == nullptr, "set 'no_reuse' before df3d_hg_set_weights (it changes the workspace plan)");
@@ -1506,6 +1523,7 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
                 unsigned char* const ws = reinterpret_cast<unsigned char*>(lowp_dev) + h->stream_base() + st.wstream_w2d;
                 hipLaunchKernelGGL(bt_wino_pack_kernel, dim3(128 * 128 / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv2b.w_off, reinterpret_cast<float*>(ws));
                 hipLaunchKernelGGL(bt_wino_pack_w3_kernel, dim3(BRF_W3_STAGES * 512 / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv3b.w_off, ws + WN_U_BYTES);
+                hipLaunchKernelGGL(c1r_pack_kernel, dim3(C1_NSTAGE * 512 / 256), dim3(256), 0, df3d::as_stream(stream), blob_dev + st.conv.w_off, ws + WN_STREAM_BYTES);
             }
         }
         if (h->uses_zero_page)

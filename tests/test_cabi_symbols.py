@@ -160,7 +160,7 @@ def test_f32s_engine_shares_the_f32_plan_and_needs_its_weight_copy(native_lib):
     # permuted rows (128 KiB): option "wino" (round 6); without it the two engines' streams are the same
     with_wino = native_lib.df3d_hg_lowp_bytes(f32)
     assert native_lib.df3d_hg_set_option(f32, b"wino", 0) == 0
-    assert with_wino - native_lib.df3d_hg_lowp_bytes(f32) == 23 * ((1 << 20) + (128 << 10)) + (1 << 20) + (256 << 10) + (256 << 10) + (64 << 10)
+    assert with_wino - native_lib.df3d_hg_lowp_bytes(f32) == 23 * ((1 << 20) + (128 << 10) + (128 << 10)) + (1 << 20) + (256 << 10) + (256 << 10) + (64 << 10)   # per identity block: U, W3 (permuted rows), W1 for the LDS-resident conv1
     assert native_lib.df3d_hg_lowp_bytes(f32s) == copy + native_lib.df3d_hg_lowp_bytes(f32)
     rc = native_lib.df3d_hg_set_weights(f32s, ctypes.c_void_p(256), None, None)
     assert rc == -1 and b"f32s" in native_lib.df3d_last_error()

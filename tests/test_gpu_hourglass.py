@@ -563,6 +563,33 @@ def test_fp32_winograd_tail_matches_the_direct_kernels_within_fp32_tolerance(nat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("height,width,n", [(256, 512, 5), (128, 256, 2), (64, 192, 1)])
+def test_fp32_resident_conv1_is_bit_identical_to_the_ring_form(native_lib, cuda, oracle_net, height, width, n):
+    """fp32 `wino` engines run conv1 of the plain identity bottlenecks with W1 resident in LDS (csrc/hg_c1_res_f32.h: one workgroup per CU, no
+    barrier after the prologue, x straight from global memory into MFMA operands, W1's rows permuted for 16-byte stores).  The bias is the
+    accumulators' start value and K ascends as in conv1_ring_f32_kernel, so EVERY plan step -- the heat-maps with them -- is the ring form's bit
+    for bit (option `c1res` = 0 selects it, between forwards: neither the plan nor the weight streams change), at level sizes where a wave has
+    many, one or no 32-pixel tile, on a NaN-poisoned workspace."""
+    from deepfly3d_amd import _native
+    from deepfly3d_amd.hourglass import HourglassEngine
+
+    sd = {k: v.detach().numpy() for k, v in oracle_net.state_dict().items()}
+    img = torch.rand((n, height, width, 3), generator=torch.Generator().manual_seed(17 * height + width), dtype=torch.float32).to(cuda)
+    eng = HourglassEngine(sd, dtype="f32", device=cuda, height=height, width=width, wino=1)
+    outs = []
+    for c1res in (1, 0, 1):
+        _native.check(eng.lib.df3d_hg_set_option(eng.h, b"c1res", c1res), "df3d_hg_set_option")
+        steps = []
+        for k in range(1, len(eng.steps()) + 1):
+            eng._workspace(n).fill_(0xFF)
+            steps.append(eng.forward_upto(img, k).clone())
+        outs.append(steps)
+    for k, (name, _) in enumerate(eng.steps()):
+        assert torch.equal(outs[0][k], outs[1][k]), f"step {k + 1} {name}: resident conv1 differs from the ring form"
+        assert torch.equal(outs[0][k], outs[2][k]), f"step {k + 1} {name}: not repeat-stable"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["f16", "f32s"])
 def test_reduced_precision_overflow_is_an_error_not_a_result(native_lib, cuda, dtype):
     """The f16 / f32s engines need every operand inside the IEEE-half range.  (1) Weights beyond it are refused when they are loaded, with the
