@@ -19,6 +19,10 @@
 
 namespace hgk {
 
+#ifndef C1R_ABL
+#define C1R_ABL 0   // development builds: 1 no bn1 + ReLU clumps, 2 no x loads (and no waits for them), 4 no stores, 8 no MFMAs
+#endif
+
 constexpr int C1R_W_BYTES = C1_NSTAGE * BR_STAGE_BYTES;                 // 131 072
 constexpr int C1R_LDS_BYTES = C1R_W_BYTES + 512 * 4 + 128 * 4;         // weights | bn1 scale, shift | b1
 static_assert(C1R_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
@@ -69,9 +73,13 @@ __global__ __launch_bounds__(256, 1) void conv1_res_f32_kernel(Conv1Args p) {
     auto issue_half = [&](f32x4 (&x)[4][4], long long tile, int h) {
         const unsigned char* const sb = in + (size_t)tile * (32 * 1024) + h * 512;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) wn_xload4s<32>(x[m], sb + m * 128, xlane);
+        for (int m = 0; m < 4; ++m) {
+            if (C1R_ABL & 2) asm volatile("" : "+v"(x[m][0]), "+v"(x[m][1]), "+v"(x[m][2]), "+v"(x[m][3]));
+            else wn_xload4s<32>(x[m], sb + m * 128, xlane);
+        }
     };
     auto bn_relu = [&](f32x4 (&x)[4], int q0) {   // one clump: 16 fused multiply-adds, 16 maxima
+        if (C1R_ABL & 1) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 cs = *reinterpret_cast<const f32x4*>(cs_l + 8 * (q0 + j));
@@ -81,17 +89,28 @@ __global__ __launch_bounds__(256, 1) void conv1_res_f32_kernel(Conv1Args p) {
         }
     };
     f32x16 o[4];   // tile i, register r: channel 4 l31 + i of pixel (r & 3) + 8 (r >> 2) + 4 half
+    // A tile is 128 groups of four MFMAs: group n = (load q = n >> 2, accumulator tile i = n & 3) needs ONE 16-byte weight fragment; group n + 1's is
+    // requested before group n's MFMAs are issued (two register sets; the tile's last group requests the next tile's first).  Measured and not
+    // kept: the sixteen MFMAs of a load rotating over the four accumulators (four in a row on one accumulator are no slower).
+    f32x4 wfq[2];
+    auto wf_of = [&](int n) {
+        const int q = (n >> 2) & 31, i = n & 3;
+        return *reinterpret_cast<const f32x4*>(((q & 1) ? wf1 : wf0) + (q >> 1) * BR_STAGE_BYTES + i * 2048);
+    };
     auto multiply = [&](const f32x4 (&x)[4], int q0) {   // 64 MFMAs: K = channels 8 q0 .. 8 q0 + 31, stage q >> 1, chunk pair q & 1
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = q0 + j, s = q >> 1, jj = q & 1;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const f32x4 wf = *reinterpret_cast<const f32x4*>((jj ? wf1 : wf0) + s * BR_STAGE_BYTES + i * 2048);
-                mfma_quad<float>(x[j][0], x[j][1], x[j][2], x[j][3], wf, o[i]);
+                const int n = 4 * (q0 + j) + i;
+                wfq[(n + 1) & 1] = wf_of(n + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (C1R_ABL & 8) o[i][0] += x[j][0] * wfq[n & 1][0];
+                else mfma_quad<float>(x[j][0], x[j][1], x[j][2], x[j][3], wfq[n & 1], o[i]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        }
     };
+    wfq[0] = wf_of(0);
 
     issue_half(xa, t, 0);
     issue_half(xb, t, 1);
@@ -108,10 +127,10 @@ __global__ __launch_bounds__(256, 1) void conv1_res_f32_kernel(Conv1Args p) {
         // first half: behind its sixteen loads stand the second half's sixteen and, from the second tile on, the sixteen stores of the tile before
         if (first) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) wn_uwait<16>(xa[m]);
+            for (int m = 0; m < 4; ++m) if (!(C1R_ABL & 2)) wn_uwait<16>(xa[m]);
         } else {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) wn_uwait<32>(xa[m]);
+            for (int m = 0; m < 4; ++m) if (!(C1R_ABL & 2)) wn_uwait<32>(xa[m]);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -123,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void conv1_res_f32_kernel(Conv1Args p) {
         issue_half(xa, tn, 0);   // the next tile's first half, into the registers just multiplied
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) wn_uwait<16>(xb[m]);   // (behind them: the sixteen loads just issued)
+        for (int m = 0; m < 4; ++m) if (!(C1R_ABL & 2)) wn_uwait<16>(xb[m]);   // (behind them: the sixteen loads just issued)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             bn_relu(xb[m], 16 + 4 * m);
@@ -136,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void conv1_res_f32_kernel(Conv1Args p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const f32x4 v = {br_relu(o[0][r]), br_relu(o[1][r]), br_relu(o[2][r]), br_relu(o[3][r])};
-            *reinterpret_cast<f32x4*>(ot + ((r & 3) + 8 * (r >> 2)) * 512 + olane) = v;
+            if (!(C1R_ABL & 4) || v[0] == 12345.678f) *reinterpret_cast<f32x4*>(ot + ((r & 3) + 8 * (r >> 2)) * 512 + olane) = v;
         }
         __builtin_amdgcn_sched_barrier(0);
         issue_half(xb, tn, 1);
