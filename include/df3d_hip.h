@@ -359,7 +359,9 @@ int df3d_hg_set_weights(df3d_hg* h, const float* blob_dev, void* lowp_dev, void*
  * the reference form the aliasing tests compare the default plan with, bit for bit; before the weights;
  * "wino" = 1 (default) | 0 (exact fp32 with "split1"): the 3x3 of the 256->128->128->256 identity blocks as Winograd F(2x2, 3x3) -- 16 instead of 36 multiplies per
  * 2x2 output patch and (cin, cout) pair, 1 MB more stream space per block; the SAME float32 tolerance against the reference arithmetic, but NOT bit-identical
- * to the direct form ("wino" = 0: the bit-identity reference of the other options); before the weights */
+ * to the direct form ("wino" = 0: the bit-identity reference of the other options); before the weights;
+ * "c1res" = 1 (default) | 0 (with "wino"): conv1 of the plain identity blocks with its 128 KB of weights resident in LDS (128 KB more stream space per block,
+ * allocated with "wino") instead of streamed through the LDS ring -- bit-identical either way; may be set between forwards */
 int df3d_hg_set_option(df3d_hg* h, const char* key, int value);
 size_t df3d_hg_workspace_bytes(const df3d_hg* h, int n);
 int df3d_hg_forward(df3d_hg* h, const float* images_dev, int n, float* heatmaps_dev, void* workspace_dev,
